@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by IMPORTING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference; never on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 TORCH_COMPILE_DISABLE=1 python tests/golden/make_golden.py [--curve]
+
+The reference's third-party imports that are absent here (timm, fairscale,
+torchdiffeq, diffusers, torchvision, taming) are replaced by minimal stand-ins
+inserted into ``sys.modules`` *before* import (recipe: SURVEY.md §8c).  The
+stand-ins are harness code, not product code.  Outputs are data only
+(inputs / expected outputs, hashes); no reference source text is stored.
+
+Weights are regenerated on both sides from ``weights.det_weights`` so the
+fixtures stay small.
+"""
+import argparse
+import hashlib
+import os
+import sys
+import types
+from dataclasses import dataclass
+
+os.environ.setdefault("TORCH_COMPILE_DISABLE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/LDMAE"
+sys.path.insert(0, HERE)
+from weights import det_weights, det_randn  # noqa: E402
+
+
+# --------------------------------------------------------------------------- shims
+def install_shims():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class PatchEmbed(nn.Module):
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, bias=True):
+            super().__init__()
+            self.patch_size = (patch_size, patch_size)
+            self.grid_size = (img_size // patch_size, img_size // patch_size)
+            self.num_patches = self.grid_size[0] * self.grid_size[1]
+            self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+            self.norm = nn.Identity()
+
+        def forward(self, x):
+            return self.norm(self.proj(x).flatten(2).transpose(1, 2))
+
+    class Mlp(nn.Module):
+        def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+            super().__init__()
+            self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+            self.act = act_layer()
+            self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    class DropPath(nn.Identity):
+        def __init__(self, p=0.0):
+            super().__init__()
+
+    mod("timm")
+    mod("timm.models")
+    mod("timm.models.vision_transformer", PatchEmbed=PatchEmbed, Mlp=Mlp, DropPath=DropPath)
+    mod("fairscale")
+    mod("fairscale.nn")
+    mod("fairscale.nn.model_parallel")
+    mod("fairscale.nn.model_parallel.initialize")
+    mod("fairscale.nn.model_parallel.layers", ColumnParallelLinear=object, ParallelEmbedding=object,
+        RowParallelLinear=object)
+
+    def odeint(fn, x, t, method="euler", atol=None, rtol=None):
+        assert method == "euler"
+        xs = [x]
+        for k in range(len(t) - 1):
+            x = x + (t[k + 1] - t[k]) * fn(t[k], x)
+            xs.append(x)
+        return torch.stack(xs)
+    mod("torchdiffeq", odeint=odeint)
+
+    class BaseOutput:            # attribute access only; subclasses are @dataclass
+        pass
+    mod("diffusers", ConfigMixin=object, ModelMixin=object)
+    mod("diffusers.utils", BaseOutput=BaseOutput)
+
+    class _Inert:
+        def __init__(self, *a, **k):
+            pass
+    tv = mod("torchvision")
+    tr = mod("torchvision.transforms", **{n: _Inert for n in
+             ["Compose", "Lambda", "RandomHorizontalFlip", "ToTensor", "Normalize", "RandomResizedCrop", "Resize"]})
+    tr.functional = mod("torchvision.transforms.functional")
+    tv.transforms = tr
+    mod("torchvision.datasets", ImageFolder=_Inert)
+    mod("taming")
+    mod("taming.modules")
+    mod("taming.modules.losses")
+    mod("taming.modules.losses.lpips", LPIPS=_Inert)
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()
+
+
+def load_det(model, seed=0, skip=()):
+    shapes = {k: tuple(v.shape) for k, v in model.named_parameters()}
+    w = det_weights(shapes, seed)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k in w and k not in skip:
+                p.copy_(w[k])
+
+
+# --------------------------------------------------------------------------- DiT tiny
+TINY = dict(input_size=8, patch_size=1, in_channels=16, hidden_size=192, depth=2, num_heads=3,
+            num_classes=10, class_dropout_prob=0.5)
+FLAGS = dict(use_qknorm=True, use_swiglu=True, use_rope=True, use_rmsnorm=True, wo_shift=False)
+
+
+def gen_dit_tiny(out):
+    from models.lightningdit import LightningDiT
+    from transport import create_transport
+    torch.manual_seed(0)
+    m = LightningDiT(**TINY, **FLAGS)
+    load_det(m, seed=1)
+    m.train()
+    B = 2
+    x1 = det_randn("x1", (B, 16, 8, 8), 7)
+    y = torch.tensor([3, 7])
+    # model-only forward with controlled label drop (sample 1 dropped)
+    taps = {}
+    hooks = [blk.register_forward_hook(lambda mod, i, o, n=n: taps.__setitem__(n, o.detach().clone()))
+             for n, blk in enumerate(m.blocks)]
+    torch.manual_seed(123)
+    drop = torch.rand(B) < TINY["class_dropout_prob"]
+    torch.manual_seed(123)
+    t_in = torch.tensor([0.3, 0.8])
+    xt_in = det_randn("xt", (B, 16, 8, 8), 7)
+    o = m(xt_in, t_in, y)
+    for h in hooks:
+        h.remove()
+    out.update(dit_xt=xt_in.numpy(), dit_t=t_in.numpy(), dit_y=y.numpy(), dit_drop=drop.numpy(),
+               dit_out=o.detach().numpy(), dit_blk0=taps[0].numpy(), dit_blk1=taps[1].numpy())
+    # full loss + grads through reference transport with seeded RNGs
+    tr = create_transport("Linear", "velocity", None, None, None, use_cosine_loss=False, use_lognorm=True)
+    torch.manual_seed(5)
+    np.random.seed(5)
+    terms = tr.training_losses(m, x1, dict(y=y))
+    loss = terms["loss"].mean()
+    loss.backward()
+    # replay the draws to record them
+    torch.manual_seed(5)
+    np.random.seed(5)
+    x0 = torch.randn_like(x1)
+    z = np.random.standard_normal(B)
+    t = torch.tensor(1 / (1 + np.exp(-z)), dtype=torch.float32)
+    drop2 = torch.rand(B) < TINY["class_dropout_prob"]
+    out.update(tl_x1=x1.numpy(), tl_x0=x0.numpy(), tl_t=t.numpy(), tl_drop=drop2.numpy(),
+               tl_loss_b=terms["loss"].detach().numpy(), tl_pred=terms["pred"].detach().numpy())
+    names, gn, gs, gh = [], [], [], []
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        gn.append(float(p.grad.double().norm()))
+        gs.append(float(p.grad.double().sum()))
+        gh.append(p.grad.flatten()[:8].numpy().copy())
+    out.update(tl_grad_names=np.array(names), tl_grad_norm=np.array(gn), tl_grad_sum=np.array(gs),
+               tl_grad_head=np.stack(gh))
+    # CFG forward (eval) on doubled batch + 3-step Euler sample with shift
+    m.eval()
+    from transport import Sampler
+    z0 = det_randn("z0", (2, 16, 8, 8), 9)
+    zz = torch.cat([z0, z0], 0)
+    yy = torch.tensor([1, 4, 10, 10])
+    with torch.no_grad():
+        o_cfg_lo = m.forward_with_cfg(zz, torch.full((4,), 0.05), yy, 4.0, True, 0.10)
+        o_cfg_hi = m.forward_with_cfg(zz, torch.full((4,), 0.50), yy, 4.0, True, 0.10)
+        fn = Sampler(tr).sample_ode(sampling_method="euler", num_steps=4, atol=1e-6, rtol=1e-3, reverse=False,
+                                    timestep_shift=0.3)
+        traj = fn(zz, m.forward_with_cfg, y=yy, cfg_scale=4.0, cfg_interval=True, cfg_interval_start=0.10)
+    out.update(cfg_z=zz.numpy(), cfg_y=yy.numpy(), cfg_lo=o_cfg_lo.numpy(), cfg_hi=o_cfg_hi.numpy(),
+               euler_last=traj[-1].numpy())
+
+
+# --------------------------------------------------------------------------- tables / kernels at real width
+def gen_tables_and_kernels(out):
+    from models.lightningdit import LightningDiT_models, modulate
+    from models.rmsnorm import RMSNorm
+    from models.swiglu_ffn import SwiGLUFFN
+    from transport.integrators import ode
+    m = LightningDiT_models["LightningDiT-B/1"](input_size=32, num_classes=1000, in_channels=16, **FLAGS)
+    out.update(b1_pos_sha=sha(m.pos_embed), b1_pos_head=m.pos_embed[0, :3, :].numpy().copy(),
+               b1_pos_tail=m.pos_embed[0, -2:, :].numpy().copy(),
+               b1_cos_sha=sha(m.feat_rope.freqs_cos), b1_sin_sha=sha(m.feat_rope.freqs_sin),
+               b1_cos_rows=m.feat_rope.freqs_cos[[0, 1, 33, 1023]].numpy().copy(),
+               b1_sin_rows=m.feat_rope.freqs_sin[[0, 1, 33, 1023]].numpy().copy(),
+               b1_nparams=np.array(sum(p.numel() for p in m.parameters())),
+               b1_keys=np.array(sorted(m.state_dict().keys())))
+    # RMSNorm + modulate at width 768
+    x = det_randn("k5_x", (2, 8, 768), 3)
+    w = 1 + 0.1 * det_randn("k5_w", (768,), 3)
+    sh, sc = 0.3 * det_randn("k5_sh", (2, 768), 3), 0.3 * det_randn("k5_sc", (2, 768), 3)
+    n = RMSNorm(768)
+    with torch.no_grad():
+        n.weight.copy_(w)
+        out["k5_out"] = modulate(n(x), sh, sc).numpy()
+    # RoPE on [1, 2, 1024, 64]
+    q = det_randn("k8_q", (1, 2, 1024, 64), 3)
+    rq = m.feat_rope(q)
+    out.update(k8_head=rq[0, :, :4].numpy().copy(), k8_tail=rq[0, :, -4:].numpy().copy(), k8_sha=sha(rq))
+    # SwiGLU 768 -> 2048 -> 768 on 8 rows
+    f = SwiGLUFFN(768, 2048)
+    load_det(f, seed=4)
+    with torch.no_grad():
+        out["k11_out"] = f(det_randn("k11_x", (8, 768), 3)).numpy()
+    # attention of block 0 on one sample at full sequence
+    a = m.blocks[0].attn
+    load_det(a, seed=6)
+    with torch.no_grad():
+        ao = a(det_randn("k9_x", (1, 1024, 768), 3) * 0.5, rope=m.feat_rope)
+    out.update(k9_head=ao[0, :4].numpy().copy(), k9_tail=ao[0, -4:].numpy().copy(), k9_sha=sha(ao),
+               k9_norm=np.array(float(ao.double().norm())))
+    # timestep embedding + shifted Euler grid
+    from models.lightningdit import TimestepEmbedder
+    out["k2_emb"] = TimestepEmbedder.timestep_embedding(torch.tensor([0.0, 0.25, 0.9]), 256).numpy()
+    o = ode(drift=None, t0=0, t1=1, sampler_type="euler", num_steps=250, atol=1e-6, rtol=1e-3, timestep_shift=0.3)
+    out["euler_grid"] = o.t.numpy()
+    # logit-normal t draw
+    from transport import create_transport
+    tr = create_transport("Linear", "velocity", None, None, None, use_cosine_loss=False, use_lognorm=True)
+    np.random.seed(11)
+    out["lognorm_t_seed11"] = tr.sample_logit_normal(0, 1, size=16).numpy()
+
+
+# --------------------------------------------------------------------------- VMAE
+def gen_mae(out):
+    sys.path.insert(0, os.path.join(REF, "tokenizer"))
+    from tokenizer import models_mae
+    torch.manual_seed(0)
+    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True,
+                                            img_size=256)
+    out.update(mae_nparams=np.array(sum(p.numel() for p in m.parameters())),
+               mae_keys=np.array(sorted(m.state_dict().keys())),
+               mae_pos_sha=sha(m.pos_embed), mae_pos_head=m.pos_embed[0, :3].numpy().copy())
+    load_det(m, seed=2, skip=("pos_embed", "decoder_pos_embed"))
+    m.eval()
+    imgs = det_randn("mae_img", (2, 3, 256, 256), 2).clamp(-1, 1)
+    for tag, ratio in (("75", 0.75), ("25", 0.25)):
+        torch.manual_seed(42)
+        noise = torch.rand(2, 1024)
+        torch.manual_seed(42)
+        with torch.no_grad():
+            lat, mask, ids_restore = m.forward_encoder(imgs, ratio)
+        srt = np.sort(noise.numpy(), axis=1)
+        assert (np.diff(srt, axis=1) > 0).all(), "noise has ties; pick another seed"
+        out.update({f"mae{tag}_mask": mask.numpy(), f"mae{tag}_ids_restore": ids_restore.numpy(),
+                    f"mae{tag}_lat_head": lat[:, :4].numpy().copy(), f"mae{tag}_lat_sha": sha(lat),
+                    f"mae{tag}_lat_norm": np.array(float(lat.double().norm())),
+                    f"mae{tag}_lat_shape": np.array(lat.shape)})
+        out["mae_noise"] = noise.numpy()
+    with torch.no_grad():
+        mom = m._encode(imgs)
+        z = mom[:, :16]
+        rec = m.decode(z).sample
+    out.update(mae_moments_head=mom[:, :, :2, :2].numpy().copy(), mae_moments_norm=np.array(float(mom.double().norm())),
+               mae_rec_head=rec[:, :, :4, :4].numpy().copy(), mae_rec_norm=np.array(float(rec.double().norm())))
+    img8 = torch.clamp(127.5 * rec + 128.0, 0, 255).permute(0, 2, 3, 1).to(torch.uint8).numpy()
+    out["mae_img8_sha"] = np.array(hashlib.sha256(img8.tobytes()).hexdigest())
+    out["mae_img8_head"] = img8[:, :4, :4].copy()
+
+
+# --------------------------------------------------------------------------- 100-step loss curve, B/1 bs=4
+def ref_style_init(model, seed):
+    """Reference init *scheme* (zero adaLN / final, Xavier Linears) with name-keyed
+    values so the oracle / HIP side can rebuild the identical start point."""
+    import math
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k == "pos_embed":
+                continue
+            z = det_randn(k, p.shape, seed)
+            if "norm" in k and k.endswith("weight"):
+                p.fill_(1.0)
+            elif k.endswith(".bias") or "adaLN_modulation" in k or k.startswith("final_layer.linear"):
+                p.zero_()
+            elif k.startswith("y_embedder") or k.startswith("t_embedder"):
+                p.copy_(0.02 * z)
+            else:
+                fan_out, fan_in = p.shape[0], int(np.prod(p.shape[1:]))
+                p.copy_(z * math.sqrt(2.0 / (fan_in + fan_out)))
+
+
+def gen_curve(out, steps=100, B=4):
+    import time
+    from copy import deepcopy
+    from collections import OrderedDict
+    from models.lightningdit import LightningDiT_models
+    from transport import create_transport
+    torch.manual_seed(0)
+    m = LightningDiT_models["LightningDiT-B/1"](input_size=32, num_classes=1000, in_channels=16,
+                                                 class_dropout_prob=0.1, **FLAGS)
+    ref_style_init(m, seed=10)
+    ema = deepcopy(m)
+    for p in ema.parameters():
+        p.requires_grad = False
+    m.train()
+    tr = create_transport("Linear", "velocity", None, None, None, use_cosine_loss=False, use_lognorm=True)
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-4, weight_decay=0, betas=(0.9, 0.95))
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    losses = []
+    x0_sha = None
+    for s in range(steps):
+        t0 = time.time()
+        x = torch.randn(B, 16, 32, 32)
+        y = torch.randint(0, 1000, (B,))
+        if s == 0:
+            st, ns = torch.get_rng_state(), np.random.get_state()
+            x0_sha = sha(torch.randn_like(x))
+            torch.set_rng_state(st)
+            np.random.set_state(ns)
+        loss = tr.training_losses(m, x, dict(y=y))["loss"].mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        with torch.no_grad():
+            ep, mp = OrderedDict(ema.named_parameters()), OrderedDict(m.named_parameters())
+            for k, p in mp.items():
+                ep[k].mul_(0.9999).add_(p.data, alpha=1 - 0.9999)
+        losses.append(float(loss))
+        print(f"[curve] step {s} loss {losses[-1]:.6f} ({time.time() - t0:.1f}s)", flush=True)
+    sdm, sde = m.state_dict(), ema.state_dict()
+    probe = ["blocks.0.attn.qkv.weight", "blocks.11.mlp.w3.weight", "final_layer.linear.weight",
+             "blocks.5.adaLN_modulation.1.weight", "y_embedder.embedding_table.weight"]
+    out.update(curve_losses=np.array(losses), curve_x0_sha=np.array(x0_sha), curve_probe=np.array(probe),
+               curve_param_norm=np.array([float(sdm[k].double().norm()) for k in probe]),
+               curve_ema_norm=np.array([float(sde[k].double().norm()) for k in probe]),
+               curve_param_head=np.stack([sdm[k].flatten()[:8].numpy() for k in probe]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--curve", action="store_true", help="also run the 100-step B/1 bs=4 loss curve (~15 min)")
+    ap.add_argument("--only-curve", action="store_true")
+    ap.add_argument("--threads", type=int, default=8)
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    install_shims()
+    sys.path.insert(0, REF)
+    if not args.only_curve:
+        for name, fn in (("dit_tiny", gen_dit_tiny), ("kernels", gen_tables_and_kernels), ("mae", gen_mae)):
+            out = {}
+            fn(out)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print("wrote", name, sorted(out)[:6], "...")
+    if args.curve or args.only_curve:
+        out = {}
+        gen_curve(out)
+        np.savez_compressed(os.path.join(HERE, "curve.npz"), **out)
+        print("wrote curve")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,37 @@
+"""Deterministic, name-keyed test weights shared by make_golden.py (which loads
+them into the *reference* model) and by the tests (which load them into the
+oracle and the HIP path).  Weights are never stored in fixtures: both sides
+regenerate them from (name, shape, seed) with torch's CPU generator.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+
+def det_randn(name: str, shape, seed: int = 0) -> torch.Tensor:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(name.encode()) + 1000003 * seed) % (2 ** 31))
+    return torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+
+
+def det_weights(shapes: dict, seed: int = 0, skip=("pos_embed", "decoder_pos_embed")) -> dict:
+    """Non-degenerate values for every parameter: adaLN / final layers are NOT
+    zero (zero-init layers make goldens test nothing)."""
+    out = {}
+    for k, shp in shapes.items():
+        if k in skip:
+            continue
+        z = det_randn(k, shp, seed)
+        if k.endswith("norm.weight") or "norm1.weight" in k or "norm2.weight" in k or "norm_final.weight" in k:
+            out[k] = 1.0 + 0.1 * z
+        elif k.endswith(".bias"):
+            out[k] = 0.05 * z
+        elif "embedding_table" in k:
+            out[k] = 0.5 * z
+        elif "adaLN_modulation" in k:
+            out[k] = z * (0.5 / math.sqrt(int(np.prod(shp[1:]))))
+        else:
+            out[k] = z / math.sqrt(int(np.prod(shp[1:])))
+    return out

@@ -1,0 +1,173 @@
+"""Pin the oracle: every golden vector produced by importing the reference
+(tests/golden/make_golden.py) must be reproduced by the CPU restatement."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import dit, mae, train, transport
+from weights import det_randn, det_weights
+
+TINY = dit.DiTConfig(input_size=8, patch_size=1, in_channels=16, hidden_size=192, depth=2, num_heads=3,
+                     num_classes=10, class_dropout_prob=0.5)
+B1 = dit.DiTConfig(**dit.DIT_B_1)
+
+
+def sha(t):
+    return hashlib.sha256(t.detach().contiguous().numpy().tobytes()).hexdigest()
+
+
+def tiny_sd(seed=1):
+    sd = det_weights(dit.param_shapes(TINY), seed)
+    sd.update(dit.fixed_tables(TINY))
+    return sd
+
+
+def test_b1_tables_bit_exact(golden):
+    g = golden("kernels")
+    tb = dit.fixed_tables(B1)
+    assert sha(tb["pos_embed"]) == str(g["b1_pos_sha"])
+    assert sha(tb["feat_rope.freqs_cos"]) == str(g["b1_cos_sha"])
+    assert sha(tb["feat_rope.freqs_sin"]) == str(g["b1_sin_sha"])
+    np.testing.assert_array_equal(tb["feat_rope.freqs_cos"][[0, 1, 33, 1023]].numpy(), g["b1_cos_rows"])
+
+
+def test_b1_state_dict_keys_and_param_count(golden):
+    g = golden("kernels")
+    shapes = dit.param_shapes(B1)
+    keys = sorted(list(shapes) + ["feat_rope.freqs_cos", "feat_rope.freqs_sin"])
+    assert keys == [str(k) for k in g["b1_keys"]]
+    assert sum(int(np.prod(s)) for s in shapes.values()) == int(g["b1_nparams"])
+
+
+def test_dit_tiny_forward(golden):
+    g = golden("dit_tiny")
+    sd = tiny_sd()
+    taps = {}
+    out = dit.dit_forward(sd, torch.from_numpy(g["dit_xt"]), torch.from_numpy(g["dit_t"]),
+                          torch.from_numpy(g["dit_y"]), TINY, True, torch.from_numpy(g["dit_drop"]), taps)
+    assert bool(g["dit_drop"].any()) and not bool(g["dit_drop"].all())
+    assert rel_err(taps["blocks.0.out"], g["dit_blk0"]) < 2e-6
+    assert rel_err(taps["blocks.1.out"], g["dit_blk1"]) < 2e-6
+    assert rel_err(out, g["dit_out"]) < 2e-6
+
+
+def test_dit_tiny_loss_and_grads(golden):
+    g = golden("dit_tiny")
+    sd = tiny_sd()
+    # the oracle's own host draws must reproduce the reference's (x0 torch, t numpy, drop torch)
+    torch.manual_seed(5)
+    np.random.seed(5)
+    x1 = torch.from_numpy(g["tl_x1"])
+    t, x0, _ = transport.sample(x1)
+    drop = torch.rand(2) < TINY.class_dropout_prob
+    np.testing.assert_array_equal(x0.numpy(), g["tl_x0"])
+    np.testing.assert_array_equal(t.numpy(), g["tl_t"])
+    np.testing.assert_array_equal(drop.numpy(), g["tl_drop"])
+    y = torch.from_numpy(g["dit_y"])
+    keys = train.trainable_keys(TINY)
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    full = dict(sd)
+    full.update(leaves)
+    terms = transport.training_losses(lambda xt, tt: dit.dit_forward(full, xt, tt, y, TINY, True, drop), x1, t, x0)
+    assert rel_err(terms["loss"], g["tl_loss_b"]) < 2e-6
+    assert rel_err(terms["pred"], g["tl_pred"]) < 2e-6
+    terms["loss"].mean().backward()
+    names = [str(n) for n in g["tl_grad_names"]]
+    assert set(names) == set(keys)
+    for i, k in enumerate(names):
+        gr = leaves[k].grad
+        assert abs(float(gr.double().norm()) - g["tl_grad_norm"][i]) <= 2e-5 * g["tl_grad_norm"][i] + 1e-9, k
+        np.testing.assert_allclose(gr.flatten()[:8].numpy(), g["tl_grad_head"][i], rtol=2e-4, atol=2e-7, err_msg=k)
+
+
+def test_cfg_and_euler(golden):
+    g = golden("dit_tiny")
+    sd = tiny_sd()
+    z, y = torch.from_numpy(g["cfg_z"]), torch.from_numpy(g["cfg_y"])
+    lo = dit.dit_forward_with_cfg(sd, z, torch.full((4,), 0.05), y, TINY, 4.0, True, 0.10)
+    hi = dit.dit_forward_with_cfg(sd, z, torch.full((4,), 0.50), y, TINY, 4.0, True, 0.10)
+    assert rel_err(lo, g["cfg_lo"]) < 2e-6 and rel_err(hi, g["cfg_hi"]) < 2e-6
+    grid = transport.shifted_time_grid(4, 0.3)
+    traj = transport.euler_ode(lambda x, t: dit.dit_forward_with_cfg(sd, x, t, y, TINY, 4.0, True, 0.10), z, grid)
+    assert rel_err(traj[-1], g["euler_last"]) < 5e-6
+
+
+def test_kernel_vectors_real_width(golden):
+    g = golden("kernels")
+    x = det_randn("k5_x", (2, 8, 768), 3)
+    w = 1 + 0.1 * det_randn("k5_w", (768,), 3)
+    sh, sc = 0.3 * det_randn("k5_sh", (2, 768), 3), 0.3 * det_randn("k5_sc", (2, 768), 3)
+    assert rel_err(dit.modulate(dit.rmsnorm(x, w), sh, sc), g["k5_out"]) < 1e-6
+    cos, sin = dit.rope_tables(64, 32)
+    rq = dit.apply_rope(det_randn("k8_q", (1, 2, 1024, 64), 3), cos, sin)
+    assert sha(rq) == str(g["k8_sha"])
+    sdf = det_weights({"w12.weight": (4096, 768), "w12.bias": (4096,), "w3.weight": (768, 2048), "w3.bias": (768,)}, 4)
+    assert rel_err(dit.swiglu(sdf, "", det_randn("k11_x", (8, 768), 3)), g["k11_out"]) < 2e-6
+    sda = det_weights({"qkv.weight": (2304, 768), "qkv.bias": (2304,), "q_norm.weight": (64,), "k_norm.weight": (64,),
+                       "proj.weight": (768, 768), "proj.bias": (768,)}, 6)
+    ao = dit.attention(sda, "", det_randn("k9_x", (1, 1024, 768), 3) * 0.5, B1, cos, sin)
+    assert rel_err(ao[0, :4], g["k9_head"]) < 5e-6 and rel_err(ao[0, -4:], g["k9_tail"]) < 5e-6
+    assert abs(float(ao.double().norm()) - float(g["k9_norm"])) < 1e-5 * float(g["k9_norm"])
+    np.testing.assert_allclose(dit.timestep_embedding(torch.tensor([0.0, 0.25, 0.9])).numpy(), g["k2_emb"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(transport.shifted_time_grid(250, 0.3).numpy(), g["euler_grid"], rtol=0, atol=1e-7)
+    np.random.seed(11)
+    np.testing.assert_array_equal(transport.sample_logit_normal(16).numpy(), g["lognorm_t_seed11"])
+
+
+def test_mae_masking_bit_exact_and_encoder(golden):
+    g = golden("mae")
+    cfg = mae.MAEConfig()
+    shapes = mae.param_shapes(cfg)
+    sd = det_weights(shapes, 2)
+    sd.update(mae.fixed_tables(cfg))
+    assert sha(sd["pos_embed"]) == str(g["mae_pos_sha"])
+    assert sorted(list(shapes) + ["pos_embed", "decoder_pos_embed"]) == [str(k) for k in g["mae_keys"]]
+    assert sum(int(np.prod(s)) for s in shapes.values()) + 2 * 1024 * 192 == int(g["mae_nparams"])
+    imgs = det_randn("mae_img", (2, 3, 256, 256), 2).clamp(-1, 1)
+    noise = torch.from_numpy(g["mae_noise"])
+    for tag, ratio in (("75", 0.75), ("25", 0.25)):
+        lat, mask, ids = mae.forward_encoder(sd, imgs, noise, ratio, cfg)
+        np.testing.assert_array_equal(mask.numpy(), g[f"mae{tag}_mask"])          # bit-exact
+        np.testing.assert_array_equal(ids.numpy(), g[f"mae{tag}_ids_restore"])     # bit-exact
+        assert list(lat.shape) == list(g[f"mae{tag}_lat_shape"])
+        assert rel_err(lat[:, :4], g[f"mae{tag}_lat_head"]) < 5e-6
+        assert abs(float(lat.double().norm()) - float(g[f"mae{tag}_lat_norm"])) < 1e-5 * float(g[f"mae{tag}_lat_norm"])
+    mom = mae.encode_moments(sd, imgs, cfg)
+    assert rel_err(mom[:, :, :2, :2], g["mae_moments_head"]) < 5e-6
+    rec = mae.decode(sd, mom[:, :16], cfg)
+    assert rel_err(rec[:, :, :4, :4], g["mae_rec_head"]) < 1e-5
+    img8 = mae.to_uint8_images(rec)
+    assert (np.abs(img8[:, :4, :4].astype(int) - g["mae_img8_head"].astype(int)) <= 1).all()
+
+
+def test_masking_ties_are_broken_by_index():
+    noise = np.zeros((1, 8), dtype=np.float32)
+    noise[0, 5] = -1
+    keep, mask, restore = mae.random_masking_ids(noise, 0.5)
+    assert keep.tolist() == [[5, 0, 1, 2]]
+    assert mask.tolist() == [[0, 0, 0, 1, 1, 0, 1, 1]]
+
+
+def test_adamw_restatement_matches_torch_optim():
+    torch.manual_seed(0)
+    p0 = {"a": torch.randn(5, 7), "b": torch.randn(11)}
+    ref = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+    opt = torch.optim.AdamW(ref.values(), lr=2e-4, weight_decay=0, betas=(0.9, 0.95))
+    sd = {k: v.clone() for k, v in p0.items()}
+    st = train.AdamWState(list(sd), sd)
+    for _ in range(5):
+        grads = {k: torch.randn_like(v) for k, v in sd.items()}
+        for k in ref:
+            ref[k].grad = grads[k].clone()
+        opt.step()
+        train.adamw_step(sd, grads, st)
+    for k in sd:
+        np.testing.assert_allclose(sd[k].numpy(), ref[k].detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_curve_fixture_present(golden):
+    g = golden("curve")
+    assert len(g["curve_losses"]) == 100
