@@ -1,0 +1,150 @@
+/* libldmae_hip -- C ABI of the MI355X (gfx950) kernels behind the LDMAE hot path.
+ *
+ * The reference (isno0907/ldmae) has NO native code and NO FFI: its seam for this path is the
+ * Python module API (models/lightningdit.py, tokenizer/models_mae.py).  This header
+ * is what a binding for that seam calls: one entry per fused region of the LightningDiT block /
+ * VMAE encoder, each citing the reference lines whose arithmetic it replaces (paths relative to
+ * /root/reference/LDMAE).  The ctypes binding lives in ldmae_amd/_lib.py; INTEGRATION.md shows the
+ * stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - plain device pointers + explicit sizes, no torch types; `stream` is a hipStream_t (NULL = default).
+ *  - every call only ENQUEUES on `stream`: no allocation, no synchronisation, no global mutable state
+ *    (callable from the Python main thread and the autograd thread concurrently).  Workspaces are
+ *    caller-owned.
+ *  - return 0 on success, negative on error; ldmae_last_error() gives the thread-local message.
+ *  - dtype codes select the activation type: LDMAE_F32 (parity path, exact-f32 MFMA) or LDMAE_BF16
+ *    (throughput path, bf16 MFMA with f32 accumulation).  Residual stream, norms' statistics,
+ *    modulation vectors, gradients of parameters and optimizer state are always f32.
+ *  - "rows" M = batch * tokens, row-major, token-major activations [M, D].
+ */
+#ifndef LDMAE_HIP_H
+#define LDMAE_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDMAE_OK 0
+#define LDMAE_ERR_INVALID (-1)   /* bad argument / unsupported shape */
+#define LDMAE_ERR_HIP (-2)       /* HIP runtime error at launch */
+
+#define LDMAE_F32 0
+#define LDMAE_BF16 1
+
+/* GEMM epilogues */
+#define LDMAE_EPI_BIAS 0       /* C = acc + bias (+ beta*C)                                   */
+#define LDMAE_EPI_GATE_RES 1   /* y = acc + bias ; xout = xin + gate[b]*y  (gate NULL -> 1)    */
+#define LDMAE_EPI_BIAS_POS 2   /* C = acc + bias + pos[m % rows_per_batch]  (patch-embed)      */
+#define LDMAE_EPI_BIAS_GELU 3  /* C = gelu_erf(acc + bias)  (VMAE Mlp fc1), pre-activation to C2 */
+
+const char* ldmae_last_error(void);
+const char* ldmae_version(void);
+const char* ldmae_arch(void);     /* "gfx950" */
+
+/* ---- Linear layers -------------------------------------------------------------------------- */
+/* C[M,N] = A[M,K] . B[N,K]^T with fused epilogue.  Replaces nn.Linear forward (lightningdit.py:59,
+ * 64,68,88; swiglu_ffn.py:33,36; models_mae.py:125,127,133,143) and, with the [in,out] weight copy
+ * as B, the input-gradient GEMM of the same layers.
+ *   EPI_GATE_RES fuses `x = x + gate.unsqueeze(1) * branch(...)` (lightningdit.py:248-249):
+ *   C (optional, dtype out_dtype) receives y for the backward pass, xin/xout are the f32 residual
+ *   stream (may alias), gate is a [batch, gate_ld] f32 view, rows_per_batch = tokens per sample. */
+int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                  int M, int N, int K, const float* bias, float beta, const float* xin, float* xout,
+                  const float* gate, int gate_ld, int rows_per_batch, void* stream);
+/* C[N,K] (f32) = beta*C + A[M,N]^T . B[M,K]: weight gradient of the same layers (contraction over
+ * token rows, split over workgroups; partial slabs are summed in fixed order -> deterministic). */
+int ldmae_gemm_tn_splits(int dtype, int M, int N, int K);
+long ldmae_gemm_tn_workspace_bytes(int dtype, int M, int N, int K);
+int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int M, int N, int K, float beta,
+                  float* workspace, long workspace_bytes, void* stream);
+/* out[N] (f32) = beta*out + column sums of X[M,N]: bias gradients. workspace >= ldmae_colsum_workspace_bytes */
+long ldmae_colsum_workspace_bytes(int M, int N);
+int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, float beta, float* workspace, void* stream);
+
+/* f32 master weight [R,C] -> dst[R,C] (dtype) and, if dstT != NULL, dstT[C,R] (the [in,out] copy) */
+int ldmae_cast_weight(int dst_dtype, const float* src, void* dst, void* dstT, int R, int C, void* stream);
+int ldmae_cast(int src_dtype, int dst_dtype, const void* src, void* dst, long n, void* stream);
+
+/* ---- adaLN-modulated RMSNorm (rmsnorm.py:51-77 + lightningdit.py:26-30) ----------------------- */
+/* out = rmsnorm(x; w, eps) * (1 + scale[b]) + shift[b];  rstd[M] saved for backward.
+ * shift/scale are [batch, mod_ld] f32 views (column slices of the adaLN output). */
+int ldmae_rmsnorm_modulate_fwd(int out_dtype, const float* x, const float* w, const float* shift, const float* scale,
+                               int mod_ld, void* out, float* rstd, int M, int D, int rows_per_batch, float eps, void* stream);
+/* dx_accum += d(x); dshift/dscale [batch, dmod_ld] = per-sample sums; dw[D] += sum (beta_w).  workspace from
+ * ldmae_rmsnorm_modulate_bwd_workspace_bytes. */
+long ldmae_rmsnorm_modulate_bwd_workspace_bytes(int M, int D, int rows_per_batch);
+int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
+                               const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                               float beta_w, int M, int D, int rows_per_batch, float* workspace, void* stream);
+
+/* ---- attention front end (lightningdit.py:68-74; rmsnorm.py on head_dim; pos_embed.py:38-42,135) */
+/* qkv [B,N,3,H,hd] -> q,k = rope(rmsnorm(.)*w) and v, each [B,H,N,hd]. cos/sin [N,hd] f32. */
+int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq, const float* wk, const float* cos, const float* sin,
+                          void* q, void* k, void* v, int B, int N, int H, int hd, float eps, void* stream);
+long ldmae_qknorm_rope_bwd_workspace_bytes(int B, int N, int H, int hd);
+int ldmae_qknorm_rope_bwd(int dtype, const void* dq, const void* dk, const void* dv, const void* qkv, const float* wq,
+                          const float* wk, const float* cos, const float* sin, void* dqkv, float* dwq, float* dwk, float beta_w,
+                          int B, int N, int H, int hd, float eps, float* workspace, void* stream);
+
+/* ---- attention core (F.scaled_dot_product_attention, lightningdit.py:76-80; manual softmax attention
+ *      models_mae.py:135-141).  q,k,v [B,H,N,hd]; o [B,N,H*hd]; lse [B,H,N] f32 (natural log). */
+int ldmae_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N, int hd,
+                        float scale, void* stream);
+/* delta [B,H,N] f32 workspace; dq,dk,dv [B,H,N,hd]; do_ [B,N,H*hd] */
+int ldmae_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                        void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, void* stream);
+
+/* ---- SwiGLU (swiglu_ffn.py:34-35) ------------------------------------------------------------ */
+int ldmae_swiglu_fwd(int dtype, const void* h12, void* hid, int M, int Hs, void* stream);
+int ldmae_swiglu_bwd(int dtype, const void* dhid, const void* h12, void* dh12, int M, int Hs, void* stream);
+
+/* ---- gated residual backward (lightningdit.py:248-249): dy = dxout * gate[b]; dgate[b] = sum_n dxout*y */
+long ldmae_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch);
+int ldmae_gate_bwd(int dtype, const float* dxout, const void* y, const float* gate, int gate_ld, void* dy, float* dgate,
+                   int dgate_ld, int M, int D, int rows_per_batch, float* workspace, void* stream);
+
+/* ---- embedders (lightningdit.py:109-137, 152-169) -------------------------------------------- */
+int ldmae_timestep_embedding(const float* t, float* out, int B, int dim, float max_period, void* stream);
+int ldmae_silu_fwd(int out_dtype, const float* x, void* out, long n, void* stream);
+int ldmae_silu_bwd(const float* dy, const float* x, float* dx, long n, void* stream);   /* dx = dy * silu'(x) */
+/* out[b] = table[drop[b] ? num_classes : y[b]]; drop may be NULL */
+int ldmae_label_embed_fwd(const float* table, const long long* y, const unsigned char* drop, float* out, int B, int D,
+                          int num_classes, void* stream);
+/* dtable[rows,D] += scatter of dout (deterministic: one workgroup per table row, fixed b order) */
+int ldmae_label_embed_bwd(const float* dout, const long long* y, const unsigned char* drop, float* dtable, int B, int D,
+                          int num_classes, int rows, void* stream);
+
+/* ---- optimizer (train_accum.py:121,240 AdamW; :336-347 EMA) ---------------------------------- */
+/* one pass over flat f32 buffers: AdamW(lr,b1,b2,eps,wd) on p with grad g (scaled by grad_scale), then
+ * ema = decay*ema + (1-decay)*p.  step >= 1. */
+int ldmae_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, int step, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, double ema_decay, double grad_scale, void* stream);
+int ldmae_ema_only(float* ema, const float* p, long n, double ema_decay, void* stream);
+
+/* ---- VMAE masked-token encoder (tokenizer/models_mae.py) ------------------------------------- */
+/* random_masking (:472-497) on caller-supplied noise[N,L] f32: stable ascending argsort (ties -> lower
+ * index first).  ids_restore i64 [N,L], mask f32 [N,L], ids_keep i64 [N,keep]. L <= 4096. */
+int ldmae_random_masking(const float* noise, long long* ids_restore, float* mask, long long* ids_keep, int N, int L, int keep,
+                         void* stream);
+/* out[n,j,:] = x[n, ids[n,j], :]  (torch.gather on dim 1, :486); bwd scatters (ids unique per n) */
+int ldmae_gather_rows(const float* x, const long long* ids, float* out, int N, int L, int keep, int D, void* stream);
+int ldmae_scatter_rows(const float* dout, const long long* ids, float* dx, int N, int L, int keep, int D, void* stream);
+/* LayerNorm with affine (models_mae.py:163,171,369; eps 1e-6).  mean/rstd [M] saved. */
+int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w, const float* b, void* out, float* mean, float* rstd,
+                        int M, int D, float eps, void* stream);
+long ldmae_layernorm_bwd_workspace_bytes(int M, int D);
+int ldmae_layernorm_bwd(int dtype, const void* dout, const float* x, const float* w, const float* mean, const float* rstd,
+                        float* dx_accum, float* dw, float* db, float beta_w, int M, int D, float* workspace, void* stream);
+/* exact-erf GELU (timm Mlp act, models_mae.py:172) */
+int ldmae_gelu_fwd(int dtype, const void* x, void* out, long n, void* stream);
+int ldmae_gelu_bwd(int dtype, const void* dout, const void* x, void* dx, long n, void* stream);
+
+/* ---- optional per-kernel timing hook used by bench.py for the roofline line ------------------- */
+/* When enabled, ldmae_gemm_nt brackets each launch with HIP events on the launch stream. */
+int ldmae_prof_enable(int on);
+int ldmae_prof_collect(double* total_ms, double* total_flops, long* launches);   /* syncs the events; resets */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,115 @@
+"""ctypes binding of libldmae_hip.so (include/ldmae_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails the
+caller gets a RuntimeError.  torch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldmae_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_GATE_RES, EPI_BIAS_POS, EPI_BIAS_GELU = 0, 1, 2, 3
+
+_vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
+
+# name -> (restype, argtypes); mirrors include/ldmae_hip.h one to one
+SIGNATURES = {
+    "ldmae_last_error": (C.c_char_p, []),
+    "ldmae_version": (C.c_char_p, []),
+    "ldmae_arch": (C.c_char_p, []),
+    "ldmae_gemm_nt": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _i, _i, _vp]),
+    "ldmae_gemm_tn_splits": (_i, [_i, _i, _i, _i]),
+    "ldmae_gemm_tn_workspace_bytes": (_l, [_i, _i, _i, _i]),
+    "ldmae_gemm_tn": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _l, _vp]),
+    "ldmae_colsum_workspace_bytes": (_l, [_i, _i]),
+    "ldmae_colsum": (_i, [_i, _vp, _i, _i, _i, _vp, _f, _vp, _vp]),
+    "ldmae_cast_weight": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
+    "ldmae_cast": (_i, [_i, _i, _vp, _vp, _l, _vp]),
+    "ldmae_rmsnorm_modulate_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "ldmae_rmsnorm_modulate_bwd_workspace_bytes": (_l, [_i, _i, _i]),
+    "ldmae_rmsnorm_modulate_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i, _i, _vp, _vp]),
+    "ldmae_qknorm_rope_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ldmae_qknorm_rope_bwd_workspace_bytes": (_l, [_i, _i, _i, _i]),
+    "ldmae_qknorm_rope_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _f, _vp, _vp]),
+    "ldmae_attention_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ldmae_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ldmae_swiglu_fwd": (_i, [_i, _vp, _vp, _i, _i, _vp]),
+    "ldmae_swiglu_bwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
+    "ldmae_gate_bwd_workspace_bytes": (_l, [_i, _i, _i]),
+    "ldmae_gate_bwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ldmae_timestep_embedding": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "ldmae_silu_fwd": (_i, [_i, _vp, _vp, _l, _vp]),
+    "ldmae_silu_bwd": (_i, [_vp, _vp, _vp, _l, _vp]),
+    "ldmae_label_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ldmae_label_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ldmae_adamw_ema": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _d, _d, _d, _d, _d, _d, _d, _vp]),
+    "ldmae_ema_only": (_i, [_vp, _vp, _l, _d, _vp]),
+    "ldmae_random_masking": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ldmae_gather_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ldmae_scatter_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ldmae_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "ldmae_layernorm_bwd_workspace_bytes": (_l, [_i, _i]),
+    "ldmae_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
+    "ldmae_gelu_fwd": (_i, [_i, _vp, _vp, _l, _vp]),
+    "ldmae_gelu_bwd": (_i, [_i, _vp, _vp, _vp, _l, _vp]),
+    "ldmae_prof_enable": (_i, [_i]),
+    "ldmae_prof_collect": (_i, [C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library (once) and declare every prototype.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ldmae_amd/csrc`).  ldmae_amd has no CPU / PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ldmae_last_error().decode()
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise RuntimeError with the library's message on failure."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be CUDA/HIP and contiguous."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("ldmae_amd ops need tensors on a HIP device (no CPU fallback); got " + str(t.device))
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f"unsupported activation dtype {dtype} (float32 or bfloat16)")

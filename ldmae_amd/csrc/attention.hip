@@ -1,0 +1,643 @@
+// Flash-style attention for the LightningDiT block (hd = 64) on gfx950: softmax(q k^T * scale) v,
+// non-causal, no mask (lightningdit.py:76-80).  q,k,v are head-major [B,H,N,hd]; o / do are
+// token-major [B,N,H*hd] (the layout the proj GEMM consumes).
+//
+// bf16 path: mfma_f32_32x32x16_bf16.  Scores are computed TRANSPOSED (S^T = K . Q^T) so a lane owns one
+// query column: the row max / row sum are in-register plus one cross-half shuffle, and the f32
+// accumulator tile is re-used directly as the B operand of the next product (P^T for O^T = V^T . P^T)
+// with the k-order of the 32x32 C/D map (verified by csrc/probe/mfma_probe.hip).  K/V tiles sit in LDS
+// in ONE image that serves both row reads (ds_read_b128) and transposed reads (ds_read_b64_tr_b16):
+// 8-row x 32-col sub-tiles of 512 B with a 2-bit XOR on the 16-B chunk; filled by global_load_lds with
+// the permutation applied to the per-lane SOURCE address.
+//
+// Backward = two passes without atomics (bitwise reproducible):
+//   dKdV: a wave owns 32 keys (key on the lane), sweeps 64-query tiles: S, dP, then dV^T += dO^T P,
+//         dK^T += Q^T dS with Q / dO read both by rows and transposed from the same LDS image.
+//   dQ  : a wave owns 32 queries (query on the lane), sweeps 64-key tiles: S^T, dP^T, dQ^T += K^T dS^T.
+// f32 path (parity contract): same structure on mfma_f32_32x32x2f32 with padded f32 LDS tiles.
+#include "common.h"
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
+
+// byte offset of 16-B chunk `ch` of row `row` in the dual-use LDS image of a [rows][HD] bf16 tile
+template <int HD> __device__ __forceinline__ int tile_off(int row, int ch) {
+  return (HD * 16) * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+// inverse: LDS byte offset (multiple of 16) -> (row, ch)
+template <int HD> __device__ __forceinline__ void tile_inv(int off, int& row, int& ch) {
+  const int grp = off / (HD * 16), within = off % (HD * 16);
+  const int sub = within >> 9, rem = within & 511, r7 = rem >> 6, pos = (rem & 63) >> 4;
+  row = grp * 8 + r7;
+  ch = sub * 4 + (pos ^ ((row >> 2) & 3));
+}
+// stage a [ROWS][HD] bf16 tile (global row stride ld elements) into LDS with global_load_lds; 256 threads
+template <int HD, int ROWS>
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ g, long ld, int row_limit, char* lds, int wave, int lane) {
+  constexpr int PIECES = ROWS * HD * 2 / 1024;
+  static_assert(PIECES % 4 == 0 || PIECES == 2 || PIECES == 1, "tile too small");
+#pragma unroll
+  for (int i = 0; i < (PIECES + 3) / 4; ++i) {
+    const int pi = wave * ((PIECES + 3) / 4) + i;
+    if (pi < PIECES) {
+      int row, ch;
+      tile_inv<HD>(pi * 1024 + lane * 16, row, ch);
+      row = min(row, row_limit);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(g + (long)row * ld + ch * 8), LDS_PTR(void, lds + pi * 1024), 16, 0, 0);
+    }
+  }
+}
+// A-operand fragment for a product that contracts over the tile's ROW index (transposed read):
+// rows r0 + {4h.. , 8+4h..} in the acc-as-operand k order, 32 columns starting at c0 (lane r = column)
+template <int HD> __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int r0, int c0, int lane) {
+  const int h = lane >> 5, g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int row = r0 + 4 * h + q, ch = (c0 >> 3) + 2 * (g & 1) + (p >> 1);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + tile_off<HD>(row, ch) + ((p & 1) << 3)));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + tile_off<HD>(row + 8, ch) + ((p & 1) << 3)));
+  union { bf16x8 v; s16x4 h2[2]; } u;
+  u.h2[0] = lo; u.h2[1] = hi;
+  return u.v;
+}
+// A-operand fragment by rows: row r0 + (lane&31), k chunk (2*ks + h)
+template <int HD> __device__ __forceinline__ bf16x8 frag_row(const char* tile, int r0, int ks, int lane) {
+  return *(const bf16x8*)(tile + tile_off<HD>(r0 + (lane & 31), 2 * ks + (lane >> 5)));
+}
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16)x[8 * s + j];
+  return f;
+}
+__device__ __forceinline__ int acc_row(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
+
+// ================================================================================================ forward, bf16
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                            bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c) {
+  constexpr int KS = HD / 16, DB = HD / 32, TB = 64 * HD * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int qblocks = (N + 127) / 128;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lid / qblocks, q0 = (lid % qblocks) * 128 + wave * 32;
+  const bool active = q0 < N;
+  const bf16* qp = Q + (size_t)bh * N * HD;
+  const bf16* kp = K + (size_t)bh * N * HD;
+  const bf16* vp = V + (size_t)bh * N * HD;
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + (size_t)min(q0 + r, N - 1) * HD + ks * 16 + 8 * h);
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) oacc[d][t] = 0.f;
+  float ms = -1e30f, l = 0.f;
+  const int nt = N / 64;
+  auto stage = [&](int buf, int kt) {
+    stage_tile<HD, 64>(kp + (size_t)kt * 64 * HD, HD, 63, smem + buf * 2 * TB, wave, lane);
+    stage_tile<HD, 64>(vp + (size_t)kt * 64 * HD, HD, 63, smem + buf * 2 * TB + TB, wave, lane);
+  };
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nt; ++kt) {
+    if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+    const char* Kt = smem + cur * 2 * TB;
+    const char* Vt = Kt + TB;
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) s[kb][t] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[kb] = MFMA_BF16(frag_row<HD>(Kt, kb * 32, ks, lane), qf[ks], s[kb]);
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) mx = fmaxf(mx, fmaxf(s[0][t], s[1][t]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float ms_new = fmaxf(ms, mx * c), alpha = exp2f(ms - ms_new);
+    ms = ms_new;
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { const float p = exp2f(s[kb][t] * c - ms); s[kb][t] = p; rs += p; }
+    l = l * alpha + rs;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) oacc[d][t] *= alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(s[kb], s2);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) oacc[d] = MFMA_BF16(frag_tr<HD>(Vt, kb * 32 + 16 * s2, d * 32, lane), pf, oacc[d]);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (!active) return;
+  const float inv = 1.f / l;
+  const int b = bh / H, hh = bh % H;
+  bf16* op = O + ((size_t)(b * N + q0 + r) * H + hh) * HD;
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      bf16x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (bf16)(oacc[d][4 * t4 + j] * inv);
+      *(bf16x4*)(op + d * 32 + 8 * t4 + 4 * h) = w;
+    }
+  if (h == 0) LSE[(size_t)bh * N + q0 + r] = (ms + log2f(l)) * 0.6931471805599453f;
+}
+
+// delta[b,h,n] = sum_d o[b,n,h,d] * do[b,n,h,d]
+template <typename T>
+__global__ void attn_delta_kernel(const T* __restrict__ O, const T* __restrict__ dO, float* __restrict__ delta, int B, int H, int N, int hd) {
+  const long items = (long)B * N * H;
+  const int lpr = 8;                     // lanes per (b,n,h) row
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / lpr;
+  const int sub = threadIdx.x % lpr;
+  for (long it = gid; it < items; it += (long)gridDim.x * 256 / lpr) {
+    const int hh = it % H, n = (it / H) % N, b = it / ((long)H * N);
+    const T* o = O + (size_t)it * hd;
+    const T* g = dO + (size_t)it * hd;
+    float s = 0.f;
+    for (int d = sub * 8; d < hd; d += lpr * 8) {
+      float a[8], e[8];
+      Vec8<T>::load(o + d, a); Vec8<T>::load(g + d, e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += a[j] * e[j];
+    }
+    s = group_sum<8>(s);
+    if (sub == 0) delta[((size_t)b * H + hh) * N + n] = s;
+  }
+}
+
+// ================================================================================================ backward dK/dV, bf16
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                                 const bf16* __restrict__ dO, const float* __restrict__ LSE,
+                                                                 const float* __restrict__ DELTA, bf16* __restrict__ dK, bf16* __restrict__ dV,
+                                                                 int H, int N, float scale) {
+  constexpr int KS = HD / 16, DB = HD / 32, TB = 64 * HD * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q tile | dO tile | lse2[64] delta[64]]
+  constexpr int BUF = 2 * TB + 512;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const float c = scale * 1.4426950408889634f;
+  const int kblocks = (N + 127) / 128;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lid / kblocks, k0 = (lid % kblocks) * 128 + wave * 32;
+  const bool active = k0 < N;
+  const int b = bh / H, hh = bh % H;
+  const bf16* qp = Q + (size_t)bh * N * HD;
+  const bf16* dop = dO + ((size_t)b * N * H + hh) * HD;     // row stride H*HD
+  const long dold = (long)H * HD;
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const size_t o = ((size_t)bh * N + min(k0 + r, N - 1)) * HD + ks * 16 + 8 * h;
+    kf[ks] = *(const bf16x8*)(K + o);
+    vf[ks] = *(const bf16x8*)(V + o);
+  }
+  f32x16 dkacc[DB], dvacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { dkacc[d][t] = 0.f; dvacc[d][t] = 0.f; }
+  const int nt = N / 64;
+  auto stage = [&](int buf, int qt) {
+    char* base = smem + buf * BUF;
+    stage_tile<HD, 64>(qp + (size_t)qt * 64 * HD, HD, 63, base, wave, lane);
+    stage_tile<HD, 64>(dop + (size_t)qt * 64 * dold, dold, 63, base + TB, wave, lane);
+    if (threadIdx.x < 64) ((float*)(base + 2 * TB))[threadIdx.x] = LSE[(size_t)bh * N + qt * 64 + threadIdx.x] * 1.4426950408889634f;
+    else if (threadIdx.x < 128) ((float*)(base + 2 * TB))[threadIdx.x] = DELTA[(size_t)bh * N + qt * 64 + threadIdx.x - 64];
+  };
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int qt = 0; qt < nt; ++qt) {
+    if (qt + 1 < nt) stage(cur ^ 1, qt + 1);
+    const char* Qt = smem + cur * BUF;
+    const char* dOt = Qt + TB;
+    const float* lse2 = (const float*)(Qt + 2 * TB);
+    const float* dl = lse2 + 64;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s = MFMA_BF16(frag_row<HD>(Qt, qb * 32, ks, lane), kf[ks], s);
+        dp = MFMA_BF16(frag_row<HD>(dOt, qb * 32, ks, lane), vf[ks], dp);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = qb * 32 + acc_row(t, h);
+        const float p = exp2f(s[t] * c - lse2[row]);
+        s[t] = p;
+        dp[t] = p * (dp[t] - dl[row]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(s, s2), dsf = acc_frag(dp, s2);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          dvacc[d] = MFMA_BF16(frag_tr<HD>(dOt, qb * 32 + 16 * s2, d * 32, lane), pf, dvacc[d]);
+          dkacc[d] = MFMA_BF16(frag_tr<HD>(Qt, qb * 32 + 16 * s2, d * 32, lane), dsf, dkacc[d]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (!active) return;
+  bf16* dkp = dK + ((size_t)bh * N + k0 + r) * HD;
+  bf16* dvp = dV + ((size_t)bh * N + k0 + r) * HD;
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      bf16x4 wk, wv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { wk[j] = (bf16)(dkacc[d][4 * t4 + j] * scale); wv[j] = (bf16)dvacc[d][4 * t4 + j]; }
+      *(bf16x4*)(dkp + d * 32 + 8 * t4 + 4 * h) = wk;
+      *(bf16x4*)(dvp + d * 32 + 8 * t4 + 4 * h) = wv;
+    }
+}
+
+// ================================================================================================ backward dQ, bf16
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                               const bf16* __restrict__ dO, const float* __restrict__ LSE,
+                                                               const float* __restrict__ DELTA, bf16* __restrict__ dQ, int H, int N, float scale) {
+  constexpr int KS = HD / 16, DB = HD / 32, TB = 64 * HD * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const float c = scale * 1.4426950408889634f;
+  const int qblocks = (N + 127) / 128;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lid / qblocks, q0 = (lid % qblocks) * 128 + wave * 32;
+  const bool active = q0 < N;
+  const int b = bh / H, hh = bh % H;
+  const int qrow = min(q0 + r, N - 1);
+  const bf16* kp = K + (size_t)bh * N * HD;
+  const bf16* vp = V + (size_t)bh * N * HD;
+  bf16x8 qf[KS], dof[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = *(const bf16x8*)(Q + ((size_t)bh * N + qrow) * HD + ks * 16 + 8 * h);
+    dof[ks] = *(const bf16x8*)(dO + (((size_t)b * N + qrow) * H + hh) * HD + ks * 16 + 8 * h);
+  }
+  const float lse2 = LSE[(size_t)bh * N + qrow] * 1.4426950408889634f, dl = DELTA[(size_t)bh * N + qrow];
+  f32x16 dqacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dqacc[d][t] = 0.f;
+  const int nt = N / 64;
+  auto stage = [&](int buf, int kt) {
+    stage_tile<HD, 64>(kp + (size_t)kt * 64 * HD, HD, 63, smem + buf * 2 * TB, wave, lane);
+    stage_tile<HD, 64>(vp + (size_t)kt * 64 * HD, HD, 63, smem + buf * 2 * TB + TB, wave, lane);
+  };
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nt; ++kt) {
+    if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
+    const char* Kt = smem + cur * 2 * TB;
+    const char* Vt = Kt + TB;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s = MFMA_BF16(frag_row<HD>(Kt, kb * 32, ks, lane), qf[ks], s);
+        dp = MFMA_BF16(frag_row<HD>(Vt, kb * 32, ks, lane), dof[ks], dp);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) dp[t] = exp2f(s[t] * c - lse2) * (dp[t] - dl);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 dsf = acc_frag(dp, s2);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) dqacc[d] = MFMA_BF16(frag_tr<HD>(Kt, kb * 32 + 16 * s2, d * 32, lane), dsf, dqacc[d]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (!active) return;
+  bf16* dqp = dQ + ((size_t)bh * N + q0 + r) * HD;
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      bf16x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (bf16)(dqacc[d][4 * t4 + j] * scale);
+      *(bf16x4*)(dqp + d * 32 + 8 * t4 + 4 * h) = w;
+    }
+}
+
+// ================================================================================================ f32 path (parity)
+// Tiles are f32 [rows][LD] with LD = HD + 1 (odd stride: conflict-free row reads); operands are single
+// floats: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31] per 32x32x2 step.
+template <int HD, int ROWS>
+__device__ __forceinline__ void stage_tile_f32(const float* __restrict__ g, long ld, int nrows_valid, float* lds) {
+  constexpr int LD = HD + 1;
+  for (int i = threadIdx.x; i < ROWS * HD; i += 256) {
+    const int row = i / HD, d = i % HD;
+    lds[row * LD + d] = row < nrows_valid ? g[(long)row * ld + d] : 0.f;
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                           float* __restrict__ O, float* __restrict__ LSE, int H, int N, float c) {
+  constexpr int LD = HD + 1, DB = (HD + 31) / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Qs = (float*)smem;            // [128][LD]
+  float* Ks = Qs + 128 * LD;           // [64][LD]
+  float* Vs = Ks + 64 * LD;            // [64][LD]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int qblocks = (N + 127) / 128;
+  const int bh = blockIdx.x / qblocks, qb0 = (blockIdx.x % qblocks) * 128, q0 = qb0 + wave * 32;
+  const bool active = q0 < N;
+  stage_tile_f32<HD, 128>(Q + ((size_t)bh * N + qb0) * HD, HD, N - qb0, Qs);
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) oacc[d][t] = 0.f;
+  float ms = -1e30f, l = 0.f;
+  for (int kt = 0; kt < N / 64; ++kt) {
+    __syncthreads();
+    stage_tile_f32<HD, 64>(K + ((size_t)bh * N + kt * 64) * HD, HD, 64, Ks);
+    stage_tile_f32<HD, 64>(V + ((size_t)bh * N + kt * 64) * HD, HD, 64, Vs);
+    __syncthreads();
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) s[kb][t] = 0.f;
+#pragma unroll 8
+      for (int kk = 0; kk < HD; kk += 2) s[kb] = MFMA_F32(Ks[(kb * 32 + r) * LD + kk + h], Qs[(wave * 32 + r) * LD + kk + h], s[kb]);
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) mx = fmaxf(mx, fmaxf(s[0][t], s[1][t]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float ms_new = fmaxf(ms, mx * c), alpha = exp2f(ms - ms_new);
+    ms = ms_new;
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { const float p = exp2f(s[kb][t] * c - ms); s[kb][t] = p; rs += p; }
+    l = l * alpha + rs;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) oacc[d][t] *= alpha;
+      const bool dv = d * 32 + r < HD;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float a = dv ? Vs[(kb * 32 + acc_row(t, h)) * LD + d * 32 + r] : 0.f;
+          oacc[d] = MFMA_F32(a, s[kb][t], oacc[d]);
+        }
+    }
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (!active) return;
+  const float inv = 1.f / l;
+  const int b = bh / H, hh = bh % H;
+  float* op = O + ((size_t)(b * N + q0 + r) * H + hh) * HD;
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int dd = d * 32 + acc_row(t, h);
+      if (dd < HD) op[dd] = oacc[d][t] * inv;
+    }
+  if (h == 0) LSE[(size_t)bh * N + q0 + r] = (ms + log2f(l)) * 0.6931471805599453f;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                                const float* __restrict__ dO, const float* __restrict__ LSE,
+                                                                const float* __restrict__ DELTA, float* __restrict__ dK, float* __restrict__ dV,
+                                                                int H, int N, float scale) {
+  constexpr int LD = HD + 1, DB = (HD + 31) / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Ks = (float*)smem;            // [128][LD]
+  float* Vs = Ks + 128 * LD;           // [128][LD]
+  float* Qs = Vs + 128 * LD;           // [64][LD]
+  float* dOs = Qs + 64 * LD;           // [64][LD]
+  float* lse2 = dOs + 64 * LD;         // [64]
+  float* dl = lse2 + 64;               // [64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const float c = scale * 1.4426950408889634f;
+  const int kblocks = (N + 127) / 128;
+  const int bh = blockIdx.x / kblocks, kb0 = (blockIdx.x % kblocks) * 128, k0 = kb0 + wave * 32;
+  const bool active = k0 < N;
+  const int b = bh / H, hh = bh % H;
+  stage_tile_f32<HD, 128>(K + ((size_t)bh * N + kb0) * HD, HD, N - kb0, Ks);
+  stage_tile_f32<HD, 128>(V + ((size_t)bh * N + kb0) * HD, HD, N - kb0, Vs);
+  f32x16 dkacc[DB], dvacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { dkacc[d][t] = 0.f; dvacc[d][t] = 0.f; }
+  for (int qt = 0; qt < N / 64; ++qt) {
+    __syncthreads();
+    stage_tile_f32<HD, 64>(Q + ((size_t)bh * N + qt * 64) * HD, HD, 64, Qs);
+    stage_tile_f32<HD, 64>(dO + (((size_t)b * N + qt * 64) * H + hh) * HD, (long)H * HD, 64, dOs);
+    if (threadIdx.x < 64) lse2[threadIdx.x] = LSE[(size_t)bh * N + qt * 64 + threadIdx.x] * 1.4426950408889634f;
+    else if (threadIdx.x < 128) dl[threadIdx.x - 64] = DELTA[(size_t)bh * N + qt * 64 + threadIdx.x - 64];
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
+#pragma unroll 8
+      for (int kk = 0; kk < HD; kk += 2) {
+        s = MFMA_F32(Qs[(qb * 32 + r) * LD + kk + h], Ks[(wave * 32 + r) * LD + kk + h], s);
+        dp = MFMA_F32(dOs[(qb * 32 + r) * LD + kk + h], Vs[(wave * 32 + r) * LD + kk + h], dp);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = qb * 32 + acc_row(t, h);
+        const float p = exp2f(s[t] * c - lse2[row]);
+        s[t] = p;
+        dp[t] = p * (dp[t] - dl[row]);
+      }
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const bool dv = d * 32 + r < HD;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int row = qb * 32 + acc_row(t, h);
+          dvacc[d] = MFMA_F32(dv ? dOs[row * LD + d * 32 + r] : 0.f, s[t], dvacc[d]);
+          dkacc[d] = MFMA_F32(dv ? Qs[row * LD + d * 32 + r] : 0.f, dp[t], dkacc[d]);
+        }
+      }
+    }
+  }
+  if (!active) return;
+  float* dkp = dK + ((size_t)bh * N + k0 + r) * HD;
+  float* dvp = dV + ((size_t)bh * N + k0 + r) * HD;
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int dd = d * 32 + acc_row(t, h);
+      if (dd < HD) { dkp[dd] = dkacc[d][t] * scale; dvp[dd] = dvacc[d][t]; }
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                              const float* __restrict__ dO, const float* __restrict__ LSE,
+                                                              const float* __restrict__ DELTA, float* __restrict__ dQ, int H, int N, float scale) {
+  constexpr int LD = HD + 1, DB = (HD + 31) / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Qs = (float*)smem;            // [128][LD]
+  float* dOs = Qs + 128 * LD;          // [128][LD]
+  float* Ks = dOs + 128 * LD;          // [64][LD]
+  float* Vs = Ks + 64 * LD;            // [64][LD]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const float c = scale * 1.4426950408889634f;
+  const int qblocks = (N + 127) / 128;
+  const int bh = blockIdx.x / qblocks, qb0 = (blockIdx.x % qblocks) * 128, q0 = qb0 + wave * 32;
+  const bool active = q0 < N;
+  const int b = bh / H, hh = bh % H;
+  const int qrow = min(q0 + r, N - 1);
+  stage_tile_f32<HD, 128>(Q + ((size_t)bh * N + qb0) * HD, HD, N - qb0, Qs);
+  stage_tile_f32<HD, 128>(dO + (((size_t)b * N + qb0) * H + hh) * HD, (long)H * HD, N - qb0, dOs);
+  const float lse2 = LSE[(size_t)bh * N + qrow] * 1.4426950408889634f, dl = DELTA[(size_t)bh * N + qrow];
+  f32x16 dqacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dqacc[d][t] = 0.f;
+  for (int kt = 0; kt < N / 64; ++kt) {
+    __syncthreads();
+    stage_tile_f32<HD, 64>(K + ((size_t)bh * N + kt * 64) * HD, HD, 64, Ks);
+    stage_tile_f32<HD, 64>(V + ((size_t)bh * N + kt * 64) * HD, HD, 64, Vs);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
+#pragma unroll 8
+      for (int kk = 0; kk < HD; kk += 2) {
+        s = MFMA_F32(Ks[(kb * 32 + r) * LD + kk + h], Qs[(wave * 32 + r) * LD + kk + h], s);
+        dp = MFMA_F32(Vs[(kb * 32 + r) * LD + kk + h], dOs[(wave * 32 + r) * LD + kk + h], dp);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) dp[t] = exp2f(s[t] * c - lse2) * (dp[t] - dl);
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const bool dv = d * 32 + r < HD;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          dqacc[d] = MFMA_F32(dv ? Ks[(kb * 32 + acc_row(t, h)) * LD + d * 32 + r] : 0.f, dp[t], dqacc[d]);
+      }
+    }
+  }
+  if (!active) return;
+  float* dqp = dQ + ((size_t)bh * N + q0 + r) * HD;
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int dd = d * 32 + acc_row(t, h);
+      if (dd < HD) dqp[dd] = dqacc[d][t] * scale;
+    }
+}
+
+// ================================================================================================ C ABI
+#define ATTN_HD_DISPATCH(hd, MACRO) \
+  switch (hd) { case 64: MACRO(64); break; case 128: MACRO(128); break; default: LDMAE_FAIL(LDMAE_ERR_INVALID, "attention(bf16): head_dim %d unsupported (64, 128)", hd); }
+#define ATTN_HD_DISPATCH_F32(hd, MACRO) \
+  switch (hd) { case 16: MACRO(16); break; case 32: MACRO(32); break; case 64: MACRO(64); break; case 72: MACRO(72); break; case 128: MACRO(128); break; \
+    default: LDMAE_FAIL(LDMAE_ERR_INVALID, "attention(f32): head_dim %d unsupported (16, 32, 64, 72, 128)", hd); }
+
+static int attn_check(const char* who, int dtype, int B, int H, int N, int hd) {
+  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "%s: bad dtype %d", who, dtype);
+  LDMAE_REQUIRE(B > 0 && H > 0 && N > 0 && hd > 0, "%s: empty problem", who);
+  LDMAE_REQUIRE(N % 64 == 0, "%s: sequence length N=%d must be a multiple of 64", who, N);
+  return LDMAE_OK;
+}
+
+extern "C" int ldmae_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N, int hd,
+                                   float scale, void* stream) {
+  LDMAE_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
+  if (int e = attn_check("attention_fwd", dtype, B, H, N, hd)) return e;
+  hipStream_t st = as_stream(stream);
+  const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
+  const float c = scale * 1.4426950408889634f;
+  if (dtype == LDMAE_BF16) {
+#define L(HD) hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(grid), dim3(256), 2 * 2 * 64 * HD * 2, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c)
+    ATTN_HD_DISPATCH(hd, L);
+#undef L
+  } else {
+#define L(HD) { const size_t lds = (size_t)(128 + 64 + 64) * (HD + 1) * 4; \
+    hipFuncSetAttribute((const void*)attn_fwd_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(attn_fwd_f32_kernel<HD>, dim3(grid), dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, H, N, c); }
+    ATTN_HD_DISPATCH_F32(hd, L);
+#undef L
+  }
+  LDMAE_CHECK_LAUNCH("attention_fwd");
+  return LDMAE_OK;
+}
+
+extern "C" int ldmae_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                                   void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, void* stream) {
+  LDMAE_REQUIRE(q && k && v && o && do_ && lse && dq && dk && dv && delta, "attention_bwd: null pointer");
+  if (int e = attn_check("attention_bwd", dtype, B, H, N, hd)) return e;
+  LDMAE_REQUIRE(hd % 8 == 0, "attention_bwd: head_dim %d must be a multiple of 8", hd);
+  hipStream_t st = as_stream(stream);
+  const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
+  const long items = (long)B * N * H;
+  const unsigned dgrid = (unsigned)((items * 8 + 255) / 256 < 8192 ? (items * 8 + 255) / 256 : 8192);
+  if (dtype == LDMAE_BF16) {
+    hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(dgrid), dim3(256), 0, st, (const bf16*)o, (const bf16*)do_, delta, B, H, N, hd);
+#define L(HD) { \
+    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), 2 * (2 * 64 * HD * 2 + 512), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale); \
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), 2 * 2 * 64 * HD * 2, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale); }
+    ATTN_HD_DISPATCH(hd, L);
+#undef L
+  } else {
+    hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(dgrid), dim3(256), 0, st, (const float*)o, (const float*)do_, delta, B, H, N, hd);
+#define L(HD) { const size_t l1 = (size_t)(128 + 128 + 64 + 64) * (HD + 1) * 4 + 512; \
+    hipFuncSetAttribute((const void*)attn_bwd_dkdv_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
+    hipFuncSetAttribute((const void*)attn_bwd_dq_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
+    hipLaunchKernelGGL(attn_bwd_dkdv_f32_kernel<HD>, dim3(grid), dim3(256), l1, st, (const float*)q, (const float*)k, (const float*)v, (const float*)do_, lse, delta, (float*)dk, (float*)dv, H, N, scale); \
+    hipLaunchKernelGGL(attn_bwd_dq_f32_kernel<HD>, dim3(grid), dim3(256), l1, st, (const float*)q, (const float*)k, (const float*)v, (const float*)do_, lse, delta, (float*)dq, H, N, scale); }
+    ATTN_HD_DISPATCH_F32(hd, L);
+#undef L
+  }
+  LDMAE_CHECK_LAUNCH("attention_bwd");
+  return LDMAE_OK;
+}

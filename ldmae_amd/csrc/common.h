@@ -1,0 +1,92 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) kernels of libldmae_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ldmae_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---------------------------------------------------------------- error plumbing
+void ldmae_set_error(const char* fmt, ...);
+#define LDMAE_FAIL(code, ...) do { ldmae_set_error(__VA_ARGS__); return (code); } while (0)
+#define LDMAE_REQUIRE(cond, ...) do { if (!(cond)) LDMAE_FAIL(LDMAE_ERR_INVALID, __VA_ARGS__); } while (0)
+#define LDMAE_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) LDMAE_FAIL(LDMAE_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); } while (0)
+
+// ---------------------------------------------------------------- scalar conversions
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32, RNE, NaN-safe
+
+// 8-element vector load/store as floats (16 B for bf16, 2 x 16 B for f32); pointers 16-B aligned
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct Vec8<bf16> {
+  static __device__ __forceinline__ void load(const bf16* p, float (&v)[8]) {
+    bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+  }
+  static __device__ __forceinline__ void store(bf16* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
+    *(bf16x8*)p = a;
+  }
+};
+
+// ---------------------------------------------------------------- wave / block reductions (wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over a power-of-two sub-group of lanes (width <= 64)
+template <int W> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware bijective block remap (8 XCDs, blocks dealt round-robin): consecutive
+// logical tiles land on one XCD so neighbours share that XCD's L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// timing hook (core.hip)
+bool ldmae_prof_is_on();
+long ldmae_prof_begin(hipStream_t st, double flops);
+void ldmae_prof_end(long idx, hipStream_t st);
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }

@@ -1,0 +1,675 @@
+// HBM-bound row / elementwise kernels of the LightningDiT block (gfx950, wave64).
+// One wave per row for the norm kernels (12 elements per lane at D = 768, shuffles for the
+// row reduce); per-sample and per-column gradient sums are two-stage (per-workgroup partial
+// rows, then a fixed-order reduce) so results are bitwise reproducible run to run.
+#include "common.h"
+
+// ------------------------------------------------------------------ small vector helpers
+template <typename T> __device__ __forceinline__ float4 load4(const T* p);
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* p) {
+  bf16x4 v = *(const bf16x4*)p;
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, float4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) { *(float4*)p = v; }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, float4 v) {
+  bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+  *(bf16x4*)p = o;
+}
+__device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+// out[o*out_ld + c] = beta*out + sum_{r<group} P[(o*group + r)*p_ld + c]   (fixed order)
+__global__ void group_reduce_kernel(const float* __restrict__ P, int p_ld, int nout, int cols, int group, float* __restrict__ out,
+                                    int out_ld, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
+  if (c >= cols || o >= nout) return;
+  const float* p = P + (size_t)o * group * p_ld + c;
+  float s = 0.f;
+  for (int r = 0; r < group; ++r) s += p[(size_t)r * p_ld];
+  float* q = out + (size_t)o * out_ld + c;
+  *q = (beta != 0.f ? beta * *q : 0.f) + s;
+}
+static void group_reduce(const float* P, int p_ld, int nout, int cols, int group, float* out, int out_ld, float beta, hipStream_t st) {
+  hipLaunchKernelGGL(group_reduce_kernel, dim3(cdiv(cols, 256), nout), dim3(256), 0, st, P, p_ld, nout, cols, group, out, out_ld, beta);
+}
+
+// rows per workgroup for the per-sample reductions: largest of 64/32/16/8/4 dividing rows_per_batch
+static int pick_rows_per_wg(int rows_per_batch) {
+  for (int r = 64; r >= 4; r >>= 1) if (rows_per_batch % r == 0) return r;
+  return 0;
+}
+
+// ------------------------------------------------------------------ RMSNorm + modulate
+template <int NCH, typename OutT>
+__global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ shift, const float* __restrict__ scale,
+                                                              int mod_ld, OutT* __restrict__ out, float* __restrict__ rstd, int M, int D,
+                                                              int rpb, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nch = D >> 2;
+  float4 wv[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) { const int c = lane + 64 * i; wv[i] = c < nch ? *(const float4*)(w + 4 * c) : f4(0.f); }
+  for (int r = 0; r < 4; ++r) {
+    const int m = (blockIdx.x * 4 + wave) * 4 + r;
+    if (m >= M) return;
+    const int b = m / rpb;
+    float4 xv[NCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = c < nch ? *(const float4*)(x + (size_t)m * D + 4 * c) : f4(0.f);
+      ss += hsum(xv[i] * xv[i]);
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)D + eps);
+    if (lane == 0 && rstd) rstd[m] = rs;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float4 y = (xv[i] * rs) * wv[i];
+        if (scale) y = y * (f4(1.f) + *(const float4*)(scale + (size_t)b * mod_ld + 4 * c));
+        if (shift) y = y + *(const float4*)(shift + (size_t)b * mod_ld + 4 * c);
+        store4<OutT>(out + (size_t)m * D + 4 * c, y);
+      }
+    }
+  }
+}
+
+// partials P[wg][3][D] = {sum dout, sum dout*y, sum dy*n} over the workgroup's rows (one sample)
+template <int NCH, typename T>
+__global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x,
+                                                              const float* __restrict__ w, const float* __restrict__ scale, int mod_ld,
+                                                              const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ P,
+                                                              int M, int D, int rpb, int rows_per_wg) {
+  extern __shared__ float red[];   // [4 waves][3][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nch = D >> 2;
+  const int m_base = blockIdx.x * rows_per_wg, b = m_base / rpb;
+  float4 wv[NCH], sc1[NCH], a_sh[NCH], a_sc[NCH], a_w[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    wv[i] = c < nch ? *(const float4*)(w + 4 * c) : f4(0.f);
+    sc1[i] = (c < nch && scale) ? f4(1.f) + *(const float4*)(scale + (size_t)b * mod_ld + 4 * c) : f4(1.f);
+    a_sh[i] = a_sc[i] = a_w[i] = f4(0.f);
+  }
+  for (int r = wave; r < rows_per_wg; r += 4) {
+    const int m = m_base + r;
+    if (m >= M) break;
+    const float rs = rstd[m];
+    float4 nv[NCH], dn[NCH];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const float4 g = load4<T>(dout + (size_t)m * D + 4 * c);
+        nv[i] = *(const float4*)(x + (size_t)m * D + 4 * c) * rs;
+        const float4 dy = g * sc1[i];
+        a_sh[i] = a_sh[i] + g;
+        a_sc[i] = a_sc[i] + g * (nv[i] * wv[i]);
+        a_w[i] = a_w[i] + dy * nv[i];
+        dn[i] = dy * wv[i];
+        dot += hsum(dn[i] * nv[i]);
+      } else { nv[i] = dn[i] = f4(0.f); }
+    }
+    dot = wave_sum(dot) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float* p = dx + (size_t)m * D + 4 * c;
+        *(float4*)p = *(const float4*)p + (dn[i] - nv[i] * dot) * rs;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      *(float4*)(red + (wave * 3 + 0) * D + 4 * c) = a_sh[i];
+      *(float4*)(red + (wave * 3 + 1) * D + 4 * c) = a_sc[i];
+      *(float4*)(red + (wave * 3 + 2) * D + 4 * c) = a_w[i];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * D; i += 256)
+    P[(size_t)blockIdx.x * 3 * D + i] = (red[i] + red[3 * D + i]) + (red[6 * D + i] + red[9 * D + i]);
+}
+
+// per-sample reduce of the partials: dshift/dscale [B, dmod_ld], dwb [B, D]
+__global__ void mod_partials_reduce_kernel(const float* __restrict__ P, int D, int gps, float* __restrict__ dshift,
+                                           float* __restrict__ dscale, int dmod_ld, float* __restrict__ dwb) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (d >= D) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int g = 0; g < gps; ++g) {
+    const float* p = P + ((size_t)b * gps + g) * 3 * D + d;
+    s0 += p[0]; s1 += p[D]; s2 += p[2 * D];
+  }
+  if (dshift) dshift[(size_t)b * dmod_ld + d] = s0;
+  if (dscale) dscale[(size_t)b * dmod_ld + d] = s1;
+  dwb[(size_t)b * D + d] = s2;
+}
+
+#define DISPATCH_NCH(D, CALL)                                   \
+  switch (((D) / 4 + 63) / 64) {                                \
+    case 1: { constexpr int NCH = 1; CALL; } break;             \
+    case 2: { constexpr int NCH = 2; CALL; } break;             \
+    case 3: { constexpr int NCH = 3; CALL; } break;             \
+    case 4: { constexpr int NCH = 4; CALL; } break;             \
+    case 5: { constexpr int NCH = 5; CALL; } break;             \
+    case 6: { constexpr int NCH = 6; CALL; } break;             \
+    case 7: { constexpr int NCH = 7; CALL; } break;             \
+    case 8: { constexpr int NCH = 8; CALL; } break;             \
+    default: LDMAE_FAIL(LDMAE_ERR_INVALID, "row width D=%d > 2048 unsupported", (D)); }
+
+extern "C" int ldmae_rmsnorm_modulate_fwd(int out_dtype, const float* x, const float* w, const float* shift, const float* scale,
+                                          int mod_ld, void* out, float* rstd, int M, int D, int rows_per_batch, float eps, void* stream) {
+  LDMAE_REQUIRE(x && w && out && M > 0 && D > 0, "rmsnorm_modulate_fwd: null pointer or empty");
+  LDMAE_REQUIRE(D % 4 == 0 && (mod_ld % 4 == 0 || (!shift && !scale)), "rmsnorm_modulate_fwd: D=%d mod_ld=%d must be multiples of 4", D, mod_ld);
+  LDMAE_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0, "rmsnorm_modulate_fwd: M=%d %% rows_per_batch=%d != 0", M, rows_per_batch);
+  hipStream_t st = as_stream(stream);
+  const unsigned grid = cdiv(M, 16);
+  if (out_dtype == LDMAE_BF16) {
+    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, bf16>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (bf16*)out, rstd, M, D, rows_per_batch, eps));
+  } else {
+    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, float>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (float*)out, rstd, M, D, rows_per_batch, eps));
+  }
+  LDMAE_CHECK_LAUNCH("rmsnorm_modulate_fwd");
+  return LDMAE_OK;
+}
+
+extern "C" long ldmae_rmsnorm_modulate_bwd_workspace_bytes(int M, int D, int rows_per_batch) {
+  const int rw = pick_rows_per_wg(rows_per_batch);
+  if (rw == 0) return -1;
+  return ((long)(M / rw) * 3 * D + (long)(M / rows_per_batch) * D) * 4;
+}
+
+extern "C" int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
+                                          const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                                          float beta_w, int M, int D, int rows_per_batch, float* workspace, void* stream) {
+  LDMAE_REQUIRE(dout && x && w && rstd && dx_accum && dw && workspace, "rmsnorm_modulate_bwd: null pointer");
+  LDMAE_REQUIRE(D % 4 == 0 && M > 0 && rows_per_batch > 0 && M % rows_per_batch == 0, "rmsnorm_modulate_bwd: bad shape M=%d D=%d rpb=%d", M, D, rows_per_batch);
+  const int rw = pick_rows_per_wg(rows_per_batch);
+  LDMAE_REQUIRE(rw > 0, "rmsnorm_modulate_bwd: rows_per_batch=%d must be a multiple of 4", rows_per_batch);
+  hipStream_t st = as_stream(stream);
+  const int G = M / rw, B = M / rows_per_batch, gps = rows_per_batch / rw;
+  float* P = workspace;
+  float* dwb = workspace + (size_t)G * 3 * D;
+  const size_t lds = (size_t)4 * 3 * D * sizeof(float);
+  if (dtype == LDMAE_BF16) {
+    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NCH, bf16>), dim3(G), dim3(256), lds, st, (const bf16*)dout, x, w, scale, mod_ld, rstd, dx_accum, P, M, D, rows_per_batch, rw));
+  } else {
+    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NCH, float>), dim3(G), dim3(256), lds, st, (const float*)dout, x, w, scale, mod_ld, rstd, dx_accum, P, M, D, rows_per_batch, rw));
+  }
+  LDMAE_CHECK_LAUNCH("rmsnorm_modulate_bwd");
+  hipLaunchKernelGGL(mod_partials_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, P, D, gps, dshift, dscale, dmod_ld, dwb);
+  group_reduce(dwb, D, 1, D, B, dw, D, beta_w, st);
+  LDMAE_CHECK_LAUNCH("rmsnorm_modulate_bwd reduce");
+  return LDMAE_OK;
+}
+
+// ------------------------------------------------------------------ QK-RMSNorm + RoPE + head-major relayout
+// item = (b, n, h); LPR lanes per item, 4 elements per lane.
+__device__ __forceinline__ float4 rope_apply(float4 t, float4 c, float4 s) {
+  return make_float4(t.x * c.x - t.y * s.x, t.y * c.y + t.x * s.y, t.z * c.z - t.w * s.z, t.w * c.w + t.z * s.w);
+}
+__device__ __forceinline__ float4 rope_apply_bwd(float4 g, float4 c, float4 s) {
+  return make_float4(g.x * c.x + g.y * s.y, g.y * c.y - g.x * s.x, g.z * c.z + g.w * s.w, g.w * c.w - g.z * s.z);
+}
+
+template <int LPR, typename T>
+__global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ wq,
+                                                              const float* __restrict__ wk, const float* __restrict__ cosT,
+                                                              const float* __restrict__ sinT, T* __restrict__ q, T* __restrict__ k,
+                                                              T* __restrict__ v, int B, int N, int H, int hd, float eps) {
+  const int sub = threadIdx.x % LPR, c4 = sub * 4;
+  const bool act = c4 < hd;
+  const long items = (long)B * N * H;
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / LPR, gstride = (long)gridDim.x * 256 / LPR;
+  const float4 wqv = act ? *(const float4*)(wq + c4) : f4(0.f), wkv = act ? *(const float4*)(wk + c4) : f4(0.f);
+  for (long it = gid; it < items; it += gstride) {
+    const int h = it % H, n = (it / H) % N, b = it / ((long)H * N);
+    const T* src = qkv + ((size_t)(b * N + n) * 3 * H + h) * hd + c4;
+    const size_t dst = ((size_t)(b * H + h) * N + n) * hd + c4;
+    float4 qv = f4(0.f), kv = f4(0.f), vv = f4(0.f), cs = f4(0.f), sn = f4(0.f);
+    if (act) {
+      qv = load4<T>(src); kv = load4<T>(src + (size_t)H * hd); vv = load4<T>(src + (size_t)2 * H * hd);
+      cs = *(const float4*)(cosT + (size_t)n * hd + c4); sn = *(const float4*)(sinT + (size_t)n * hd + c4);
+    }
+    const float rq = rsqrtf(group_sum<LPR>(hsum(qv * qv)) / (float)hd + eps);
+    const float rk = rsqrtf(group_sum<LPR>(hsum(kv * kv)) / (float)hd + eps);
+    if (act) {
+      store4<T>(q + dst, rope_apply((qv * rq) * wqv, cs, sn));
+      store4<T>(k + dst, rope_apply((kv * rk) * wkv, cs, sn));
+      store4<T>(v + dst, vv);
+    }
+  }
+}
+
+template <int LPR, typename T>
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restrict__ dq, const T* __restrict__ dk, const T* __restrict__ dv,
+                                                              const T* __restrict__ qkv, const float* __restrict__ wq,
+                                                              const float* __restrict__ wk, const float* __restrict__ cosT,
+                                                              const float* __restrict__ sinT, T* __restrict__ dqkv, float* __restrict__ P,
+                                                              int B, int N, int H, int hd, float eps) {
+  __shared__ float4 red[256][2];
+  const int sub = threadIdx.x % LPR, c4 = sub * 4;
+  const bool act = c4 < hd;
+  const long items = (long)B * N * H;
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / LPR, gstride = (long)gridDim.x * 256 / LPR;
+  const float4 wqv = act ? *(const float4*)(wq + c4) : f4(0.f), wkv = act ? *(const float4*)(wk + c4) : f4(0.f);
+  float4 awq = f4(0.f), awk = f4(0.f);
+  for (long it = gid; it < items; it += gstride) {
+    const int h = it % H, n = (it / H) % N, b = it / ((long)H * N);
+    const size_t so = ((size_t)(b * N + n) * 3 * H + h) * hd + c4;
+    const size_t go = ((size_t)(b * H + h) * N + n) * hd + c4;
+    float4 qv = f4(0.f), kv = f4(0.f), gq = f4(0.f), gk = f4(0.f), gv = f4(0.f), cs = f4(0.f), sn = f4(0.f);
+    if (act) {
+      qv = load4<T>(qkv + so); kv = load4<T>(qkv + so + (size_t)H * hd);
+      gq = load4<T>(dq + go); gk = load4<T>(dk + go); gv = load4<T>(dv + go);
+      cs = *(const float4*)(cosT + (size_t)n * hd + c4); sn = *(const float4*)(sinT + (size_t)n * hd + c4);
+    }
+    const float rq = rsqrtf(group_sum<LPR>(hsum(qv * qv)) / (float)hd + eps);
+    const float rk = rsqrtf(group_sum<LPR>(hsum(kv * kv)) / (float)hd + eps);
+    const float4 nq = qv * rq, nk = kv * rk;
+    const float4 tq = rope_apply_bwd(gq, cs, sn), tk = rope_apply_bwd(gk, cs, sn);   // grad wrt (n * w)
+    awq = awq + tq * nq; awk = awk + tk * nk;
+    const float4 dnq = tq * wqv, dnk = tk * wkv;
+    const float mq = group_sum<LPR>(hsum(dnq * nq)) / (float)hd, mk = group_sum<LPR>(hsum(dnk * nk)) / (float)hd;
+    if (act) {
+      store4<T>(dqkv + so, (dnq - nq * mq) * rq);
+      store4<T>(dqkv + so + (size_t)H * hd, (dnk - nk * mk) * rk);
+      store4<T>(dqkv + so + (size_t)2 * H * hd, gv);
+    }
+  }
+  red[threadIdx.x][0] = awq; red[threadIdx.x][1] = awk;
+  __syncthreads();
+  if (threadIdx.x < LPR && act) {
+    float4 sq = f4(0.f), sk = f4(0.f);
+    for (int t = threadIdx.x; t < 256; t += LPR) { sq = sq + red[t][0]; sk = sk + red[t][1]; }
+    *(float4*)(P + (size_t)blockIdx.x * 2 * hd + c4) = sq;
+    *(float4*)(P + (size_t)blockIdx.x * 2 * hd + hd + c4) = sk;
+  }
+}
+
+static unsigned qk_grid(long items, int lpr) {
+  long wg = (items * lpr + 255) / 256;
+  return (unsigned)(wg < 4096 ? (wg > 0 ? wg : 1) : 4096);
+}
+
+extern "C" int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq, const float* wk, const float* cos, const float* sin,
+                                     void* q, void* k, void* v, int B, int N, int H, int hd, float eps, void* stream) {
+  LDMAE_REQUIRE(qkv && wq && wk && cos && sin && q && k && v, "qknorm_rope_fwd: null pointer");
+  LDMAE_REQUIRE(hd % 8 == 0 && hd <= 128 && B > 0 && N > 0 && H > 0, "qknorm_rope_fwd: head_dim=%d must be a multiple of 8 and <= 128", hd);
+  hipStream_t st = as_stream(stream);
+  const long items = (long)B * N * H;
+#define QK_FWD(LPR, T) hipLaunchKernelGGL((qknorm_rope_fwd_kernel<LPR, T>), dim3(qk_grid(items, LPR)), dim3(256), 0, st, (const T*)qkv, wq, wk, cos, sin, (T*)q, (T*)k, (T*)v, B, N, H, hd, eps)
+  if (hd <= 64) { if (dtype == LDMAE_BF16) QK_FWD(16, bf16); else QK_FWD(16, float); }
+  else { if (dtype == LDMAE_BF16) QK_FWD(32, bf16); else QK_FWD(32, float); }
+#undef QK_FWD
+  LDMAE_CHECK_LAUNCH("qknorm_rope_fwd");
+  return LDMAE_OK;
+}
+
+extern "C" long ldmae_qknorm_rope_bwd_workspace_bytes(int B, int N, int H, int hd) {
+  const int lpr = hd <= 64 ? 16 : 32;
+  return (long)qk_grid((long)B * N * H, lpr) * 2 * hd * 4;
+}
+
+extern "C" int ldmae_qknorm_rope_bwd(int dtype, const void* dq, const void* dk, const void* dv, const void* qkv, const float* wq,
+                                     const float* wk, const float* cos, const float* sin, void* dqkv, float* dwq, float* dwk, float beta_w,
+                                     int B, int N, int H, int hd, float eps, float* workspace, void* stream) {
+  LDMAE_REQUIRE(dq && dk && dv && qkv && wq && wk && cos && sin && dqkv && dwq && dwk && workspace, "qknorm_rope_bwd: null pointer");
+  LDMAE_REQUIRE(hd % 8 == 0 && hd <= 128 && B > 0 && N > 0 && H > 0, "qknorm_rope_bwd: head_dim=%d must be a multiple of 8 and <= 128", hd);
+  hipStream_t st = as_stream(stream);
+  const long items = (long)B * N * H;
+  const int lpr = hd <= 64 ? 16 : 32;
+  const unsigned grid = qk_grid(items, lpr);
+#define QK_BWD(LPR, T) hipLaunchKernelGGL((qknorm_rope_bwd_kernel<LPR, T>), dim3(grid), dim3(256), 0, st, (const T*)dq, (const T*)dk, (const T*)dv, (const T*)qkv, wq, wk, cos, sin, (T*)dqkv, workspace, B, N, H, hd, eps)
+  if (hd <= 64) { if (dtype == LDMAE_BF16) QK_BWD(16, bf16); else QK_BWD(16, float); }
+  else { if (dtype == LDMAE_BF16) QK_BWD(32, bf16); else QK_BWD(32, float); }
+#undef QK_BWD
+  LDMAE_CHECK_LAUNCH("qknorm_rope_bwd");
+  group_reduce(workspace, 2 * hd, 1, hd, grid, dwq, hd, beta_w, st);
+  group_reduce(workspace + hd, 2 * hd, 1, hd, grid, dwk, hd, beta_w, st);
+  LDMAE_CHECK_LAUNCH("qknorm_rope_bwd reduce");
+  return LDMAE_OK;
+}
+
+// ------------------------------------------------------------------ SwiGLU
+template <typename T>
+__global__ void swiglu_fwd_kernel(const T* __restrict__ h12, T* __restrict__ hid, long M, int Hs) {
+  const long n8 = M * Hs / 8, per_row = Hs / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / per_row, c = (i % per_row) * 8;
+    float a[8], b[8], o[8];
+    Vec8<T>::load(h12 + m * 2 * Hs + c, a);
+    Vec8<T>::load(h12 + m * 2 * Hs + Hs + c, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = a[j] / (1.f + __expf(-a[j])) * b[j];
+    Vec8<T>::store(hid + m * Hs + c, o);
+  }
+}
+template <typename T>
+__global__ void swiglu_bwd_kernel(const T* __restrict__ dhid, const T* __restrict__ h12, T* __restrict__ dh12, long M, int Hs) {
+  const long n8 = M * Hs / 8, per_row = Hs / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / per_row, c = (i % per_row) * 8;
+    float a[8], b[8], g[8], da[8], db[8];
+    Vec8<T>::load(h12 + m * 2 * Hs + c, a);
+    Vec8<T>::load(h12 + m * 2 * Hs + Hs + c, b);
+    Vec8<T>::load(dhid + m * Hs + c, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = 1.f / (1.f + __expf(-a[j]));
+      da[j] = g[j] * b[j] * s * (1.f + a[j] * (1.f - s));
+      db[j] = g[j] * a[j] * s;
+    }
+    Vec8<T>::store(dh12 + m * 2 * Hs + c, da);
+    Vec8<T>::store(dh12 + m * 2 * Hs + Hs + c, db);
+  }
+}
+static unsigned ew_grid(long n) { long g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
+extern "C" int ldmae_swiglu_fwd(int dtype, const void* h12, void* hid, int M, int Hs, void* stream) {
+  LDMAE_REQUIRE(h12 && hid && M > 0 && Hs > 0 && Hs % 8 == 0, "swiglu_fwd: bad arguments (Hs=%d must be a multiple of 8)", Hs);
+  const unsigned grid = ew_grid((long)M * Hs / 8);
+  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(swiglu_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)h12, (bf16*)hid, (long)M, Hs);
+  else hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)h12, (float*)hid, (long)M, Hs);
+  LDMAE_CHECK_LAUNCH("swiglu_fwd");
+  return LDMAE_OK;
+}
+extern "C" int ldmae_swiglu_bwd(int dtype, const void* dhid, const void* h12, void* dh12, int M, int Hs, void* stream) {
+  LDMAE_REQUIRE(dhid && h12 && dh12 && M > 0 && Hs > 0 && Hs % 8 == 0, "swiglu_bwd: bad arguments (Hs=%d must be a multiple of 8)", Hs);
+  const unsigned grid = ew_grid((long)M * Hs / 8);
+  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(swiglu_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)dhid, (const bf16*)h12, (bf16*)dh12, (long)M, Hs);
+  else hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)dhid, (const float*)h12, (float*)dh12, (long)M, Hs);
+  LDMAE_CHECK_LAUNCH("swiglu_bwd");
+  return LDMAE_OK;
+}
+
+// ------------------------------------------------------------------ gated residual backward
+template <int NCH, typename T>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dxo, const T* __restrict__ y, const float* __restrict__ gate,
+                                                       int gate_ld, T* __restrict__ dy, float* __restrict__ P, int M, int D, int rpb,
+                                                       int rows_per_wg) {
+  extern __shared__ float red[];   // [4][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nch = D >> 2;
+  const int m_base = blockIdx.x * rows_per_wg, b = m_base / rpb;
+  float4 gv[NCH], acc[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    gv[i] = (c < nch && gate) ? *(const float4*)(gate + (size_t)b * gate_ld + 4 * c) : f4(1.f);
+    acc[i] = f4(0.f);
+  }
+  for (int r = wave; r < rows_per_wg; r += 4) {
+    const int m = m_base + r;
+    if (m >= M) break;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const float4 g = *(const float4*)(dxo + (size_t)m * D + 4 * c);
+        if (P) acc[i] = acc[i] + g * load4<T>(y + (size_t)m * D + 4 * c);
+        store4<T>(dy + (size_t)m * D + 4 * c, g * gv[i]);
+      }
+    }
+  }
+  if (!P) return;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) { const int c = lane + 64 * i; if (c < nch) *(float4*)(red + wave * D + 4 * c) = acc[i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) P[(size_t)blockIdx.x * D + i] = (red[i] + red[D + i]) + (red[2 * D + i] + red[3 * D + i]);
+}
+
+extern "C" long ldmae_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch) {
+  const int rw = pick_rows_per_wg(rows_per_batch);
+  return rw ? (long)(M / rw) * D * 4 : -1;
+}
+
+extern "C" int ldmae_gate_bwd(int dtype, const float* dxout, const void* y, const float* gate, int gate_ld, void* dy, float* dgate,
+                              int dgate_ld, int M, int D, int rows_per_batch, float* workspace, void* stream) {
+  LDMAE_REQUIRE(dxout && dy && M > 0 && D % 4 == 0, "gate_bwd: null pointer or D=%d not a multiple of 4", D);
+  LDMAE_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0, "gate_bwd: M=%d %% rows_per_batch=%d != 0", M, rows_per_batch);
+  LDMAE_REQUIRE(!dgate || (y && gate && workspace), "gate_bwd: dgate requested without y/gate/workspace");
+  const int rw = pick_rows_per_wg(rows_per_batch);
+  LDMAE_REQUIRE(rw > 0, "gate_bwd: rows_per_batch=%d must be a multiple of 4", rows_per_batch);
+  hipStream_t st = as_stream(stream);
+  const int G = M / rw;
+  float* P = dgate ? workspace : nullptr;
+  const size_t lds = (size_t)4 * D * sizeof(float);
+  if (dtype == LDMAE_BF16) {
+    DISPATCH_NCH(D, hipLaunchKernelGGL((gate_bwd_kernel<NCH, bf16>), dim3(G), dim3(256), lds, st, dxout, (const bf16*)y, gate, gate_ld, (bf16*)dy, P, M, D, rows_per_batch, rw));
+  } else {
+    DISPATCH_NCH(D, hipLaunchKernelGGL((gate_bwd_kernel<NCH, float>), dim3(G), dim3(256), lds, st, dxout, (const float*)y, gate, gate_ld, (float*)dy, P, M, D, rows_per_batch, rw));
+  }
+  LDMAE_CHECK_LAUNCH("gate_bwd");
+  if (dgate) {
+    group_reduce(P, D, M / rows_per_batch, D, rows_per_batch / rw, dgate, dgate_ld, 0.f, st);
+    LDMAE_CHECK_LAUNCH("gate_bwd reduce");
+  }
+  return LDMAE_OK;
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+constexpr int CS_ROWS = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ldx, int M, int N, float* __restrict__ P) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= N) return;
+  const int m0 = blockIdx.y * CS_ROWS, m1 = min(M, m0 + CS_ROWS);
+  float4 s = f4(0.f);
+  for (int m = m0; m < m1; ++m) s = s + load4<T>(X + (size_t)m * ldx + c);
+  *(float4*)(P + (size_t)blockIdx.y * N + c) = s;
+}
+extern "C" long ldmae_colsum_workspace_bytes(int M, int N) { return (long)cdiv(M, CS_ROWS) * N * 4; }
+extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, float beta, float* workspace, void* stream) {
+  LDMAE_REQUIRE(X && out && workspace && M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0, "colsum: bad arguments (N=%d ldx=%d multiples of 4)", N, ldx);
+  hipStream_t st = as_stream(stream);
+  const int G = cdiv(M, CS_ROWS);
+  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(cdiv(N, 1024), G), dim3(256), 0, st, (const bf16*)X, ldx, M, N, workspace);
+  else hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(N, 1024), G), dim3(256), 0, st, (const float*)X, ldx, M, N, workspace);
+  group_reduce(workspace, N, 1, N, G, out, N, beta, st);
+  LDMAE_CHECK_LAUNCH("colsum");
+  return LDMAE_OK;
+}
+
+// ------------------------------------------------------------------ casts
+template <typename S, typename Dt>
+__global__ void cast_kernel(const S* __restrict__ s, Dt* __restrict__ d, long n) {
+  const long n8 = n / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    Vec8<S>::load(s + i * 8, v);
+    Vec8<Dt>::store(d + i * 8, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) d[n8 * 8 + threadIdx.x] = from_f<Dt>(to_f<S>(s[n8 * 8 + threadIdx.x]));
+}
+extern "C" int ldmae_cast(int src_dtype, int dst_dtype, const void* src, void* dst, long n, void* stream) {
+  LDMAE_REQUIRE(src && dst && n > 0, "cast: null pointer or empty");
+  LDMAE_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "cast: pointers must be 16-B aligned");
+  hipStream_t st = as_stream(stream);
+  const unsigned grid = ew_grid(n / 8 + 1);
+  if (src_dtype == LDMAE_F32 && dst_dtype == LDMAE_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, st, (const float*)src, (bf16*)dst, n);
+  else if (src_dtype == LDMAE_BF16 && dst_dtype == LDMAE_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, st, (const bf16*)src, (float*)dst, n);
+  else if (src_dtype == LDMAE_F32 && dst_dtype == LDMAE_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+  else LDMAE_FAIL(LDMAE_ERR_INVALID, "cast: unsupported %d -> %d", src_dtype, dst_dtype);
+  LDMAE_CHECK_LAUNCH("cast");
+  return LDMAE_OK;
+}
+
+// f32 [R,C] -> T [R,C] and T [C,R] through a 32x33 LDS tile
+template <typename T>
+__global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, T* __restrict__ dstT, int R, int C) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) { v = src[(size_t)r * C + c]; if (dst) dst[(size_t)r * C + c] = from_f<T>(v); }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  if (!dstT) return;
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (r < R && c < C) dstT[(size_t)c * R + r] = from_f<T>(tile[tx][j]);
+  }
+}
+extern "C" int ldmae_cast_weight(int dst_dtype, const float* src, void* dst, void* dstT, int R, int C, void* stream) {
+  LDMAE_REQUIRE(src && (dst || dstT) && R > 0 && C > 0, "cast_weight: null pointer or empty");
+  dim3 grid(cdiv(C, 32), cdiv(R, 32));
+  if (dst_dtype == LDMAE_BF16) hipLaunchKernelGGL(cast_weight_kernel<bf16>, grid, dim3(256), 0, as_stream(stream), src, (bf16*)dst, (bf16*)dstT, R, C);
+  else hipLaunchKernelGGL(cast_weight_kernel<float>, grid, dim3(256), 0, as_stream(stream), src, (float*)dst, (float*)dstT, R, C);
+  LDMAE_CHECK_LAUNCH("cast_weight");
+  return LDMAE_OK;
+}
+
+// ------------------------------------------------------------------ embedders
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim, float max_period) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, j = i % half;
+  // lightningdit.py:124-129: freqs = exp(-log(max_period) * j / half); args = t * freqs; [cos | sin]
+  const float freq = expf(-logf(max_period) * (float)j / (float)half);
+  const float a = t[b] * freq;
+  out[(size_t)b * dim + j] = cosf(a);
+  out[(size_t)b * dim + half + j] = sinf(a);
+  if ((dim & 1) && j == 0) out[(size_t)b * dim + dim - 1] = 0.f;
+}
+extern "C" int ldmae_timestep_embedding(const float* t, float* out, int B, int dim, float max_period, void* stream) {
+  LDMAE_REQUIRE(t && out && B > 0 && dim >= 2, "timestep_embedding: bad arguments");
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv((long)B * (dim / 2), 256)), dim3(256), 0, as_stream(stream), t, out, B, dim, max_period);
+  LDMAE_CHECK_LAUNCH("timestep_embedding");
+  return LDMAE_OK;
+}
+
+template <typename OutT>
+__global__ void silu_fwd_kernel(const float* __restrict__ x, OutT* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    out[i] = from_f<OutT>(v / (1.f + expf(-v)));
+  }
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i], s = 1.f / (1.f + expf(-v));
+    dx[i] = dy[i] * s * (1.f + v * (1.f - s));
+  }
+}
+extern "C" int ldmae_silu_fwd(int out_dtype, const float* x, void* out, long n, void* stream) {
+  LDMAE_REQUIRE(x && out && n > 0, "silu_fwd: bad arguments");
+  if (out_dtype == LDMAE_BF16) hipLaunchKernelGGL(silu_fwd_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), x, (bf16*)out, n);
+  else hipLaunchKernelGGL(silu_fwd_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), x, (float*)out, n);
+  LDMAE_CHECK_LAUNCH("silu_fwd");
+  return LDMAE_OK;
+}
+extern "C" int ldmae_silu_bwd(const float* dy, const float* x, float* dx, long n, void* stream) {
+  LDMAE_REQUIRE(dy && x && dx && n > 0, "silu_bwd: bad arguments");
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), dy, x, dx, n);
+  LDMAE_CHECK_LAUNCH("silu_bwd");
+  return LDMAE_OK;
+}
+
+__global__ void label_embed_fwd_kernel(const float* __restrict__ table, const long long* __restrict__ y, const unsigned char* __restrict__ drop,
+                                       float* __restrict__ out, int B, int D, int num_classes) {
+  const int b = blockIdx.x;
+  const long long row = (drop && drop[b]) ? num_classes : y[b];
+  for (int d = threadIdx.x; d < D; d += blockDim.x) out[(size_t)b * D + d] = table[(size_t)row * D + d];
+}
+__global__ void label_embed_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ y, const unsigned char* __restrict__ drop,
+                                       float* __restrict__ dtable, int B, int D, int num_classes) {
+  const int row = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float s = 0.f;
+    bool any = false;
+    for (int b = 0; b < B; ++b) {
+      const long long r = (drop && drop[b]) ? num_classes : y[b];
+      if (r == row) { s += dout[(size_t)b * D + d]; any = true; }
+    }
+    if (any) dtable[(size_t)row * D + d] += s;
+  }
+}
+extern "C" int ldmae_label_embed_fwd(const float* table, const long long* y, const unsigned char* drop, float* out, int B, int D,
+                                     int num_classes, void* stream) {
+  LDMAE_REQUIRE(table && y && out && B > 0 && D > 0, "label_embed_fwd: bad arguments");
+  hipLaunchKernelGGL(label_embed_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), table, y, drop, out, B, D, num_classes);
+  LDMAE_CHECK_LAUNCH("label_embed_fwd");
+  return LDMAE_OK;
+}
+extern "C" int ldmae_label_embed_bwd(const float* dout, const long long* y, const unsigned char* drop, float* dtable, int B, int D,
+                                     int num_classes, int rows, void* stream) {
+  LDMAE_REQUIRE(dout && y && dtable && B > 0 && D > 0 && rows > 0, "label_embed_bwd: bad arguments");
+  hipLaunchKernelGGL(label_embed_bwd_kernel, dim3(rows), dim3(256), 0, as_stream(stream), dout, y, drop, dtable, B, D, num_classes);
+  LDMAE_CHECK_LAUNCH("label_embed_bwd");
+  return LDMAE_OK;
+}
+
+// ------------------------------------------------------------------ fused AdamW + EMA over flat f32 buffers
+// Scalars are prepared on the host exactly as torch does (python doubles rounded to f32 at the point of use):
+// torch/optim/adamw.py _single_tensor_adamw (train_accum.py:121) then ema.mul_(d).add_(p, alpha=1-d) (:336-347).
+struct AdamArgs { float decay_mul, w1, beta2, w2, bc2_sqrt, eps, neg_step, ema_d, ema_a, gscale; };
+__global__ void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 float* __restrict__ ema, long n, AdamArgs a) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    float4 pv = *(float4*)(p + i), gv = *(const float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
+    float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    float ea[4] = {0, 0, 0, 0};
+    if (ema) { float4 e = *(float4*)(ema + i); ea[0] = e.x; ea[1] = e.y; ea[2] = e.z; ea[3] = e.w; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = a.gscale == 1.f ? ga[j] : ga[j] * a.gscale;
+      pa[j] = pa[j] * a.decay_mul;                                  // p.mul_(1 - lr*wd)
+      ma[j] = ma[j] + a.w1 * (gj - ma[j]);                          // exp_avg.lerp_(grad, 1-beta1)
+      va[j] = va[j] * a.beta2 + a.w2 * (gj * gj);                   // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+      const float denom = sqrtf(va[j]) / a.bc2_sqrt + a.eps;        // (sqrt(v)/bc2_sqrt).add_(eps)
+      pa[j] = pa[j] + a.neg_step * (ma[j] / denom);                 // p.addcdiv_(m, denom, value=-step_size)
+      ea[j] = ea[j] * a.ema_d + a.ema_a * pa[j];
+    }
+    *(float4*)(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    *(float4*)(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+    *(float4*)(v + i) = make_float4(va[0], va[1], va[2], va[3]);
+    if (ema) *(float4*)(ema + i) = make_float4(ea[0], ea[1], ea[2], ea[3]);
+  }
+}
+extern "C" int ldmae_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, int step, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, double ema_decay, double grad_scale, void* stream) {
+  LDMAE_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw_ema: bad arguments");
+  LDMAE_REQUIRE(n % 4 == 0, "adamw_ema: flat length %ld must be padded to a multiple of 4", n);
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+  AdamArgs a;
+  a.decay_mul = (float)(1.0 - lr * weight_decay);
+  a.w1 = (float)(1.0 - beta1);
+  a.beta2 = (float)beta2;
+  a.w2 = (float)(1.0 - beta2);
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.eps = (float)eps;
+  a.neg_step = (float)(-(lr / bc1));
+  a.ema_d = (float)ema_decay;
+  a.ema_a = (float)(1.0 - ema_decay);
+  a.gscale = (float)grad_scale;
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, as_stream(stream), p, g, m, v, ema, n, a);
+  LDMAE_CHECK_LAUNCH("adamw_ema");
+  return LDMAE_OK;
+}
+__global__ void ema_only_kernel(float* __restrict__ ema, const float* __restrict__ p, long n, float d, float a) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ema[i] = ema[i] * d + a * p[i];
+}
+extern "C" int ldmae_ema_only(float* ema, const float* p, long n, double ema_decay, void* stream) {
+  LDMAE_REQUIRE(ema && p && n > 0, "ema_only: bad arguments");
+  hipLaunchKernelGGL(ema_only_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), ema, p, n, (float)ema_decay, (float)(1.0 - ema_decay));
+  LDMAE_CHECK_LAUNCH("ema_only");
+  return LDMAE_OK;
+}

@@ -1,0 +1,498 @@
+// MFMA GEMMs for the LightningDiT / VMAE linears (gfx950, wave64).
+//
+//   NT : C[M,N] = A[M,K] . B[N,K]^T   (both operands contraction-contiguous: Linear fwd,
+//        and dX = dY . W with the [in,out] transposed weight copy)
+//   TN : C[N,K] = A[M,N]^T . B[M,K]   (weight gradients; contraction over the token rows,
+//        operands fetched K-major and transposed on the LDS read with ds_read_b64_tr_b16)
+//
+// bf16: mfma_f32_16x16x32_bf16, LDS tiles filled by global_load_lds (16 B/lane, swizzle on
+// the SOURCE address, linear LDS image), two buffers, one barrier per K-step.
+// f32 : mfma_f32_16x16x4f32 (exact f32 FMA chain), register staged.  The f32 path exists
+// for the fp32 parity contract (1e-4 vs the CPU oracle); bf16 is the throughput path.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by all NT kernels.  Accumulator tile layout (16x16 MFMA C/D map):
+//   col = lane & 15 ; row = (lane >> 4) * 4 + reg
+// ------------------------------------------------------------------------------------------------
+struct EpiArgs {
+  void* C;              // output [M,N] (dtype out_dt)      -- EPI_BIAS: result; EPI_GATE_RES: y (may be null)
+  void* C2;             // EPI_BIAS_GELU: pre-activation copy (may be null)
+  const float* bias;    // [N] or null
+  // EPI_GATE_RES: xout[m,n] = xin[m,n] + gate[m / rows_per_batch, n] * (acc + bias)
+  const float* xin;     // [M,N] f32
+  float* xout;          // [M,N] f32 (may alias xin)
+  const float* gate;    // [B, gate_ld] f32 (a column slice of the adaLN output)
+  int gate_ld;
+  int rows_per_batch;
+  int ldc;              // row stride of C in elements
+  float beta;           // EPI_BIAS with f32 out: C = acc + bias + beta*C   (beta 0 or 1: gradient accumulation)
+};
+
+template <int EPI, typename OutT>
+__device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M, int N, float acc) {
+  if (m >= M || n >= N) return;
+  float y = acc + (e.bias ? e.bias[n] : 0.f);
+  if (EPI == LDMAE_EPI_BIAS) {
+    OutT* C = (OutT*)e.C;
+    if (e.beta != 0.f) y += e.beta * to_f<OutT>(C[(size_t)m * e.ldc + n]);
+    C[(size_t)m * e.ldc + n] = from_f<OutT>(y);
+  } else if (EPI == LDMAE_EPI_BIAS_POS) {
+    y += e.xin[(size_t)(m % e.rows_per_batch) * N + n];
+    ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
+  } else if (EPI == LDMAE_EPI_BIAS_GELU) {
+    if (e.C2) ((OutT*)e.C2)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
+    ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(0.5f * y * (1.f + erff(y * 0.70710678118654752f)));
+  } else {  // LDMAE_EPI_GATE_RES
+    if (e.C) ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
+    const size_t o = (size_t)m * N + n;
+    const float gt = e.gate ? e.gate[(size_t)(m / e.rows_per_batch) * e.gate_ld + n] : 1.f;
+    e.xout[o] = e.xin[o] + gt * y;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 NT GEMM: 128x128 tile, 256 threads (2x2 waves, 64x64 per wave = 4x4 MFMA tiles), BK = 64.
+// LDS image per operand tile: [128 rows][64 k] bf16, 128-B rows, 16-B chunk c of row r stored at
+// chunk position c ^ ((r >> 1) & 7)  -> ds_read_b128 fragment reads are bank-conflict free.
+// ------------------------------------------------------------------------------------------------
+constexpr int NT_BM = 128, NT_BN = 128, NT_BK = 64;
+constexpr int NT_TILE_BYTES = NT_BM * NT_BK * 2;   // 16 KiB per operand tile
+
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                           int M, int N, int K, int lda, int ldb, EpiArgs e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buf][A 16K | B 16K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned tiles_n = (N + NT_BN - 1) / NT_BN;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (lid / tiles_n) * NT_BM, n0 = (lid % tiles_n) * NT_BN;
+
+  // staging: each wave issues 4 A pieces + 4 B pieces per K-step; piece = 8 rows x 128 B
+  const bf16* asrc[4];
+  const bf16* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    asrc[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;
+    bsrc[i] = B + (size_t)min(n0 + r, N - 1) * ldb + c * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * 2 * NT_TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + kt * NT_BK), LDS_PTR(void, base + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(bsrc[i] + kt * NT_BK), LDS_PTR(void, base + NT_TILE_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (bytes) inside a tile for kk = 0; kk = 1 flips chunk bit 2 (c += 4)
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wm * 64 + i * 16 + (lane & 15), rb = wn * 64 + i * 16 + (lane & 15);
+    aoff[i] = ra * 128 + (((lane >> 4) ^ ((ra >> 1) & 7)) << 4);
+    boff[i] = rb * 128 + (((lane >> 4) ^ ((rb >> 1) & 7)) << 4);
+  }
+
+  const int nk = K / NT_BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* ta = smem + cur * 2 * NT_TILE_BYTES;
+    const char* tb = ta + NT_TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *(const bf16x8*)(ta + (aoff[i] ^ (kk << 6)));
+        bfr[i] = *(const bf16x8*)(tb + (boff[i] ^ (kk << 6)));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        epi_store<EPI, OutT>(e, m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r, n0 + wn * 64 + j * 16 + (lane & 15), M, N, acc[i][j][r]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 NT GEMM: 64x64 tile, 256 threads (2x2 waves, 32x32 per wave), BK = 16, register staged.
+// ------------------------------------------------------------------------------------------------
+constexpr int F_BM = 64, F_BN = 64, F_BK = 16, F_LD = 20;   // LDS row stride (floats), 80 B keeps 16-B alignment
+
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          int M, int N, int K, int lda, int ldb, EpiArgs e) {
+  __shared__ __attribute__((aligned(16))) float As[2][F_BM * F_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][F_BN * F_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned tiles_n = (N + F_BN - 1) / F_BN;
+  const int m0 = (blockIdx.x / tiles_n) * F_BM, n0 = (blockIdx.x % tiles_n) * F_BN;
+  const int lr = tid >> 2, lc = (tid & 3) * 4;
+  const float* ap = A + (size_t)min(m0 + lr, M - 1) * lda + lc;
+  const float* bp = B + (size_t)min(n0 + lr, N - 1) * ldb + lc;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = K / F_BK;
+  float4 ra = *(const float4*)ap, rb = *(const float4*)bp;
+  *(float4*)&As[0][lr * F_LD + lc] = ra;
+  *(float4*)&Bs[0][lr * F_LD + lc] = rb;
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) { ra = *(const float4*)(ap + (kt + 1) * F_BK); rb = *(const float4*)(bp + (kt + 1) * F_BK); }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = As[cur][(wm * 32 + i * 16 + (lane & 15)) * F_LD + kk * 4 + (lane >> 4)];
+        bfr[i] = Bs[cur][(wn * 32 + i * 16 + (lane & 15)) * F_LD + kk * 4 + (lane >> 4)];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      *(float4*)&As[cur ^ 1][lr * F_LD + lc] = ra;
+      *(float4*)&Bs[cur ^ 1][lr * F_LD + lc] = rb;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        epi_store<EPI, OutT>(e, m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, n0 + wn * 32 + j * 16 + (lane & 15), M, N, acc[i][j][r]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 TN GEMM (weight gradient): P[s][N,K] = sum over rows m in split s of A[m,n] * B[m,k].
+// 128(n) x 128(k) output tile, 256 threads (2x2 waves, 64x64 per wave), 64 rows of M per step.
+// LDS image per operand: [64 m][128 cols] bf16, 256-B rows, 16-B chunk ch of row r stored at
+// ch ^ sw(r), sw(r) = ((r&3)<<2) | ((r>>2)&3)  -> conflict-free ds_read_b64_tr_b16 (guide T10 (b)).
+// ------------------------------------------------------------------------------------------------
+constexpr int TN_BN = 128, TN_BK = 128, TN_BM = 64;
+constexpr int TN_TILE_BYTES = TN_BM * 128 * 2;   // 16 KiB
+
+__device__ __forceinline__ int tn_sw(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
+                                                           float* __restrict__ P, int M, int N, int K, int lda, int ldb,
+                                                           int rows_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles_k = (K + TN_BK - 1) / TN_BK, tiles_n = (N + TN_BN - 1) / TN_BN;
+  const int tile = blockIdx.x % (tiles_k * tiles_n), split = blockIdx.x / (tiles_k * tiles_n);
+  const int n0 = (tile / tiles_k) * TN_BN, k0 = (tile % tiles_k) * TN_BK;
+  const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+  // staging: per operand 16 pieces of 4 rows x 256 B; wave issues 4 + 4.  Column chunks beyond N / K
+  // are clamped to the last valid chunk (their products land in output columns that are never stored).
+  int arow[4], acol[4], bcol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 4 + (lane >> 4);
+    const int ch = (lane & 15) ^ tn_sw(r);
+    arow[i] = r;
+    acol[i] = min(n0 + ch * 8, N - 8);
+    bcol[i] = min(k0 + ch * 8, K - 8);
+  }
+  auto stage = [&](int buf, int mt) {
+    char* base = smem + buf * 2 * TN_TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t m = (size_t)min(mt + arow[i], M - 1);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(A + m * lda + acol[i]), LDS_PTR(void, base + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(B + m * ldb + bcol[i]), LDS_PTR(void, base + TN_TILE_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transposed fragment read: lane (g = l>>4, i = l&15, q = i>>2, p = i&3) supplies row 8g+q (+4), cols c0+4p..+3
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  auto frag = [&](const char* tile_base, int mstep, int c0) -> bf16x8 {
+    const int r0 = mstep * 32 + 8 * g + q, r1 = r0 + 4;
+    const int ch = (c0 >> 3) + (p >> 1);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile_base + r0 * 256 + ((ch ^ tn_sw(r0)) << 4) + ((p & 1) << 3)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile_base + r1 * 256 + ((ch ^ tn_sw(r1)) << 4) + ((p & 1) << 3)));
+    union { bf16x8 v; s16x4 h[2]; } u;
+    u.h[0] = lo; u.h[1] = hi;
+    return u.v;
+  };
+
+  const int nsteps = (mend - mbeg + TN_BM - 1) / TN_BM;
+  // rows past mend inside the last step must contribute zero: handled by requiring rows_per_split % 64 == 0
+  // and M % 64 == 0 on the host side (checked there).
+  if (nsteps > 0) {
+    stage(0, mbeg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  int cur = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) stage(cur ^ 1, mbeg + (st + 1) * TN_BM);
+    const char* ta = smem + cur * 2 * TN_TILE_BYTES;
+    const char* tb = ta + TN_TILE_BYTES;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = frag(ta, ms, wn * 64 + i * 16);
+        bfr[i] = frag(tb, ms, wk * 64 + i * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  float* out = P + (size_t)split * N * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4 + r, k = k0 + wk * 64 + j * 16 + (lane & 15);
+        if (n < N && k < K) out[(size_t)n * K + k] = acc[i][j][r];
+      }
+}
+
+// f32 TN: 64(n) x 64(k) tile, 16 rows of M per step; A[l&15][k=l>>4] fragments are single floats
+constexpr int FT_BN = 64, FT_BK = 64, FT_BM = 16, FT_LD = 68;
+
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          float* __restrict__ P, int M, int N, int K, int lda, int ldb,
+                                                          int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) float As[2][FT_BM * FT_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][FT_BM * FT_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles_k = (K + FT_BK - 1) / FT_BK, tiles_n = (N + FT_BN - 1) / FT_BN;
+  const int tile = blockIdx.x % (tiles_k * tiles_n), split = blockIdx.x / (tiles_k * tiles_n);
+  const int n0 = (tile / tiles_k) * FT_BN, k0 = (tile % tiles_k) * FT_BK;
+  const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+  const int lr = tid >> 4, lc = (tid & 15) * 4;      // 16 rows x 16 float4
+  const int an = min(n0 + lc, N - 4), bk = min(k0 + lc, K - 4);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto ld = [&](int mt, float4& ra, float4& rb) {
+    const int m = mt + lr;
+    if (m < mend) { ra = *(const float4*)(A + (size_t)m * lda + an); rb = *(const float4*)(B + (size_t)m * ldb + bk); }
+    else { ra = make_float4(0, 0, 0, 0); rb = ra; }
+  };
+  const int nsteps = (mend - mbeg + FT_BM - 1) / FT_BM;
+  float4 ra, rb;
+  if (nsteps > 0) {
+    ld(mbeg, ra, rb);
+    *(float4*)&As[0][lr * FT_LD + lc] = ra;
+    *(float4*)&Bs[0][lr * FT_LD + lc] = rb;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    if (st + 1 < nsteps) ld(mbeg + (st + 1) * FT_BM, ra, rb);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = As[cur][(kk * 4 + (lane >> 4)) * FT_LD + wn * 32 + i * 16 + (lane & 15)];
+        bfr[i] = Bs[cur][(kk * 4 + (lane >> 4)) * FT_LD + wk * 32 + i * 16 + (lane & 15)];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) {
+      *(float4*)&As[cur ^ 1][lr * FT_LD + lc] = ra;
+      *(float4*)&Bs[cur ^ 1][lr * FT_LD + lc] = rb;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  float* out = P + (size_t)split * N * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 32 + i * 16 + (lane >> 4) * 4 + r, k = k0 + wk * 32 + j * 16 + (lane & 15);
+        if (n < N && k < K) out[(size_t)n * K + k] = acc[i][j][r];
+      }
+}
+
+// sum the split-K partial slabs in fixed order (deterministic): out = beta*out + sum_s P[s]
+__global__ void splitk_reduce_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int splits, float beta) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    float4 s = *(const float4*)(P + i);
+    for (int k = 1; k < splits; ++k) {
+      float4 t = *(const float4*)(P + (size_t)k * n + i);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    if (beta != 0.f) {
+      float4 o = *(const float4*)(out + i);
+      s.x += beta * o.x; s.y += beta * o.y; s.z += beta * o.z; s.w += beta * o.w;
+    }
+    *(float4*)(out + i) = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+template <typename OutT>
+static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
+                     hipStream_t st) {
+  const long pi = ldmae_prof_is_on() ? ldmae_prof_begin(st, 2.0 * M * N * K) : -1;
+#define NT_LAUNCH(E)                                                                                                             \
+  if (dtype == LDMAE_BF16)                                                                                                       \
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<E, OutT>), dim3(cdiv(M, NT_BM) * cdiv(N, NT_BN)), dim3(256), 4 * NT_TILE_BYTES, st, \
+                       (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                                                    \
+  else                                                                                                                           \
+    hipLaunchKernelGGL((gemm_nt_f32_kernel<E, OutT>), dim3(cdiv(M, F_BM) * cdiv(N, F_BN)), dim3(256), 0, st, (const float*)A,    \
+                       (const float*)B, M, N, K, lda, ldb, e)
+  switch (epi) {
+    case LDMAE_EPI_BIAS: NT_LAUNCH(LDMAE_EPI_BIAS); break;
+    case LDMAE_EPI_GATE_RES: NT_LAUNCH(LDMAE_EPI_GATE_RES); break;
+    case LDMAE_EPI_BIAS_POS: NT_LAUNCH(LDMAE_EPI_BIAS_POS); break;
+    default: NT_LAUNCH(LDMAE_EPI_BIAS_GELU); break;
+  }
+#undef NT_LAUNCH
+  if (pi >= 0) ldmae_prof_end(pi, st);
+  LDMAE_CHECK_LAUNCH("gemm_nt");
+  return LDMAE_OK;
+}
+
+extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                             int M, int N, int K, const float* bias, float beta, const float* xin, float* xout,
+                             const float* gate, int gate_ld, int rows_per_batch, void* stream) {
+  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "gemm_nt: bad dtype %d", dtype);
+  LDMAE_REQUIRE(out_dtype == LDMAE_F32 || out_dtype == LDMAE_BF16, "gemm_nt: bad out_dtype %d", out_dtype);
+  LDMAE_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+  LDMAE_REQUIRE(A && B, "gemm_nt: null operand");
+  const int kq = dtype == LDMAE_BF16 ? NT_BK : F_BK, al = dtype == LDMAE_BF16 ? 8 : 4;
+  LDMAE_REQUIRE(K % kq == 0, "gemm_nt: K=%d must be a multiple of %d", K, kq);
+  LDMAE_REQUIRE(lda % al == 0 && ldb % al == 0 && lda >= K && ldb >= K, "gemm_nt: lda=%d ldb=%d need 16-B aligned rows >= K", lda, ldb);
+  LDMAE_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_nt: operands must be 16-B aligned");
+  EpiArgs e{};
+  e.C = C; e.bias = bias; e.ldc = ldc; e.beta = beta;
+  if (epi == LDMAE_EPI_BIAS) {
+    LDMAE_REQUIRE(C && ldc >= N, "gemm_nt: C null or ldc < N");
+    LDMAE_REQUIRE(beta == 0.f || beta == 1.f, "gemm_nt: beta must be 0 or 1");
+  } else if (epi == LDMAE_EPI_GATE_RES) {
+    LDMAE_REQUIRE(xin && xout && rows_per_batch > 0 && (!gate || gate_ld >= N), "gemm_nt: gated-residual epilogue needs xin/xout (gate optional)");
+    LDMAE_REQUIRE(M % rows_per_batch == 0, "gemm_nt: M=%d not a multiple of rows_per_batch=%d", M, rows_per_batch);
+    e.xin = xin; e.xout = xout; e.gate = gate; e.gate_ld = gate_ld; e.rows_per_batch = rows_per_batch;
+  } else if (epi == LDMAE_EPI_BIAS_POS) {
+    LDMAE_REQUIRE(C && ldc >= N && xin && rows_per_batch > 0, "gemm_nt: pos epilogue needs C and pos table in xin");
+    e.xin = xin; e.rows_per_batch = rows_per_batch;
+  } else if (epi == LDMAE_EPI_BIAS_GELU) {
+    LDMAE_REQUIRE(C && ldc >= N, "gemm_nt: gelu epilogue needs C");
+    e.C2 = xout;   /* pre-activation copy, same dtype/ld as C */
+  } else {
+    LDMAE_FAIL(LDMAE_ERR_INVALID, "gemm_nt: unknown epilogue %d", epi);
+  }
+  return out_dtype == LDMAE_BF16 ? launch_nt<bf16>(dtype, epi, A, B, M, N, K, lda, ldb, e, as_stream(stream))
+                                 : launch_nt<float>(dtype, epi, A, B, M, N, K, lda, ldb, e, as_stream(stream));
+}
+
+extern "C" long ldmae_gemm_tn_workspace_bytes(int dtype, int M, int N, int K) {
+  int splits = ldmae_gemm_tn_splits(dtype, M, N, K);
+  return splits <= 1 ? 0 : (long)splits * N * K * 4;
+}
+
+extern "C" int ldmae_gemm_tn_splits(int dtype, int M, int N, int K) {
+  const int bn = dtype == LDMAE_BF16 ? TN_BN : FT_BN, bk = dtype == LDMAE_BF16 ? TN_BK : FT_BK;
+  const long tiles = (long)cdiv(N, bn) * cdiv(K, bk);
+  const int step = 64;
+  long want = (2048 + tiles - 1) / tiles;                     // aim for >= ~2048 workgroups (8 per CU)
+  long maxs = M / (step * 8) > 0 ? M / (step * 8) : 1;        // at least 8 steps of 64 rows per split
+  long s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return (int)s;
+}
+
+extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int M, int N, int K, float beta,
+                             float* workspace, long workspace_bytes, void* stream) {
+  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "gemm_tn: bad dtype %d", dtype);
+  LDMAE_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "gemm_tn: empty problem or null pointer");
+  LDMAE_REQUIRE(beta == 0.f || beta == 1.f, "gemm_tn: beta must be 0 or 1");
+  const int al = dtype == LDMAE_BF16 ? 8 : 4;
+  LDMAE_REQUIRE(N % al == 0 && K % al == 0 && lda % al == 0 && ldb % al == 0, "gemm_tn: N=%d K=%d lda=%d ldb=%d must be multiples of %d", N, K, lda, ldb, al);
+  LDMAE_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0, "gemm_tn: pointers must be 16-B aligned");
+  if (dtype == LDMAE_BF16) LDMAE_REQUIRE(M % TN_BM == 0, "gemm_tn(bf16): M=%d must be a multiple of %d", M, TN_BM);
+  int splits = ldmae_gemm_tn_splits(dtype, M, N, K);
+  int rows = (int)(((long)M + splits - 1) / splits);
+  rows = (rows + 63) / 64 * 64;
+  splits = (M + rows - 1) / rows;
+  hipStream_t st = as_stream(stream);
+  float* P = C;
+  const bool direct = (splits == 1 && beta == 0.f);
+  if (!direct) {
+    LDMAE_REQUIRE(workspace && workspace_bytes >= (long)splits * N * K * 4, "gemm_tn: workspace too small (%ld < %ld)", workspace_bytes, (long)splits * N * K * 4);
+    P = workspace;
+  }
+  if (dtype == LDMAE_BF16) {
+    const unsigned grid = cdiv(N, TN_BN) * cdiv(K, TN_BK) * splits;
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 4 * TN_TILE_BYTES, st, (const bf16*)A, (const bf16*)B, P, M, N, K, lda, ldb, rows);
+  } else {
+    const unsigned grid = cdiv(N, FT_BN) * cdiv(K, FT_BK) * splits;
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(grid), dim3(256), 0, st, (const float*)A, (const float*)B, P, M, N, K, lda, ldb, rows);
+  }
+  LDMAE_CHECK_LAUNCH("gemm_tn");
+  if (!direct) {
+    const long n = (long)N * K;
+    const unsigned grid = (unsigned)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, P, C, n, splits, beta);
+    LDMAE_CHECK_LAUNCH("splitk_reduce");
+  }
+  return LDMAE_OK;
+}

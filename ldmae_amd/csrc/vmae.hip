@@ -1,0 +1,197 @@
+// VMAE masked-token encoder kernels (tokenizer/models_mae.py): random_masking as an in-LDS bitonic
+// sort of (noise, index) keys -- integer / index work, bit-exact against the oracle --, token
+// gather / scatter, affine LayerNorm and exact-erf GELU.
+#include "common.h"
+
+// order-preserving map f32 -> u32 (handles negatives; noise is in [0,1) but be general)
+__device__ __forceinline__ unsigned f32_ordered(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// One workgroup per sample.  Sorts 64-bit keys (ordered(noise) << 32 | index) ascending: equal noise
+// values are ordered by index == a stable argsort (models_mae.py:484).  L padded to a power of two LP.
+__global__ __launch_bounds__(256) void random_masking_kernel(const float* __restrict__ noise, long long* __restrict__ ids_restore,
+                                                             float* __restrict__ mask, long long* __restrict__ ids_keep, int L, int LP, int keep) {
+  extern __shared__ unsigned long long keys[];
+  const int n = blockIdx.x;
+  for (int i = threadIdx.x; i < LP; i += 256)
+    keys[i] = i < L ? (((unsigned long long)f32_ordered(noise[(size_t)n * L + i]) << 32) | (unsigned)i) : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= LP; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < LP; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], b = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  // keys[j] low word = ids_shuffle[j];  ids_restore[ids_shuffle[j]] = j;  mask = (rank >= keep)
+  for (int j = threadIdx.x; j < L; j += 256) {
+    const unsigned idx = (unsigned)keys[j];
+    ids_restore[(size_t)n * L + idx] = j;
+    mask[(size_t)n * L + idx] = j < keep ? 0.f : 1.f;
+    if (j < keep) ids_keep[(size_t)n * keep + j] = idx;
+  }
+}
+
+extern "C" int ldmae_random_masking(const float* noise, long long* ids_restore, float* mask, long long* ids_keep, int N, int L, int keep,
+                                    void* stream) {
+  LDMAE_REQUIRE(noise && ids_restore && mask && ids_keep, "random_masking: null pointer");
+  LDMAE_REQUIRE(N > 0 && L > 0 && L <= 4096 && keep >= 0 && keep <= L, "random_masking: bad shape N=%d L=%d keep=%d (L <= 4096)", N, L, keep);
+  int LP = 1;
+  while (LP < L) LP <<= 1;
+  hipLaunchKernelGGL(random_masking_kernel, dim3(N), dim3(256), (size_t)LP * 8, as_stream(stream), noise, ids_restore, mask, ids_keep, L, LP, keep);
+  LDMAE_CHECK_LAUNCH("random_masking");
+  return LDMAE_OK;
+}
+
+// out[n, j, :] = x[n, ids[n, j], :]
+__global__ void gather_rows_kernel(const float* __restrict__ x, const long long* __restrict__ ids, float* __restrict__ out, int L, int keep, int D) {
+  const int n = blockIdx.y, j = blockIdx.x;
+  const long long src = ids[(size_t)n * keep + j];
+  const float4* s = (const float4*)(x + ((size_t)n * L + src) * D);
+  float4* d = (float4*)(out + ((size_t)n * keep + j) * D);
+  for (int i = threadIdx.x; i < D / 4; i += blockDim.x) d[i] = s[i];
+}
+// dx[n, ids[n, j], :] = dout[n, j, :]   (dx must be zeroed by the caller; ids unique per sample)
+__global__ void scatter_rows_kernel(const float* __restrict__ dout, const long long* __restrict__ ids, float* __restrict__ dx, int L, int keep, int D) {
+  const int n = blockIdx.y, j = blockIdx.x;
+  const long long dst = ids[(size_t)n * keep + j];
+  const float4* s = (const float4*)(dout + ((size_t)n * keep + j) * D);
+  float4* d = (float4*)(dx + ((size_t)n * L + dst) * D);
+  for (int i = threadIdx.x; i < D / 4; i += blockDim.x) d[i] = s[i];
+}
+extern "C" int ldmae_gather_rows(const float* x, const long long* ids, float* out, int N, int L, int keep, int D, void* stream) {
+  LDMAE_REQUIRE(x && ids && out && N > 0 && L > 0 && keep > 0 && D % 4 == 0, "gather_rows: bad arguments (D=%d multiple of 4)", D);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(keep, N), dim3(64), 0, as_stream(stream), x, ids, out, L, keep, D);
+  LDMAE_CHECK_LAUNCH("gather_rows");
+  return LDMAE_OK;
+}
+extern "C" int ldmae_scatter_rows(const float* dout, const long long* ids, float* dx, int N, int L, int keep, int D, void* stream) {
+  LDMAE_REQUIRE(dout && ids && dx && N > 0 && L > 0 && keep > 0 && D % 4 == 0, "scatter_rows: bad arguments (D=%d multiple of 4)", D);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(keep, N), dim3(64), 0, as_stream(stream), dout, ids, dx, L, keep, D);
+  LDMAE_CHECK_LAUNCH("scatter_rows");
+  return LDMAE_OK;
+}
+
+// ------------------------------------------------------------------ LayerNorm (affine), one wave per row
+template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = from_f<T>(v); }
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                            OutT* __restrict__ out, float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= M) return;
+  const float* xr = x + (size_t)m * D;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += xr[d];
+  const float mu = wave_sum(s) / (float)D;
+  float v = 0.f;
+  for (int d = lane; d < D; d += 64) { const float c = xr[d] - mu; v += c * c; }
+  const float rs = rsqrtf(wave_sum(v) / (float)D + eps);
+  if (lane == 0) { if (mean) mean[m] = mu; if (rstd) rstd[m] = rs; }
+  for (int d = lane; d < D; d += 64) st1<OutT>(out + (size_t)m * D + d, (xr[d] - mu) * rs * w[d] + b[d]);
+}
+
+// dx_accum += dLN/dx ; partial dw/db per workgroup (4 rows) -> reduced in fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+                                                            float* __restrict__ P, int M, int D, int rows_per_wg) {
+  extern __shared__ float red[];   // [4][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 8 * D; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float* rw = red + wave * 2 * D;
+  for (int r = wave; r < rows_per_wg; r += 4) {
+    const int m = blockIdx.x * rows_per_wg + r;
+    if (m >= M) break;
+    const float mu = mean[m], rs = rstd[m];
+    const float* xr = x + (size_t)m * D;
+    const T* gr = dout + (size_t)m * D;
+    float s1 = 0.f, s2 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float g = to_f<T>(gr[d]), xh = (xr[d] - mu) * rs, gy = g * w[d];
+      s1 += gy; s2 += gy * xh;
+      rw[d] += g * xh; rw[D + d] += g;
+    }
+    s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+    for (int d = lane; d < D; d += 64) {
+      const float g = to_f<T>(gr[d]), xh = (xr[d] - mu) * rs;
+      dx[(size_t)m * D + d] += rs * (g * w[d] - s1 - xh * s2);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * D; i += 256)
+    P[(size_t)blockIdx.x * 2 * D + i] = (red[i] + red[2 * D + i]) + (red[4 * D + i] + red[6 * D + i]);
+}
+
+__global__ void ln_reduce_kernel(const float* __restrict__ P, int G, int D, float* __restrict__ dw, float* __restrict__ db, float beta) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float a = 0.f, c = 0.f;
+  for (int g = 0; g < G; ++g) { a += P[(size_t)g * 2 * D + d]; c += P[(size_t)g * 2 * D + D + d]; }
+  dw[d] = (beta != 0.f ? beta * dw[d] : 0.f) + a;
+  db[d] = (beta != 0.f ? beta * db[d] : 0.f) + c;
+}
+
+constexpr int LN_ROWS = 64;
+extern "C" int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w, const float* b, void* out, float* mean, float* rstd,
+                                   int M, int D, float eps, void* stream) {
+  LDMAE_REQUIRE(x && w && b && out && M > 0 && D > 0, "layernorm_fwd: bad arguments");
+  if (out_dtype == LDMAE_BF16) hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), x, w, b, (bf16*)out, mean, rstd, M, D, eps);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), x, w, b, (float*)out, mean, rstd, M, D, eps);
+  LDMAE_CHECK_LAUNCH("layernorm_fwd");
+  return LDMAE_OK;
+}
+extern "C" long ldmae_layernorm_bwd_workspace_bytes(int M, int D) { return (long)cdiv(M, LN_ROWS) * 2 * D * 4; }
+extern "C" int ldmae_layernorm_bwd(int dtype, const void* dout, const float* x, const float* w, const float* mean, const float* rstd,
+                                   float* dx_accum, float* dw, float* db, float beta_w, int M, int D, float* workspace, void* stream) {
+  LDMAE_REQUIRE(dout && x && w && mean && rstd && dx_accum && dw && db && workspace && M > 0 && D > 0, "layernorm_bwd: bad arguments");
+  hipStream_t st = as_stream(stream);
+  const int G = cdiv(M, LN_ROWS);
+  const size_t lds = (size_t)8 * D * 4;
+  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(G), dim3(256), lds, st, (const bf16*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(G), dim3(256), lds, st, (const float*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS);
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, workspace, G, D, dw, db, beta_w);
+  LDMAE_CHECK_LAUNCH("layernorm_bwd");
+  return LDMAE_OK;
+}
+
+// ------------------------------------------------------------------ exact GELU
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = to_f<T>(x[i]);
+    out[i] = from_f<T>(0.5f * v * (1.f + erff(v * 0.70710678118654752f)));
+  }
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x, T* __restrict__ dx, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = to_f<T>(x[i]);
+    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f)), pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+    dx[i] = from_f<T>(to_f<T>(dout[i]) * (cdf + v * pdf));
+  }
+}
+static unsigned gelu_grid(long n) { long g = (n + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+extern "C" int ldmae_gelu_fwd(int dtype, const void* x, void* out, long n, void* stream) {
+  LDMAE_REQUIRE(x && out && n > 0, "gelu_fwd: bad arguments");
+  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const bf16*)x, (bf16*)out, n);
+  else hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)out, n);
+  LDMAE_CHECK_LAUNCH("gelu_fwd");
+  return LDMAE_OK;
+}
+extern "C" int ldmae_gelu_bwd(int dtype, const void* dout, const void* x, void* dx, long n, void* stream) {
+  LDMAE_REQUIRE(dout && x && dx && n > 0, "gelu_bwd: bad arguments");
+  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const bf16*)dout, (const bf16*)x, (bf16*)dx, n);
+  else hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const float*)dout, (const float*)x, (float*)dx, n);
+  LDMAE_CHECK_LAUNCH("gelu_bwd");
+  return LDMAE_OK;
+}

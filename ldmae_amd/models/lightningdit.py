@@ -1,0 +1,492 @@
+"""LightningDiT on hand-written gfx950 kernels -- drop-in for the reference module
+``models/lightningdit.py`` (same class names, constructor kwargs, attributes,
+state-dict keys; reference lines cited per class, relative to
+/root/reference/LDMAE/models/lightningdit.py).
+
+Each ``LightningDiTBlock`` runs as ONE ``torch.autograd.Function`` whose forward
+and backward are explicit sequences of C-ABI kernel launches
+(``ldmae_amd.ops``); there is no PyTorch math on the path and no CPU fallback.
+
+Precision: inside ``torch.autocast(dtype=bfloat16)`` (what ``accelerate
+--mixed_precision bf16`` sets up, run_train.sh:9,20) the activations are bf16
+with f32 accumulation; otherwise everything is f32 (the parity path).  The
+residual stream, modulation vectors, norm statistics and all parameter
+gradients are f32 in both modes -- the explicit form of the reference's
+autocast behaviour (SURVEY.md §7 "mixed-precision semantics").
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.utils.checkpoint import checkpoint
+
+from .. import ops
+from ..tables import sincos_2d
+from .pos_embed import VisionRotaryEmbeddingFast
+from .rmsnorm import RMSNorm
+from .swiglu_ffn import SwiGLUFFN
+
+
+def _act_dtype(override=None):
+    if override is not None:
+        return override
+    if torch.is_autocast_enabled():
+        d = torch.get_autocast_gpu_dtype()
+        if d != torch.bfloat16:
+            raise RuntimeError(f"ldmae_amd: autocast dtype {d} unsupported (bfloat16 or no autocast)")
+        return torch.bfloat16
+    return torch.float32
+
+
+def _wcopies(w, dtype):
+    """(W in act dtype, W^T [in,out] in act dtype) from the f32 master weight."""
+    if dtype == torch.float32:
+        return w, ops.cast_weight(w, dtype, transposed=True, straight=False)[1]
+    return ops.cast_weight(w, dtype, transposed=True, straight=True)
+
+
+# ----------------------------------------------------------------------------- autograd Functions
+class _SiluFn(torch.autograd.Function):
+    """SiLU of the conditioning vector (first op of every adaLN_modulation, :233-236, :262-265)."""
+
+    @staticmethod
+    def forward(ctx, c):
+        c = c.contiguous()
+        ctx.save_for_backward(c)
+        return ops.silu_fwd(c)
+
+    @staticmethod
+    def backward(ctx, g):
+        (c,) = ctx.saved_tensors
+        return ops.silu_bwd(g.contiguous(), c)
+
+
+class _LinearF32Fn(torch.autograd.Function):
+    """y = act(x) @ W^T + b in f32 for the tiny conditioning GEMMs (t-embedder MLP, :100-104)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        return ops.gemm_nt(x, w, b, out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        dx = ops.gemm_nt(g, ops.cast_weight(w, torch.float32, True, False)[1]) if ctx.needs_input_grad[0] else None
+        return dx, ops.gemm_tn(g, x), ops.colsum(g)
+
+
+class _TimestepFreqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, dim):
+        return ops.timestep_embedding(t, dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None
+
+
+class _LabelEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, y, drop, num_classes):
+        ctx.save_for_backward(y, drop)
+        ctx.num_classes, ctx.rows = num_classes, table.shape[0]
+        return ops.label_embed_fwd(table, y, drop, num_classes)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, drop = ctx.saved_tensors
+        return ops.label_embed_bwd(g, y, drop, ctx.num_classes, ctx.rows), None, None, None
+
+
+class _PatchEmbedFn(torch.autograd.Function):
+    """tokens @ W^T + b + pos_embed (timm PatchEmbed as used at :309,402 then + pos_embed)."""
+
+    @staticmethod
+    def forward(ctx, tok, w2d, b, pos, T):
+        tok = tok.contiguous()
+        ctx.save_for_backward(tok, w2d)
+        return ops.gemm_nt_pos(tok, w2d, b, pos, T)
+
+    @staticmethod
+    def backward(ctx, g):
+        tok, w2d = ctx.saved_tensors
+        g = g.contiguous()
+        dtok = ops.gemm_nt(g, ops.cast_weight(w2d, torch.float32, True, False)[1]) if ctx.needs_input_grad[0] else None
+        return dtok, ops.gemm_tn(g, tok), ops.colsum(g), None, None
+
+
+class _DiTBlockFn(torch.autograd.Function):
+    """LightningDiTBlock.forward (:239-250) with RMSNorm, QK-norm, RoPE, SwiGLU, shift."""
+
+    @staticmethod
+    def forward(ctx, x, sc, cos, sin, H, eps, dtype,
+                n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12, b12, w3, b3, adaw, adab):
+        B, N, D = x.shape
+        M, hd = B * N, D // H
+        x2 = x.contiguous().view(M, D)
+        sc = sc.contiguous()
+        mod = ops.gemm_nt(sc, adaw, adab, out_dtype=torch.float32)                       # [B, 6D] f32
+        sh1, s1, g1, sh2, s2, g2 = (mod[:, i * D:(i + 1) * D] for i in range(6))          # :246 chunk order
+        Wqkv, WqkvT = _wcopies(qkvw, dtype)
+        Wp, WpT = _wcopies(pw, dtype)
+        W12, W12T = _wcopies(w12, dtype)
+        W3, W3T = _wcopies(w3, dtype)
+        # attention branch (:248)
+        xm1, rstd1 = ops.rmsnorm_modulate_fwd(x2, n1w, sh1, s1, N, dtype, eps)
+        qkv = ops.gemm_nt(xm1, Wqkv, qkvb)                                               # [M, 3D] == [B,N,3,H,hd]
+        q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
+        o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)                                  # [B,N,D]
+        xmid, y1 = ops.gemm_nt_gate_res(o.view(M, D), Wp, pb, x2, g1, N)
+        # MLP branch (:249)
+        xm2, rstd2 = ops.rmsnorm_modulate_fwd(xmid, n2w, sh2, s2, N, dtype, eps)
+        h12 = ops.gemm_nt(xm2, W12, b12)
+        hid = ops.swiglu_fwd(h12)
+        xout, y2 = ops.gemm_nt_gate_res(hid, W3, b3, xmid, g2, N)
+        ctx.save_for_backward(x2, sc, cos, sin, mod, rstd1, xm1, qkv, q, k, v, o, lse, y1, xmid, rstd2, xm2, h12, hid, y2,
+                              n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T)
+        ctx.dims = (B, N, D, H, hd, eps, dtype)
+        return xout.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x2, sc, cos, sin, mod, rstd1, xm1, qkv, q, k, v, o, lse, y1, xmid, rstd2, xm2, h12, hid, y2,
+         n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T) = ctx.saved_tensors
+        B, N, D, H, hd, eps, dtype = ctx.dims
+        M = B * N
+        # f32 residual-stream gradient, accumulated IN PLACE when the engine hands us a whole contiguous
+        # buffer (block outputs feed only the next block / final layer, whose backward allocates it).
+        dx = gout.view(M, D) if (gout.is_contiguous() and gout._base is None) else gout.contiguous().view(M, D).clone()
+        dmod = torch.empty_like(mod)
+        s1, g1, s2, g2 = mod[:, D:2 * D], mod[:, 2 * D:3 * D], mod[:, 4 * D:5 * D], mod[:, 5 * D:6 * D]
+        # ---- MLP branch
+        dy2 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype)
+        dW3, db3 = ops.gemm_tn(dy2, hid), ops.colsum(dy2)
+        dh12 = ops.swiglu_bwd(ops.gemm_nt(dy2, W3T), h12)
+        dW12, db12 = ops.gemm_tn(dh12, xm2), ops.colsum(dh12)
+        dxm2 = ops.gemm_nt(dh12, W12T)
+        dn2 = ops.rmsnorm_modulate_bwd(dxm2, xmid, n2w, s2, rstd2, dx, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D], N)
+        # ---- attention branch
+        dy1 = ops.gate_bwd(dx, y1, g1, dmod[:, 2 * D:3 * D], N, dtype)
+        dWp, dbp = ops.gemm_tn(dy1, o.view(M, D)), ops.colsum(dy1)
+        do = ops.gemm_nt(dy1, WpT)
+        dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
+        dqkv, dqn, dkn = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
+        dqkv = dqkv.view(M, 3 * D)
+        dWqkv, dbqkv = ops.gemm_tn(dqkv, xm1), ops.colsum(dqkv)
+        dxm1 = ops.gemm_nt(dqkv, WqkvT)
+        dn1 = ops.rmsnorm_modulate_bwd(dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N)
+        # ---- adaLN (f32 in both modes)
+        dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
+        dsc = ops.gemm_nt(dmod, ops.cast_weight(adaw, torch.float32, True, False)[1])
+        return (dx.view(B, N, D), dsc, None, None, None, None, None,
+                dn1, dWqkv, dbqkv, dqn, dkn, dWp, dbp, dn2, dW12, db12, dW3, db3, dadaw, dadab)
+
+
+class _FinalLayerFn(torch.autograd.Function):
+    """FinalLayer.forward (:267-272): adaLN(2) -> RMSNorm -> modulate -> Linear."""
+
+    @staticmethod
+    def forward(ctx, x, sc, eps, dtype, nw, lw, lb, adaw, adab):
+        B, N, D = x.shape
+        M = B * N
+        x2 = x.contiguous().view(M, D)
+        sc = sc.contiguous()
+        mod = ops.gemm_nt(sc, adaw, adab, out_dtype=torch.float32)
+        xf, rstd = ops.rmsnorm_modulate_fwd(x2, nw, mod[:, :D], mod[:, D:], N, dtype, eps)
+        out = ops.gemm_nt(xf, ops.cast(lw, dtype), lb, out_dtype=torch.float32)
+        ctx.save_for_backward(x2, sc, mod, rstd, xf, nw, lw, adaw)
+        ctx.dims = (B, N, D, dtype)
+        return out.view(B, N, -1)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x2, sc, mod, rstd, xf, nw, lw, adaw = ctx.saved_tensors
+        B, N, D, dtype = ctx.dims
+        M = B * N
+        g = gout.contiguous().view(M, -1)
+        ga = ops.cast(g, dtype)
+        dlw, dlb = ops.gemm_tn(ga, xf), ops.colsum(g)
+        dxf = ops.gemm_nt(g, ops.cast_weight(lw, torch.float32, True, False)[1], out_dtype=dtype)     # K = p*p*C (16): f32 MFMA
+        dx = torch.zeros(M, D, dtype=torch.float32, device=g.device)
+        dmod = torch.empty_like(mod)
+        dnw = ops.rmsnorm_modulate_bwd(dxf, x2, nw, mod[:, D:], rstd, dx, dmod[:, :D], dmod[:, D:], N)
+        dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
+        dsc = ops.gemm_nt(dmod, ops.cast_weight(adaw, torch.float32, True, False)[1])
+        return dx.view(B, N, D), dsc, None, None, dnw, dlw, dlb, dadaw, dadab
+
+
+# ----------------------------------------------------------------------------- modules (reference names / keys)
+class PatchEmbed(nn.Module):
+    """Stand-in for timm.models.vision_transformer.PatchEmbed with the attributes the reference
+    touches (.proj.weight/bias, .patch_size, .num_patches, .grid_size; :309-312,354-356,382)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, bias=True):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+        self.norm = nn.Identity()
+
+    def tokens(self, x):
+        """[B,C,H,W] -> [B*T, C*p*p] in the conv weight's (c, i, j) order (layout plumbing only)."""
+        B, C, Hh, Ww = x.shape
+        p = self.patch_size[0]
+        if p == 1:
+            return x.float().reshape(B, C, Hh * Ww).transpose(1, 2).reshape(B * Hh * Ww, C)
+        x = x.float().reshape(B, C, Hh // p, p, Ww // p, p).permute(0, 2, 4, 1, 3, 5)
+        return x.reshape(B * (Hh // p) * (Ww // p), C * p * p)
+
+    def forward(self, x, pos=None):
+        B = x.shape[0]
+        w2d = self.proj.weight.view(self.proj.weight.shape[0], -1)
+        if pos is None:
+            pos = torch.zeros(self.num_patches, w2d.shape[0], device=x.device)
+        return _PatchEmbedFn.apply(self.tokens(x), w2d, self.proj.bias, pos, self.num_patches).view(B, self.num_patches, -1)
+
+
+class TimestepEmbedder(nn.Module):
+    """:94-137."""
+
+    def __init__(self, hidden_size: int, frequency_embedding_size: int = 256) -> None:
+        super().__init__()
+        self.frequency_embedding_size = frequency_embedding_size
+        self.mlp = nn.Sequential(nn.Linear(frequency_embedding_size, hidden_size, bias=True), nn.SiLU(),
+                                 nn.Linear(hidden_size, hidden_size, bias=True))
+
+    @staticmethod
+    def timestep_embedding(t, dim, max_period=10000):
+        return _TimestepFreqFn.apply(t, dim)
+
+    def forward(self, t):
+        f = self.timestep_embedding(t, self.frequency_embedding_size)
+        h = _LinearF32Fn.apply(f, self.mlp[0].weight, self.mlp[0].bias)
+        return _LinearF32Fn.apply(_SiluFn.apply(h), self.mlp[2].weight, self.mlp[2].bias)
+
+
+class LabelEmbedder(nn.Module):
+    """:140-169.  The label-drop draw (`torch.rand(B) < p`, :157) happens here on the device RNG,
+    exactly where the reference draws it."""
+
+    def __init__(self, num_classes, hidden_size, dropout_prob):
+        super().__init__()
+        use_cfg_embedding = dropout_prob > 0
+        self.embedding_table = nn.Embedding(num_classes + use_cfg_embedding, hidden_size)
+        self.num_classes = num_classes
+        self.dropout_prob = dropout_prob
+
+    def token_drop_ids(self, labels, force_drop_ids=None):
+        if force_drop_ids is None:
+            return torch.rand(labels.shape[0], device=labels.device) < self.dropout_prob
+        return force_drop_ids == 1
+
+    def forward(self, labels, train, force_drop_ids=None):
+        drop = None
+        if (train and self.dropout_prob > 0) or (force_drop_ids is not None):
+            drop = self.token_drop_ids(labels, force_drop_ids).to(torch.uint8).contiguous()
+        return _LabelEmbedFn.apply(self.embedding_table.weight, labels.to(torch.int64).contiguous(), drop, self.num_classes)
+
+
+class Attention(nn.Module):
+    """Parameter container of :32-64 (qkv, q_norm, k_norm, proj); computed inside _DiTBlockFn."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_norm=False, use_rmsnorm=False, **_):
+        super().__init__()
+        assert dim % num_heads == 0, 'dim should be divisible by num_heads'
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.q_norm = RMSNorm(self.head_dim) if qk_norm else nn.Identity()
+        self.k_norm = RMSNorm(self.head_dim) if qk_norm else nn.Identity()
+        self.proj = nn.Linear(dim, dim)
+
+
+class LightningDiTBlock(nn.Module):
+    """:171-250.  Accelerated configuration = the shipped one (use_qknorm, use_swiglu, use_rmsnorm,
+    wo_shift=False; configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml:26-33)."""
+
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, use_qknorm=False, use_swiglu=False, use_rmsnorm=False,
+                 wo_shift=False, **block_kwargs):
+        super().__init__()
+        if not (use_qknorm and use_swiglu and use_rmsnorm) or wo_shift:
+            raise NotImplementedError(
+                "ldmae_amd accelerates the shipped LightningDiT configuration only: use_qknorm=use_swiglu=use_rmsnorm=True, "
+                "wo_shift=False (reference configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml:26-33)")
+        self.norm1 = RMSNorm(hidden_size)
+        self.norm2 = RMSNorm(hidden_size)
+        self.attn = Attention(hidden_size, num_heads=num_heads, qkv_bias=True, qk_norm=True, use_rmsnorm=True)
+        self.mlp = SwiGLUFFN(hidden_size, int(2 / 3 * int(hidden_size * mlp_ratio)))
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
+        self.wo_shift = wo_shift
+        self.precision = None
+
+    def forward(self, x, c, feat_rope=None, _silu_c=None):
+        if feat_rope is None:
+            raise NotImplementedError("ldmae_amd LightningDiTBlock needs feat_rope (use_rope=True)")
+        sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
+        a, m = self.attn, self.mlp
+        return _DiTBlockFn.apply(
+            x.float(), sc, feat_rope.freqs_cos, feat_rope.freqs_sin, a.num_heads, self.norm1.eps, _act_dtype(self.precision),
+            self.norm1.weight, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.k_norm.weight, a.proj.weight, a.proj.bias,
+            self.norm2.weight, m.w12.weight, m.w12.bias, m.w3.weight, m.w3.bias,
+            self.adaLN_modulation[1].weight, self.adaLN_modulation[1].bias)
+
+
+class FinalLayer(nn.Module):
+    """:252-272."""
+
+    def __init__(self, hidden_size, patch_size, out_channels, use_rmsnorm=False):
+        super().__init__()
+        if not use_rmsnorm:
+            raise NotImplementedError("ldmae_amd FinalLayer: use_rmsnorm=True only")
+        self.norm_final = RMSNorm(hidden_size)
+        self.linear = nn.Linear(hidden_size, patch_size * patch_size * out_channels, bias=True)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
+        self.precision = None
+
+    def forward(self, x, c, _silu_c=None):
+        sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
+        return _FinalLayerFn.apply(x.float(), sc, self.norm_final.eps, _act_dtype(self.precision), self.norm_final.weight,
+                                   self.linear.weight, self.linear.bias, self.adaLN_modulation[1].weight,
+                                   self.adaLN_modulation[1].bias)
+
+
+class LightningDiT(nn.Module):
+    """:275-442 -- same constructor signature, attributes and state-dict keys."""
+
+    def __init__(self, input_size=32, patch_size=2, in_channels=32, hidden_size=1152, depth=28, num_heads=16, mlp_ratio=4.0,
+                 class_dropout_prob=0.1, num_classes=1000, learn_sigma=False, use_qknorm=False, use_swiglu=False,
+                 use_rope=False, use_rmsnorm=False, wo_shift=False, use_checkpoint=False):
+        super().__init__()
+        if not use_rope:
+            raise NotImplementedError("ldmae_amd LightningDiT: use_rope=True only (the shipped configuration)")
+        self.learn_sigma = learn_sigma
+        self.in_channels = in_channels
+        self.out_channels = in_channels if not learn_sigma else in_channels * 2
+        self.patch_size = patch_size
+        self.num_heads = num_heads
+        self.use_rope = use_rope
+        self.use_rmsnorm = use_rmsnorm
+        self.depth = depth
+        self.hidden_size = hidden_size
+        self.use_checkpoint = use_checkpoint
+        self.x_embedder = PatchEmbed(input_size, patch_size, in_channels, hidden_size, bias=True)
+        self.t_embedder = TimestepEmbedder(hidden_size)
+        self.y_embedder = LabelEmbedder(num_classes, hidden_size, class_dropout_prob)
+        num_patches = self.x_embedder.num_patches
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches, hidden_size), requires_grad=False)
+        self.feat_rope = VisionRotaryEmbeddingFast(dim=hidden_size // num_heads // 2, pt_seq_len=input_size // patch_size)
+        self.blocks = nn.ModuleList([
+            LightningDiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio, use_qknorm=use_qknorm, use_swiglu=use_swiglu,
+                              use_rmsnorm=use_rmsnorm, wo_shift=wo_shift) for _ in range(depth)])
+        self.final_layer = FinalLayer(hidden_size, patch_size, self.out_channels, use_rmsnorm=use_rmsnorm)
+        self.precision = None          # None: follow torch.autocast; or torch.float32 / torch.bfloat16
+        self.initialize_weights()
+
+    def set_precision(self, dtype):
+        self.precision = dtype
+        for b in self.blocks:
+            b.precision = dtype
+        self.final_layer.precision = dtype
+        return self
+
+    def initialize_weights(self):
+        """:340-374."""
+        def _basic_init(module):
+            if isinstance(module, nn.Linear):
+                torch.nn.init.xavier_uniform_(module.weight)
+                if module.bias is not None:
+                    nn.init.constant_(module.bias, 0)
+        self.apply(_basic_init)
+        pos_embed = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], int(self.x_embedder.num_patches ** 0.5))
+        self.pos_embed.data.copy_(torch.from_numpy(pos_embed).float().unsqueeze(0))
+        w = self.x_embedder.proj.weight.data
+        nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        nn.init.constant_(self.x_embedder.proj.bias, 0)
+        nn.init.normal_(self.y_embedder.embedding_table.weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        for block in self.blocks:
+            nn.init.constant_(block.adaLN_modulation[-1].weight, 0)
+            nn.init.constant_(block.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.adaLN_modulation[-1].weight, 0)
+        nn.init.constant_(self.final_layer.adaLN_modulation[-1].bias, 0)
+        nn.init.constant_(self.final_layer.linear.weight, 0)
+        nn.init.constant_(self.final_layer.linear.bias, 0)
+
+    def unpatchify(self, x):
+        """:376-389 (pure re-layout of the [N, T, p*p*C] kernel output)."""
+        c = self.out_channels
+        p = self.x_embedder.patch_size[0]
+        h = w = int(x.shape[1] ** 0.5)
+        assert h * w == x.shape[1]
+        x = x.reshape(shape=(x.shape[0], h, w, p, p, c))
+        x = torch.einsum('nhwpqc->nchpwq', x)
+        return x.reshape(shape=(x.shape[0], c, h * p, h * p))
+
+    def forward(self, x, t=None, y=None):
+        """:391-418."""
+        x = self.x_embedder(x, self.pos_embed[0])
+        t = self.t_embedder(t)
+        y = self.y_embedder(y, self.training)
+        c = t + y
+        sc = _SiluFn.apply(c)
+        for block in self.blocks:
+            if self.use_checkpoint:
+                x = checkpoint(block, x, c, self.feat_rope, sc, use_reentrant=True)
+            else:
+                x = block(x, c, self.feat_rope, sc)
+        x = self.final_layer(x, c, sc)
+        x = self.unpatchify(x)
+        if self.learn_sigma:
+            x, _ = x.chunk(2, dim=1)
+        return x
+
+    def forward_with_cfg(self, x, t, y, cfg_scale, cfg_interval=None, cfg_interval_start=None):
+        """:420-442 (CFG on the first three channels only; interval gate on t[0])."""
+        half = x[: len(x) // 2]
+        combined = torch.cat([half, half], dim=0)
+        model_out = self.forward(combined, t, y)
+        eps, rest = model_out[:, :3], model_out[:, 3:]
+        cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)
+        half_eps = uncond_eps + cfg_scale * (cond_eps - uncond_eps)
+        if cfg_interval is True:
+            timestep = t[0]
+            if timestep < cfg_interval_start:
+                half_eps = cond_eps
+        eps = torch.cat([half_eps, half_eps], dim=0)
+        return torch.cat([eps, rest], dim=1)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False, extra_tokens=0):
+    """Reference name kept (:444-458); the table itself is built in ldmae_amd/tables.py."""
+    return sincos_2d(embed_dim, grid_size, np.float64, cls_token=bool(cls_token and extra_tokens > 0))
+
+
+# ----------------------------------------------------------------------------- registry (:498-531)
+def LightningDiT_XL_1(**kw): return LightningDiT(depth=28, hidden_size=1152, patch_size=1, num_heads=16, **kw)
+def LightningDiT_XL_2(**kw): return LightningDiT(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kw)
+def LightningDiT_L_2(**kw): return LightningDiT(depth=24, hidden_size=1024, patch_size=2, num_heads=16, **kw)
+def LightningDiT_B_1(**kw): return LightningDiT(depth=12, hidden_size=768, patch_size=1, num_heads=12, **kw)
+def LightningDiT_B_2(**kw): return LightningDiT(depth=12, hidden_size=768, patch_size=2, num_heads=12, **kw)
+def LightningDiT_1p0B_1(**kw): return LightningDiT(depth=24, hidden_size=1536, patch_size=1, num_heads=24, **kw)
+def LightningDiT_1p0B_2(**kw): return LightningDiT(depth=24, hidden_size=1536, patch_size=2, num_heads=24, **kw)
+def LightningDiT_1p6B_1(**kw): return LightningDiT(depth=28, hidden_size=1792, patch_size=1, num_heads=28, **kw)
+def LightningDiT_1p6B_2(**kw): return LightningDiT(depth=28, hidden_size=1792, patch_size=2, num_heads=28, **kw)
+
+
+LightningDiT_models = {
+    'LightningDiT-B/1': LightningDiT_B_1, 'LightningDiT-B/2': LightningDiT_B_2,
+    'LightningDiT-L/2': LightningDiT_L_2,
+    'LightningDiT-XL/1': LightningDiT_XL_1, 'LightningDiT-XL/2': LightningDiT_XL_2,
+    'LightningDiT-1p0B/1': LightningDiT_1p0B_1, 'LightningDiT-1p0B/2': LightningDiT_1p0B_2,
+    'LightningDiT-1p6B/1': LightningDiT_1p6B_1, 'LightningDiT-1p6B/2': LightningDiT_1p6B_2,
+}

@@ -1,0 +1,288 @@
+"""Thin tensor-level wrappers over the C ABI (one python function per entry point).
+
+Every function allocates its outputs with torch (caching allocator) and enqueues
+the kernel on torch's current stream.  No function here computes anything in
+PyTorch: if the library is missing, or a tensor is on the CPU, they raise.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from ._lib import BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_GATE_RES, F32, call, dt, ptr, stream
+
+_ws = {}
+
+
+def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
+    """Grow-only f32 scratch buffer per (device, slot)."""
+    key = (device, slot)
+    n = max(1, (int(nbytes) + 3) // 4)
+    t = _ws.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(int(n * 1.25) + 1024, dtype=torch.float32, device=device)
+        _ws[key] = t
+    return t
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- GEMMs
+def gemm_nt(a, b, bias=None, out_dtype=None, out=None, beta=0.0):
+    """out[M,N] = a[M,K] @ b[N,K]^T + bias (+ beta*out)."""
+    M, K = a.shape
+    N = b.shape[0]
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    call("ldmae_gemm_nt", dt(a.dtype), dt(out.dtype), EPI_BIAS, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
+         M, N, K, ptr(bias), float(beta), None, None, None, 0, 0, stream())
+    return out
+
+
+def gemm_nt_gate_res(a, b, bias, xin, gate, rows_per_batch, save_y=True, xout=None):
+    """y = a @ b^T + bias ; xout = xin + gate[batch] * y.  Returns (xout, y or None).  gate: [B, D] view (any row stride)."""
+    M, K = a.shape
+    N = b.shape[0]
+    y = torch.empty(M, N, dtype=a.dtype, device=a.device) if save_y else None
+    if xout is None:
+        xout = torch.empty_like(xin)
+    call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_GATE_RES, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(y), N,
+         M, N, K, ptr(bias), 0.0, ptr(xin), ptr(xout), ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch, stream())
+    return xout, y
+
+
+def gemm_nt_pos(a, b, bias, pos, rows_per_batch):
+    """out = a @ b^T + bias + pos[row % rows_per_batch]   (f32 out; patch embed)."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    call("ldmae_gemm_nt", dt(a.dtype), F32, EPI_BIAS_POS, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
+         M, N, K, ptr(bias), 0.0, ptr(pos), None, None, 0, rows_per_batch, stream())
+    return out
+
+
+def gemm_nt_gelu(a, b, bias, save_pre=True):
+    """(gelu(a @ b^T + bias), pre-activation or None)."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    pre = torch.empty_like(out) if save_pre else None
+    call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_BIAS_GELU, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
+         M, N, K, ptr(bias), 0.0, None, ptr(pre), None, 0, 0, stream())
+    return out, pre
+
+
+def gemm_tn(a, b, out=None, beta=0.0):
+    """out[N,K] (f32) = beta*out + a[M,N]^T @ b[M,K]   (weight gradient)."""
+    M, N = a.shape
+    K = b.shape[1]
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.float32, device=a.device)
+        beta = 0.0
+    d = dt(a.dtype)
+    nb = L.load().ldmae_gemm_tn_workspace_bytes(d, M, N, K)
+    nb = max(nb, N * K * 4) if beta != 0.0 else nb
+    ws = workspace(nb, a.device, "tn")
+    call("ldmae_gemm_tn", d, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), M, N, K, float(beta), ptr(ws), ws.numel() * 4, stream())
+    return out
+
+
+def colsum(x, out=None, beta=0.0):
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+        beta = 0.0
+    ws = workspace(L.load().ldmae_colsum_workspace_bytes(M, N), x.device, "colsum")
+    call("ldmae_colsum", dt(x.dtype), ptr(x), x.stride(0), M, N, ptr(out), float(beta), ptr(ws), stream())
+    return out
+
+
+def cast_weight(w, dtype, transposed=True, straight=True):
+    """f32 master weight [R,C] -> (copy in `dtype` or None, [C,R] transposed copy or None)."""
+    R, C = w.shape
+    dst = torch.empty(R, C, dtype=dtype, device=w.device) if straight else None
+    dstT = torch.empty(C, R, dtype=dtype, device=w.device) if transposed else None
+    call("ldmae_cast_weight", dt(dtype), ptr(w), ptr(dst), ptr(dstT), R, C, stream())
+    return dst, dstT
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    call("ldmae_cast", dt(x.dtype), dt(dtype), ptr(_c(x)), ptr(out), x.numel(), stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- norms / elementwise
+def rmsnorm_modulate_fwd(x, w, shift, scale, rows_per_batch, out_dtype, eps=1e-6):
+    M, D = x.shape
+    out = torch.empty(M, D, dtype=out_dtype, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    ld = shift.stride(0) if shift is not None else (scale.stride(0) if scale is not None else 0)
+    call("ldmae_rmsnorm_modulate_fwd", dt(out_dtype), ptr(x), ptr(w), ptr(shift), ptr(scale), ld, ptr(out), ptr(rstd), M, D,
+         rows_per_batch, eps, stream())
+    return out, rstd
+
+
+def rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx_accum, dshift, dscale, rows_per_batch):
+    """dx_accum += dx (in place); writes dshift/dscale views ([B,D], any row stride); returns dw [D]."""
+    M, D = x.shape
+    dw = torch.empty(D, dtype=torch.float32, device=x.device)
+    ws = workspace(L.load().ldmae_rmsnorm_modulate_bwd_workspace_bytes(M, D, rows_per_batch), x.device)
+    call("ldmae_rmsnorm_modulate_bwd", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(scale), scale.stride(0) if scale is not None else 0,
+         ptr(rstd), ptr(dx_accum), ptr(dshift), ptr(dscale), dshift.stride(0) if dshift is not None else 0, ptr(dw), 0.0, M, D,
+         rows_per_batch, ptr(ws), stream())
+    return dw
+
+
+def qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6):
+    q = torch.empty(B, H, N, hd, dtype=qkv.dtype, device=qkv.device)
+    k = torch.empty_like(q)
+    v = torch.empty_like(q)
+    call("ldmae_qknorm_rope_fwd", dt(qkv.dtype), ptr(qkv), ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(q), ptr(k), ptr(v), B, N, H, hd, eps, stream())
+    return q, k, v
+
+
+def qknorm_rope_bwd(dq, dk, dv, qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6):
+    dqkv = torch.empty_like(qkv)
+    dwq = torch.empty(hd, dtype=torch.float32, device=qkv.device)
+    dwk = torch.empty_like(dwq)
+    ws = workspace(L.load().ldmae_qknorm_rope_bwd_workspace_bytes(B, N, H, hd), qkv.device)
+    call("ldmae_qknorm_rope_bwd", dt(qkv.dtype), ptr(dq), ptr(dk), ptr(dv), ptr(qkv), ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(dqkv),
+         ptr(dwq), ptr(dwk), 0.0, B, N, H, hd, eps, ptr(ws), stream())
+    return dqkv, dwq, dwk
+
+
+def attention_fwd(q, k, v, scale):
+    B, H, N, hd = q.shape
+    o = torch.empty(B, N, H * hd, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
+    call("ldmae_attention_fwd", dt(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, H, N, hd, float(scale), stream())
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, do, lse, scale):
+    B, H, N, hd = q.shape
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
+    call("ldmae_attention_bwd", dt(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta),
+         B, H, N, hd, float(scale), stream())
+    return dq, dk, dv
+
+
+def swiglu_fwd(h12):
+    M, H2 = h12.shape
+    hid = torch.empty(M, H2 // 2, dtype=h12.dtype, device=h12.device)
+    call("ldmae_swiglu_fwd", dt(h12.dtype), ptr(h12), ptr(hid), M, H2 // 2, stream())
+    return hid
+
+
+def swiglu_bwd(dhid, h12):
+    M, H2 = h12.shape
+    dh12 = torch.empty_like(h12)
+    call("ldmae_swiglu_bwd", dt(h12.dtype), ptr(dhid), ptr(h12), ptr(dh12), M, H2 // 2, stream())
+    return dh12
+
+
+def gate_bwd(dxout, y, gate, dgate, rows_per_batch, act_dtype):
+    """dy = dxout * gate[b] (act dtype);  dgate view [B,D] <- sum_n dxout*y (skipped when dgate is None)."""
+    M, D = dxout.shape
+    dy = torch.empty(M, D, dtype=act_dtype, device=dxout.device)
+    ws = workspace(L.load().ldmae_gate_bwd_workspace_bytes(M, D, rows_per_batch), dxout.device) if dgate is not None else None
+    call("ldmae_gate_bwd", dt(act_dtype), ptr(dxout), ptr(y), ptr(gate), gate.stride(0) if gate is not None else 0, ptr(dy), ptr(dgate),
+         dgate.stride(0) if dgate is not None else 0, M, D, rows_per_batch, ptr(ws), stream())
+    return dy
+
+
+def timestep_embedding(t, dim=256, max_period=10000.0):
+    out = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
+    call("ldmae_timestep_embedding", ptr(_c(t.float())), ptr(out), t.shape[0], dim, float(max_period), stream())
+    return out
+
+
+def silu_fwd(x, out_dtype=torch.float32):
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    call("ldmae_silu_fwd", dt(out_dtype), ptr(x), ptr(out), x.numel(), stream())
+    return out
+
+
+def silu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    call("ldmae_silu_bwd", ptr(_c(dy)), ptr(x), ptr(dx), x.numel(), stream())
+    return dx
+
+
+def label_embed_fwd(table, y, drop, num_classes):
+    B, D = y.shape[0], table.shape[1]
+    out = torch.empty(B, D, dtype=torch.float32, device=table.device)
+    call("ldmae_label_embed_fwd", ptr(table), ptr(y), ptr(drop), ptr(out), B, D, num_classes, stream())
+    return out
+
+
+def label_embed_bwd(dout, y, drop, num_classes, rows):
+    dtable = torch.zeros(rows, dout.shape[1], dtype=torch.float32, device=dout.device)
+    call("ldmae_label_embed_bwd", ptr(_c(dout)), ptr(y), ptr(drop), ptr(dtable), dout.shape[0], dout.shape[1], num_classes, rows, stream())
+    return dtable
+
+
+def adamw_ema(p, g, m, v, ema, step, lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale=1.0):
+    call("ldmae_adamw_ema", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), int(step), float(lr), float(beta1), float(beta2),
+         float(eps), float(weight_decay), float(ema_decay), float(grad_scale), stream())
+
+
+def ema_only(ema, p, ema_decay):
+    call("ldmae_ema_only", ptr(ema), ptr(p), p.numel(), float(ema_decay), stream())
+
+
+# ----------------------------------------------------------------------------- VMAE
+def random_masking(noise, keep):
+    N, Lq = noise.shape
+    ids_restore = torch.empty(N, Lq, dtype=torch.int64, device=noise.device)
+    mask = torch.empty(N, Lq, dtype=torch.float32, device=noise.device)
+    ids_keep = torch.empty(N, keep, dtype=torch.int64, device=noise.device)
+    call("ldmae_random_masking", ptr(_c(noise)), ptr(ids_restore), ptr(mask), ptr(ids_keep), N, Lq, keep, stream())
+    return ids_keep, mask, ids_restore
+
+
+def gather_rows(x, ids):
+    N, Lq, D = x.shape
+    keep = ids.shape[1]
+    out = torch.empty(N, keep, D, dtype=torch.float32, device=x.device)
+    call("ldmae_gather_rows", ptr(x), ptr(ids), ptr(out), N, Lq, keep, D, stream())
+    return out
+
+
+def scatter_rows(dout, ids, Lq):
+    N, keep, D = dout.shape
+    dx = torch.zeros(N, Lq, D, dtype=torch.float32, device=dout.device)
+    call("ldmae_scatter_rows", ptr(_c(dout)), ptr(ids), ptr(dx), N, Lq, keep, D, stream())
+    return dx
+
+
+def layernorm_fwd(x, w, b, out_dtype, eps=1e-6):
+    M, D = x.shape
+    out = torch.empty(M, D, dtype=out_dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    call("ldmae_layernorm_fwd", dt(out_dtype), ptr(x), ptr(w), ptr(b), ptr(out), ptr(mean), ptr(rstd), M, D, eps, stream())
+    return out, mean, rstd
+
+
+def layernorm_bwd(dout, x, w, mean, rstd, dx_accum):
+    M, D = x.shape
+    dw = torch.empty(D, dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dw)
+    ws = workspace(L.load().ldmae_layernorm_bwd_workspace_bytes(M, D), x.device)
+    call("ldmae_layernorm_bwd", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(mean), ptr(rstd), ptr(dx_accum), ptr(dw), ptr(db), 0.0,
+         M, D, ptr(ws), stream())
+    return dw, db
+
+
+def gelu_bwd(dout, pre):
+    dx = torch.empty_like(pre)
+    call("ldmae_gelu_bwd", dt(pre.dtype), ptr(dout), ptr(pre), ptr(dx), pre.numel(), stream())
+    return dx

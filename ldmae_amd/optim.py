@@ -1,0 +1,103 @@
+"""Flat parameter / gradient storage and the fused AdamW + EMA step.
+
+Replaces ``torch.optim.AdamW(...).step(); opt.zero_grad(); update_ema(ema, model)`` of the reference
+loop (LDMAE/train_accum.py:121, 240-243, 336-347) with ONE kernel pass over contiguous f32 buffers
+(p, g, m, v, ema): 36 B/parameter of HBM traffic instead of ~150 small launches x 2 for the EMA
+alone.  The same contiguous gradient buffer is what the data-parallel reducer all-reduces
+(``ldmae_amd.distributed``).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+
+_ALIGN = 64   # elements (256 B): keeps every parameter view 16-B aligned for the GEMM operand loads
+
+
+class FlatParams:
+    """Moves every parameter of ``module`` into one contiguous f32 buffer (trainable first, frozen after)
+    and gives trainable parameters ``.grad`` views into a second one.  Names / shapes / state_dict are
+    unchanged; ``module.to(device)`` must happen BEFORE this."""
+
+    def __init__(self, module: torch.nn.Module):
+        named = [(n, p) for n, p in module.named_parameters()]
+        self.trainable = [(n, p) for n, p in named if p.requires_grad]
+        self.frozen = [(n, p) for n, p in named if not p.requires_grad]
+        dev = named[0][1].device
+        self.offsets = OrderedDict()
+        off = 0
+        for group in (self.trainable, self.frozen):
+            for n, p in group:
+                if p.dtype != torch.float32:
+                    raise RuntimeError(f"FlatParams: parameter {n} is {p.dtype}; master weights must be float32")
+                self.offsets[n] = (off, p.numel())
+                off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if group is self.trainable:
+                self.n_trainable = off
+        self.total = off
+        self.params = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.n_trainable, dtype=torch.float32, device=dev)
+        for n, p in self.trainable + self.frozen:
+            o, k = self.offsets[n]
+            self.params[o:o + k].copy_(p.data.reshape(-1))
+            p.data = self.params[o:o + k].view(p.shape)
+        self.attach_grads()
+
+    def attach_grads(self):
+        for n, p in self.trainable:
+            o, k = self.offsets[n]
+            p.grad = self.grads[o:o + k].view(p.shape)
+
+    def view(self, flat: torch.Tensor, name: str, shape) -> torch.Tensor:
+        o, k = self.offsets[name]
+        return flat[o:o + k].view(shape)
+
+
+class AdamWEMA:
+    """AdamW(lr, betas, eps, weight_decay) on the trainable slice + EMA(decay) over ALL parameters (the
+    reference's EMA includes the frozen ``pos_embed``, train_accum.py:343-347)."""
+
+    def __init__(self, module, lr=2e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, ema_decay=0.9999, flat: FlatParams = None):
+        self.module = module
+        self.flat = flat or FlatParams(module)
+        self.lr, self.betas, self.eps, self.weight_decay, self.ema_decay = lr, betas, eps, weight_decay, ema_decay
+        f = self.flat
+        self.m = torch.zeros_like(f.grads)
+        self.v = torch.zeros_like(f.grads)
+        self.ema = f.params.clone()          # == update_ema(ema, model, decay=0) at start (train_accum.py:166)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.flat.grads.zero_()
+        self.flat.attach_grads()
+
+    @torch.no_grad()
+    def step(self, grad_scale: float = 1.0):
+        """One optimizer step + EMA update; ``grad_scale`` folds 1/world_size (and 1/accum) into the same pass."""
+        f = self.flat
+        self.step_count += 1
+        n = f.n_trainable
+        ops.adamw_ema(f.params[:n], f.grads, self.m, self.v, self.ema[:n], self.step_count, self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.weight_decay, self.ema_decay, grad_scale)
+        if f.total > n:
+            ops.ema_only(self.ema[n:], f.params[n:], self.ema_decay)
+
+    def ema_state_dict(self):
+        """EMA weights under the module's parameter names (+ buffers copied as-is), loadable by
+        ``model.load_state_dict`` -- the ``"ema"`` entry of the reference checkpoint (train_accum.py:275-280)."""
+        sd = OrderedDict()
+        params = dict(self.module.named_parameters())
+        for k, v in self.module.state_dict().items():
+            sd[k] = self.flat.view(self.ema, k, params[k].shape).clone() if k in params else v.clone()
+        return sd
+
+    def state_dict(self):
+        return {"step": self.step_count, "m": self.m, "v": self.v, "ema": self.ema,
+                "hyper": dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, ema_decay=self.ema_decay)}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.ema.copy_(sd["ema"])

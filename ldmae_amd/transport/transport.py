@@ -1,0 +1,199 @@
+"""Transport objective + samplers (reference: LDMAE/transport/transport.py)."""
+import enum
+
+import numpy as np
+import torch as th
+
+from . import path
+from .integrators import ode, sde
+from .utils import mean_flat
+
+
+class ModelType(enum.Enum):
+    NOISE = enum.auto()
+    SCORE = enum.auto()
+    VELOCITY = enum.auto()
+
+
+class PathType(enum.Enum):
+    LINEAR = enum.auto()
+    GVP = enum.auto()
+    VP = enum.auto()
+
+
+class WeightType(enum.Enum):
+    NONE = enum.auto()
+    VELOCITY = enum.auto()
+    LIKELIHOOD = enum.auto()
+
+
+class Transport:
+    def __init__(self, *, model_type, path_type, loss_type, train_eps, sample_eps, use_cosine_loss=False, use_lognorm=False,
+                 partitial_train=None, partial_ratio=1.0, shift_lg=False):
+        self.loss_type, self.model_type = loss_type, model_type
+        self.path_sampler = {PathType.LINEAR: path.ICPlan, PathType.GVP: path.GVPCPlan, PathType.VP: path.VPCPlan}[path_type]()
+        self.train_eps, self.sample_eps = train_eps, sample_eps
+        self.use_cosine_loss, self.use_lognorm = use_cosine_loss, use_lognorm
+        self.partitial_train, self.partial_ratio, self.shift_lg = partitial_train, partial_ratio, shift_lg
+
+    def prior_logp(self, z):
+        n = int(np.prod(z.shape[1:]))
+        return -n / 2.0 * np.log(2 * np.pi) - th.sum(z.flatten(1) ** 2, dim=1) / 2.0
+
+    def check_interval(self, train_eps, sample_eps, *, diffusion_form="SBDM", sde=False, reverse=False, eval=False,
+                       last_step_size=0.0):
+        """transport.py:84-111."""
+        t0, t1 = 0, 1
+        eps = train_eps if not eval else sample_eps
+        if isinstance(self.path_sampler, path.VPCPlan):
+            t1 = 1 - eps if (not sde or last_step_size == 0) else 1 - last_step_size
+        elif self.model_type != ModelType.VELOCITY or sde:
+            t0 = eps if (diffusion_form == "SBDM" and sde) or self.model_type != ModelType.VELOCITY else 0
+            t1 = 1 - eps if (not sde or last_step_size == 0) else 1 - last_step_size
+        if reverse:
+            t0, t1 = 1 - t0, 1 - t1
+        return t0, t1
+
+    def sample_logit_normal(self, mu, sigma, size=1):
+        """transport.py:113-123.  The reference calls scipy.stats.norm.rvs with no random_state, i.e.
+        numpy's GLOBAL RandomState; `mu + sigma * standard_normal(size)` consumes that stream identically."""
+        z = mu + sigma * np.random.standard_normal(size)
+        return th.tensor(1 / (1 + np.exp(-z)), dtype=th.float32)
+
+    def sample_in_range(self, mu, sigma, target_size, range_min=0, range_max=0.5):
+        out = []
+        while len(out) < target_size:
+            s = self.sample_logit_normal(mu, sigma, size=target_size)
+            out.extend(s[(s >= range_min) & (s <= range_max)])
+        return th.tensor(out[:target_size])
+
+    def sample(self, x1, sp_timesteps=None, shifted_mu=0):
+        """transport.py:136-166: x0 on x1's device RNG, t on the host (numpy for logit-normal)."""
+        x0 = th.randn_like(x1)
+        t0, t1 = self.check_interval(self.train_eps, self.sample_eps)
+        B = x1.shape[0]
+        if not self.use_lognorm:
+            if self.partitial_train is not None and th.rand(1) < self.partial_ratio:
+                t = th.rand((B,)) * (self.partitial_train[1] - self.partitial_train[0]) + self.partitial_train[0]
+            else:
+                t = th.rand((B,)) * (t1 - t0) + t0
+        elif not self.shift_lg:
+            if self.partitial_train is not None and th.rand(1) < self.partial_ratio:
+                t = self.sample_in_range(0, 1, B, range_min=self.partitial_train[0], range_max=self.partitial_train[1])
+            else:
+                t = self.sample_logit_normal(0, 1, size=B) * (t1 - t0) + t0
+        else:
+            assert self.partitial_train is None, "Shifted lognormal distribution is not compatible with partial training"
+            t = self.sample_logit_normal(shifted_mu, 1, size=B) * (t1 - t0) + t0
+        if sp_timesteps is not None:
+            t = th.rand((B,)) * (sp_timesteps[1] - sp_timesteps[0]) + sp_timesteps[0]
+        return t.to(x1), x0, x1
+
+    def training_losses(self, model, x1, model_kwargs=None, sp_timesteps=None, shifted_mu=0):
+        """transport.py:169-215."""
+        model_kwargs = model_kwargs or {}
+        t, x0, x1 = self.sample(x1, sp_timesteps, shifted_mu)
+        t, xt, ut = self.path_sampler.plan(t, x0, x1)
+        out = model(xt, t, **model_kwargs)
+        assert out.size() == xt.size()
+        terms = {'pred': out}
+        if self.model_type == ModelType.VELOCITY:
+            terms['loss'] = mean_flat((out - ut) ** 2)
+            if self.use_cosine_loss:
+                terms['cos_loss'] = mean_flat(1 - th.nn.functional.cosine_similarity(out, ut, dim=1))
+            return terms
+        _, drift_var = self.path_sampler.compute_drift(xt, t)
+        sigma_t, _ = self.path_sampler.compute_sigma_t(path.expand_t_like_x(t, xt))
+        if self.loss_type == WeightType.VELOCITY:
+            weight = (drift_var / sigma_t) ** 2
+        elif self.loss_type == WeightType.LIKELIHOOD:
+            weight = drift_var / (sigma_t ** 2)
+        else:
+            weight = 1
+        if self.model_type == ModelType.NOISE:
+            terms['loss'] = mean_flat(weight * ((out - x0) ** 2))
+        else:
+            terms['loss'] = mean_flat(weight * ((out * sigma_t + x0) ** 2))
+        return terms
+
+    def get_drift(self):
+        ps = self.path_sampler
+
+        def velocity_ode(x, t, model, **kw):
+            return model(x, t, **kw)
+
+        def score_ode(x, t, model, **kw):
+            mean, var = ps.compute_drift(x, t)
+            return -mean + var * model(x, t, **kw)
+
+        def noise_ode(x, t, model, **kw):
+            mean, var = ps.compute_drift(x, t)
+            sigma_t, _ = ps.compute_sigma_t(path.expand_t_like_x(t, x))
+            return -mean + var * (model(x, t, **kw) / -sigma_t)
+
+        fn = {ModelType.NOISE: noise_ode, ModelType.SCORE: score_ode}.get(self.model_type, velocity_ode)
+
+        def body_fn(x, t, model, **kw):
+            out = fn(x, t, model, **kw)
+            assert out.shape == x.shape, "Output shape from ODE solver must match input shape"
+            return out
+        return body_fn
+
+    def get_score(self):
+        ps = self.path_sampler
+        if self.model_type == ModelType.NOISE:
+            return lambda x, t, model, **kw: model(x, t, **kw) / -ps.compute_sigma_t(path.expand_t_like_x(t, x))[0]
+        if self.model_type == ModelType.SCORE:
+            return lambda x, t, model, **kw: model(x, t, **kw)
+        return lambda x, t, model, **kw: ps.get_score_from_velocity(model(x, t, **kw), x, t)
+
+
+class Sampler:
+    """transport.py:270-443 (ODE and SDE samplers; likelihood evaluation is out of scope)."""
+
+    def __init__(self, transport):
+        self.transport = transport
+        self.drift = transport.get_drift()
+        self.score = transport.get_score()
+
+    def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False, timestep_shift=0.0):
+        drift = (lambda x, t, model, **kw: self.drift(x, th.ones_like(t) * (1 - t), model, **kw)) if reverse else self.drift
+        t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, sde=False, eval=True,
+                                               reverse=reverse, last_step_size=0.0)
+        return ode(drift=drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol, rtol=rtol,
+                   timestep_shift=timestep_shift).sample
+
+    def sample_sde(self, *, sampling_method="Euler", diffusion_form="SBDM", diffusion_norm=1.0, last_step="Mean",
+                   last_step_size=0.04, num_steps=250):
+        if last_step is None:
+            last_step_size = 0.0
+        ps = self.transport.path_sampler
+
+        def diffusion_fn(x, t):
+            return ps.compute_diffusion(x, t, form=diffusion_form, norm=diffusion_norm)
+
+        def sde_drift(x, t, model, **kw):
+            return self.drift(x, t, model, **kw) + diffusion_fn(x, t) * self.score(x, t, model, **kw)
+
+        t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, diffusion_form=diffusion_form,
+                                               sde=True, eval=True, reverse=False, last_step_size=last_step_size)
+        solver = sde(sde_drift, diffusion_fn, t0=t0, t1=t1, num_steps=num_steps, sampler_type=sampling_method)
+        if last_step is None:
+            last = lambda x, t, model, **kw: x
+        elif last_step == "Mean":
+            last = lambda x, t, model, **kw: x + sde_drift(x, t, model, **kw) * last_step_size
+        elif last_step == "Euler":
+            last = lambda x, t, model, **kw: x + self.drift(x, t, model, **kw) * last_step_size
+        elif last_step == "Tweedie":
+            last = lambda x, t, model, **kw: x / ps.compute_alpha_t(t)[0][0] + (ps.compute_sigma_t(t)[0][0] ** 2) / \
+                ps.compute_alpha_t(t)[0][0] * self.score(x, t, model, **kw)
+        else:
+            raise NotImplementedError()
+
+        def _sample(init, model, **kw):
+            xs = solver.sample(init, model, **kw)
+            ts = th.ones(init.size(0), device=init.device) * t1
+            xs.append(last(xs[-1], ts, model, **kw))
+            assert len(xs) == num_steps, "Samples does not match the number of steps"
+            return xs
+        return _sample

@@ -35,3 +35,24 @@ def det_weights(shapes: dict, seed: int = 0, skip=("pos_embed", "decoder_pos_emb
         else:
             out[k] = z / math.sqrt(int(np.prod(shp[1:])))
     return out
+
+
+def ref_style_init(shapes: dict, seed: int = 10) -> dict:
+    """The reference's init SCHEME (lightningdit.py:340-374: Xavier Linears, zero biases / adaLN / final linear,
+    N(0,.02) embedders, unit norms) with name-keyed values -- identical to make_golden.ref_style_init, which
+    loads the same numbers into the reference model for the 100-step loss curve."""
+    out = {}
+    for k, shp in shapes.items():
+        if k == "pos_embed":
+            continue
+        z = det_randn(k, shp, seed)
+        if "norm" in k and k.endswith("weight"):
+            out[k] = torch.ones(shp)
+        elif k.endswith(".bias") or "adaLN_modulation" in k or k.startswith("final_layer.linear"):
+            out[k] = torch.zeros(shp)
+        elif k.startswith("y_embedder") or k.startswith("t_embedder"):
+            out[k] = 0.02 * z
+        else:
+            fan_out, fan_in = shp[0], int(np.prod(shp[1:]))
+            out[k] = z * math.sqrt(2.0 / (fan_in + fan_out))
+    return out

@@ -1,0 +1,303 @@
+"""Parity of every HIP kernel against the CPU oracle / a plain f32-f64 torch restatement of the same op,
+called through the C ABI (ldmae_amd.ops -> ctypes -> libldmae_hip.so).
+
+Tolerances: f32 path 1e-4 relative (north-star contract; most kernels are ~1e-6); bf16 path is checked
+against the same math on bf16-rounded inputs with 2e-2 (bf16 has 8 significant bits); integer / index
+outputs are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import dit as odit
+from oracle import mae as omae
+from oracle import train as otrain
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = torch.float32, torch.bfloat16
+TOL = {F32: 1e-4, BF16: 2e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ldmae_amd import _lib, ops
+    assert _lib.load().ldmae_arch() == b"gfx950"
+    return ops
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, dtype):
+    """Round to the activation dtype and back (what the kernel sees)."""
+    return t.to(dtype).float()
+
+
+# ----------------------------------------------------------------------------- GEMMs
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,N,K", [(128, 384, 192), (200, 80, 64), (256, 16, 768), (64, 4608, 192), (1024, 768, 2048)])
+def test_gemm_nt_bias(ops, dtype, M, N, K):
+    a, b, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = q(a, dtype).double() @ q(b, dtype).double().T + bias.double()
+    out = ops.gemm_nt(dev(a, dtype), dev(b, dtype), dev(bias))
+    assert out.dtype == dtype and rel_err(out.float().cpu(), ref) < TOL[dtype]
+    out32 = ops.gemm_nt(dev(a, dtype), dev(b, dtype), dev(bias), out_dtype=F32)
+    assert rel_err(out32.cpu(), ref) < (1e-5 if dtype == F32 else 1e-6 + 1e-5)
+    # beta = 1 accumulates
+    ops.gemm_nt(dev(a, dtype), dev(b, dtype), None, out=out32, beta=1.0)
+    assert rel_err(out32.cpu(), 2 * ref - bias.double()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gemm_nt_gate_res_pos_gelu(ops, dtype):
+    B, T, D, K = 3, 64, 192, 128
+    M = B * T
+    a, w, bias = rnd(M, K, seed=1), rnd(D, K, seed=2, scale=K ** -0.5), rnd(D, seed=3)
+    xin, mod = rnd(M, D, seed=4), rnd(B, 6 * D, seed=5)
+    gate = mod[:, 2 * D:3 * D]
+    y = q(a, dtype).double() @ q(w, dtype).double().T + bias.double()
+    ref = xin.double() + gate.double().repeat_interleave(T, 0) * y
+    modd = dev(mod)
+    xo, ysave = ops.gemm_nt_gate_res(dev(a, dtype), dev(w, dtype), dev(bias), dev(xin), modd[:, 2 * D:3 * D], T)
+    assert rel_err(xo.cpu(), ref) < TOL[dtype] and rel_err(ysave.float().cpu(), y) < TOL[dtype]
+    # ungated residual (VMAE)
+    xo2, _ = ops.gemm_nt_gate_res(dev(a, dtype), dev(w, dtype), dev(bias), dev(xin), None, T, save_y=False)
+    assert rel_err(xo2.cpu(), xin.double() + y) < TOL[dtype]
+    pos = rnd(T, D, seed=6)
+    a32, w32 = rnd(M, 16, seed=7), rnd(D, 16, seed=8)
+    o = ops.gemm_nt_pos(dev(a32), dev(w32), dev(bias), dev(pos), T)
+    assert rel_err(o.cpu(), a32.double() @ w32.double().T + bias.double() + pos.double().repeat(B, 1)) < 1e-5
+    g, pre = ops.gemm_nt_gelu(dev(a, dtype), dev(w, dtype), dev(bias))
+    assert rel_err(pre.float().cpu(), y) < TOL[dtype]
+    assert rel_err(g.float().cpu(), torch.nn.functional.gelu(y)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,N,K", [(128, 384, 192), (4096, 16, 768), (8192, 576, 192), (256, 1152, 200)])
+def test_gemm_tn(ops, dtype, M, N, K):
+    if dtype == BF16 and K % 8:
+        pytest.skip("bf16 needs K % 8 == 0")
+    a, b = rnd(M, N, seed=1), rnd(M, K, seed=2)
+    ref = q(a, dtype).double().T @ q(b, dtype).double()
+    out = ops.gemm_tn(dev(a, dtype), dev(b, dtype))
+    assert out.dtype == F32 and rel_err(out.cpu(), ref) < 1e-5
+    out2 = ops.gemm_tn(dev(a, dtype), dev(b, dtype), out=out.clone(), beta=1.0)
+    assert rel_err(out2.cpu(), 2 * ref) < 1e-5
+    # deterministic: two launches are bitwise identical
+    assert torch.equal(ops.gemm_tn(dev(a, dtype), dev(b, dtype)), out)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_colsum_cast(ops, dtype):
+    x = rnd(1000, 576, seed=3)
+    assert rel_err(ops.colsum(dev(x, dtype)).cpu(), q(x, dtype).double().sum(0)) < 1e-5
+    w = rnd(80, 200, seed=4)
+    s, t = ops.cast_weight(dev(w), dtype)
+    assert torch.equal(s.cpu(), w.to(dtype)) and torch.equal(t.cpu(), w.to(dtype).T.contiguous())
+    assert torch.equal(ops.cast(dev(rnd(1003, seed=5)), BF16).cpu(), rnd(1003, seed=5).to(BF16))
+
+
+# ----------------------------------------------------------------------------- norm / elementwise
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("D", [192, 768, 1152])
+def test_rmsnorm_modulate(ops, dtype, D):
+    B, T = 2, 64
+    M = B * T
+    x = rnd(M, D, seed=1).requires_grad_(True)
+    w = (1 + 0.1 * rnd(D, seed=2)).requires_grad_(True)
+    mod = (0.3 * rnd(B, 6 * D, seed=3)).requires_grad_(True)
+    sh, sc = mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D]
+    ref = odit.modulate(odit.rmsnorm(x.view(B, T, D), w), sh, sc).view(M, D)
+    g = rnd(M, D, seed=4)
+    gq = q(g, dtype)
+    ref.backward(gq)
+    modd = dev(mod.detach())
+    out, rstd = ops.rmsnorm_modulate_fwd(dev(x.detach()), dev(w.detach()), modd[:, 3 * D:4 * D], modd[:, 4 * D:5 * D], T, dtype)
+    assert rel_err(out.float().cpu(), ref.detach()) < (1e-5 if dtype == F32 else 1e-2)
+    dx = dev(rnd(M, D, seed=5))
+    dx0 = dx.clone()
+    dmod = torch.zeros(B, 6 * D, device="cuda")
+    dw = ops.rmsnorm_modulate_bwd(dev(g, dtype), dev(x.detach()), dev(w.detach()), modd[:, 4 * D:5 * D], rstd, dx,
+                                  dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D], T)
+    assert rel_err((dx - dx0).cpu(), x.grad) < 1e-4
+    assert rel_err(dw.cpu(), w.grad) < 1e-4
+    assert rel_err(dmod.cpu(), mod.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("hd,H", [(64, 3), (72, 2)])
+def test_qknorm_rope(ops, dtype, hd, H):
+    B, grid = 2, 8
+    N = grid * grid
+    cos, sin = odit.rope_tables(hd, grid)
+    qkv = q(rnd(B, N, 3, H, hd, seed=1), dtype).requires_grad_(True)
+    wq, wk = (1 + 0.1 * rnd(hd, seed=2)).requires_grad_(True), (1 + 0.1 * rnd(hd, seed=3)).requires_grad_(True)
+    t = qkv.permute(2, 0, 3, 1, 4)
+    rq = odit.apply_rope(odit.rmsnorm(t[0], wq), cos, sin)
+    rk = odit.apply_rope(odit.rmsnorm(t[1], wk), cos, sin)
+    gq_, gk_, gv_ = q(rnd(B, H, N, hd, seed=4), dtype), q(rnd(B, H, N, hd, seed=5), dtype), q(rnd(B, H, N, hd, seed=6), dtype)
+    (rq * gq_).sum().add((rk * gk_).sum()).add((t[2] * gv_).sum()).backward()
+    qd, kd, vd = ops.qknorm_rope_fwd(dev(qkv.detach(), dtype), dev(wq.detach()), dev(wk.detach()), dev(cos), dev(sin), B, N, H, hd)
+    tol = 1e-5 if dtype == F32 else 1e-2
+    assert rel_err(qd.float().cpu(), rq.detach()) < tol and rel_err(kd.float().cpu(), rk.detach()) < tol
+    assert torch.equal(vd.float().cpu(), t[2].detach().contiguous())
+    dqkv, dwq, dwk = ops.qknorm_rope_bwd(dev(gq_, dtype), dev(gk_, dtype), dev(gv_, dtype), dev(qkv.detach(), dtype), dev(wq.detach()),
+                                         dev(wk.detach()), dev(cos), dev(sin), B, N, H, hd)
+    assert rel_err(dqkv.float().cpu(), qkv.grad) < tol
+    assert rel_err(dwq.cpu(), wq.grad) < 1e-4 and rel_err(dwk.cpu(), wk.grad) < 1e-4
+
+
+def _attn_ref(qq, kk, vv, scale):
+    s = (qq @ kk.transpose(-2, -1)) * scale
+    o = s.softmax(-1) @ vv
+    B, H, N, hd = qq.shape
+    return o.transpose(1, 2).reshape(B, N, H * hd), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype,hd,N", [(F32, 64, 64), (F32, 64, 192), (F32, 16, 256), (F32, 72, 128), (BF16, 64, 64), (BF16, 64, 192),
+                                        (BF16, 64, 1024)])
+def test_attention(ops, dtype, hd, N):
+    B, H = 2, 3
+    mk = lambda s: q(rnd(B, H, N, hd, seed=s), dtype).double().requires_grad_(True)
+    qq, kk, vv = mk(1), mk(2), mk(3)
+    scale = hd ** -0.5
+    o, lse = _attn_ref(qq, kk, vv, scale)
+    g = q(rnd(B, N, H * hd, seed=4), dtype).double()
+    o.backward(g)
+    od, lsed = ops.attention_fwd(dev(qq.detach().float(), dtype), dev(kk.detach().float(), dtype), dev(vv.detach().float(), dtype), scale)
+    tol = 2e-5 if dtype == F32 else 2e-2
+    assert rel_err(od.float().cpu(), o.detach()) < tol
+    assert rel_err(lsed.cpu(), lse.detach()) < (1e-5 if dtype == F32 else 2e-3)
+    dq, dk, dv = ops.attention_bwd(dev(qq.detach().float(), dtype), dev(kk.detach().float(), dtype), dev(vv.detach().float(), dtype),
+                                   od, dev(g.float(), dtype), lsed, scale)
+    for got, ref in ((dq, qq.grad), (dk, kk.grad), (dv, vv.grad)):
+        assert rel_err(got.float().cpu(), ref) < (1e-4 if dtype == F32 else 3e-2)
+
+
+def test_attention_softmax_rescale_branch(ops):
+    """Force the running max to jump at a chosen key tile (guide rule 26): one huge score late in the sequence."""
+    B, H, N, hd = 1, 1, 256, 64
+    qq, kk, vv = rnd(B, H, N, hd, seed=1), rnd(B, H, N, hd, seed=2), rnd(B, H, N, hd, seed=3)
+    kk[0, 0, 200] = qq[0, 0, 5] * 8.0
+    o, lse = _attn_ref(qq.double(), kk.double(), vv.double(), hd ** -0.5)
+    for dtype in (F32, BF16):
+        od, lsed = ops.attention_fwd(dev(qq, dtype), dev(kk, dtype), dev(vv, dtype), hd ** -0.5)
+        o_r, lse_r = _attn_ref(q(qq, dtype).double(), q(kk, dtype).double(), q(vv, dtype).double(), hd ** -0.5)
+        assert rel_err(od.float().cpu(), o_r) < (2e-5 if dtype == F32 else 2e-2)
+        assert rel_err(lsed.cpu(), lse_r) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_swiglu_gate_silu(ops, dtype):
+    M, Hs, B, T, D = 128, 512, 2, 64, 192
+    h12 = q(rnd(M, 2 * Hs, seed=1), dtype).requires_grad_(True)
+    x1, x2 = h12.chunk(2, -1)
+    ref = torch.nn.functional.silu(x1) * x2
+    g = q(rnd(M, Hs, seed=2), dtype)
+    ref.backward(g)
+    tol = 1e-5 if dtype == F32 else 1e-2
+    assert rel_err(ops.swiglu_fwd(dev(h12.detach(), dtype)).float().cpu(), ref.detach()) < tol
+    assert rel_err(ops.swiglu_bwd(dev(g, dtype), dev(h12.detach(), dtype)).float().cpu(), h12.grad) < tol
+    dxo, y, mod = rnd(M, D, seed=3), q(rnd(M, D, seed=4), dtype), rnd(B, 6 * D, seed=5)
+    modd = dev(mod)
+    dmod = torch.zeros(B, 6 * D, device="cuda")
+    dy = ops.gate_bwd(dev(dxo), dev(y, dtype), modd[:, 5 * D:], dmod[:, 5 * D:], T, dtype)
+    gate = mod[:, 5 * D:].repeat_interleave(T, 0)
+    assert rel_err(dy.float().cpu(), dxo * gate) < tol
+    assert rel_err(dmod[:, 5 * D:].cpu(), (dxo * y).view(B, T, D).sum(1)) < 1e-5
+    if dtype == F32:
+        c = rnd(5, 192, seed=6).requires_grad_(True)
+        torch.nn.functional.silu(c).backward(g[:5, :192])
+        assert rel_err(ops.silu_fwd(dev(c.detach())).cpu(), torch.nn.functional.silu(c.detach())) < 1e-6
+        assert rel_err(ops.silu_bwd(dev(g[:5, :192].contiguous()), dev(c.detach())).cpu(), c.grad) < 1e-5
+
+
+def test_embedders(ops, golden):
+    g = golden("kernels")
+    t = torch.tensor([0.0, 0.25, 0.9])
+    np.testing.assert_allclose(ops.timestep_embedding(dev(t)).cpu().numpy(), g["k2_emb"], atol=2e-6)      # vs reference golden
+    table = rnd(11, 192, seed=1)
+    y, drop = torch.tensor([3, 7, 3, 0]), torch.tensor([0, 1, 0, 0], dtype=torch.uint8)
+    out = ops.label_embed_fwd(dev(table), dev(y), dev(drop), 10)
+    assert torch.equal(out.cpu(), table[torch.tensor([3, 10, 3, 0])])
+    gg = rnd(4, 192, seed=2)
+    ref = torch.zeros(11, 192).index_add_(0, torch.tensor([3, 10, 3, 0]), gg)
+    assert rel_err(ops.label_embed_bwd(dev(gg), dev(y), dev(drop), 10, 11).cpu(), ref) < 1e-6
+
+
+def test_adamw_ema_matches_oracle(ops):
+    n = 4096 + 64
+    p0, g1, g2 = rnd(n, seed=1), rnd(n, seed=2), rnd(n, seed=3)
+    sd = {"p": p0.clone()}
+    st = otrain.AdamWState(["p"], sd)
+    ema = {"p": p0.clone()}
+    p, m, v, e = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), dev(p0)
+    for step, g in enumerate((g1, g2), 1):
+        otrain.adamw_step(sd, {"p": g}, st)
+        otrain.ema_update(ema, sd, ["p"])
+        ops.adamw_ema(p, dev(g), m, v, e, step, 2e-4, 0.9, 0.95, 1e-8, 0.0, 0.9999)
+    np.testing.assert_allclose(p.cpu().numpy(), sd["p"].numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(e.cpu().numpy(), ema["p"].numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(v.cpu().numpy(), st.v["p"].numpy(), rtol=2e-6, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- VMAE
+@pytest.mark.parametrize("L,ratio", [(1024, 0.75), (1024, 0.25), (256, 0.75), (200, 0.5)])
+def test_random_masking_bit_exact(ops, L, ratio):
+    N = 5
+    noise = torch.rand(N, L, generator=torch.Generator().manual_seed(L))
+    noise[1, 10:20] = noise[1, 5]           # ties -> index order
+    noise[2] = 0.5                          # all equal
+    keep = omae.len_keep(L, ratio)
+    ids_keep, mask, ids_restore = ops.random_masking(dev(noise), keep)
+    rk, rm, rr = omae.random_masking_ids(noise.numpy(), ratio)
+    np.testing.assert_array_equal(ids_restore.cpu().numpy(), rr)
+    np.testing.assert_array_equal(mask.cpu().numpy(), rm)
+    np.testing.assert_array_equal(ids_keep.cpu().numpy(), rk)
+    x = rnd(N, L, 192, seed=1)
+    xm = ops.gather_rows(dev(x), ids_keep)
+    assert torch.equal(xm.cpu(), torch.gather(x, 1, torch.from_numpy(rk).unsqueeze(-1).expand(-1, -1, 192)))
+    back = ops.scatter_rows(xm, ids_keep, L).cpu()
+    assert torch.equal(back, x * (1 - torch.from_numpy(rm)).unsqueeze(-1))
+
+
+def test_random_masking_golden(ops, golden):
+    g = golden("mae")
+    for tag, ratio in (("75", 0.75), ("25", 0.25)):
+        _, mask, ids = ops.random_masking(dev(torch.from_numpy(g["mae_noise"])), omae.len_keep(1024, ratio))
+        np.testing.assert_array_equal(mask.cpu().numpy(), g[f"mae{tag}_mask"])
+        np.testing.assert_array_equal(ids.cpu().numpy(), g[f"mae{tag}_ids_restore"])
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_layernorm_gelu(ops, dtype):
+    M, D = 300, 192
+    x = rnd(M, D, seed=1).requires_grad_(True)
+    w, b = (1 + 0.1 * rnd(D, seed=2)).requires_grad_(True), (0.1 * rnd(D, seed=3)).requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x, (D,), w, b, 1e-6)
+    g = q(rnd(M, D, seed=4), dtype)
+    ref.backward(g)
+    out, mean, rstd = ops.layernorm_fwd(dev(x.detach()), dev(w.detach()), dev(b.detach()), dtype)
+    assert rel_err(out.float().cpu(), ref.detach()) < (1e-5 if dtype == F32 else 1e-2)
+    dx = torch.zeros(M, D, device="cuda")
+    dw, db = ops.layernorm_bwd(dev(g, dtype), dev(x.detach()), dev(w.detach()), mean, rstd, dx)
+    assert rel_err(dx.cpu(), x.grad) < 1e-4 and rel_err(dw.cpu(), w.grad) < 1e-4 and rel_err(db.cpu(), b.grad) < 1e-4
+    pre = q(rnd(M, D, seed=5), dtype).requires_grad_(True)
+    torch.nn.functional.gelu(pre).backward(g)
+    assert rel_err(ops.gelu_bwd(dev(g, dtype), dev(pre.detach(), dtype)).float().cpu(), pre.grad) < (1e-5 if dtype == F32 else 1e-2)
+
+
+def test_errors_are_loud(ops):
+    a = torch.zeros(128, 100, device="cuda", dtype=BF16)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm_nt(a, a)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm_nt(torch.zeros(4, 16), torch.zeros(4, 16))
