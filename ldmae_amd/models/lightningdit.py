@@ -33,8 +33,8 @@ from .swiglu_ffn import SwiGLUFFN
 def _act_dtype(override=None):
     if override is not None:
         return override
-    if torch.is_autocast_enabled():
-        d = torch.get_autocast_gpu_dtype()
+    if torch.is_autocast_enabled("cuda"):
+        d = torch.get_autocast_dtype("cuda")
         if d != torch.bfloat16:
             raise RuntimeError(f"ldmae_amd: autocast dtype {d} unsupported (bfloat16 or no autocast)")
         return torch.bfloat16
@@ -328,13 +328,13 @@ class LightningDiTBlock(nn.Module):
         self.wo_shift = wo_shift
         self.precision = None
 
-    def forward(self, x, c, feat_rope=None, _silu_c=None):
+    def forward(self, x, c, feat_rope=None, _silu_c=None, _dtype=None):
         if feat_rope is None:
             raise NotImplementedError("ldmae_amd LightningDiTBlock needs feat_rope (use_rope=True)")
         sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
         a, m = self.attn, self.mlp
         return _DiTBlockFn.apply(
-            x.float(), sc, feat_rope.freqs_cos, feat_rope.freqs_sin, a.num_heads, self.norm1.eps, _act_dtype(self.precision),
+            x.float(), sc, feat_rope.freqs_cos, feat_rope.freqs_sin, a.num_heads, self.norm1.eps, _dtype or _act_dtype(self.precision),
             self.norm1.weight, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.k_norm.weight, a.proj.weight, a.proj.bias,
             self.norm2.weight, m.w12.weight, m.w12.bias, m.w3.weight, m.w3.bias,
             self.adaLN_modulation[1].weight, self.adaLN_modulation[1].bias)
@@ -352,9 +352,9 @@ class FinalLayer(nn.Module):
         self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
         self.precision = None
 
-    def forward(self, x, c, _silu_c=None):
+    def forward(self, x, c, _silu_c=None, _dtype=None):
         sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
-        return _FinalLayerFn.apply(x.float(), sc, self.norm_final.eps, _act_dtype(self.precision), self.norm_final.weight,
+        return _FinalLayerFn.apply(x.float(), sc, self.norm_final.eps, _dtype or _act_dtype(self.precision), self.norm_final.weight,
                                    self.linear.weight, self.linear.bias, self.adaLN_modulation[1].weight,
                                    self.adaLN_modulation[1].bias)
 
@@ -433,21 +433,25 @@ class LightningDiT(nn.Module):
         return x.reshape(shape=(x.shape[0], c, h * p, h * p))
 
     def forward(self, x, t=None, y=None):
-        """:391-418."""
-        x = self.x_embedder(x, self.pos_embed[0])
-        t = self.t_embedder(t)
-        y = self.y_embedder(y, self.training)
-        c = t + y
-        sc = _SiluFn.apply(c)
-        for block in self.blocks:
-            if self.use_checkpoint:
-                x = checkpoint(block, x, c, self.feat_rope, sc, use_reentrant=True)
-            else:
-                x = block(x, c, self.feat_rope, sc)
-        x = self.final_layer(x, c, sc)
-        x = self.unpatchify(x)
-        if self.learn_sigma:
-            x, _ = x.chunk(2, dim=1)
+        """:391-418.  The activation dtype is read from the ambient autocast state once; the body then runs with
+        autocast disabled so the few torch re-layout ops around the kernels stay f32 (the reference's output is
+        f32 too: accelerate converts outputs to fp32)."""
+        dtype = _act_dtype(self.precision)
+        with torch.autocast(device_type="cuda", enabled=False):
+            x = self.x_embedder(x, self.pos_embed[0])
+            t = self.t_embedder(t)
+            y = self.y_embedder(y, self.training)
+            c = t + y
+            sc = _SiluFn.apply(c)
+            for block in self.blocks:
+                if self.use_checkpoint:
+                    x = checkpoint(block, x, c, self.feat_rope, sc, dtype, use_reentrant=True)
+                else:
+                    x = block(x, c, self.feat_rope, sc, dtype)
+            x = self.final_layer(x, c, sc, dtype)
+            x = self.unpatchify(x)
+            if self.learn_sigma:
+                x, _ = x.chunk(2, dim=1)
         return x
 
     def forward_with_cfg(self, x, t, y, cfg_scale, cfg_interval=None, cfg_interval_start=None):
