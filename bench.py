@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LightningDiT-B/1 (f8d16) flow-matching TRAIN STEP throughput on synthetic 32x32x16 latents.
+
+    python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = what LDMAE/train_accum.py:204-246 does per optimizer step at gradient_accumulation_steps=1:
+transport.training_losses (x0 ~ N(0,I), t ~ logit-normal, xt, ut) -> model fwd (bf16 autocast) -> velocity MSE ->
+backward (+ bucketed RCCL all-reduce overlapped on a side stream when N > 1) -> fused AdamW + EMA.  Inputs (latents,
+labels) are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+METRIC = "DiT-B train-step images/sec (32×32×16 latents) at 1/2/4/8 MI355X"
+FLOPS_PER_IMAGE = 638.22e9        # 212.74 GFLOP fwd x 3 (fwd+bwd), algorithmic
+PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md chip table)
+
+
+def build(device, per_gpu_batch):
+    from ldmae_amd.distributed import GradBucketReducer
+    from ldmae_amd.models.lightningdit import LightningDiT_models
+    from ldmae_amd.optim import AdamWEMA
+    from ldmae_amd.transport import create_transport
+    # configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml: model / optimizer / transport sections
+    model = LightningDiT_models["LightningDiT-B/1"](input_size=32, num_classes=1000, use_qknorm=True, use_swiglu=True, use_rope=True,
+                                                     use_rmsnorm=True, wo_shift=False, in_channels=16, use_checkpoint=False,
+                                                     class_dropout_prob=0.1)
+    # the reference zero-initialises adaLN / final layer; random-init them so every kernel does real work from step 0
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "adaLN_modulation" in n or n.startswith("final_layer.linear"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    model = model.to(device).train()
+    opt = AdamWEMA(model, lr=2e-4, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9999)
+    reducer = GradBucketReducer(opt.flat)
+    reducer.broadcast_params(0)
+    opt.ema.copy_(opt.flat.params)
+    transport = create_transport("Linear", "velocity", None, None, None, use_cosine_loss=False, use_lognorm=True)
+    return model, opt, reducer, transport
+
+
+def train_step(model, opt, reducer, transport, x, y):
+    opt.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = transport.training_losses(model, x, dict(y=y))["loss"].mean()
+    loss.backward()
+    opt.step(grad_scale=reducer.finish())
+    return loss
+
+
+def cpu_baseline(max_seconds=30.0):
+    """The CPU oracle (a port of the reference step; the reference itself cannot travel) on this box's host cores:
+    BASELINE config 1 -- LightningDiT-B/1, bs=4, fp32, AdamW + EMA, eager.  Bounded sample: 1 untimed + up to 3 timed steps."""
+    from oracle import dit as odit, train as otrain
+    cfg = odit.DiTConfig(**odit.DIT_B_1)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    sd = odit.init_weights(cfg)
+    for k in sd:
+        if "adaLN_modulation" in k or k.startswith("final_layer.linear"):
+            sd[k] = torch.randn(sd[k].shape) * 0.02
+    times = []
+    t_begin = time.perf_counter()
+    batches = [otrain.draw_batch(4, cfg) for _ in range(4)]
+    keys = otrain.trainable_keys(cfg)
+    st = otrain.AdamWState(keys, sd)
+    ema = {k: sd[k].clone() for k in keys + ["pos_embed"]}
+    for i, (x1, y, t, x0, drop) in enumerate(batches):
+        t0 = time.perf_counter()
+        _, grads, _ = otrain.loss_and_grads(sd, cfg, x1, y, t, x0, drop)
+        with torch.no_grad():
+            otrain.adamw_step(sd, grads, st)
+            otrain.ema_update(ema, sd, keys + ["pos_embed"])
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_begin > max_seconds and times:
+            break
+    sps = float(np.median(times))
+    return {"value": round(4.0 / sps, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"LightningDiT-B/1 bs=4 fp32 eager CPU step (fwd+bwd+AdamW+EMA), median of {len(times)} steps after 1 warm-up, "
+                      f"{sps:.2f} s/step, torch {torch.__version__} on {os.cpu_count()} visible CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from ldmae_amd import _lib
+    lib = _lib.load()
+    model, opt, reducer, transport = build(device, args.batch)
+    seed = 0 * world + rank                      # inference.py:87 convention
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    x = torch.randn(args.batch, 16, 32, 32, device=device)     # latents are channel-normalised -> N(0,1) (img_latent_dataset.py:86-88)
+    y = torch.randint(0, 1000, (args.batch,), device=device)
+
+    for _ in range(args.warmup):
+        train_step(model, opt, reducer, transport, x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lib.ldmae_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(model, opt, reducer, transport, x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.ldmae_prof_enable(0)
+    import ctypes as C
+    ms, fl, nl = C.c_double(), C.c_double(), C.c_long()
+    lib.ldmae_prof_collect(C.byref(ms), C.byref(fl), C.byref(nl))
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item())
+    if not np.isfinite(final_loss):
+        raise RuntimeError("non-finite loss in bench")
+
+    if rank == 0:
+        ips = args.batch * world * args.steps / elapsed
+        gemm_tflops = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        out = {
+            "metric": METRIC, "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "LightningDiT-B/1 f8d16 bf16 train step (fwd+bwd+AdamW+EMA), 1024 tokens x 768, synthetic ImageNet-256 "
+                                   "latents 32x32x16", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}", "loss": round(final_loss, 5)},
+            "step_mfma_frac": round(FLOPS_PER_IMAGE * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (all Linear fwd + dX GEMMs)",
+                         "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4),
+                         "avg_launch_gflop": round(fl.value / max(1, nl.value) / 1e9, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -390,7 +390,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, float* __restr
 template <typename OutT>
 static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
                      hipStream_t st) {
-  const long pi = ldmae_prof_is_on() ? ldmae_prof_begin(st, 2.0 * M * N * K) : -1;
+  const long pi = (ldmae_prof_is_on() && dtype == LDMAE_BF16) ? ldmae_prof_begin(st, 2.0 * M * N * K) : -1;
 #define NT_LAUNCH(E)                                                                                                             \
   if (dtype == LDMAE_BF16)                                                                                                       \
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<E, OutT>), dim3(cdiv(M, NT_BM) * cdiv(N, NT_BN)), dim3(256), 4 * NT_TILE_BYTES, st, \

@@ -1,0 +1,65 @@
+"""world_size-2 gloo test of the data-parallel gradient path (the N>1 path of bench.py / the train driver): bucketed
+all-reduce of the flat gradient slab launched from post-accumulate-grad hooks == sum of per-rank gradients."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ldmae_amd.distributed import GradBucketReducer
+    from ldmae_amd.optim import FlatParams
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(), torch.nn.Linear(32, 4))
+    if rank == 1:                                   # desynchronise, then broadcast_params must repair it
+        with torch.no_grad():
+            net[0].weight.add_(1.0)
+    flat = FlatParams(net)
+    red = GradBucketReducer(flat, bucket_bytes=512)           # several buckets
+    red.broadcast_params(0)
+    assert len(red.buckets) >= 3
+    torch.manual_seed(100 + rank)
+    x = torch.randn(8, 16)
+    local = None
+    for it in range(2):                             # two steps: counters re-arm
+        flat.grads.zero_()
+        net(x).pow(2).mean().backward()
+        local = flat.grads.clone() if local is None else local
+        scale = red.finish()
+        assert scale == 0.5
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    expect = sum(gathered)
+    ok = torch.allclose(flat.grads, expect, rtol=1e-6, atol=1e-7)
+    params = [torch.zeros_like(flat.params) for _ in range(world)]
+    dist.all_gather(params, flat.params)
+    same = torch.equal(params[0], params[1])
+    if rank == 0:
+        out.put((ok, same))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_matches_sum_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    ok, same = q.get(timeout=5)
+    assert ok and same
