@@ -32,11 +32,15 @@ def _worker(rank, world, port, out):
     assert len(red.buckets) >= 3
     torch.manual_seed(100 + rank)
     x = torch.randn(8, 16)
-    local = None
+    # this rank's own gradient, computed without touching .grad (no hooks fire for autograd.grad)
+    own = torch.autograd.grad(net(x).pow(2).mean(), [p for _, p in flat.trainable])
+    local = torch.zeros_like(flat.grads)
+    for (n, p), g in zip(flat.trainable, own):
+        o, k = flat.offsets[n]
+        local[o:o + k] = g.reshape(-1)
     for it in range(2):                             # two steps: counters re-arm
         flat.grads.zero_()
-        net(x).pow(2).mean().backward()
-        local = flat.grads.clone() if local is None else local
+        net(x).pow(2).mean().backward()             # hooks launch the bucket all-reduces while backward runs
         scale = red.finish()
         assert scale == 0.5
     gathered = [torch.zeros_like(local) for _ in range(world)]
