@@ -55,7 +55,8 @@ int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, int lda, con
  * token rows, split over workgroups; partial slabs are summed in fixed order -> deterministic). */
 int ldmae_gemm_tn_splits(int dtype, int M, int N, int K);
 long ldmae_gemm_tn_workspace_bytes(int dtype, int M, int N, int K);
-int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int M, int N, int K, float beta,
+/* dbias (optional, [N] f32) = beta*dbias + column sums of A: the bias gradient of the same layer, fused. */
+int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, float* dbias, int M, int N, int K, float beta,
                   float* workspace, long workspace_bytes, void* stream);
 /* out[N] (f32) = beta*out + column sums of X[M,N]: bias gradients. workspace >= ldmae_colsum_workspace_bytes */
 long ldmae_colsum_workspace_bytes(int M, int N);
@@ -143,6 +144,9 @@ int ldmae_gelu_bwd(int dtype, const void* dout, const void* x, void* dx, long n,
 /* When enabled, ldmae_gemm_nt brackets each launch with HIP events on the launch stream. */
 int ldmae_prof_enable(int on);
 int ldmae_prof_collect(double* total_ms, double* total_flops, long* launches);   /* syncs the events; resets */
+
+/* kernel-variant selection for tuning / A-B measurements (key 0: bf16 NT GEMM variant, key 1: bf16 TN GEMM variant) */
+int ldmae_tune(int key, int value);
 
 #ifdef __cplusplus
 }

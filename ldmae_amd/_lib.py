@@ -26,7 +26,7 @@ SIGNATURES = {
     "ldmae_gemm_nt": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _i, _i, _vp]),
     "ldmae_gemm_tn_splits": (_i, [_i, _i, _i, _i]),
     "ldmae_gemm_tn_workspace_bytes": (_l, [_i, _i, _i, _i]),
-    "ldmae_gemm_tn": (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _l, _vp]),
+    "ldmae_gemm_tn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _l, _vp]),
     "ldmae_colsum_workspace_bytes": (_l, [_i, _i]),
     "ldmae_colsum": (_i, [_i, _vp, _i, _i, _i, _vp, _f, _vp, _vp]),
     "ldmae_cast_weight": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
@@ -58,6 +58,7 @@ SIGNATURES = {
     "ldmae_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
     "ldmae_gelu_fwd": (_i, [_i, _vp, _vp, _l, _vp]),
     "ldmae_gelu_bwd": (_i, [_i, _vp, _vp, _vp, _l, _vp]),
+    "ldmae_tune": (_i, [_i, _i]),
     "ldmae_prof_enable": (_i, [_i]),
     "ldmae_prof_collect": (_i, [C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
 }

@@ -83,6 +83,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+int ldmae_tune_get(int key);
 // timing hook (core.hip)
 bool ldmae_prof_is_on();
 long ldmae_prof_begin(hipStream_t st, double flops);

@@ -66,3 +66,12 @@ extern "C" int ldmae_prof_collect(double* total_ms, double* total_flops, long* l
   g_prof.clear();
   return LDMAE_OK;
 }
+
+// ---------------------------------------------------------------- tuning knobs (kernel variant selection; not part of the reference seam)
+static int g_tune[16] = {0};
+int ldmae_tune_get(int key) { return (key >= 0 && key < 16) ? g_tune[key] : 0; }
+extern "C" int ldmae_tune(int key, int value) {
+  if (key < 0 || key >= 16) LDMAE_FAIL(LDMAE_ERR_INVALID, "tune: key %d out of range", key);
+  g_tune[key] = value;
+  return LDMAE_OK;
+}

@@ -24,19 +24,30 @@ __device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_fl
 __device__ __forceinline__ float4 operator*(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 
-// out[o*out_ld + c] = beta*out + sum_{r<group} P[(o*group + r)*p_ld + c]   (fixed order)
-__global__ void group_reduce_kernel(const float* __restrict__ P, int p_ld, int nout, int cols, int group, float* __restrict__ out,
-                                    int out_ld, float beta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y;
-  if (c >= cols || o >= nout) return;
-  const float* p = P + (size_t)o * group * p_ld + c;
+// out[o*out_ld + c] = beta*out + sum_{r<group} P[(o*group + r)*p_ld + c]; 8 row-lanes per column stride the group,
+// partial sums are combined in a fixed order (bitwise reproducible).
+__global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restrict__ P, int p_ld, int nout, int cols, int group,
+                                                           float* __restrict__ out, int out_ld, float beta) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, o = blockIdx.y;
   float s = 0.f;
-  for (int r = 0; r < group; ++r) s += p[(size_t)r * p_ld];
-  float* q = out + (size_t)o * out_ld + c;
-  *q = (beta != 0.f ? beta * *q : 0.f) + s;
+  if (c < cols) {
+    const float* p = P + (size_t)o * group * p_ld + c;
+    for (int r = rl; r < group; r += 8) s += p[(size_t)r * p_ld];
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][cl];
+    float* q = out + (size_t)o * out_ld + c;
+    *q = (beta != 0.f ? beta * *q : 0.f) + t;
+  }
 }
 static void group_reduce(const float* P, int p_ld, int nout, int cols, int group, float* out, int out_ld, float beta, hipStream_t st) {
-  hipLaunchKernelGGL(group_reduce_kernel, dim3(cdiv(cols, 256), nout), dim3(256), 0, st, P, p_ld, nout, cols, group, out, out_ld, beta);
+  hipLaunchKernelGGL(group_reduce_kernel, dim3(cdiv(cols, 32), nout), dim3(256), 0, st, P, p_ld, nout, cols, group, out, out_ld, beta);
 }
 
 // rows per workgroup for the per-sample reductions: largest of 64/32/16/8/4 dividing rows_per_batch
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
 
 static unsigned qk_grid(long items, int lpr) {
   long wg = (items * lpr + 255) / 256;
-  return (unsigned)(wg < 4096 ? (wg > 0 ? wg : 1) : 4096);
+  return (unsigned)(wg < 2048 ? (wg > 0 ? wg : 1) : 2048);
 }
 
 extern "C" int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq, const float* wk, const float* cos, const float* sin,

@@ -140,6 +140,153 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const bf16* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 NT GEMM, ring-pipelined: BM x BN tile, WM x WN waves, BK = 32, STAGES LDS buffers filled by
+// global_load_lds that stay in flight ACROSS the per-K-step barrier (raw s_barrier + counted vmcnt, never
+// __syncthreads in the loop), so L2/HBM latency is covered by STAGES-2 K-steps of MFMA work.
+// LDS stage image: [BM + BN rows][32 k] bf16 = 64-B rows; 16-B chunk c of row r sits at position
+// c ^ F[(r >> 2) & 3], F = {0,2,3,1}: conflict-free for the ds_read_b128 lane groups of the 16x16x32 operands.
+// Epilogue: accumulators -> per-wave f32 LDS tile -> row-contiguous 16-B global accesses (fused bias /
+// gated residual / pos / GELU).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ring_f(int g) { return (0x78 >> (2 * g)) & 3; }
+
+// Vector epilogue for a 64-row x 4-column strip: per-column constants (bias, gate) are loaded once, then
+// one 16-B access per row.  `fast` = the whole strip is in range and (for the gated form) inside one sample.
+template <int EPI, typename OutT> struct Epi4 {
+  const EpiArgs& e;
+  int n, N;
+  float4 bias, gate;
+  __device__ __forceinline__ Epi4(const EpiArgs& e_, int m_first, int n_, int N_) : e(e_), n(n_), N(N_) {
+    bias = e.bias ? *(const float4*)(e.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gate = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (EPI == LDMAE_EPI_GATE_RES && e.gate) gate = *(const float4*)(e.gate + (size_t)(m_first / e.rows_per_batch) * e.gate_ld + n);
+  }
+  static __device__ __forceinline__ void put(void* base, size_t off, float4 v) {
+    OutT* p = (OutT*)base + off;
+    if constexpr (sizeof(OutT) == 4) *(float4*)p = v;
+    else { bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w; *(bf16x4*)p = o; }
+  }
+  __device__ __forceinline__ void apply(int m, float4 a) const {
+    a.x += bias.x; a.y += bias.y; a.z += bias.z; a.w += bias.w;
+    const size_t oc = (size_t)m * e.ldc + n;
+    if (EPI == LDMAE_EPI_BIAS) {
+      if (e.beta != 0.f) {
+        const OutT* p = (const OutT*)e.C + oc;
+        a.x += e.beta * to_f<OutT>(p[0]); a.y += e.beta * to_f<OutT>(p[1]); a.z += e.beta * to_f<OutT>(p[2]); a.w += e.beta * to_f<OutT>(p[3]);
+      }
+      put(e.C, oc, a);
+    } else if (EPI == LDMAE_EPI_BIAS_POS) {
+      const float4 q = *(const float4*)(e.xin + (size_t)(m % e.rows_per_batch) * N + n);
+      put(e.C, oc, make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w));
+    } else if (EPI == LDMAE_EPI_BIAS_GELU) {
+      if (e.C2) put(e.C2, oc, a);
+      auto g = [](float y) { return 0.5f * y * (1.f + erff(y * 0.70710678118654752f)); };
+      put(e.C, oc, make_float4(g(a.x), g(a.y), g(a.z), g(a.w)));
+    } else {
+      if (e.C) put(e.C, oc, a);
+      const size_t o = (size_t)m * N + n;
+      const float4 xi = *(const float4*)(e.xin + o);
+      *(float4*)(e.xout + o) = make_float4(xi.x + gate.x * a.x, xi.y + gate.y * a.y, xi.z + gate.z * a.z, xi.w + gate.w * a.w);
+    }
+  }
+};
+
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, typename OutT>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N,
+                                                                  int K, int lda, int ldb, EpiArgs e) {
+  constexpr int NW = WM * WN, TM = BM / WM, TNn = BN / WN, MI = TM / 16, NI = TNn / 16;
+  constexpr int STAGE_BYTES = (BM + BN) * 64, PIECES = (BM + BN) / 16, PPW = PIECES / NW;
+  static_assert(PIECES % NW == 0, "pieces must divide over waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const unsigned tiles_n = (N + BN - 1) / BN;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+
+  const bf16* src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = wave * PPW + i;                        // 0 .. PIECES-1 ; A pieces first
+    const int row = piece * 16 + (lane >> 2);                // row inside the stage image
+    const int c = (lane & 3) ^ ring_f((lane >> 4) & 3);      // global chunk stored at LDS position lane&3
+    src[i] = row < BM ? A + (size_t)min(m0 + row, M - 1) * lda + c * 8 : B + (size_t)min(n0 + row - BM, N - 1) * ldb + c * 8;
+  }
+  auto issue = [&](int kt) {
+    char* base = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + kt * 32), LDS_PTR(void, base + (wave * PPW + i) * 1024), 16, 0, 0);
+  };
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fpos = ((lane >> 4) ^ ring_f((lane >> 2) & 3)) << 4;
+  const int a_off = (wm * TM + (lane & 15)) * 64 + fpos, b_off = (BM + wn * TNn + (lane & 15)) * 64 + fpos;
+
+  const int nk = K / 32;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(STAGES - 2, nk - 1 - kt);          // stages allowed to stay in flight
+    if (ahead >= 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+    const char* st = smem + (kt % STAGES) * STAGE_BYTES;
+    bf16x8 af[MI], bfr[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  }
+  // ---- epilogue through a per-wave f32 LDS tile [64][68], 64 output rows at a time
+  __syncthreads();
+  constexpr int ELD = 68;
+  float* ew = (float*)smem + wave * (64 * ELD);
+  const bool nfast = (N % 4 == 0) && (e.ldc % 4 == 0) && (EPI != LDMAE_EPI_GATE_RES || e.rows_per_batch % 64 == 0);
+#pragma unroll
+  for (int half = 0; half < TM / 64; ++half) {
+#pragma unroll
+    for (int cblk = 0; cblk < TNn / 64; ++cblk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ew[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[half * 4 + i][cblk * 4 + j][r];
+      const int mb = m0 + wm * TM + half * 64, nb = n0 + wn * TNn + cblk * 64, col = (lane & 15) * 4;
+      if (nfast && mb + 64 <= M && nb + 64 <= N) {
+        const Epi4<EPI, OutT> ep(e, mb, nb + col, N);
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 4 + (lane >> 4);
+          ep.apply(mb + row, *(const float4*)(ew + row * ELD + col));
+        }
+      } else {
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 4 + (lane >> 4);
+          const float4 v = *(const float4*)(ew + row * ELD + col);
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int j = 0; j < 4; ++j) epi_store<EPI, OutT>(e, mb + row, nb + col + j, M, N, vv[j]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // f32 NT GEMM: 64x64 tile, 256 threads (2x2 waves, 32x32 per wave), BK = 16, register staged.
 // ------------------------------------------------------------------------------------------------
 constexpr int F_BM = 64, F_BN = 64, F_BK = 16, F_LD = 20;   // LDS row stride (floats), 80 B keeps 16-B alignment
@@ -299,6 +446,136 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restric
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 TN GEMM, ring-pipelined: 256(n) x 256(k) output tile, 8 waves (2 x 4, 128 x 64 per wave), 32 token rows per
+// step, STAGES LDS buffers in flight across the per-step barrier (same protocol as gemm_nt_ring_kernel).
+// Stage image: A rows then B rows, [32 m][256 cols] bf16 = 512-B rows; 16-B chunk ch of row r sits at
+// ch ^ sw(r), sw(r) = ((r&3)<<1) | (((r>>3)&1)<<3): the 32 lanes of a ds_read_b64_tr_b16 half hit 32 distinct
+// 8-B bank pairs.  Optional fused bias gradient: waves of the k-tile-0 column also run one MFMA per A fragment
+// against an all-ones B operand (column sums of A on the matrix core, no extra pass over dY).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tnr_sw(int r) { return ((r & 3) << 1) | (((r >> 3) & 1) << 3); }
+
+template <int STAGES>
+__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, float* __restrict__ P,
+                                                           float* __restrict__ Pb, int M, int N, int K, int lda, int ldb,
+                                                           int rows_per_split) {
+  constexpr int BNn = 256, BKk = 256, WNn = 2, WKk = 4, MI = 8, NI = 4, STEP = 32;
+  constexpr int OP_BYTES = STEP * 512, STAGE_BYTES = 2 * OP_BYTES, PPW = (2 * OP_BYTES / 1024) / 8;   // 32 pieces / 8 waves = 4
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave / WKk, wk = wave % WKk;
+  const int tiles_k = (K + BKk - 1) / BKk, tiles_n = (N + BNn - 1) / BNn;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = lid % (tiles_k * tiles_n), split = lid / (tiles_k * tiles_n);
+  const int n0 = (tile / tiles_k) * BNn, k0 = (tile % tiles_k) * BKk;
+  const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+  const int nsteps = (mend - mbeg) / STEP;               // host guarantees multiples of 32
+  const bool want_bias = Pb != nullptr && k0 == 0 && wk == 0;
+
+  const bf16* src[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int piece = wave * PPW + i;                    // 0..15 A, 16..31 B ; piece = 2 rows x 512 B
+    const bool isB = piece >= 16;
+    const int row = (piece & 15) * 2 + (lane >> 5);
+    const int ch = (lane & 31) ^ tnr_sw(row);
+    const int col = isB ? min(k0 + ch * 8, K - 8) : min(n0 + ch * 8, N - 8);
+    src[i] = (isB ? B + (size_t)row * ldb : A + (size_t)row * lda) + col;
+  }
+  const size_t astep = (size_t)STEP * lda, bstep = (size_t)STEP * ldb;
+  auto issue = [&](int st) {
+    char* base = smem + (st % STAGES) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const bool isB = (wave * PPW + i) >= 16;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (size_t)mbeg * (isB ? ldb : lda) + st * (isB ? bstep : astep)),
+                                       LDS_PTR(void, base + (wave * PPW + i) * 1024), 16, 0, 0);
+    }
+  };
+  f32x4 acc[MI][NI], accb[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // transposed fragment: rows 8g+q (+4), 16 columns starting at c0
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int r0 = 8 * g + q, r1 = r0 + 4;
+  auto frag = [&](const char* op, int c0) -> bf16x8 {
+    const int ch = (c0 >> 3) + (p >> 1);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, op + r0 * 512 + ((ch ^ tnr_sw(r0)) << 4) + ((p & 1) << 3)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, op + r1 * 512 + ((ch ^ tnr_sw(r1)) << 4) + ((p & 1) << 3)));
+    union { bf16x8 v; s16x4 h[2]; } u;
+    u.h[0] = lo; u.h[1] = hi;
+    return u.v;
+  };
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nsteps) issue(s);
+  for (int st = 0; st < nsteps; ++st) {
+    const int ahead = min(STAGES - 2, nsteps - 1 - st);
+    if (ahead >= 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + STAGES - 1 < nsteps) issue(st + STAGES - 1);
+    const char* ta = smem + (st % STAGES) * STAGE_BYTES;
+    const char* tb = ta + OP_BYTES;
+    bf16x8 af[MI], bfr[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bfr[j] = frag(tb, wk * 64 + j * 16);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[i] = frag(ta, wn * 128 + i * 16);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (want_bias) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  // ---- epilogue: f32 partial tile through a per-wave LDS tile for row-contiguous stores
+  __syncthreads();
+  constexpr int ELD = 68;
+  float* ew = (float*)smem + wave * (64 * ELD);
+  float* out = P + (size_t)split * N * K;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ew[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[half * 4 + i][j][r];
+    const int nb = n0 + wn * 128 + half * 64, kb = k0 + wk * 64, col = (lane & 15) * 4;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + (lane >> 4);
+      const float4 v = *(const float4*)(ew + row * ELD + col);
+      if (nb + row < N && kb + col < K) *(float4*)(out + (size_t)(nb + row) * K + kb + col) = v;   // K % 4 == 0 (host check)
+    }
+  }
+  if (want_bias && (lane & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 128 + i * 16 + (lane >> 4) * 4 + r;
+        if (n < N) Pb[(size_t)split * N + n] = accb[i][r];
+      }
+  }
+}
+
 // f32 TN: 64(n) x 64(k) tile, 16 rows of M per step; A[l&15][k=l>>4] fragments are single floats
 constexpr int FT_BN = 64, FT_BK = 64, FT_BM = 16, FT_LD = 68;
 
@@ -391,8 +668,29 @@ template <typename OutT>
 static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
                      hipStream_t st) {
   const long pi = (ldmae_prof_is_on() && dtype == LDMAE_BF16) ? ldmae_prof_begin(st, 2.0 * M * N * K) : -1;
+  const int variant = ldmae_tune_get(0) == 0 ? 4 : ldmae_tune_get(0) - 1;  // default: 256x256 ring, 3 stages; tune value v selects variant v-1
+#define RING(E, BM_, BN_, WM_, WN_, ST_)                                                                                          \
+  {                                                                                                                               \
+    constexpr int lds_ring = ST_ * (BM_ + BN_) * 64, lds_epi = WM_ * WN_ * 64 * 68 * 4;                                           \
+    constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;                                                                   \
+    static bool attr_done = false;                                                                                                 \
+    if (!attr_done) {                                                                                                              \
+      hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BM_, BN_, WM_, WN_, ST_, E, OutT>,                                      \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                        \
+      attr_done = true;                                                                                                            \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<BM_, BN_, WM_, WN_, ST_, E, OutT>), dim3(cdiv(M, BM_) * cdiv(N, BN_)),                \
+                       dim3(WM_ * WN_ * 64), lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                      \
+  }
 #define NT_LAUNCH(E)                                                                                                             \
-  if (dtype == LDMAE_BF16)                                                                                                       \
+  if (dtype == LDMAE_BF16 && variant == 1 && K % 32 == 0) RING(E, 128, 128, 2, 2, 4)                                              \
+  else if (dtype == LDMAE_BF16 && variant == 2 && K % 32 == 0) RING(E, 256, 128, 4, 2, 4)                                         \
+  else if (dtype == LDMAE_BF16 && variant == 3 && K % 32 == 0) RING(E, 256, 256, 2, 4, 4)                                         \
+  else if (dtype == LDMAE_BF16 && variant == 4 && K % 32 == 0) RING(E, 256, 256, 2, 4, 3)                                         \
+  else if (dtype == LDMAE_BF16 && variant == 5 && K % 32 == 0) RING(E, 128, 256, 2, 2, 3)                                         \
+  else if (dtype == LDMAE_BF16 && variant == 6 && K % 32 == 0) RING(E, 256, 128, 2, 2, 3)                                         \
+  else if (dtype == LDMAE_BF16 && variant == 7 && K % 32 == 0) RING(E, 128, 256, 2, 2, 4)                                         \
+  else if (dtype == LDMAE_BF16)                                                                                                   \
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<E, OutT>), dim3(cdiv(M, NT_BM) * cdiv(N, NT_BN)), dim3(256), 4 * NT_TILE_BYTES, st, \
                        (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                                                    \
   else                                                                                                                           \
@@ -405,6 +703,7 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
     default: NT_LAUNCH(LDMAE_EPI_BIAS_GELU); break;
   }
 #undef NT_LAUNCH
+#undef RING
   if (pi >= 0) ldmae_prof_end(pi, st);
   LDMAE_CHECK_LAUNCH("gemm_nt");
   return LDMAE_OK;
@@ -443,25 +742,30 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
                                  : launch_nt<float>(dtype, epi, A, B, M, N, K, lda, ldb, e, as_stream(stream));
 }
 
-extern "C" long ldmae_gemm_tn_workspace_bytes(int dtype, int M, int N, int K) {
-  int splits = ldmae_gemm_tn_splits(dtype, M, N, K);
-  return splits <= 1 ? 0 : (long)splits * N * K * 4;
-}
-
-extern "C" int ldmae_gemm_tn_splits(int dtype, int M, int N, int K) {
-  const int bn = dtype == LDMAE_BF16 ? TN_BN : FT_BN, bk = dtype == LDMAE_BF16 ? TN_BK : FT_BK;
+static int tn_plan(int dtype, int M, int N, int K, int* rows_out) {
+  const bool ring = dtype == LDMAE_BF16 && ldmae_tune_get(1) == 0 && M % 32 == 0;
+  const int bn = ring ? 256 : (dtype == LDMAE_BF16 ? TN_BN : FT_BN), bk = ring ? 256 : (dtype == LDMAE_BF16 ? TN_BK : FT_BK);
   const long tiles = (long)cdiv(N, bn) * cdiv(K, bk);
-  const int step = 64;
-  long want = (2048 + tiles - 1) / tiles;                     // aim for >= ~2048 workgroups (8 per CU)
-  long maxs = M / (step * 8) > 0 ? M / (step * 8) : 1;        // at least 8 steps of 64 rows per split
+  const long target = ring ? 512 : 2048;                     // ring: 1 workgroup / CU -> two rounds of 256
+  long want = target / tiles;
+  long maxs = M / (64 * 8) > 0 ? M / (64 * 8) : 1;           // at least 8 steps of 64 rows per split
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
-  if (s > 64) s = 64;
-  return (int)s;
+  if (s > 128) s = 128;
+  int rows = (int)(((long)M + s - 1) / s);
+  rows = (rows + 63) / 64 * 64;
+  if (rows_out) *rows_out = rows;
+  return (M + rows - 1) / rows;
 }
 
-extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, int M, int N, int K, float beta,
-                             float* workspace, long workspace_bytes, void* stream) {
+extern "C" int ldmae_gemm_tn_splits(int dtype, int M, int N, int K) { return tn_plan(dtype, M, N, K, nullptr); }
+
+extern "C" long ldmae_gemm_tn_workspace_bytes(int dtype, int M, int N, int K) {
+  return (long)tn_plan(dtype, M, N, K, nullptr) * ((long)N * K + N) * 4;
+}
+
+extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, float* dbias, int M, int N, int K,
+                             float beta, float* workspace, long workspace_bytes, void* stream) {
   LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "gemm_tn: bad dtype %d", dtype);
   LDMAE_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "gemm_tn: empty problem or null pointer");
   LDMAE_REQUIRE(beta == 0.f || beta == 1.f, "gemm_tn: beta must be 0 or 1");
@@ -469,18 +773,21 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   LDMAE_REQUIRE(N % al == 0 && K % al == 0 && lda % al == 0 && ldb % al == 0, "gemm_tn: N=%d K=%d lda=%d ldb=%d must be multiples of %d", N, K, lda, ldb, al);
   LDMAE_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0, "gemm_tn: pointers must be 16-B aligned");
   if (dtype == LDMAE_BF16) LDMAE_REQUIRE(M % TN_BM == 0, "gemm_tn(bf16): M=%d must be a multiple of %d", M, TN_BM);
-  int splits = ldmae_gemm_tn_splits(dtype, M, N, K);
-  int rows = (int)(((long)M + splits - 1) / splits);
-  rows = (rows + 63) / 64 * 64;
-  splits = (M + rows - 1) / rows;
+  int rows = 0;
+  const int splits = tn_plan(dtype, M, N, K, &rows);
+  const bool ring = dtype == LDMAE_BF16 && ldmae_tune_get(1) == 0 && M % 32 == 0;
   hipStream_t st = as_stream(stream);
-  float* P = C;
-  const bool direct = (splits == 1 && beta == 0.f);
-  if (!direct) {
-    LDMAE_REQUIRE(workspace && workspace_bytes >= (long)splits * N * K * 4, "gemm_tn: workspace too small (%ld < %ld)", workspace_bytes, (long)splits * N * K * 4);
-    P = workspace;
-  }
-  if (dtype == LDMAE_BF16) {
+  LDMAE_REQUIRE(workspace && workspace_bytes >= (long)splits * ((long)N * K + N) * 4, "gemm_tn: workspace too small (%ld < %ld)",
+                workspace_bytes, (long)splits * ((long)N * K + N) * 4);
+  float* P = workspace;
+  float* Pb = workspace + (size_t)splits * N * K;
+  if (ring) {
+    constexpr int lds = 8 * 64 * 68 * 4;   // epilogue region (139 KiB) >= 3 stages x 32 KiB
+    static bool attr_done = false;
+    if (!attr_done) { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    const unsigned grid = cdiv(N, 256) * cdiv(K, 256) * splits;
+    hipLaunchKernelGGL(gemm_tn_ring_kernel<3>, dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+  } else if (dtype == LDMAE_BF16) {
     const unsigned grid = cdiv(N, TN_BN) * cdiv(K, TN_BK) * splits;
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 4 * TN_TILE_BYTES, st, (const bf16*)A, (const bf16*)B, P, M, N, K, lda, ldb, rows);
   } else {
@@ -488,11 +795,16 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
     hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(grid), dim3(256), 0, st, (const float*)A, (const float*)B, P, M, N, K, lda, ldb, rows);
   }
   LDMAE_CHECK_LAUNCH("gemm_tn");
-  if (!direct) {
+  {
     const long n = (long)N * K;
     const unsigned grid = (unsigned)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, P, C, n, splits, beta);
+    if (dbias && ring) hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(N / 4, 256)), dim3(256), 0, st, Pb, dbias, (long)N, splits, beta);
     LDMAE_CHECK_LAUNCH("splitk_reduce");
+  }
+  if (dbias && !ring) {   // non-ring paths: separate column-sum pass (elementwise.hip), re-using the workspace
+    LDMAE_REQUIRE(workspace_bytes >= ldmae_colsum_workspace_bytes(M, N), "gemm_tn: workspace too small for the bias-gradient pass");
+    return ldmae_colsum(dtype, A, lda, M, N, dbias, beta, workspace, stream);
   }
   return LDMAE_OK;
 }

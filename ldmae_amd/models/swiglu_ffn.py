@@ -27,9 +27,9 @@ class _SwiGLUFn(torch.autograd.Function):
     def backward(ctx, g):
         x2, h12, hid, W12T, W3T = ctx.saved_tensors
         g2 = g.contiguous().view(x2.shape[0], -1)
-        dw3, db3 = ops.gemm_tn(g2, hid), ops.colsum(g2)
+        dw3, db3 = ops.gemm_tn(g2, hid, with_bias=True)
         dh12 = ops.swiglu_bwd(ops.gemm_nt(g2, W3T), h12)
-        dw12, db12 = ops.gemm_tn(dh12, x2), ops.colsum(dh12)
+        dw12, db12 = ops.gemm_tn(dh12, x2, with_bias=True)
         return ops.gemm_nt(dh12, W12T).view(*g.shape[:-1], -1), dw12, db12, dw3, db3
 
 

@@ -75,19 +75,21 @@ def gemm_nt_gelu(a, b, bias, save_pre=True):
     return out, pre
 
 
-def gemm_tn(a, b, out=None, beta=0.0):
-    """out[N,K] (f32) = beta*out + a[M,N]^T @ b[M,K]   (weight gradient)."""
+def gemm_tn(a, b, out=None, beta=0.0, with_bias=False):
+    """out[N,K] (f32) = beta*out + a[M,N]^T @ b[M,K]   (weight gradient).  with_bias: also return the column sums of `a`
+    (the bias gradient of the same Linear), fused into the same kernel on the bf16 path."""
     M, N = a.shape
     K = b.shape[1]
     if out is None:
         out = torch.empty(N, K, dtype=torch.float32, device=a.device)
         beta = 0.0
+    dbias = torch.empty(N, dtype=torch.float32, device=a.device) if with_bias else None
     d = dt(a.dtype)
-    nb = L.load().ldmae_gemm_tn_workspace_bytes(d, M, N, K)
-    nb = max(nb, N * K * 4) if beta != 0.0 else nb
+    nb = max(L.load().ldmae_gemm_tn_workspace_bytes(d, M, N, K), L.load().ldmae_colsum_workspace_bytes(M, N) if with_bias else 0)
     ws = workspace(nb, a.device, "tn")
-    call("ldmae_gemm_tn", d, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), M, N, K, float(beta), ptr(ws), ws.numel() * 4, stream())
-    return out
+    call("ldmae_gemm_tn", d, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), ptr(dbias), M, N, K, float(beta), ptr(ws), ws.numel() * 4,
+         stream())
+    return (out, dbias) if with_bias else out
 
 
 def colsum(x, out=None, beta=0.0):

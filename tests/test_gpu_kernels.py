@@ -81,7 +81,7 @@ def test_gemm_nt_gate_res_pos_gelu(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("M,N,K", [(128, 384, 192), (4096, 16, 768), (8192, 576, 192), (256, 1152, 200)])
+@pytest.mark.parametrize("M,N,K", [(128, 384, 192), (4096, 16, 768), (8192, 576, 192), (256, 1152, 200), (16384, 768, 2048), (32768, 2304, 768)])
 def test_gemm_tn(ops, dtype, M, N, K):
     if dtype == BF16 and K % 8:
         pytest.skip("bf16 needs K % 8 == 0")
@@ -93,6 +93,8 @@ def test_gemm_tn(ops, dtype, M, N, K):
     assert rel_err(out2.cpu(), 2 * ref) < 1e-5
     # deterministic: two launches are bitwise identical
     assert torch.equal(ops.gemm_tn(dev(a, dtype), dev(b, dtype)), out)
+    out3, db = ops.gemm_tn(dev(a, dtype), dev(b, dtype), with_bias=True)      # fused bias gradient = column sums of a
+    assert torch.equal(out3, out) and rel_err(db.cpu(), q(a, dtype).double().sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
