@@ -70,6 +70,20 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
 }
 __device__ __forceinline__ int acc_row(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
+// K/V (Q/dO) tiles travel through a STAGES-deep LDS ring: global_load_lds stays in flight across the per-tile
+// barrier (raw s_barrier + counted vmcnt), `ahead` = number of later stages allowed to be still in flight.
+template <int PPW, int STAGES> __device__ __forceinline__ void ring_wait(int ahead) {
+  if (ahead >= 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
+  else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
+constexpr int ATT_STAGES = 3;
+template <int I> struct IC { static constexpr int value = I; };
+// running-max update threshold (log2 units): the O / l rescale is skipped while no query of the wave saw its
+// maximum grow by more than this (P then stays <= 2^RESCALE_THR; exact softmax either way after the final 1/l)
+constexpr float RESCALE_THR = 6.0f;
+
 // ================================================================================================ forward, bf16
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
@@ -94,17 +108,21 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     for (int t = 0; t < 16; ++t) oacc[d][t] = 0.f;
   float ms = -1e30f, l = 0.f;
   const int nt = N / 64;
-  auto stage = [&](int buf, int kt) {
-    stage_tile<HD, 64>(kp + (size_t)kt * 64 * HD, HD, 63, smem + buf * 2 * TB, wave, lane);
-    stage_tile<HD, 64>(vp + (size_t)kt * 64 * HD, HD, 63, smem + buf * 2 * TB + TB, wave, lane);
+  constexpr int PPW = 2 * (TB / 1024) / 4;
+  auto stage = [&](int kt) {
+    char* base = smem + (kt % ATT_STAGES) * 2 * TB;
+    stage_tile<HD, 64>(kp + (size_t)kt * 64 * HD, HD, 63, base, wave, lane);
+    stage_tile<HD, 64>(vp + (size_t)kt * 64 * HD, HD, 63, base + TB, wave, lane);
   };
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nt; ++kt) {
-    if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
-    const char* Kt = smem + cur * 2 * TB;
+#pragma unroll
+  for (int st = 0; st < ATT_STAGES - 1; ++st)
+    if (st < nt) stage(st);
+  auto body = [&](auto ST, int kt) {
+    constexpr int st = decltype(ST)::value;
+    ring_wait<PPW, ATT_STAGES>(min(ATT_STAGES - 2, nt - 1 - kt));
+    __builtin_amdgcn_s_barrier();
+    if (kt + ATT_STAGES - 1 < nt) stage(kt + ATT_STAGES - 1);
+    const char* Kt = smem + st * 2 * TB;
     const char* Vt = Kt + TB;
     f32x16 s[2];
 #pragma unroll
@@ -117,19 +135,22 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     float mx = s[0][0];
 #pragma unroll
     for (int t = 0; t < 16; ++t) mx = fmaxf(mx, fmaxf(s[0][t], s[1][t]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float ms_new = fmaxf(ms, mx * c), alpha = exp2f(ms - ms_new);
-    ms = ms_new;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
+    if (__builtin_amdgcn_ballot_w64(mx > ms + RESCALE_THR) != 0) {      // wave-uniform: some query's max grew a lot
+      const float ms_new = fmaxf(ms, mx), alpha = EXP2(ms - ms_new);
+      ms = ms_new;
+      l *= alpha;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) oacc[d][t] *= alpha;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) { const float p = exp2f(s[kb][t] * c - ms); s[kb][t] = p; rs += p; }
-    l = l * alpha + rs;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int t = 0; t < 16; ++t) oacc[d][t] *= alpha;
+      for (int t = 0; t < 16; ++t) { const float p = EXP2(s[kb][t] * c - ms); s[kb][t] = p; rs += p; }
+    l += rs;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -138,9 +159,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
 #pragma unroll
         for (int d = 0; d < DB; ++d) oacc[d] = MFMA_BF16(frag_tr<HD>(Vt, kb * 32 + 16 * s2, d * 32, lane), pf, oacc[d]);
       }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
+  };
+  for (int kt = 0; kt < nt; kt += ATT_STAGES) {
+    body(IC<0>{}, kt);
+    if (kt + 1 < nt) body(IC<1>{}, kt + 1);
+    if (kt + 2 < nt) body(IC<2>{}, kt + 2);
   }
   l += __shfl_xor(l, 32, 64);
   if (!active) return;
@@ -190,7 +213,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
                                                                  int H, int N, float scale) {
   constexpr int KS = HD / 16, DB = HD / 32, TB = 64 * HD * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q tile | dO tile | lse2[64] delta[64]]
-  constexpr int BUF = 2 * TB + 512;
+  constexpr int BUF = 2 * TB + 1024;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const float c = scale * 1.4426950408889634f;
   const int kblocks = (N + 127) / 128;
@@ -214,23 +237,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
 #pragma unroll
     for (int t = 0; t < 16; ++t) { dkacc[d][t] = 0.f; dvacc[d][t] = 0.f; }
   const int nt = N / 64;
-  auto stage = [&](int buf, int qt) {
-    char* base = smem + buf * BUF;
+  constexpr int PPW = 2 * (TB / 1024) / 4 + 1;
+  const float* rowc = (wave & 1) ? DELTA + (size_t)bh * N : LSE + (size_t)bh * N;     // wave 0/2: lse, wave 1/3: delta
+  auto stage = [&](int qt) {
+    char* base = smem + (qt % ATT_STAGES) * BUF;
     stage_tile<HD, 64>(qp + (size_t)qt * 64 * HD, HD, 63, base, wave, lane);
     stage_tile<HD, 64>(dop + (size_t)qt * 64 * dold, dold, 63, base + TB, wave, lane);
-    if (threadIdx.x < 64) ((float*)(base + 2 * TB))[threadIdx.x] = LSE[(size_t)bh * N + qt * 64 + threadIdx.x] * 1.4426950408889634f;
-    else if (threadIdx.x < 128) ((float*)(base + 2 * TB))[threadIdx.x] = DELTA[(size_t)bh * N + qt * 64 + threadIdx.x - 64];
+    // 64 floats of lse (slot 0) / delta (slot 1); waves 2,3 fill scratch slots so every wave issues PPW loads
+    __builtin_amdgcn_global_load_lds(GLB_PTR(rowc + qt * 64 + lane), LDS_PTR(void, base + 2 * TB + wave * 256), 4, 0, 0);
   };
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int qt = 0; qt < nt; ++qt) {
-    if (qt + 1 < nt) stage(cur ^ 1, qt + 1);
-    const char* Qt = smem + cur * BUF;
+#pragma unroll
+  for (int st = 0; st < ATT_STAGES - 1; ++st)
+    if (st < nt) stage(st);
+  auto body = [&](auto ST, int qt) {
+    constexpr int st = decltype(ST)::value;
+    ring_wait<PPW, ATT_STAGES>(min(ATT_STAGES - 2, nt - 1 - qt));
+    __builtin_amdgcn_s_barrier();
+    if (qt + ATT_STAGES - 1 < nt) stage(qt + ATT_STAGES - 1);
+    const char* Qt = smem + st * BUF;
     const char* dOt = Qt + TB;
-    const float* lse2 = (const float*)(Qt + 2 * TB);
-    const float* dl = lse2 + 64;
+    const float* lse_t = (const float*)(Qt + 2 * TB);
+    const float* dl = lse_t + 64;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16 s, dp;
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int row = qb * 32 + acc_row(t, h);
-        const float p = exp2f(s[t] * c - lse2[row]);
+        const float p = EXP2(s[t] * c - lse_t[row] * 1.4426950408889634f);
         s[t] = p;
         dp[t] = p * (dp[t] - dl[row]);
       }
@@ -258,9 +285,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
+  };
+  for (int qt = 0; qt < nt; qt += ATT_STAGES) {
+    body(IC<0>{}, qt);
+    if (qt + 1 < nt) body(IC<1>{}, qt + 1);
+    if (qt + 2 < nt) body(IC<2>{}, qt + 2);
   }
   if (!active) return;
   bf16* dkp = dK + ((size_t)bh * N + k0 + r) * HD;
@@ -307,17 +336,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
 #pragma unroll
     for (int t = 0; t < 16; ++t) dqacc[d][t] = 0.f;
   const int nt = N / 64;
-  auto stage = [&](int buf, int kt) {
-    stage_tile<HD, 64>(kp + (size_t)kt * 64 * HD, HD, 63, smem + buf * 2 * TB, wave, lane);
-    stage_tile<HD, 64>(vp + (size_t)kt * 64 * HD, HD, 63, smem + buf * 2 * TB + TB, wave, lane);
+  constexpr int PPW = 2 * (TB / 1024) / 4;
+  auto stage = [&](int kt) {
+    char* base = smem + (kt % ATT_STAGES) * 2 * TB;
+    stage_tile<HD, 64>(kp + (size_t)kt * 64 * HD, HD, 63, base, wave, lane);
+    stage_tile<HD, 64>(vp + (size_t)kt * 64 * HD, HD, 63, base + TB, wave, lane);
   };
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nt; ++kt) {
-    if (kt + 1 < nt) stage(cur ^ 1, kt + 1);
-    const char* Kt = smem + cur * 2 * TB;
+#pragma unroll
+  for (int st = 0; st < ATT_STAGES - 1; ++st)
+    if (st < nt) stage(st);
+  auto body = [&](auto ST, int kt) {
+    constexpr int st = decltype(ST)::value;
+    ring_wait<PPW, ATT_STAGES>(min(ATT_STAGES - 2, nt - 1 - kt));
+    __builtin_amdgcn_s_barrier();
+    if (kt + ATT_STAGES - 1 < nt) stage(kt + ATT_STAGES - 1);
+    const char* Kt = smem + st * 2 * TB;
     const char* Vt = Kt + TB;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -330,7 +363,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
         dp = MFMA_BF16(frag_row<HD>(Vt, kb * 32, ks, lane), dof[ks], dp);
       }
 #pragma unroll
-      for (int t = 0; t < 16; ++t) dp[t] = exp2f(s[t] * c - lse2) * (dp[t] - dl);
+      for (int t = 0; t < 16; ++t) dp[t] = EXP2(s[t] * c - lse2) * (dp[t] - dl);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 dsf = acc_frag(dp, s2);
@@ -338,9 +371,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
         for (int d = 0; d < DB; ++d) dqacc[d] = MFMA_BF16(frag_tr<HD>(Kt, kb * 32 + 16 * s2, d * 32, lane), dsf, dqacc[d]);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
+  };
+  for (int kt = 0; kt < nt; kt += ATT_STAGES) {
+    body(IC<0>{}, kt);
+    if (kt + 1 < nt) body(IC<1>{}, kt + 1);
+    if (kt + 2 < nt) body(IC<2>{}, kt + 2);
   }
   if (!active) return;
   bf16* dqp = dQ + ((size_t)bh * N + q0 + r) * HD;
@@ -598,7 +633,7 @@ extern "C" int ldmae_attention_fwd(int dtype, const void* q, const void* k, cons
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const float c = scale * 1.4426950408889634f;
   if (dtype == LDMAE_BF16) {
-#define L(HD) hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(grid), dim3(256), 2 * 2 * 64 * HD * 2, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c)
+#define L(HD) hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(grid), dim3(256), ATT_STAGES * 2 * 64 * HD * 2, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c)
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {
@@ -624,8 +659,8 @@ extern "C" int ldmae_attention_bwd(int dtype, const void* q, const void* k, cons
   if (dtype == LDMAE_BF16) {
     hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(dgrid), dim3(256), 0, st, (const bf16*)o, (const bf16*)do_, delta, B, H, N, hd);
 #define L(HD) { \
-    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), 2 * (2 * 64 * HD * 2 + 512), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale); \
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), 2 * 2 * 64 * HD * 2, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale); }
+    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), ATT_STAGES * (2 * 64 * HD * 2 + 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale); \
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), ATT_STAGES * 2 * 64 * HD * 2, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale); }
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {

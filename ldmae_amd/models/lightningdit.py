@@ -159,9 +159,9 @@ class _DiTBlockFn(torch.autograd.Function):
          n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T) = ctx.saved_tensors
         B, N, D, H, hd, eps, dtype = ctx.dims
         M = B * N
-        # f32 residual-stream gradient, accumulated IN PLACE when the engine hands us a whole contiguous
-        # buffer (block outputs feed only the next block / final layer, whose backward allocates it).
-        dx = gout.view(M, D) if (gout.is_contiguous() and gout._base is None) else gout.contiguous().view(M, D).clone()
+        # f32 residual-stream gradient: accumulated IN PLACE in the buffer the engine hands us (block outputs feed
+        # only the next block / final layer, whose backward allocates that buffer) -- no 805 MB copy per block.
+        dx = gout.view(M, D) if gout.is_contiguous() else gout.contiguous().view(M, D)
         dmod = torch.empty_like(mod)
         s1, g1, s2, g2 = mod[:, D:2 * D], mod[:, 2 * D:3 * D], mod[:, 4 * D:5 * D], mod[:, 5 * D:6 * D]
         # ---- MLP branch
