@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldmae_hip.so")
 
 F32, BF16 = 0, 1
-EPI_BIAS, EPI_GATE_RES, EPI_BIAS_POS, EPI_BIAS_GELU = 0, 1, 2, 3
+EPI_BIAS, EPI_GATE_RES, EPI_BIAS_POS, EPI_BIAS_GELU, EPI_SWIGLU, EPI_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
 
 _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 

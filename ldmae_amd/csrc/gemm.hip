@@ -211,7 +211,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
     const int piece = wave * PPW + i;                        // 0 .. PIECES-1 ; A pieces first
     const int row = piece * 16 + (lane >> 2);                // row inside the stage image
     const int c = (lane & 3) ^ ring_f((lane >> 4) & 3);      // global chunk stored at LDS position lane&3
-    src[i] = row < BM ? A + (size_t)min(m0 + row, M - 1) * lda + c * 8 : B + (size_t)min(n0 + row - BM, N - 1) * ldb + c * 8;
+    int brow = n0 + row - BM;
+    if constexpr (EPI == LDMAE_EPI_SWIGLU) {   // wave slice of 64 B-rows = 32 rows of x1 | the matching 32 rows of x2 (N = 2*Hs)
+      const int rl = row - BM;
+      brow = ((rl & 32) ? (N >> 1) : 0) + (n0 >> 1) + (rl >> 6) * 32 + (rl & 31);
+    }
+    src[i] = row < BM ? A + (size_t)min(m0 + row, M - 1) * lda + c * 8 : B + (size_t)min(brow, N - 1) * ldb + c * 8;
   }
   auto issue = [&](int kt) {
     char* base = smem + (kt % STAGES) * STAGE_BYTES;
@@ -255,6 +260,80 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
   __syncthreads();
   constexpr int ELD = 68;
   float* ew = (float*)smem + wave * (64 * ELD);
+  if constexpr (EPI == LDMAE_EPI_SWIGLU) {
+    // ew cols 0..31 = x1 (hid columns hc0..), 32..63 = x2.  Values are rounded to bf16 BEFORE silu so the result is
+    // bit-identical to the unfused ldmae_swiglu_fwd on the stored h12.
+    static_assert(EPI != LDMAE_EPI_SWIGLU || TNn == 64, "swiglu epilogue needs 64-column wave slices");
+    const int Hs = N >> 1, hc = (n0 >> 1) + wn * 32 + (lane & 7) * 4;
+    bf16* h12 = (bf16*)e.C;
+    bf16* hid = (bf16*)e.xout;
+    const float4 b1 = e.bias ? *(const float4*)(e.bias + hc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b2 = e.bias ? *(const float4*)(e.bias + Hs + hc) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int half = 0; half < TM / 64; ++half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ew[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[half * 4 + i][j][r];
+      const int mb = m0 + wm * TM + half * 64;
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), m = mb + row;
+        const float4 u = *(const float4*)(ew + row * ELD + (lane & 7) * 4), v = *(const float4*)(ew + row * ELD + 32 + (lane & 7) * 4);
+        if (m < M && hc < Hs) {
+          bf16x4 x1, x2, ho;
+          x1[0] = (bf16)(u.x + b1.x); x1[1] = (bf16)(u.y + b1.y); x1[2] = (bf16)(u.z + b1.z); x1[3] = (bf16)(u.w + b1.w);
+          x2[0] = (bf16)(v.x + b2.x); x2[1] = (bf16)(v.y + b2.y); x2[2] = (bf16)(v.z + b2.z); x2[3] = (bf16)(v.w + b2.w);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float a = (float)x1[j]; ho[j] = (bf16)(a / (1.f + __expf(-a)) * (float)x2[j]); }
+          *(bf16x4*)(h12 + (size_t)m * N + hc) = x1;
+          *(bf16x4*)(h12 + (size_t)m * N + Hs + hc) = x2;
+          *(bf16x4*)(hid + (size_t)m * Hs + hc) = ho;
+        }
+      }
+    }
+    return;
+  }
+  if constexpr (EPI == LDMAE_EPI_SWIGLU_BWD) {
+    // acc = dhid (N = Hs columns); a,b = h12[:, n], h12[:, Hs+n]; dh12 = (g*b*s*(1+a(1-s)), g*a*s) with g rounded to bf16 first
+    const int Hs = N;
+    const bf16* h12 = (const bf16*)e.xin;
+    bf16* dh12 = (bf16*)e.C;
+#pragma unroll
+    for (int half = 0; half < TM / 64; ++half) {
+#pragma unroll
+      for (int cblk = 0; cblk < TNn / 64; ++cblk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ew[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[half * 4 + i][cblk * 4 + j][r];
+        const int mb = m0 + wm * TM + half * 64, n = n0 + wn * TNn + cblk * 64 + (lane & 15) * 4;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 4 + (lane >> 4), m = mb + row;
+          const float4 gv = *(const float4*)(ew + row * ELD + (lane & 15) * 4);
+          if (m < M && n < Hs) {
+            const bf16x4 av = *(const bf16x4*)(h12 + (size_t)m * 2 * Hs + n), bv = *(const bf16x4*)(h12 + (size_t)m * 2 * Hs + Hs + n);
+            const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+            bf16x4 da, db;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float g = (float)(bf16)gg[j], a = (float)av[j], b = (float)bv[j], sg = 1.f / (1.f + __expf(-a));
+              da[j] = (bf16)(g * b * sg * (1.f + a * (1.f - sg)));
+              db[j] = (bf16)(g * a * sg);
+            }
+            *(bf16x4*)(dh12 + (size_t)m * 2 * Hs + n) = da;
+            *(bf16x4*)(dh12 + (size_t)m * 2 * Hs + Hs + n) = db;
+          }
+        }
+      }
+    }
+    return;
+  }
   const bool nfast = (N % 4 == 0) && (e.ldc % 4 == 0) && (EPI != LDMAE_EPI_GATE_RES || e.rows_per_batch % 64 == 0);
 #pragma unroll
   for (int half = 0; half < TM / 64; ++half) {
@@ -700,6 +779,8 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
     case LDMAE_EPI_BIAS: NT_LAUNCH(LDMAE_EPI_BIAS); break;
     case LDMAE_EPI_GATE_RES: NT_LAUNCH(LDMAE_EPI_GATE_RES); break;
     case LDMAE_EPI_BIAS_POS: NT_LAUNCH(LDMAE_EPI_BIAS_POS); break;
+    case LDMAE_EPI_SWIGLU: RING(LDMAE_EPI_SWIGLU, 256, 256, 2, 4, 3); break;
+    case LDMAE_EPI_SWIGLU_BWD: RING(LDMAE_EPI_SWIGLU_BWD, 256, 256, 2, 4, 3); break;
     default: NT_LAUNCH(LDMAE_EPI_BIAS_GELU); break;
   }
 #undef NT_LAUNCH
@@ -735,6 +816,14 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
   } else if (epi == LDMAE_EPI_BIAS_GELU) {
     LDMAE_REQUIRE(C && ldc >= N, "gemm_nt: gelu epilogue needs C");
     e.C2 = xout;   /* pre-activation copy, same dtype/ld as C */
+  } else if (epi == LDMAE_EPI_SWIGLU) {
+    LDMAE_REQUIRE(dtype == LDMAE_BF16 && out_dtype == LDMAE_BF16, "gemm_nt: swiglu epilogue is bf16 only");
+    LDMAE_REQUIRE(C && xout && N % 256 == 0 && K % 32 == 0 && ldc == N, "gemm_nt: swiglu epilogue needs h12 (C, ldc = N), hid (xout), N %% 256 == 0 (N=%d)", N);
+    e.xout = xout;
+  } else if (epi == LDMAE_EPI_SWIGLU_BWD) {
+    LDMAE_REQUIRE(dtype == LDMAE_BF16 && out_dtype == LDMAE_BF16, "gemm_nt: swiglu-bwd epilogue is bf16 only");
+    LDMAE_REQUIRE(C && xin && N % 4 == 0 && K % 32 == 0, "gemm_nt: swiglu-bwd epilogue needs dh12 (C) and h12 (xin)");
+    e.xin = xin;
   } else {
     LDMAE_FAIL(LDMAE_ERR_INVALID, "gemm_nt: unknown epilogue %d", epi);
   }

@@ -145,8 +145,7 @@ class _DiTBlockFn(torch.autograd.Function):
         xmid, y1 = ops.gemm_nt_gate_res(o.view(M, D), Wp, pb, x2, g1, N)
         # MLP branch (:249)
         xm2, rstd2 = ops.rmsnorm_modulate_fwd(xmid, n2w, sh2, s2, N, dtype, eps)
-        h12 = ops.gemm_nt(xm2, W12, b12)
-        hid = ops.swiglu_fwd(h12)
+        h12, hid = ops.gemm_nt_swiglu(xm2, W12, b12)
         xout, y2 = ops.gemm_nt_gate_res(hid, W3, b3, xmid, g2, N)
         ctx.save_for_backward(x2, sc, cos, sin, mod, rstd1, xm1, qkv, q, k, v, o, lse, y1, xmid, rstd2, xm2, h12, hid, y2,
                               n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T)
@@ -167,7 +166,7 @@ class _DiTBlockFn(torch.autograd.Function):
         # ---- MLP branch
         dy2 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype)
         dW3, db3 = ops.gemm_tn(dy2, hid, with_bias=True)
-        dh12 = ops.swiglu_bwd(ops.gemm_nt(dy2, W3T), h12)
+        dh12 = ops.gemm_nt_swiglu_bwd(dy2, W3T, h12)
         dW12, db12 = ops.gemm_tn(dh12, xm2, with_bias=True)
         dxm2 = ops.gemm_nt(dh12, W12T)
         dn2 = ops.rmsnorm_modulate_bwd(dxm2, xmid, n2w, s2, rstd2, dx, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D], N)

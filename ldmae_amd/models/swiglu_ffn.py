@@ -17,8 +17,7 @@ class _SwiGLUFn(torch.autograd.Function):
         dt = x2.dtype
         W12, W12T = (w12, ops.cast_weight(w12, dt, True, False)[1]) if dt == torch.float32 else ops.cast_weight(w12, dt)
         W3, W3T = (w3, ops.cast_weight(w3, dt, True, False)[1]) if dt == torch.float32 else ops.cast_weight(w3, dt)
-        h12 = ops.gemm_nt(x2, W12, b12)
-        hid = ops.swiglu_fwd(h12)
+        h12, hid = ops.gemm_nt_swiglu(x2, W12, b12)
         out = ops.gemm_nt(hid, W3, b3)
         ctx.save_for_backward(x2, h12, hid, W12T, W3T)
         return out.view(*shp[:-1], -1)
@@ -28,7 +27,7 @@ class _SwiGLUFn(torch.autograd.Function):
         x2, h12, hid, W12T, W3T = ctx.saved_tensors
         g2 = g.contiguous().view(x2.shape[0], -1)
         dw3, db3 = ops.gemm_tn(g2, hid, with_bias=True)
-        dh12 = ops.swiglu_bwd(ops.gemm_nt(g2, W3T), h12)
+        dh12 = ops.gemm_nt_swiglu_bwd(g2, W3T, h12)
         dw12, db12 = ops.gemm_tn(dh12, x2, with_bias=True)
         return ops.gemm_nt(dh12, W12T).view(*g.shape[:-1], -1), dw12, db12, dw3, db3
 

@@ -9,7 +9,8 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
-from ._lib import BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_GATE_RES, F32, call, dt, ptr, stream
+from ._lib import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_GATE_RES, EPI_SWIGLU, EPI_SWIGLU_BWD, F32, call, dt, ptr,
+                   stream)
 
 _ws = {}
 
@@ -73,6 +74,33 @@ def gemm_nt_gelu(a, b, bias, save_pre=True):
     call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_BIAS_GELU, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
          M, N, K, ptr(bias), 0.0, None, ptr(pre), None, 0, 0, stream())
     return out, pre
+
+
+def gemm_nt_swiglu(a, w12, b12):
+    """(h12, hid): h12 = a @ w12^T + b12 ([x1 | x2]), hid = silu(x1) * x2.  bf16: one GEMM with the SwiGLU epilogue;
+    otherwise the GEMM followed by ldmae_swiglu_fwd (same numbers: the epilogue rounds to bf16 before the activation)."""
+    M, K = a.shape
+    N = w12.shape[0]
+    if a.dtype == torch.bfloat16 and N % 256 == 0 and K % 64 == 0:
+        h12 = torch.empty(M, N, dtype=a.dtype, device=a.device)
+        hid = torch.empty(M, N // 2, dtype=a.dtype, device=a.device)
+        call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU, ptr(a), a.stride(0), ptr(w12), w12.stride(0), ptr(h12), N, M, N, K, ptr(b12), 0.0,
+             None, ptr(hid), None, 0, 0, stream())
+        return h12, hid
+    h12 = gemm_nt(a, w12, b12)
+    return h12, swiglu_fwd(h12)
+
+
+def gemm_nt_swiglu_bwd(dy, w3t, h12):
+    """dh12 = swiglu_bwd(dy @ w3t^T, h12)   (w3t = [Hs, D] transposed copy of w3)."""
+    M, K = dy.shape
+    Hs = w3t.shape[0]
+    if dy.dtype == torch.bfloat16 and Hs % 4 == 0 and K % 64 == 0:
+        dh12 = torch.empty_like(h12)
+        call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU_BWD, ptr(dy), dy.stride(0), ptr(w3t), w3t.stride(0), ptr(dh12), 2 * Hs, M, Hs, K, None, 0.0,
+             ptr(h12), None, None, 0, 0, stream())
+        return dh12
+    return swiglu_bwd(gemm_nt(dy, w3t), h12)
 
 
 def gemm_tn(a, b, out=None, beta=0.0, with_bias=False):

@@ -222,6 +222,21 @@ def test_swiglu_gate_silu(ops, dtype):
         assert rel_err(ops.silu_bwd(dev(g[:5, :192].contiguous()), dev(c.detach())).cpu(), c.grad) < 1e-5
 
 
+def test_fused_swiglu_gemm_epilogues_match_unfused(ops):
+    M, D, Hs = 512, 192, 512
+    a, w12, b12 = dev(rnd(M, D, seed=1), BF16), dev(rnd(2 * Hs, D, seed=2, scale=D ** -0.5), BF16), dev(rnd(2 * Hs, seed=3))
+    h12, hid = ops.gemm_nt_swiglu(a, w12, b12)
+    h12_ref = ops.gemm_nt(a, w12, b12)
+    assert torch.equal(h12, h12_ref) and torch.equal(hid, ops.swiglu_fwd(h12_ref))
+    dy, w3t = dev(rnd(M, D, seed=4), BF16), dev(rnd(Hs, D, seed=5, scale=D ** -0.5), BF16)
+    assert torch.equal(ops.gemm_nt_swiglu_bwd(dy, w3t, h12), ops.swiglu_bwd(ops.gemm_nt(dy, w3t), h12))
+    # f32 path: unfused kernels behind the same entry points
+    a32, w32 = dev(rnd(64, D, seed=1)), dev(rnd(2 * Hs, D, seed=2, scale=D ** -0.5))
+    h32, hid32 = ops.gemm_nt_swiglu(a32, w32, b12)
+    x1, x2 = h32.chunk(2, -1)
+    assert rel_err(hid32.cpu(), (torch.nn.functional.silu(x1) * x2).cpu()) < 1e-5
+
+
 def test_embedders(ops, golden):
     g = golden("kernels")
     t = torch.tensor([0.0, 0.25, 0.9])
