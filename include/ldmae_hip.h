@@ -81,7 +81,8 @@ int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const float* x, cons
                                float beta_w, int M, int D, int rows_per_batch, float* workspace, void* stream);
 
 /* ---- attention front end (lightningdit.py:68-74; rmsnorm.py on head_dim; pos_embed.py:38-42,135) */
-/* qkv [B,N,3,H,hd] -> q,k = rope(rmsnorm(.)*w) and v, each [B,H,N,hd]. cos/sin [N,hd] f32. */
+/* qkv [B,N,3,H,hd] -> q,k = rope(rmsnorm(.)*w) and v, each [B,H,N,hd]. cos/sin [N,hd] f32.
+ * wq = wk = cos = sin = NULL: plain head-major relayout (VMAE attention has no QK-norm / RoPE, models_mae.py:133-134). */
 int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq, const float* wk, const float* cos, const float* sin,
                           void* q, void* k, void* v, int B, int N, int H, int hd, float eps, void* stream);
 long ldmae_qknorm_rope_bwd_workspace_bytes(int B, int N, int H, int hd);
@@ -141,6 +142,8 @@ int ldmae_layernorm_bwd(int dtype, const void* dout, const float* x, const float
 /* exact-erf GELU (timm Mlp act, models_mae.py:172) */
 int ldmae_gelu_fwd(int dtype, const void* x, void* out, long n, void* stream);
 int ldmae_gelu_bwd(int dtype, const void* dout, const void* x, void* dx, long n, void* stream);
+/* 3x3 / stride 1 / pad 1 convolution on [B,C,H,W] f32 (conv_decoder_pred.conv_smoother, models_mae.py:254,275), inference only */
+int ldmae_conv3x3(const float* x, const float* w, const float* b, float* out, int B, int C, int H, int W, void* stream);
 
 /* ---- optional per-kernel timing hook used by bench.py for the roofline line ------------------- */
 /* When enabled, ldmae_gemm_nt brackets each launch with HIP events on the launch stream. */

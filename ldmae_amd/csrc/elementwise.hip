@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const T* __restric
   const bool act = c4 < hd;
   const long items = (long)B * N * H;
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / LPR, gstride = (long)gridDim.x * 256 / LPR;
-  const float4 wqv = act ? *(const float4*)(wq + c4) : f4(0.f), wkv = act ? *(const float4*)(wk + c4) : f4(0.f);
+  const bool plain = wq == nullptr;     // VMAE attention: head-major relayout only (models_mae.py:133-134)
+  const float4 wqv = (act && !plain) ? *(const float4*)(wq + c4) : f4(0.f), wkv = (act && !plain) ? *(const float4*)(wk + c4) : f4(0.f);
   for (long it = gid; it < items; it += gstride) {
     const int h = it % H, n = (it / H) % N, b = it / ((long)H * N);
     const T* src = qkv + ((size_t)(b * N + n) * 3 * H + h) * hd + c4;
@@ -254,7 +255,11 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const T* __restric
     float4 qv = f4(0.f), kv = f4(0.f), vv = f4(0.f), cs = f4(0.f), sn = f4(0.f);
     if (act) {
       qv = load4<T>(src); kv = load4<T>(src + (size_t)H * hd); vv = load4<T>(src + (size_t)2 * H * hd);
-      cs = *(const float4*)(cosT + (size_t)n * hd + c4); sn = *(const float4*)(sinT + (size_t)n * hd + c4);
+      if (!plain) { cs = *(const float4*)(cosT + (size_t)n * hd + c4); sn = *(const float4*)(sinT + (size_t)n * hd + c4); }
+    }
+    if (plain) {
+      if (act) { store4<T>(q + dst, qv); store4<T>(k + dst, kv); store4<T>(v + dst, vv); }
+      continue;
     }
     const float rq = rsqrtf(group_sum<LPR>(hsum(qv * qv)) / (float)hd + eps);
     const float rk = rsqrtf(group_sum<LPR>(hsum(kv * kv)) / (float)hd + eps);
@@ -277,12 +282,21 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
   const bool act = c4 < hd;
   const long items = (long)B * N * H;
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / LPR, gstride = (long)gridDim.x * 256 / LPR;
-  const float4 wqv = act ? *(const float4*)(wq + c4) : f4(0.f), wkv = act ? *(const float4*)(wk + c4) : f4(0.f);
+  const bool plain = wq == nullptr;
+  const float4 wqv = (act && !plain) ? *(const float4*)(wq + c4) : f4(0.f), wkv = (act && !plain) ? *(const float4*)(wk + c4) : f4(0.f);
   float4 awq = f4(0.f), awk = f4(0.f);
   for (long it = gid; it < items; it += gstride) {
     const int h = it % H, n = (it / H) % N, b = it / ((long)H * N);
     const size_t so = ((size_t)(b * N + n) * 3 * H + h) * hd + c4;
     const size_t go = ((size_t)(b * H + h) * N + n) * hd + c4;
+    if (plain) {
+      if (act) {
+        store4<T>(dqkv + so, load4<T>(dq + go));
+        store4<T>(dqkv + so + (size_t)H * hd, load4<T>(dk + go));
+        store4<T>(dqkv + so + (size_t)2 * H * hd, load4<T>(dv + go));
+      }
+      continue;
+    }
     float4 qv = f4(0.f), kv = f4(0.f), gq = f4(0.f), gk = f4(0.f), gv = f4(0.f), cs = f4(0.f), sn = f4(0.f);
     if (act) {
       qv = load4<T>(qkv + so); kv = load4<T>(qkv + so + (size_t)H * hd);
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
       store4<T>(dqkv + so + (size_t)2 * H * hd, gv);
     }
   }
+  if (plain) return;
   red[threadIdx.x][0] = awq; red[threadIdx.x][1] = awk;
   __syncthreads();
   if (threadIdx.x < LPR && act) {
@@ -319,7 +334,8 @@ static unsigned qk_grid(long items, int lpr) {
 
 extern "C" int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq, const float* wk, const float* cos, const float* sin,
                                      void* q, void* k, void* v, int B, int N, int H, int hd, float eps, void* stream) {
-  LDMAE_REQUIRE(qkv && wq && wk && cos && sin && q && k && v, "qknorm_rope_fwd: null pointer");
+  LDMAE_REQUIRE(qkv && q && k && v, "qknorm_rope_fwd: null pointer");
+  LDMAE_REQUIRE((wq && wk && cos && sin) || (!wq && !wk), "qknorm_rope_fwd: pass all of wq/wk/cos/sin, or none (plain head-major relayout)");
   LDMAE_REQUIRE(hd % 8 == 0 && hd <= 128 && B > 0 && N > 0 && H > 0, "qknorm_rope_fwd: head_dim=%d must be a multiple of 8 and <= 128", hd);
   hipStream_t st = as_stream(stream);
   const long items = (long)B * N * H;
@@ -339,7 +355,8 @@ extern "C" long ldmae_qknorm_rope_bwd_workspace_bytes(int B, int N, int H, int h
 extern "C" int ldmae_qknorm_rope_bwd(int dtype, const void* dq, const void* dk, const void* dv, const void* qkv, const float* wq,
                                      const float* wk, const float* cos, const float* sin, void* dqkv, float* dwq, float* dwk, float beta_w,
                                      int B, int N, int H, int hd, float eps, float* workspace, void* stream) {
-  LDMAE_REQUIRE(dq && dk && dv && qkv && wq && wk && cos && sin && dqkv && dwq && dwk && workspace, "qknorm_rope_bwd: null pointer");
+  LDMAE_REQUIRE(dq && dk && dv && dqkv, "qknorm_rope_bwd: null pointer");
+  LDMAE_REQUIRE((qkv && wq && wk && cos && sin && dwq && dwk && workspace) || (!wq && !wk), "qknorm_rope_bwd: pass all norm/rope arguments, or none of wq/wk (plain relayout)");
   LDMAE_REQUIRE(hd % 8 == 0 && hd <= 128 && B > 0 && N > 0 && H > 0, "qknorm_rope_bwd: head_dim=%d must be a multiple of 8 and <= 128", hd);
   hipStream_t st = as_stream(stream);
   const long items = (long)B * N * H;
@@ -350,6 +367,7 @@ extern "C" int ldmae_qknorm_rope_bwd(int dtype, const void* dq, const void* dk, 
   else { if (dtype == LDMAE_BF16) QK_BWD(32, bf16); else QK_BWD(32, float); }
 #undef QK_BWD
   LDMAE_CHECK_LAUNCH("qknorm_rope_bwd");
+  if (!wq) return LDMAE_OK;
   group_reduce(workspace, 2 * hd, 1, hd, grid, dwq, hd, beta_w, st);
   group_reduce(workspace + hd, 2 * hd, 1, hd, grid, dwk, hd, beta_w, st);
   LDMAE_CHECK_LAUNCH("qknorm_rope_bwd reduce");

@@ -195,3 +195,28 @@ extern "C" int ldmae_gelu_bwd(int dtype, const void* dout, const void* x, void* 
   LDMAE_CHECK_LAUNCH("gelu_bwd");
   return LDMAE_OK;
 }
+
+// ------------------------------------------------------------------ 3x3 conv on RGB (conv_decoder_pred.conv_smoother, models_mae.py:254,275)
+// direct convolution, stride 1, zero padding 1, C channels in/out (C = 3); one thread per output pixel.
+__global__ void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,
+                               int B, int C, int Hh, int Ww) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C * Hh * Ww) return;
+  const int xx = i % Ww, yy = (i / Ww) % Hh, co = (i / ((long)Ww * Hh)) % C, n = i / ((long)Ww * Hh * C);
+  float s = b ? b[co] : 0.f;
+  for (int ci = 0; ci < C; ++ci)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int y2 = yy + dy, x2 = xx + dx;
+        if (y2 >= 0 && y2 < Hh && x2 >= 0 && x2 < Ww)
+          s += x[(((size_t)n * C + ci) * Hh + y2) * Ww + x2] * w[((co * C + ci) * 3 + dy + 1) * 3 + dx + 1];
+      }
+  out[i] = s;
+}
+extern "C" int ldmae_conv3x3(const float* x, const float* w, const float* b, float* out, int B, int C, int H, int W, void* stream) {
+  LDMAE_REQUIRE(x && w && out && B > 0 && C > 0 && H > 0 && W > 0, "conv3x3: bad arguments");
+  const long n = (long)B * C * H * W;
+  hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, w, b, out, B, C, H, W);
+  LDMAE_CHECK_LAUNCH("conv3x3");
+  return LDMAE_OK;
+}

@@ -293,6 +293,29 @@ def scatter_rows(dout, ids, Lq):
     return dx
 
 
+def heads_split(qkv, B, N, H, hd):
+    """[B,N,3,H,hd] -> q,k,v [B,H,N,hd] (no norm / rope)."""
+    q = torch.empty(B, H, N, hd, dtype=qkv.dtype, device=qkv.device)
+    k, v = torch.empty_like(q), torch.empty_like(q)
+    call("ldmae_qknorm_rope_fwd", dt(qkv.dtype), ptr(qkv), None, None, None, None, ptr(q), ptr(k), ptr(v), B, N, H, hd, 0.0, stream())
+    return q, k, v
+
+
+def heads_merge(dq, dk, dv, B, N, H, hd):
+    """inverse of heads_split for the gradients: -> [B*N, 3*H*hd]."""
+    dqkv = torch.empty(B * N, 3 * H * hd, dtype=dq.dtype, device=dq.device)
+    call("ldmae_qknorm_rope_bwd", dt(dq.dtype), ptr(dq), ptr(dk), ptr(dv), None, None, None, None, None, ptr(dqkv), None, None, 0.0,
+         B, N, H, hd, 0.0, None, stream())
+    return dqkv
+
+
+def conv3x3(x, w, b):
+    B, C, Hh, Ww = x.shape
+    out = torch.empty_like(x)
+    call("ldmae_conv3x3", ptr(_c(x)), ptr(_c(w)), ptr(b), ptr(out), B, C, Hh, Ww, stream())
+    return out
+
+
 def layernorm_fwd(x, w, b, out_dtype, eps=1e-6):
     M, D = x.shape
     out = torch.empty(M, D, dtype=out_dtype, device=x.device)

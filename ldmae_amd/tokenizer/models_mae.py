@@ -1,0 +1,462 @@
+"""VMAE tokenizer (masked-autoencoder ViT) on the gfx950 kernels -- mirror of the reference module
+``tokenizer/models_mae.py`` (citations relative to /root/reference/LDMAE/tokenizer/models_mae.py).
+
+Hot path = masked-token ENCODER: patch-embed GEMM(+pos) -> ``random_masking`` (in-LDS stable sort, bit-exact) -> gather
+kept tokens -> 12 pre-LN ViT blocks (LayerNorm, qkv GEMM, flash attention on the kept subset, proj GEMM + residual,
+fc1 GEMM + exact GELU, fc2 GEMM + residual) -> LayerNorm.  Each block is one autograd Function (forward + backward
+kernel sequences).  head_dim is 16: the attention core runs on the exact-f32 MFMA kernel in both precision modes
+(the bf16 flash kernel is tiled for head_dim 64/128); GEMMs follow the autocast mode.
+The decoder / ``encode`` / ``decode`` / ``decode_to_images`` docking functions re-use the same block kernels
+(inference only for the RGB smoothing conv).  Unshipped variants (gradual_resol, down_nonlinear, cls token,
+pred_with_conv, perceptual loss) raise NotImplementedError.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from functools import partial
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..models.lightningdit import PatchEmbed, _act_dtype, _wcopies
+from .util.misc import DiagonalGaussianDistribution
+from .util.pos_embed import get_2d_sincos_pos_embed
+
+
+class Config:
+    def __init__(self, scaling_factor):
+        self.scaling_factor = scaling_factor
+
+
+@dataclass
+class DecoderOutput:
+    sample: torch.Tensor
+    commit_loss: Optional[torch.Tensor] = None
+
+
+@dataclass
+class EncoderOutput:
+    latent: torch.Tensor
+
+    def sample(self):
+        return self.latent
+
+
+@dataclass
+class MAEOutput:
+    latent_dist: object
+
+
+# ----------------------------------------------------------------------------- autograd Functions
+class _ViTBlockFn(torch.autograd.Function):
+    """Block.forward (:176-187): x += proj(attn(LN1(x))); x += fc2(gelu(fc1(LN2(x))))."""
+
+    @staticmethod
+    def forward(ctx, x, H, eps, dtype, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
+        B, N, D = x.shape
+        M, hd = B * N, D // H
+        x2 = x.contiguous().view(M, D)
+        Wqkv, WqkvT = _wcopies(qkvw, dtype)
+        Wp, WpT = _wcopies(pw, dtype)
+        W1, W1T = _wcopies(f1w, dtype)
+        W2, W2T = _wcopies(f2w, dtype)
+        h1, mu1, rs1 = ops.layernorm_fwd(x2, n1w, n1b, dtype, eps)
+        qkv = ops.gemm_nt(h1, Wqkv, qkvb, out_dtype=torch.float32)            # attention core in f32 (head_dim 16)
+        q, k, v = ops.heads_split(qkv, B, N, H, hd)
+        o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)                        # [B,N,D] f32
+        oa = ops.cast(o.view(M, D), dtype)
+        xmid, _ = ops.gemm_nt_gate_res(oa, Wp, pb, x2, None, N, save_y=False)
+        h2, mu2, rs2 = ops.layernorm_fwd(xmid, n2w, n2b, dtype, eps)
+        act, pre = ops.gemm_nt_gelu(h2, W1, f1b)
+        xout, _ = ops.gemm_nt_gate_res(act, W2, f2b, xmid, None, N, save_y=False)
+        ctx.save_for_backward(x2, h1, mu1, rs1, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T)
+        ctx.dims = (B, N, D, H, hd, dtype)
+        return xout.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x2, h1, mu1, rs1, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T = ctx.saved_tensors
+        B, N, D, H, hd, dtype = ctx.dims
+        M = B * N
+        dx = gout.view(M, D) if gout.is_contiguous() else gout.contiguous().view(M, D)
+        # MLP branch
+        dy2 = ops.cast(dx, dtype)
+        dW2, db2 = ops.gemm_tn(dy2, act, with_bias=True)
+        dpre = ops.gelu_bwd(ops.gemm_nt(dy2, W2T), pre)
+        dW1, db1 = ops.gemm_tn(dpre, h2, with_bias=True)
+        dn2w, dn2b = ops.layernorm_bwd(ops.gemm_nt(dpre, W1T), xmid, n2w, mu2, rs2, dx)
+        # attention branch
+        dy1 = ops.cast(dx, dtype)
+        dWp, dbp = ops.gemm_tn(dy1, oa, with_bias=True)
+        do = ops.gemm_nt(dy1, WpT, out_dtype=torch.float32)
+        dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
+        dqkv = ops.cast(ops.heads_merge(dq, dk, dv, B, N, H, hd), dtype)
+        dWqkv, dbqkv = ops.gemm_tn(dqkv, h1, with_bias=True)
+        dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT), x2, n1w, mu1, rs1, dx)
+        return (dx.view(B, N, D), None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        shp = x.shape
+        x2 = x.contiguous().view(-1, shp[-1])
+        out, mu, rs = ops.layernorm_fwd(x2, w, b, torch.float32, eps)
+        ctx.save_for_backward(x2, w, mu, rs)
+        return out.view(shp)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, mu, rs = ctx.saved_tensors
+        dx = torch.zeros_like(x2)
+        dw, db = ops.layernorm_bwd(g.contiguous().view_as(x2), x2, w, mu, rs, dx)
+        return dx.view(g.shape), dw, db, None
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b (f32 in/out; small latent projections :307-308, 378)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shp = x.shape
+        x2 = x.contiguous().view(-1, shp[-1])
+        ctx.save_for_backward(x2, w)
+        return ops.gemm_nt(x2, w, b).view(*shp[:-1], -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w = ctx.saved_tensors
+        g2 = g.contiguous().view(x2.shape[0], -1)
+        dx = ops.gemm_nt(g2, ops.cast_weight(w, torch.float32, True, False)[1]).view(*g.shape[:-1], -1) if ctx.needs_input_grad[0] else None
+        return dx, ops.gemm_tn(g2, x2), ops.colsum(g2)
+
+
+class _GatherFn(torch.autograd.Function):
+    """torch.gather(x, 1, ids_keep) on token rows (:486)."""
+
+    @staticmethod
+    def forward(ctx, x, ids_keep):
+        ctx.save_for_backward(ids_keep)
+        ctx.L = x.shape[1]
+        return ops.gather_rows(x.contiguous(), ids_keep)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids_keep,) = ctx.saved_tensors
+        return ops.scatter_rows(g, ids_keep, ctx.L), None
+
+
+# ----------------------------------------------------------------------------- modules
+class Mlp(nn.Module):
+    """timm Mlp parameter layout (fc1 / fc2), computed inside _ViTBlockFn."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+
+class Attention(nn.Module):
+    """:117-128 parameter container."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        assert dim % num_heads == 0, 'dim should be divisible by num_heads'
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    """:149-187 with init_values=None, drop_path=0 (the shipped archs)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., init_values=None, drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        if init_values or drop_path > 0 or drop > 0 or attn_drop > 0 or not qkv_bias:
+            raise NotImplementedError("ldmae_amd Block: LayerScale / DropPath / dropout / bias-free qkv are not on the accelerated path")
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
+        self.precision = None
+
+    def forward(self, x):
+        a, m = self.attn, self.mlp
+        return _ViTBlockFn.apply(x.float(), a.num_heads, self.norm1.eps, _act_dtype(self.precision),
+                                 self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                                 self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+
+
+class conv_decoder_pred(nn.Module):
+    """:244-281 with pred_with_conv=False: linear -> unpatchify -> 3x3 conv on RGB -> patchify."""
+
+    def __init__(self, decoder_embed_dim, patch_size, in_chans, pred_with_conv=False):
+        super().__init__()
+        if pred_with_conv:
+            raise NotImplementedError("ldmae_amd conv_decoder_pred: pred_with_conv=True is not shipped")
+        self.p = patch_size
+        self.pred_with_conv = False
+        self.linear_pred = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
+        self.conv_smoother = nn.Conv2d(in_chans, in_chans, 3, 1, 1)
+
+    def forward(self, x):
+        h = w = int(x.shape[1] ** .5)
+        x = _LinearFn.apply(x, self.linear_pred.weight, self.linear_pred.bias)
+        x = x.reshape(x.shape[0], h, w, self.p, self.p, 3)
+        x = torch.einsum('nhwpqc->nchpwq', x).reshape(x.shape[0], 3, h * self.p, w * self.p)
+        if x.requires_grad:
+            raise NotImplementedError("ldmae_amd: the RGB smoothing conv is inference-only (decoder fine-tuning is out of scope)")
+        x = ops.conv3x3(x, self.conv_smoother.weight, self.conv_smoother.bias)
+        x = x.reshape(x.shape[0], 3, h, self.p, w, self.p)
+        return torch.einsum('nchpwq->nhwpqc', x).reshape(x.shape[0], h * w, self.p * self.p * 3)
+
+
+class MaskedAutoencoderViT(nn.Module):
+    """:283-973 -- constructor signature of the reference; accelerated for the shipped tokenizer configuration."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16, decoder_embed_dim=512,
+                 decoder_depth=8, decoder_num_heads=16, mlp_ratio=4., norm_layer=nn.LayerNorm, norm_pix_loss=False, latent_dim=32,
+                 ldmae_mode=False, scaling_factor=0.9654248952865601, no_cls=True, gradual_resol=False, finetune_downsample_layer=None,
+                 down_nonlinear=False, kl_loss_weight=None, smooth_output=False, pred_with_conv=False, perceptual_loss=None):
+        super().__init__()
+        if gradual_resol or down_nonlinear or not no_cls or perceptual_loss is not None:
+            raise NotImplementedError("ldmae_amd MaskedAutoencoderViT: gradual_resol / down_nonlinear / cls token / perceptual loss are "
+                                      "not used by the shipped tokenizer (mae_for_ldmae_f8d16_prev, inference.py:133-137)")
+        self.perceptual_loss, self.smooth_output, self.gradual_resol, self.kl_loss_weight = None, smooth_output, False, kl_loss_weight
+        enc_lat = 2 * latent_dim if kl_loss_weight is not None else latent_dim
+        self.to_latent = nn.Linear(embed_dim, enc_lat)
+        self.from_latent = nn.Linear(latent_dim, decoder_embed_dim)
+        self.config = Config(scaling_factor=scaling_factor)
+        self.ldmae_mode, self.img_size, self.patch_size = ldmae_mode, img_size, patch_size
+        self.latent_resolution = img_size // patch_size
+        self.tile_latent_min_size = self.latent_resolution
+        self.latent_dim, self.no_cls, self.num_extra_tokens = latent_dim, no_cls, 0
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim), requires_grad=False)
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim, bias=True)
+        if not self.ldmae_mode:
+            self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, num_patches, decoder_embed_dim), requires_grad=False)
+        self.decoder_blocks = nn.ModuleList([Block(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer)
+                                             for _ in range(decoder_depth)])
+        self.decoder_norm = norm_layer(decoder_embed_dim)
+        if smooth_output:
+            self.decoder_pred = conv_decoder_pred(decoder_embed_dim, patch_size, in_chans, pred_with_conv)
+        else:
+            self.decoder_pred = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
+        self.norm_pix_loss = norm_pix_loss
+        self.precision = None
+        self.initialize_weights()
+
+    def initialize_weights(self):
+        """:432-465."""
+        g = int(self.patch_embed.num_patches ** .5)
+        self.pos_embed.data.copy_(torch.from_numpy(get_2d_sincos_pos_embed(self.pos_embed.shape[-1], g)).float().unsqueeze(0))
+        self.decoder_pos_embed.data.copy_(torch.from_numpy(get_2d_sincos_pos_embed(self.decoder_pos_embed.shape[-1], g)).float().unsqueeze(0))
+        w = self.patch_embed.proj.weight.data
+        torch.nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        if not self.ldmae_mode:
+            torch.nn.init.normal_(self.mask_token, std=.02)
+
+        def _init(m):
+            if isinstance(m, nn.Linear):
+                torch.nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+        self.apply(_init)
+
+    def set_precision(self, dtype):
+        self.precision = dtype
+        for b in list(self.blocks) + list(self.decoder_blocks):
+            b.precision = dtype
+        return self
+
+    # ---- layout helpers (:467-495)
+    def patchify(self, imgs):
+        p = self.patch_embed.patch_size[0]
+        h = w = imgs.shape[2] // p
+        x = imgs.reshape(imgs.shape[0], 3, h, p, w, p)
+        return torch.einsum('nchpwq->nhwpqc', x).reshape(imgs.shape[0], h * w, p ** 2 * 3)
+
+    def unpatchify(self, x):
+        p = self.patch_embed.patch_size[0]
+        h = w = int(x.shape[1] ** .5)
+        x = x.reshape(x.shape[0], h, w, p, p, 3)
+        return torch.einsum('nhwpqc->nchpwq', x).reshape(x.shape[0], 3, h * p, h * p)
+
+    def random_masking(self, x, mask_ratio, noise=None):
+        """:472-497.  The uniform noise is drawn on the device RNG exactly like the reference (pass `noise` to pin it); the
+        argsort / ids_restore / mask / gather run in the HIP kernels (stable: ties broken by index)."""
+        N, L, D = x.shape
+        len_keep = int(L * (1 - mask_ratio))
+        if noise is None:
+            noise = torch.rand(N, L, device=x.device)
+        ids_keep, mask, ids_restore = ops.random_masking(noise.float().contiguous(), len_keep)
+        return _GatherFn.apply(x.float(), ids_keep), mask, ids_restore
+
+    def _embed(self, x):
+        return self.patch_embed(x, self.pos_embed[0])
+
+    def _run(self, blocks, x):
+        for blk in blocks:
+            x = blk(x)
+        return x
+
+    def forward_encoder(self, x, mask_ratio, noise=None):
+        """:499-523."""
+        dtype = _act_dtype(self.precision)
+        with torch.autocast(device_type="cuda", enabled=False):
+            x = self._embed(x)
+            x, mask, ids_restore = self.random_masking(x, mask_ratio, noise)
+            for blk in self.blocks:
+                blk.precision = dtype
+                x = blk(x)
+            x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x, mask, ids_restore
+
+    def forward_decoder(self, x, ids_restore):
+        """:525-554 (no cls token)."""
+        x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias)
+        mask_tokens = self.mask_token.repeat(x.shape[0], ids_restore.shape[1] - x.shape[1], 1)
+        x_ = torch.cat([x, mask_tokens], dim=1)
+        x = torch.gather(x_, dim=1, index=ids_restore.unsqueeze(-1).repeat(1, 1, x.shape[2]))
+        x = x + self.decoder_pos_embed
+        x = self._run(self.decoder_blocks, x)
+        x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
+        return self.decoder_pred(x) if not isinstance(self.decoder_pred, nn.Linear) else \
+            _LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)
+
+    def forward_loss(self, imgs, pred, mask, visible_loss_ratio=0.5):
+        """:733-754."""
+        target = self.patchify(imgs)
+        if self.norm_pix_loss:
+            mean, var = target.mean(dim=-1, keepdim=True), target.var(dim=-1, keepdim=True)
+            target = (target - mean) / (var + 1.e-6) ** .5
+        loss = ((pred - target) ** 2).mean(dim=-1)
+        visible_loss = (loss * (1 - mask)).sum() / (1 - mask).sum()
+        mask_loss = (loss * mask).sum() / mask.sum()
+        return (1 - visible_loss_ratio) * mask_loss + visible_loss_ratio * visible_loss, visible_loss, mask_loss
+
+    def forward(self, imgs, mask_ratio=0.75, visible_loss_ratio=0.5):
+        """forward_vanilla (:756-790).  The masked encoder runs on the kernels; the decoder's RGB smoothing conv has no backward
+        here, so end-to-end pre-training is out of scope -- this is usable under torch.no_grad()."""
+        if self.ldmae_mode:
+            raise NotImplementedError("ldmae_amd: ldmae_mode (decoder fine-tuning with LPIPS) is out of scope")
+        latent, mask, ids_restore = self.forward_encoder(imgs, mask_ratio)
+        with torch.autocast(device_type="cuda", enabled=False):
+            latent = _LinearFn.apply(latent, self.to_latent.weight, self.to_latent.bias)
+            kl_loss = None
+            if self.kl_loss_weight is not None:
+                B, N, D = latent.shape
+                posterior = DiagonalGaussianDistribution(latent.permute(0, 2, 1))
+                kl = posterior.kl()
+                kl_loss = torch.sum(kl) / kl.shape[0] / N
+                latent = posterior.sample().permute(0, 2, 1)
+            latent = _LinearFn.apply(latent.contiguous(), self.from_latent.weight, self.from_latent.bias)
+            pred = self.forward_decoder(latent, ids_restore)
+            loss, vis_loss, mask_loss = self.forward_loss(imgs, pred, mask, visible_loss_ratio)
+            if kl_loss is not None:
+                loss = loss + self.kl_loss_weight * kl_loss
+        return loss, pred, mask, vis_loss, mask_loss, kl_loss
+
+    # ---- docking functions (:817-973)
+    def _encode(self, x):
+        dtype = _act_dtype(self.precision)
+        with torch.autocast(device_type="cuda", enabled=False):
+            x = self._embed(x)
+            for blk in self.blocks:
+                blk.precision = dtype
+                x = blk(x)
+            x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
+            x = _LinearFn.apply(x, self.to_latent.weight, self.to_latent.bias)
+        g = self.latent_resolution
+        return x.reshape(x.shape[0], g, g, -1).permute(0, 3, 1, 2)
+
+    def encode(self, x, return_dict=True):
+        m = self._encode(x)
+        p = DiagonalGaussianDistribution(m) if self.kl_loss_weight is not None else EncoderOutput(m)
+        return MAEOutput(latent_dist=p) if return_dict else (p,)
+
+    def decode(self, z, return_dict=True, generator=None):
+        dtype = _act_dtype(self.precision)
+        with torch.autocast(device_type="cuda", enabled=False):
+            B = z.shape[0]
+            x = z.float().permute(0, 2, 3, 1).reshape(B, -1, z.shape[1]).contiguous()
+            x = _LinearFn.apply(x, self.from_latent.weight, self.from_latent.bias)
+            x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias) + self.decoder_pos_embed
+            for blk in self.decoder_blocks:
+                blk.precision = dtype
+                x = blk(x)
+            x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
+            x = self.decoder_pred(x) if not isinstance(self.decoder_pred, nn.Linear) else \
+                _LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)
+            img = self.unpatchify(x)
+        return DecoderOutput(sample=img) if return_dict else (img,)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    def encode_images(self, images):
+        with torch.no_grad():
+            return self.encode(images.cuda(), return_dict=False)[0].sample()
+
+    def decode_to_images(self, z):
+        """:963-973 -> uint8 NHWC numpy."""
+        with torch.no_grad():
+            images = self.decode(z.cuda(), return_dict=False)[0]
+            return torch.clamp(127.5 * images + 128.0, 0, 255).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8).numpy()
+
+
+def _ln(**kw):
+    return partial(nn.LayerNorm, eps=1e-6)
+
+
+# registry (:977-1083): the archs built on the 192/384-wide ViT used by LDMAE
+def mae_for_ldmae(**kwargs):
+    return MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=12, num_heads=12, decoder_embed_dim=192, decoder_depth=12,
+                                decoder_num_heads=12, mlp_ratio=4, norm_layer=_ln(), latent_dim=32, **kwargs)
+
+
+mae_for_ldmae_f8d32 = mae_for_ldmae
+
+
+def mae_for_ldmae_f8d16_prev(**kwargs):
+    return MaskedAutoencoderViT(patch_size=8, embed_dim=192, depth=12, num_heads=12, decoder_embed_dim=192, decoder_depth=12,
+                                decoder_num_heads=12, mlp_ratio=4, norm_layer=_ln(), latent_dim=16, **kwargs)
+
+
+def mae_for_ldmae_f8d16_prev_large(**kwargs):
+    return MaskedAutoencoderViT(patch_size=8, embed_dim=384, depth=12, num_heads=16, decoder_embed_dim=384, decoder_depth=12,
+                                decoder_num_heads=16, mlp_ratio=4, norm_layer=_ln(), latent_dim=16, **kwargs)
+
+
+def mae_for_ldmae_f8d32_flexible(**kwargs):
+    return MaskedAutoencoderViT(patch_size=8, embed_dim=192, depth=12, num_heads=12, decoder_embed_dim=192, decoder_depth=12,
+                                decoder_num_heads=12, mlp_ratio=4, norm_layer=_ln(), latent_dim=32, **kwargs)
+
+
+def mae_for_ldmae_16d(**kwargs):
+    return MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=12, num_heads=12, decoder_embed_dim=192, decoder_depth=12,
+                                decoder_num_heads=12, mlp_ratio=4, norm_layer=_ln(), latent_dim=16, **kwargs)
+
+
+def mae_for_ldmae_f16d32(**kwargs):
+    return MaskedAutoencoderViT(img_size=128, patch_size=16, embed_dim=192, depth=12, num_heads=12, decoder_embed_dim=192, decoder_depth=12,
+                                decoder_num_heads=12, mlp_ratio=4, norm_layer=_ln(), latent_dim=32, **kwargs)

@@ -1,0 +1,93 @@
+"""VMAE masked-token encoder (tokenizer/models_mae.py mirror) on the HIP kernels vs the CPU oracle and the goldens
+generated from the reference: masks / ids_restore bit-exact, latents within 1e-4 (f32)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import mae as omae
+from weights import det_randn, det_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def build(cfg_kw, sd, img_size):
+    from ldmae_amd.tokenizer import models_mae
+    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=img_size, **cfg_kw)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval()
+
+
+def full_sd(cfg, seed=2):
+    sd = det_weights(omae.param_shapes(cfg), seed)
+    sd.update(omae.fixed_tables(cfg))
+    return sd
+
+
+def test_forward_encoder_matches_reference_golden(golden):
+    g = golden("mae")
+    cfg = omae.MAEConfig()
+    m = build({}, full_sd(cfg), 256)
+    imgs = det_randn("mae_img", (2, 3, 256, 256), 2).clamp(-1, 1).cuda()
+    noise = torch.from_numpy(g["mae_noise"]).cuda()
+    for tag, ratio in (("75", 0.75), ("25", 0.25)):
+        with torch.no_grad():
+            lat, mask, ids = m.forward_encoder(imgs, ratio, noise=noise)
+        np.testing.assert_array_equal(mask.cpu().numpy(), g[f"mae{tag}_mask"])            # bit-exact
+        np.testing.assert_array_equal(ids.cpu().numpy(), g[f"mae{tag}_ids_restore"])       # bit-exact
+        assert list(lat.shape) == list(g[f"mae{tag}_lat_shape"])
+        assert rel_err(lat[:, :4].cpu(), g[f"mae{tag}_lat_head"]) < 1e-4
+        assert abs(float(lat.double().norm()) - float(g[f"mae{tag}_lat_norm"])) < 1e-4 * float(g[f"mae{tag}_lat_norm"])
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            lat16, mask16, _ = m.forward_encoder(imgs, ratio, noise=noise)
+        assert torch.equal(mask16, mask) and rel_err(lat16.cpu(), lat.cpu()) < 3e-2
+
+
+def test_encode_decode_docking_matches_reference_golden(golden):
+    g = golden("mae")
+    cfg = omae.MAEConfig()
+    m = build({}, full_sd(cfg), 256)
+    imgs = det_randn("mae_img", (2, 3, 256, 256), 2).clamp(-1, 1).cuda()
+    with torch.no_grad():
+        mom = m._encode(imgs)
+        post = m.encode(imgs).latent_dist
+        rec = m.decode(mom[:, :16]).sample
+    assert rel_err(mom[:, :, :2, :2].cpu(), g["mae_moments_head"]) < 1e-4
+    assert abs(float(mom.double().norm()) - float(g["mae_moments_norm"])) < 1e-4 * float(g["mae_moments_norm"])
+    assert torch.equal(post.mean, mom[:, :16])
+    assert rel_err(rec[:, :, :4, :4].cpu(), g["mae_rec_head"]) < 1e-4
+    assert abs(float(rec.double().norm()) - float(g["mae_rec_norm"])) < 1e-4 * float(g["mae_rec_norm"])
+    img8 = m.decode_to_images(mom[:, :16])
+    assert img8.dtype == np.uint8 and img8.shape == (2, 256, 256, 3)
+    assert (np.abs(img8[:, :4, :4].astype(int) - g["mae_img8_head"].astype(int)) <= 1).all()
+
+
+def test_masked_encoder_gradients_vs_oracle():
+    """img 128 -> 256 patches, mask 0.75 -> 64 kept tokens; every encoder parameter gradient vs torch autograd on the oracle."""
+    cfg = omae.MAEConfig(img_size=128, depth=2)
+    shapes = omae.param_shapes(cfg)
+    sd = full_sd(cfg, seed=3)
+    from ldmae_amd.tokenizer import models_mae
+    m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192,
+                                        decoder_depth=12, decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16,
+                                        no_cls=True, kl_loss_weight=1e-6, smooth_output=True)
+    own = m.state_dict()
+    own.update({k: v for k, v in sd.items() if k in own and own[k].shape == v.shape})
+    m.load_state_dict(own)
+    m = m.cuda().train()
+    imgs = det_randn("img128", (2, 3, 128, 128), 4).clamp(-1, 1)
+    noise = torch.rand(2, 256, generator=torch.Generator().manual_seed(9))
+    enc_keys = [k for k in shapes if k.startswith(("patch_embed", "blocks.0.", "blocks.1.", "norm."))]
+    leaves = {k: own[k].clone().requires_grad_(True) for k in enc_keys}
+    osd = dict(own)
+    osd.update(leaves)
+    olat, omask, oids = omae.forward_encoder(osd, imgs, noise, 0.75, cfg)
+    w = det_randn("w", tuple(olat.shape), 5)
+    (olat * w).sum().backward()
+    lat, mask, ids = m.forward_encoder(imgs.cuda(), 0.75, noise=noise.cuda())
+    assert torch.equal(mask.cpu(), omask) and torch.equal(ids.cpu(), oids)
+    assert rel_err(lat.detach().cpu(), olat.detach()) < 1e-4
+    (lat * w.cuda()).sum().backward()
+    params = dict(m.named_parameters())
+    for k in enc_keys:
+        assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 2e-4, k
