@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Sampling driver -- counterpart of the reference's LDMAE/inference.py (`run_inference.sh`): EMA checkpoint -> shifted-grid
+Euler ODE with classifier-free guidance (CFG on the first three channels, interval gate) -> latent de-normalisation -> VMAE
+``decode_to_images`` -> PNGs.  Ranks are independent replicas (seed = global_seed * world + rank, inference.py:87)."""
+import argparse
+import math
+import os
+import sys
+
+import torch
+import yaml
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (_HERE, os.path.dirname(_HERE)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from ldmae_amd.tokenizer import models_mae                  # noqa: E402
+from ldmae_amd.train_accum import build_model               # noqa: E402
+from ldmae_amd.transport import Sampler, create_transport   # noqa: E402
+
+
+def build_sampler(cfg):
+    t, s = cfg['transport'], cfg['sample']
+    tr = create_transport(t['path_type'], t['prediction'], t['loss_weight'], t['train_eps'], t['sample_eps'],
+                          use_cosine_loss=t.get('use_cosine_loss', False), use_lognorm=t.get('use_lognorm', False))
+    if s['mode'] != "ODE":
+        raise NotImplementedError(f"Sampling mode {s['mode']} is not supported.")
+    return Sampler(tr).sample_ode(sampling_method=s['sampling_method'], num_steps=s['num_sampling_steps'], atol=s['atol'], rtol=s['rtol'],
+                                  reverse=s['reverse'], timestep_shift=s.get('timestep_shift', 0))
+
+
+@torch.no_grad()
+def sample_latents(model, sample_fn, n, cfg_scale, cfg_interval_start, device, num_classes=1000, generator=None):
+    """inference.py:264-292: z ~ N(0,I); CFG on a doubled batch with the null class; Euler; drop the null half."""
+    latent = model.x_embedder.img_size[0]
+    z = torch.randn(n, model.in_channels, latent, latent, device=device, generator=generator)
+    y = torch.randint(0, num_classes, (n,), device=device, generator=generator)
+    if cfg_scale > 1.0:
+        z = torch.cat([z, z], 0)
+        y = torch.cat([y, torch.full((n,), num_classes, device=device)], 0)
+        out = sample_fn(z, model.forward_with_cfg, y=y, cfg_scale=cfg_scale, cfg_interval=True, cfg_interval_start=cfg_interval_start)[-1]
+        out, _ = out.chunk(2, dim=0)
+    else:
+        out = sample_fn(z, model.forward, y=y)[-1]
+    return out, y[:n]
+
+
+def do_sample(cfg, ckpt_path, out_dir, num_samples=None, precision="bf16"):
+    from PIL import Image
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    torch.manual_seed(cfg['train']['global_seed'] * world + rank)
+    model = build_model(cfg)
+    ck = torch.load(ckpt_path, map_location='cpu')
+    model.load_state_dict(ck["ema"] if "ema" in ck else ck)
+    model = model.to(device).eval()
+    sample_fn = build_sampler(cfg)
+    vae = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=True, no_cls=True, kl_loss_weight=True, smooth_output=True,
+                                              img_size=cfg['data']['image_size'])
+    vck = torch.load(cfg['vae']['weight_path'], map_location='cpu')
+    vae.load_state_dict(vck['model'], strict=False)
+    vae = vae.to(device).eval()
+    stats = torch.load(os.path.join(cfg['data']['data_path'] + ('_sample' if 'sample' in cfg['data'] else ''), "latents_stats.pt"))
+    mean, std = stats['mean'].to(device), stats['std'].to(device)
+    mult = cfg['data'].get('latent_multiplier', 0.18215)
+    s = cfg['sample']
+    n = s['per_proc_batch_size']
+    total = int(math.ceil((num_samples or s['fid_num']) / (n * world)) * n * world)
+    os.makedirs(out_dir, exist_ok=True)
+    done = 0
+    for it in range(total // (n * world)):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16"):
+            lat, _ = sample_latents(model, sample_fn, n, s['cfg_scale'], s.get('cfg_interval_start', 0), device, cfg['data']['num_classes'])
+        imgs = vae.decode_to_images(lat * std / mult + mean)
+        for i, im in enumerate(imgs):
+            Image.fromarray(im).save(f"{out_dir}/{i * world + rank + done:06d}.png")
+        done += n * world
+    return out_dir
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', type=str, required=True)
+    ap.add_argument('--ckpt', type=str, default=None)
+    ap.add_argument('--out', type=str, default=None)
+    a = ap.parse_args()
+    c = yaml.safe_load(open(a.config))
+    do_sample(c, a.ckpt or c['ckpt_path'], a.out or os.path.join(c['train']['output_dir'], c['train']['exp_name'], "samples"))

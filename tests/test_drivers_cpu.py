@@ -1,0 +1,53 @@
+"""Host-side logic of the driver counterparts (config / dataset / checkpoint plumbing) -- no GPU needed."""
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_yaml_is_the_reference_api():
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "ldmae_amd/configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml")))
+    assert set(cfg) == {"ckpt_path", "data", "vae", "model", "train", "optimizer", "transport", "sample"}
+    assert cfg["model"] == dict(model_type="LightningDiT-B/1", use_qknorm=True, use_swiglu=True, use_rope=True, use_rmsnorm=True,
+                                wo_shift=False, in_chans=16)
+    assert cfg["optimizer"] == dict(lr=0.0002, beta2=0.95) and cfg["train"]["global_batch_size"] == 256
+    assert cfg["transport"]["use_lognorm"] is True and cfg["sample"]["timestep_shift"] == 0.3 and cfg["sample"]["cfg_scale"] == 10.0
+    import ldmae_amd.train_accum as t
+    m = t.build_model(cfg)
+    assert m.hidden_size == 768 and m.depth == 12 and m.x_embedder.num_patches == 1024 and m.in_channels == 16
+
+
+def test_latent_dataset_roundtrip(tmp_path):
+    from safetensors.torch import save_file
+    sys.path.insert(0, os.path.join(ROOT, "ldmae_amd"))
+    from ldmae_amd.datasets.img_latent_dataset import ImgLatentDataset, SyntheticLatentDataset
+    d = tmp_path / "lat_sample"
+    d.mkdir()
+    torch.manual_seed(0)
+    for s in range(2):
+        save_file({"latents": torch.randn(5, 32, 4, 4), "latents_flip": torch.randn(5, 32, 4, 4), "labels": torch.arange(5) + 10 * s},
+                  str(d / f"latents_rank00_shard{s:03d}.safetensors"), metadata={"total_size": "5"})
+    ds = ImgLatentDataset(str(d), latent_norm=True, latent_multiplier=1.0, sample=True)
+    assert len(ds) == 10 and os.path.exists(d / "latents_stats.pt")
+    x, y = ds[7]
+    assert x.shape == (16, 4, 4) and int(y) == 12          # posterior sample of the 32-channel moments
+    assert ds._latent_mean.shape == (1, 16, 1, 1)
+    s = SyntheticLatentDataset(length=4, channels=16, size=8)
+    a, b = s[1], s[1]
+    assert torch.equal(a[0], b[0]) and a[0].shape == (16, 8, 8)
+
+
+def test_weight_init_special_case():
+    import ldmae_amd.train_accum as t
+    from ldmae_amd.models.lightningdit import LightningDiT
+    kw = dict(input_size=8, patch_size=1, hidden_size=192, depth=1, num_heads=3, num_classes=10, use_qknorm=True, use_swiglu=True,
+              use_rope=True, use_rmsnorm=True)
+    big, small = LightningDiT(in_channels=32, **kw), LightningDiT(in_channels=16, **kw)
+    ck = {"model": {"module." + k: v for k, v in big.state_dict().items()}}
+    t.load_weights_with_shape_check(small, ck, rank=1)
+    assert torch.equal(small.x_embedder.proj.weight[:, :16], big.x_embedder.proj.weight[:, :16])
+    assert torch.equal(small.blocks[0].attn.qkv.weight, big.blocks[0].attn.qkv.weight)
