@@ -166,6 +166,27 @@ template <int EPI, typename OutT> struct Epi4 {
     if constexpr (sizeof(OutT) == 4) *(float4*)p = v;
     else { bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w; *(bf16x4*)p = o; }
   }
+  // value destined for C (and C2 for GELU) without storing them; side outputs (xout) are stored here
+  __device__ __forceinline__ void compute(int m, float4 a, float4& c, float4& c2) const {
+    a.x += bias.x; a.y += bias.y; a.z += bias.z; a.w += bias.w;
+    c = a; c2 = a;
+    if (EPI == LDMAE_EPI_BIAS) {
+      if (e.beta != 0.f) {
+        const OutT* p = (const OutT*)e.C + (size_t)m * e.ldc + n;
+        c.x += e.beta * to_f<OutT>(p[0]); c.y += e.beta * to_f<OutT>(p[1]); c.z += e.beta * to_f<OutT>(p[2]); c.w += e.beta * to_f<OutT>(p[3]);
+      }
+    } else if (EPI == LDMAE_EPI_BIAS_POS) {
+      const float4 q = *(const float4*)(e.xin + (size_t)(m % e.rows_per_batch) * N + n);
+      c = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
+    } else if (EPI == LDMAE_EPI_BIAS_GELU) {
+      auto g = [](float y) { return 0.5f * y * (1.f + erff(y * 0.70710678118654752f)); };
+      c = make_float4(g(a.x), g(a.y), g(a.z), g(a.w));
+    } else if (EPI == LDMAE_EPI_GATE_RES) {
+      const size_t o = (size_t)m * N + n;
+      const float4 xi = *(const float4*)(e.xin + o);
+      *(float4*)(e.xout + o) = make_float4(xi.x + gate.x * a.x, xi.y + gate.y * a.y, xi.z + gate.z * a.z, xi.w + gate.w * a.w);
+    }
+  }
   __device__ __forceinline__ void apply(int m, float4 a) const {
     a.x += bias.x; a.y += bias.y; a.z += bias.z; a.w += bias.w;
     const size_t oc = (size_t)m * e.ldc + n;
@@ -191,7 +212,7 @@ template <int EPI, typename OutT> struct Epi4 {
   }
 };
 
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, typename OutT>
+template <int BM, int BN, int WM, int WN, int STAGES, int EPI, typename OutT, bool PREFETCH = false, int DBG = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N,
                                                                   int K, int lda, int ldb, EpiArgs e) {
   constexpr int NW = WM * WN, TM = BM / WM, TNn = BN / WN, MI = TM / 16, NI = TNn / 16;
@@ -233,35 +254,124 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
   const int a_off = (wm * TM + (lane & 15)) * 64 + fpos, b_off = (BM + wn * TNn + (lane & 15)) * 64 + fpos;
 
   const int nk = K / 32;
+  if constexpr (DBG == 4) {
+    // two K-steps per barrier: stages (2t, 2t+1) are consumed while (2t+2, 2t+3) are in flight (4 buffers)
+    static_assert(DBG != 4 || STAGES == 4, "double-step variant uses 4 stages");
+    const int nd = nk / 2;                                   // host guarantees K % 64 == 0
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < nk) issue(s);
+    for (int t = 0; t < nd; ++t) {
+      if (t + 1 < nd) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t >= 1 && 2 * t + 2 < nk) { issue(2 * t + 2); issue(2 * t + 3); }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const char* st = smem + ((2 * t + h) % STAGES) * STAGE_BYTES;
+        bf16x8 af[MI], bfr[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  } else {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue(s);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = min(STAGES - 2, nk - 1 - kt);          // stages allowed to stay in flight
-    if (ahead >= 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+  }
+  if constexpr (DBG == 4) {
+  } else if constexpr (!PREFETCH) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const int ahead = min(STAGES - 2, nk - 1 - kt);          // stages allowed to stay in flight
+      if (ahead >= 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if constexpr (DBG != 2) { if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1); }
+      const char* st = smem + (kt % STAGES) * STAGE_BYTES;
+      bf16x8 af[MI], bfr[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+      if constexpr (DBG == 1) {        // ablation: everything but the MFMAs (fragments kept live)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
+      } else {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  } else {
+    // register double-buffered fragments: the ds_reads of K-step kt+1 are issued beside the MFMAs of K-step kt
+    // (needs stage kt+1 landed at the barrier of iteration kt -> STAGES = 4, one stage less in flight)
+    static_assert(!PREFETCH || STAGES == 4, "prefetch variant uses 4 stages");
+    bf16x8 fa[2][MI], fb[2][NI];
+    auto rd = [&](int kt, bf16x8 (&a)[MI], bf16x8 (&b)[NI]) {
+      const char* st = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = *(const bf16x8*)(st + b_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8*)(st + a_off + i * 1024);
+    };
+    auto step = [&](int kt, bf16x8 (&ca)[MI], bf16x8 (&cb)[NI], bf16x8 (&na)[MI], bf16x8 (&nb)[NI]) {
+      const int ahead = min(1, nk - 2 - kt);                   // stages beyond kt+1 allowed in flight
+      if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 3 < nk) issue(kt + 3);
+      if (kt + 1 < nk) rd(kt + 1, na, nb);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
-    const char* st = smem + (kt % STAGES) * STAGE_BYTES;
-    bf16x8 af[MI], bfr[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
-    __builtin_amdgcn_s_setprio(1);
+    rd(0, fa[0], fb[0]);
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(kt, fa[0], fb[0], fa[1], fb[1]);
+      if (kt + 1 < nk) step(kt + 1, fa[1], fb[1], fa[0], fb[0]);
+    }
+  }
+  if constexpr (DBG == 3) {          // ablation: no epilogue at all (accumulators kept live)
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+      for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
   }
-  // ---- epilogue through a per-wave f32 LDS tile [64][68], 64 output rows at a time
+  // ---- epilogue: accumulators -> per-wave f32 LDS strip [16 rows][68] -> row-contiguous 16-B global accesses.
+  // One strip per MFMA row-block i (16 output rows x 64 columns); strips of 4.25 KiB keep the LDS footprint at the
+  // ring size, so two workgroups can share a CU where the register budget allows.
   __syncthreads();
   constexpr int ELD = 68;
-  float* ew = (float*)smem + wave * (64 * ELD);
+  float* ew = (float*)smem + wave * (16 * ELD);
+  auto fill = [&](int i, int cblk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ew[((lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[i][cblk * 4 + j][r];
+  };
   if constexpr (EPI == LDMAE_EPI_SWIGLU) {
-    // ew cols 0..31 = x1 (hid columns hc0..), 32..63 = x2.  Values are rounded to bf16 BEFORE silu so the result is
+    // strip cols 0..31 = x1 (hid columns hc..), 32..63 = x2.  Values are rounded to bf16 BEFORE silu so the result is
     // bit-identical to the unfused ldmae_swiglu_fwd on the stored h12.
     static_assert(EPI != LDMAE_EPI_SWIGLU || TNn == 64, "swiglu epilogue needs 64-column wave slices");
     const int Hs = N >> 1, hc = (n0 >> 1) + wn * 32 + (lane & 7) * 4;
@@ -270,17 +380,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
     const float4 b1 = e.bias ? *(const float4*)(e.bias + hc) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 b2 = e.bias ? *(const float4*)(e.bias + Hs + hc) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int half = 0; half < TM / 64; ++half) {
+    for (int i = 0; i < MI; ++i) {
+      fill(i, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ew[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[half * 4 + i][j][r];
-      const int mb = m0 + wm * TM + half * 64;
-#pragma unroll 4
-      for (int it = 0; it < 8; ++it) {
-        const int row = it * 8 + (lane >> 3), m = mb + row;
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + (lane >> 3), m = m0 + wm * TM + i * 16 + row;
         const float4 u = *(const float4*)(ew + row * ELD + (lane & 7) * 4), v = *(const float4*)(ew + row * ELD + 32 + (lane & 7) * 4);
         if (m < M && hc < Hs) {
           bf16x4 x1, x2, ho;
@@ -302,19 +406,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
     const bf16* h12 = (const bf16*)e.xin;
     bf16* dh12 = (bf16*)e.C;
 #pragma unroll
-    for (int half = 0; half < TM / 64; ++half) {
+    for (int cblk = 0; cblk < TNn / 64; ++cblk) {
+      const int n = n0 + wn * TNn + cblk * 64 + (lane & 15) * 4;
 #pragma unroll
-      for (int cblk = 0; cblk < TNn / 64; ++cblk) {
+      for (int i = 0; i < MI; ++i) {
+        fill(i, cblk);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ew[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[half * 4 + i][cblk * 4 + j][r];
-        const int mb = m0 + wm * TM + half * 64, n = n0 + wn * TNn + cblk * 64 + (lane & 15) * 4;
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-          const int row = it * 4 + (lane >> 4), m = mb + row;
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 4 + (lane >> 4), m = m0 + wm * TM + i * 16 + row;
           const float4 gv = *(const float4*)(ew + row * ELD + (lane & 15) * 4);
           if (m < M && n < Hs) {
             const bf16x4 av = *(const bf16x4*)(h12 + (size_t)m * 2 * Hs + n), bv = *(const bf16x4*)(h12 + (size_t)m * 2 * Hs + Hs + n);
@@ -334,27 +433,39 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
     }
     return;
   }
-  const bool nfast = (N % 4 == 0) && (e.ldc % 4 == 0) && (EPI != LDMAE_EPI_GATE_RES || e.rows_per_batch % 64 == 0);
+  const bool nfast = (N % 8 == 0) && (e.ldc % 8 == 0) && (EPI != LDMAE_EPI_GATE_RES || e.rows_per_batch % 16 == 0);
 #pragma unroll
-  for (int half = 0; half < TM / 64; ++half) {
+  for (int cblk = 0; cblk < TNn / 64; ++cblk) {
+    const int nb = n0 + wn * TNn + cblk * 64, col = (lane & 15) * 4;
 #pragma unroll
-    for (int cblk = 0; cblk < TNn / 64; ++cblk) {
+    for (int i = 0; i < MI; ++i) {
+      fill(i, cblk);
+      const int mb = m0 + wm * TM + i * 16;
+      if (nfast && mb + 16 <= M && nb + 64 <= N) {
+        // 8 consecutive columns per lane, 8 lanes per row: one 16-B store per lane for bf16 outputs (the store tail is
+        // issue-bound: half the store instructions of the 8-B form), full 128-B lines per row
+        const int c8 = (lane & 7) * 8;
+        const Epi4<EPI, OutT> ep0(e, mb, nb + c8, N), ep1(e, mb, nb + c8 + 4, N);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ew[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[half * 4 + i][cblk * 4 + j][r];
-      const int mb = m0 + wm * TM + half * 64, nb = n0 + wn * TNn + cblk * 64, col = (lane & 15) * 4;
-      if (nfast && mb + 64 <= M && nb + 64 <= N) {
-        const Epi4<EPI, OutT> ep(e, mb, nb + col, N);
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-          const int row = it * 4 + (lane >> 4);
-          ep.apply(mb + row, *(const float4*)(ew + row * ELD + col));
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 8 + (lane >> 3), m = mb + row;
+          float4 y0, y1, z0, z1;
+          ep0.compute(m, *(const float4*)(ew + row * ELD + c8), y0, z0);
+          ep1.compute(m, *(const float4*)(ew + row * ELD + c8 + 4), y1, z1);
+          const size_t oc = (size_t)m * e.ldc + nb + c8;
+          auto put8 = [&](void* base, float4 a, float4 b) {
+            if constexpr (sizeof(OutT) == 4) { *(float4*)((float*)base + oc) = a; *(float4*)((float*)base + oc + 4) = b; }
+            else {
+              bf16x8 o;
+              o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w; o[4] = (bf16)b.x; o[5] = (bf16)b.y; o[6] = (bf16)b.z; o[7] = (bf16)b.w;
+              *(bf16x8*)((bf16*)base + oc) = o;
+            }
+          };
+          if (e.C) put8(e.C, y0, y1);
+          if (EPI == LDMAE_EPI_BIAS_GELU && e.C2) put8(e.C2, z0, z1);
         }
       } else {
-        for (int it = 0; it < 16; ++it) {
+        for (int it = 0; it < 4; ++it) {
           const int row = it * 4 + (lane >> 4);
           const float4 v = *(const float4*)(ew + row * ELD + col);
           const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -750,7 +861,7 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
   const int variant = ldmae_tune_get(0) == 0 ? 4 : ldmae_tune_get(0) - 1;  // default: 256x256 ring, 3 stages; tune value v selects variant v-1
 #define RING(E, BM_, BN_, WM_, WN_, ST_)                                                                                          \
   {                                                                                                                               \
-    constexpr int lds_ring = ST_ * (BM_ + BN_) * 64, lds_epi = WM_ * WN_ * 64 * 68 * 4;                                           \
+    constexpr int lds_ring = ST_ * (BM_ + BN_) * 64, lds_epi = WM_ * WN_ * 16 * 68 * 4;                                           \
     constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;                                                                   \
     static bool attr_done = false;                                                                                                 \
     if (!attr_done) {                                                                                                              \
@@ -761,8 +872,44 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
     hipLaunchKernelGGL((gemm_nt_ring_kernel<BM_, BN_, WM_, WN_, ST_, E, OutT>), dim3(cdiv(M, BM_) * cdiv(N, BN_)),                \
                        dim3(WM_ * WN_ * 64), lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                      \
   }
+#define RINGP(E)                                                                                                                  \
+  {                                                                                                                               \
+    constexpr int lds = 4 * 512 * 64;                                                                                             \
+    static bool attr_done = false;                                                                                                 \
+    if (!attr_done) {                                                                                                              \
+      hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, E, OutT, true>,                                      \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                        \
+      attr_done = true;                                                                                                            \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, E, OutT, true>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512),     \
+                       lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                                            \
+  }
+#define RINGD(E, D, S)                                                                                                            \
+  {                                                                                                                               \
+    constexpr int lds = 3 * 512 * 64;                                                                                             \
+    hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 3, E, OutT, false, D>,                                    \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                          \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 3, E, OutT, false, D>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512), \
+                       lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                                            \
+  }
+#define RING2(E)                                                                                                                  \
+  {                                                                                                                               \
+    constexpr int lds = 4 * 512 * 64;                                                                                             \
+    static bool attr_done = false;                                                                                                 \
+    if (!attr_done) {                                                                                                              \
+      hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, E, OutT, false, 4>,                                  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                        \
+      attr_done = true;                                                                                                            \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, E, OutT, false, 4>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512), \
+                       lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                                            \
+  }
 #define NT_LAUNCH(E)                                                                                                             \
-  if (dtype == LDMAE_BF16 && variant == 1 && K % 32 == 0) RING(E, 128, 128, 2, 2, 4)                                              \
+  if (dtype == LDMAE_BF16 && variant == 11 && K % 64 == 0) RING2(E)                                                               \
+  else if (dtype == LDMAE_BF16 && variant == 8 && K % 32 == 0) RINGP(E)                                                                \
+  else if (dtype == LDMAE_BF16 && variant == 9 && K % 32 == 0) RING(E, 256, 128, 4, 2, 3)                                         \
+  else if (dtype == LDMAE_BF16 && variant == 10 && K % 32 == 0) RING(E, 128, 256, 2, 4, 3)                                        \
+  else if (dtype == LDMAE_BF16 && variant == 1 && K % 32 == 0) RING(E, 128, 128, 2, 2, 4)                                              \
   else if (dtype == LDMAE_BF16 && variant == 2 && K % 32 == 0) RING(E, 256, 128, 4, 2, 4)                                         \
   else if (dtype == LDMAE_BF16 && variant == 3 && K % 32 == 0) RING(E, 256, 256, 2, 4, 4)                                         \
   else if (dtype == LDMAE_BF16 && variant == 4 && K % 32 == 0) RING(E, 256, 256, 2, 4, 3)                                         \
@@ -775,6 +922,12 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
   else                                                                                                                           \
     hipLaunchKernelGGL((gemm_nt_f32_kernel<E, OutT>), dim3(cdiv(M, F_BM) * cdiv(N, F_BN)), dim3(256), 0, st, (const float*)A,    \
                        (const float*)B, M, N, K, lda, ldb, e)
+  if (dtype == LDMAE_BF16 && epi == LDMAE_EPI_BIAS && (variant >= 20 && variant <= 22)) {   // diagnostic ablations (tools/ablate_gemm.py)
+    if (variant == 20) RINGD(LDMAE_EPI_BIAS, 1, 3) else if (variant == 21) RINGD(LDMAE_EPI_BIAS, 2, 3) else RINGD(LDMAE_EPI_BIAS, 3, 3)
+    if (pi >= 0) ldmae_prof_end(pi, st);
+    LDMAE_CHECK_LAUNCH("gemm_nt");
+    return LDMAE_OK;
+  }
   switch (epi) {
     case LDMAE_EPI_BIAS: NT_LAUNCH(LDMAE_EPI_BIAS); break;
     case LDMAE_EPI_GATE_RES: NT_LAUNCH(LDMAE_EPI_GATE_RES); break;
@@ -785,6 +938,9 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
   }
 #undef NT_LAUNCH
 #undef RING
+#undef RINGP
+#undef RING2
+#undef RINGD
   if (pi >= 0) ldmae_prof_end(pi, st);
   LDMAE_CHECK_LAUNCH("gemm_nt");
   return LDMAE_OK;

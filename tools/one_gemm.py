@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Launch a few GEMMs of one shape (for rocprofv3 --pmc runs).  python3 tools/one_gemm.py kind N K [variant]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ldmae_amd import _lib, ops
+kind, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+v = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+M = 262144
+_lib.load().ldmae_tune(0 if kind == "nt" else 1, v)
+g = torch.Generator(device="cuda").manual_seed(0)
+if kind == "nt":
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    for _ in range(3):
+        ops.gemm_nt(a, w, None)
+elif kind == "tn":
+    a = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+    b = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    for _ in range(3):
+        ops.gemm_tn(a, b)
+else:
+    B, H, NN, hd = 256, 12, 1024, 64
+    q, k, vv = (torch.randn(B, H, NN, hd, device="cuda", generator=g).to(torch.bfloat16) for _ in range(3))
+    do = torch.randn(B, NN, H * hd, device="cuda", generator=g).to(torch.bfloat16)
+    for _ in range(3):
+        o, lse = ops.attention_fwd(q, k, vv, 0.125)
+        ops.attention_bwd(q, k, vv, o, do, lse, 0.125)
+torch.cuda.synchronize()
