@@ -646,12 +646,12 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restric
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tnr_sw(int r) { return ((r & 3) << 1) | (((r >> 3) & 1) << 3); }
 
-template <int STAGES>
-__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, float* __restrict__ P,
+template <int STAGES, int DBG = 0, int WNn = 2>
+__global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, float* __restrict__ P,
                                                            float* __restrict__ Pb, int M, int N, int K, int lda, int ldb,
                                                            int rows_per_split) {
-  constexpr int BNn = 256, BKk = 256, WNn = 2, WKk = 4, MI = 8, NI = 4, STEP = 32;
-  constexpr int OP_BYTES = STEP * 512, STAGE_BYTES = 2 * OP_BYTES, PPW = (2 * OP_BYTES / 1024) / 8;   // 32 pieces / 8 waves = 4
+  constexpr int BNn = 256, BKk = 256, WKk = 4, NW = WNn * WKk, MI = 256 / WNn / 16, NI = 4, STEP = 32;
+  constexpr int OP_BYTES = STEP * 512, STAGE_BYTES = 2 * OP_BYTES, PPW = (2 * OP_BYTES / 1024) / NW;   // 32 pieces over the waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -711,18 +711,26 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16* __restric
     if (s < nsteps) issue(s);
   for (int st = 0; st < nsteps; ++st) {
     const int ahead = min(STAGES - 2, nsteps - 1 - st);
-    if (ahead >= 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
+    if (ahead >= 3) { if constexpr (STAGES >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory"); }
+    else if (ahead == 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (st + STAGES - 1 < nsteps) issue(st + STAGES - 1);
+    if constexpr (DBG != 2) { if (st + STAGES - 1 < nsteps) issue(st + STAGES - 1); }
     const char* ta = smem + (st % STAGES) * STAGE_BYTES;
     const char* tb = ta + OP_BYTES;
     bf16x8 af[MI], bfr[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) bfr[j] = frag(tb, wk * 64 + j * 16);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) af[i] = frag(ta, wn * 128 + i * 16);
+    for (int i = 0; i < MI; ++i) af[i] = frag(ta, wn * (MI * 16) + i * 16);
+    if constexpr (DBG == 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+      for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
+      continue;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -734,33 +742,39 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(const bf16* __restric
     }
     __builtin_amdgcn_s_setprio(0);
   }
-  // ---- epilogue: f32 partial tile through a per-wave LDS tile for row-contiguous stores
+  // ---- epilogue: f32 partial tile through a per-wave LDS tile for row-contiguous stores (8 waves at a time: 139 KiB)
   __syncthreads();
   constexpr int ELD = 68;
-  float* ew = (float*)smem + wave * (64 * ELD);
+  float* ew = (float*)smem + (wave & 7) * (64 * ELD);
   float* out = P + (size_t)split * N * K;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int grp = 0; grp < NW / 8; ++grp) {
+    if ((wave >> 3) == grp) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int half = 0; half < MI / 4; ++half) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ew[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[half * 4 + i][j][r];
-    const int nb = n0 + wn * 128 + half * 64, kb = k0 + wk * 64, col = (lane & 15) * 4;
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ew[(i * 16 + (lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[half * 4 + i][j][r];
+        const int nb = n0 + wn * (MI * 16) + half * 64, kb = k0 + wk * 64, col = (lane & 15) * 4;
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 4 + (lane >> 4);
-      const float4 v = *(const float4*)(ew + row * ELD + col);
-      if (nb + row < N && kb + col < K) *(float4*)(out + (size_t)(nb + row) * K + kb + col) = v;   // K % 4 == 0 (host check)
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 4 + (lane >> 4);
+          const float4 v = *(const float4*)(ew + row * ELD + col);
+          if (nb + row < N && kb + col < K) *(float4*)(out + (size_t)(nb + row) * K + kb + col) = v;   // K % 4 == 0 (host check)
+        }
+      }
     }
+    if (grp + 1 < NW / 8) __syncthreads();
   }
   if (want_bias && (lane & 15) == 0) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wn * 128 + i * 16 + (lane >> 4) * 4 + r;
+        const int n = n0 + wn * (MI * 16) + i * 16 + (lane >> 4) * 4 + r;
         if (n < N) Pb[(size_t)split * N + n] = accb[i][r];
       }
   }
@@ -858,7 +872,9 @@ template <typename OutT>
 static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
                      hipStream_t st) {
   const long pi = (ldmae_prof_is_on() && dtype == LDMAE_BF16) ? ldmae_prof_begin(st, 2.0 * M * N * K) : -1;
-  const int variant = ldmae_tune_get(0) == 0 ? 4 : ldmae_tune_get(0) - 1;  // default: 256x256 ring, 3 stages; tune value v selects variant v-1
+  // default: 256x256 tile, 3-stage ring; 16 waves (64x64 each) except for the gated-residual epilogue (8 waves, 128x64 each);
+  // tune value v selects variant v-1 for A/B runs
+  const int variant = ldmae_tune_get(0) == 0 ? (epi == LDMAE_EPI_GATE_RES ? 4 : 12) : ldmae_tune_get(0) - 1;
 #define RING(E, BM_, BN_, WM_, WN_, ST_)                                                                                          \
   {                                                                                                                               \
     constexpr int lds_ring = ST_ * (BM_ + BN_) * 64, lds_epi = WM_ * WN_ * 16 * 68 * 4;                                           \
@@ -907,6 +923,8 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
 #define NT_LAUNCH(E)                                                                                                             \
   if (dtype == LDMAE_BF16 && variant == 11 && K % 64 == 0) RING2(E)                                                               \
   else if (dtype == LDMAE_BF16 && variant == 8 && K % 32 == 0) RINGP(E)                                                                \
+  else if (dtype == LDMAE_BF16 && variant == 12 && K % 32 == 0) RING(E, 256, 256, 4, 4, 3)                                        \
+  else if (dtype == LDMAE_BF16 && variant == 13 && K % 32 == 0) RING(E, 256, 256, 4, 4, 4)                                        \
   else if (dtype == LDMAE_BF16 && variant == 9 && K % 32 == 0) RING(E, 256, 128, 4, 2, 3)                                         \
   else if (dtype == LDMAE_BF16 && variant == 10 && K % 32 == 0) RING(E, 128, 256, 2, 4, 3)                                        \
   else if (dtype == LDMAE_BF16 && variant == 1 && K % 32 == 0) RING(E, 128, 128, 2, 2, 4)                                              \
@@ -932,8 +950,8 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
     case LDMAE_EPI_BIAS: NT_LAUNCH(LDMAE_EPI_BIAS); break;
     case LDMAE_EPI_GATE_RES: NT_LAUNCH(LDMAE_EPI_GATE_RES); break;
     case LDMAE_EPI_BIAS_POS: NT_LAUNCH(LDMAE_EPI_BIAS_POS); break;
-    case LDMAE_EPI_SWIGLU: RING(LDMAE_EPI_SWIGLU, 256, 256, 2, 4, 3); break;
-    case LDMAE_EPI_SWIGLU_BWD: RING(LDMAE_EPI_SWIGLU_BWD, 256, 256, 2, 4, 3); break;
+    case LDMAE_EPI_SWIGLU: RING(LDMAE_EPI_SWIGLU, 256, 256, 4, 4, 3); break;
+    case LDMAE_EPI_SWIGLU_BWD: RING(LDMAE_EPI_SWIGLU_BWD, 256, 256, 4, 4, 3); break;
     default: NT_LAUNCH(LDMAE_EPI_BIAS_GELU); break;
   }
 #undef NT_LAUNCH
@@ -1027,11 +1045,30 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   float* P = workspace;
   float* Pb = workspace + (size_t)splits * N * K;
   if (ring) {
-    constexpr int lds = 8 * 64 * 68 * 4;   // epilogue region (139 KiB) >= 3 stages x 32 KiB
+    constexpr int lds = 5 * 32768;   // 5 stages x 32 KiB = all 160 KiB of LDS (the 139 KiB epilogue region re-uses it)
     static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    if (!attr_done) {
+      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_done = true;
+    }
     const unsigned grid = cdiv(N, 256) * cdiv(K, 256) * splits;
-    hipLaunchKernelGGL(gemm_tn_ring_kernel<3>, dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+    if (ldmae_tune_get(4) == 11 || ldmae_tune_get(4) == 12) {
+      if (ldmae_tune_get(4) == 11) { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 1>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows); }
+      else { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 2>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows); }
+    } else if (ldmae_tune_get(4) == 0) {     // default: 16 waves (64x64 each), 4 stages
+      static bool a16 = false;
+      if (!a16) { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 64 * 68 * 4 > lds ? lds : lds); a16 = true; }
+      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 4>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+    } else if (ldmae_tune_get(4) == 2)
+      hipLaunchKernelGGL(gemm_tn_ring_kernel<5>, dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+    else if (ldmae_tune_get(4) == 1)
+      hipLaunchKernelGGL(gemm_tn_ring_kernel<3>, dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+    else
+      hipLaunchKernelGGL(gemm_tn_ring_kernel<4>, dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
   } else if (dtype == LDMAE_BF16) {
     const unsigned grid = cdiv(N, TN_BN) * cdiv(K, TN_BK) * splits;
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 4 * TN_TILE_BYTES, st, (const bf16*)A, (const bf16*)B, P, M, N, K, lda, ldb, rows);
