@@ -59,11 +59,22 @@ def train_step(model, opt, reducer, transport, x, y):
     return loss
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC run (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes over this same bench, FETCH_SIZE doubled per the gfx950 note); None if the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_bench.json")) as f:
+            return round(json.load(f)["gemm_nt_ring"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(max_seconds=30.0):
     """The CPU oracle (a port of the reference step; the reference itself cannot travel) on this box's host cores:
     BASELINE config 1 -- LightningDiT-B/1, bs=4, fp32, AdamW + EMA, eager.  Bounded sample: 1 untimed + up to 3 timed steps."""
     from oracle import dit as odit, train as otrain
     cfg = odit.DiTConfig(**odit.DIT_B_1)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))       # a 1-GPU box's CPU share (16 cores)
     torch.manual_seed(0)
     np.random.seed(0)
     sd = odit.init_weights(cfg)
@@ -104,9 +115,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # LDMAE_BENCH_BACKEND=gloo + LDMAE_BENCH_DEVICE=0 let two ranks share ONE GPU to rehearse the N>1 path on a 1-GPU box
+    backend = os.environ.get("LDMAE_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("LDMAE_BENCH_DEVICE", local))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.cuda.set_device(local)
@@ -141,7 +158,7 @@ def main():
     ms, fl, nl = C.c_double(), C.c_double(), C.c_long()
     lib.ldmae_prof_collect(C.byref(ms), C.byref(fl), C.byref(nl))
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
@@ -161,7 +178,8 @@ def main():
             "step_mfma_frac": round(FLOPS_PER_IMAGE * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (all Linear fwd + dX GEMMs)",
                          "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(),
+                         "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_bench.json)",
                          "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4),
                          "avg_launch_gflop": round(fl.value / max(1, nl.value) / 1e9, 2)},
         }
