@@ -254,7 +254,44 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
   const int a_off = (wm * TM + (lane & 15)) * 64 + fpos, b_off = (BM + wn * TNn + (lane & 15)) * 64 + fpos;
 
   const int nk = K / 32;
-  if constexpr (DBG == 4) {
+  if constexpr (DBG == 5) {
+    // Two wave groups (upper / lower half of the M waves; they share the SIMDs pairwise) run half a K-step apart: while one
+    // group issues its global_load_lds + fragment ds_reads (L phase) the other runs its 32 MFMAs (M phase), a barrier at every
+    // phase boundary is the metronome.  Every wave waits for its own pieces of stage kt+1 one phase before anyone reads them.
+    const bool grpB = wm >= WM / 2;
+    auto wait_next = [&](int kt) {                       // own pieces of stage kt+1 landed; later stages may stay in flight
+      const int ahead = min(STAGES - 2, nk - 2 - kt);
+      if (ahead >= 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else if (ahead == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nk) issue(s);
+    wait_next(-1);                                       // stage 0
+    __builtin_amdgcn_s_barrier();
+    if (grpB) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
+      const char* st = smem + (kt % STAGES) * STAGE_BYTES;
+      bf16x8 af[MI], bfr[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+      if (grpB) wait_next(kt);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (!grpB) wait_next(kt);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!grpB) __builtin_amdgcn_s_barrier();
+  } else if constexpr (DBG == 4) {
     // two K-steps per barrier: stages (2t, 2t+1) are consumed while (2t+2, 2t+3) are in flight (4 buffers)
     static_assert(DBG != 4 || STAGES == 4, "double-step variant uses 4 stages");
     const int nd = nk / 2;                                   // host guarantees K % 64 == 0
@@ -287,7 +324,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue(s);
   }
-  if constexpr (DBG == 4) {
+  if constexpr (DBG == 4 || DBG == 5) {
   } else if constexpr (!PREFETCH) {
     for (int kt = 0; kt < nk; ++kt) {
       const int ahead = min(STAGES - 2, nk - 1 - kt);          // stages allowed to stay in flight
@@ -646,7 +683,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restric
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tnr_sw(int r) { return ((r & 3) << 1) | (((r >> 3) & 1) << 3); }
 
-template <int STAGES, int DBG = 0, int WNn = 2>
+template <int STAGES, int DBG = 0, int WNn = 2, bool STAG = false>
 __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, float* __restrict__ P,
                                                            float* __restrict__ Pb, int M, int N, int K, int lda, int ldb,
                                                            int rows_per_split) {
@@ -709,6 +746,45 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nsteps) issue(s);
+  if constexpr (STAG) {
+    // two wave groups half a step apart (see gemm_nt_ring_kernel, DBG == 5 path): loads + transposed fragment reads of one group
+    // run beside the MFMAs of the other on every SIMD
+    const bool grpB = wn >= WNn / 2;
+    auto wait_next = [&](int st) {
+      const int ahead = min(STAGES - 2, nsteps - 2 - st);
+      if (ahead >= 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else if (ahead == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    wait_next(-1);
+    __builtin_amdgcn_s_barrier();
+    if (grpB) __builtin_amdgcn_s_barrier();
+    for (int st = 0; st < nsteps; ++st) {
+      if (st + STAGES - 1 < nsteps) issue(st + STAGES - 1);
+      const char* ta = smem + (st % STAGES) * STAGE_BYTES;
+      const char* tb = ta + OP_BYTES;
+      bf16x8 af[MI], bfr[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[j] = frag(tb, wk * 64 + j * 16);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = frag(ta, wn * (MI * 16) + i * 16);
+      if (grpB) wait_next(st);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (want_bias) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (!grpB) wait_next(st);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!grpB) __builtin_amdgcn_s_barrier();
+  } else {
   for (int st = 0; st < nsteps; ++st) {
     const int ahead = min(STAGES - 2, nsteps - 1 - st);
     if (ahead >= 3) { if constexpr (STAGES >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory"); }
@@ -741,6 +817,7 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
       for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
+  }
   }
   // ---- epilogue: f32 partial tile through a per-wave LDS tile for row-contiguous stores (8 waves at a time: 139 KiB)
   __syncthreads();
@@ -872,9 +949,9 @@ template <typename OutT>
 static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
                      hipStream_t st) {
   const long pi = (ldmae_prof_is_on() && dtype == LDMAE_BF16) ? ldmae_prof_begin(st, 2.0 * M * N * K) : -1;
-  // default: 256x256 tile, 3-stage ring; 16 waves (64x64 each) except for the gated-residual epilogue (8 waves, 128x64 each);
+  // default (variant 14): 256x256 tile, 8 waves (128x64 each), 3-stage ring, the two M wave groups staggered by half a K-step;
   // tune value v selects variant v-1 for A/B runs
-  const int variant = ldmae_tune_get(0) == 0 ? (epi == LDMAE_EPI_GATE_RES ? 4 : 12) : ldmae_tune_get(0) - 1;
+  const int variant = ldmae_tune_get(0) == 0 ? 14 : ldmae_tune_get(0) - 1;
 #define RING(E, BM_, BN_, WM_, WN_, ST_)                                                                                          \
   {                                                                                                                               \
     constexpr int lds_ring = ST_ * (BM_ + BN_) * 64, lds_epi = WM_ * WN_ * 16 * 68 * 4;                                           \
@@ -920,8 +997,23 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
     hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, E, OutT, false, 4>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512), \
                        lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                                            \
   }
+#define RINGS(E, WM_, WN_, ST_)                                                                                                    \
+  {                                                                                                                               \
+    constexpr int lds = ST_ * 512 * 64;                                                                                           \
+    static bool attr_done = false;                                                                                                 \
+    if (!attr_done) {                                                                                                              \
+      hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, WM_, WN_, ST_, E, OutT, false, 5>,                            \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                        \
+      attr_done = true;                                                                                                            \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, WM_, WN_, ST_, E, OutT, false, 5>), dim3(cdiv(M, 256) * cdiv(N, 256)),      \
+                       dim3(WM_ * WN_ * 64), lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                      \
+  }
 #define NT_LAUNCH(E)                                                                                                             \
-  if (dtype == LDMAE_BF16 && variant == 11 && K % 64 == 0) RING2(E)                                                               \
+  if (dtype == LDMAE_BF16 && variant == 14 && K % 32 == 0) RINGS(E, 2, 4, 3)                                                      \
+  else if (dtype == LDMAE_BF16 && variant == 15 && K % 32 == 0) RINGS(E, 2, 4, 4)                                                 \
+  else if (dtype == LDMAE_BF16 && variant == 16 && K % 32 == 0) RINGS(E, 4, 4, 4)                                                 \
+  else if (dtype == LDMAE_BF16 && variant == 11 && K % 64 == 0) RING2(E)                                                               \
   else if (dtype == LDMAE_BF16 && variant == 8 && K % 32 == 0) RINGP(E)                                                                \
   else if (dtype == LDMAE_BF16 && variant == 12 && K % 32 == 0) RING(E, 256, 256, 4, 4, 3)                                        \
   else if (dtype == LDMAE_BF16 && variant == 13 && K % 32 == 0) RING(E, 256, 256, 4, 4, 4)                                        \
@@ -950,14 +1042,15 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
     case LDMAE_EPI_BIAS: NT_LAUNCH(LDMAE_EPI_BIAS); break;
     case LDMAE_EPI_GATE_RES: NT_LAUNCH(LDMAE_EPI_GATE_RES); break;
     case LDMAE_EPI_BIAS_POS: NT_LAUNCH(LDMAE_EPI_BIAS_POS); break;
-    case LDMAE_EPI_SWIGLU: RING(LDMAE_EPI_SWIGLU, 256, 256, 4, 4, 3); break;
-    case LDMAE_EPI_SWIGLU_BWD: RING(LDMAE_EPI_SWIGLU_BWD, 256, 256, 4, 4, 3); break;
+    case LDMAE_EPI_SWIGLU: RINGS(LDMAE_EPI_SWIGLU, 2, 4, 3); break;
+    case LDMAE_EPI_SWIGLU_BWD: RINGS(LDMAE_EPI_SWIGLU_BWD, 2, 4, 3); break;
     default: NT_LAUNCH(LDMAE_EPI_BIAS_GELU); break;
   }
 #undef NT_LAUNCH
 #undef RING
 #undef RINGP
 #undef RING2
+#undef RINGS
 #undef RINGD
   if (pi >= 0) ldmae_prof_end(pi, st);
   LDMAE_CHECK_LAUNCH("gemm_nt");
@@ -1059,6 +1152,14 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
         hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 1>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows); }
       else { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 2>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows); }
+    } else if (ldmae_tune_get(4) == 5 || ldmae_tune_get(4) == 4) {     // staggered wave groups (measured slower for TN: 650 vs 730 TF/s)
+      static bool as_ = false;
+      if (!as_) { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                  hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); as_ = true; }
+      if (ldmae_tune_get(4) == 5)
+        hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 2, true>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+      else
+        hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 4, true>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
     } else if (ldmae_tune_get(4) == 0) {     // default: 16 waves (64x64 each), 4 stages
       static bool a16 = false;
       if (!a16) { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 64 * 68 * 4 > lds ? lds : lds); a16 = true; }
