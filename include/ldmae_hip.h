@@ -152,6 +152,9 @@ int ldmae_prof_collect(double* total_ms, double* total_flops, long* launches);  
 
 /* kernel-variant selection for tuning / A-B measurements (key 0: bf16 NT GEMM variant, key 1: bf16 TN GEMM variant) */
 int ldmae_tune(int key, int value);
+/* diagnostic: device buffer (>= 64 B x 256 workgroups x tiles-per-workgroup) that receives s_memrealtime stamps of the
+   persistent NT GEMM (tile start / main loop end / epilogue issued / stores drained); NULL (default) = off */
+void ldmae_debug_nt_stamps(void* buf);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,7 @@ SIGNATURES = {
     "ldmae_gelu_bwd": (_i, [_i, _vp, _vp, _vp, _l, _vp]),
     "ldmae_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_tune": (_i, [_i, _i]),
+    "ldmae_debug_nt_stamps": (None, [_vp]),
     "ldmae_prof_enable": (_i, [_i]),
     "ldmae_prof_collect": (_i, [C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
 }
@@ -81,6 +82,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # LDMAE_TUNE="key=value,..." presets the library's A/B knobs (ldmae_tune) for profiling runs; unset = shipped defaults
+    for kv in filter(None, os.environ.get("LDMAE_TUNE", "").split(",")):
+        k, v = kv.split("=")
+        lib.ldmae_tune(int(k), int(v))
     _lib = lib
     return lib
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ g, long ld, 
       int row, ch;
       tile_inv<HD>(pi * 1024 + lane * 16, row, ch);
       row = min(row, row_limit);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(g + (long)row * ld + ch * 8), LDS_PTR(void, lds + pi * 1024), 16, 0, 0);
+      glds16(g + (long)row * ld + ch * 8, lds + pi * 1024);
     }
   }
 }
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
     stage_tile<HD, 64>(qp + (size_t)qt * 64 * HD, HD, 63, base, wave, lane);
     stage_tile<HD, 64>(dop + (size_t)qt * 64 * dold, dold, 63, base + TB, wave, lane);
     // 64 floats of lse (slot 0) / delta (slot 1); waves 2,3 fill scratch slots so every wave issues PPW loads
-    __builtin_amdgcn_global_load_lds(GLB_PTR(rowc + qt * 64 + lane), LDS_PTR(void, base + 2 * TB + wave * 256), 4, 0, 0);
+    glds4(rowc + qt * 64 + lane, base + 2 * TB + wave * 256);
   };
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)

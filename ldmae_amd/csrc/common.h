@@ -17,6 +17,21 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// global -> LDS DMA: every lane brings 16 B (or 4 B) from its own global address to LDS byte (lds + lane * 16) (or * 4); `lds`
+// must be wave-uniform.  Issued as inline asm ON PURPOSE: when hipcc sees the builtin it may decide that later ds_reads alias
+// the DMA destination and put `s_waitcnt vmcnt(0)` before the first fragment read of every K-step (seen in 2 of 6 epilogue
+// instantiations of one GEMM kernel: the whole ring drains each step, -35 %).  Hidden from the compiler, the only vmcnt waits
+// in a main loop are the counted ones written there; compiler-counted waits for ordinary loads can then only over-wait.
+// The kernels order DMA against LDS reads themselves (counted s_waitcnt vmcnt + s_barrier).
+__device__ __forceinline__ void glds16(const void* g, const void* lds) {
+  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(void, lds));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(a) : "memory", "m0");
+}
+__device__ __forceinline__ void glds4(const void* g, const void* lds) {
+  const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(void, lds));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(a) : "memory", "m0");
+}
+
 // ---------------------------------------------------------------- error plumbing
 void ldmae_set_error(const char* fmt, ...);
 #define LDMAE_FAIL(code, ...) do { ldmae_set_error(__VA_ARGS__); return (code); } while (0)
@@ -91,3 +106,7 @@ void ldmae_prof_end(long idx, hipStream_t st);
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+// sigmoid on the fast-math units: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the 12-instruction IEEE division; every SwiGLU
+// site (fused GEMM epilogues and the standalone kernels) uses this one definition, so fused and unfused paths stay bit-identical.
+__device__ __forceinline__ float fast_sigmoid(float a) { return __builtin_amdgcn_rcpf(1.f + __expf(-a)); }

@@ -384,7 +384,7 @@ __global__ void swiglu_fwd_kernel(const T* __restrict__ h12, T* __restrict__ hid
     Vec8<T>::load(h12 + m * 2 * Hs + c, a);
     Vec8<T>::load(h12 + m * 2 * Hs + Hs + c, b);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = a[j] / (1.f + __expf(-a[j])) * b[j];
+    for (int j = 0; j < 8; ++j) o[j] = a[j] * fast_sigmoid(a[j]) * b[j];
     Vec8<T>::store(hid + m * Hs + c, o);
   }
 }
@@ -399,7 +399,7 @@ __global__ void swiglu_bwd_kernel(const T* __restrict__ dhid, const T* __restric
     Vec8<T>::load(dhid + m * Hs + c, g);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float s = 1.f / (1.f + __expf(-a[j]));
+      const float s = fast_sigmoid(a[j]);
       da[j] = g[j] * b[j] * s * (1.f + a[j] * (1.f - s));
       db[j] = g[j] * a[j] * s;
     }

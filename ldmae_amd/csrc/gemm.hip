@@ -5,8 +5,8 @@
 //   TN : C[N,K] = A[M,N]^T . B[M,K]   (weight gradients; contraction over the token rows,
 //        operands fetched K-major and transposed on the LDS read with ds_read_b64_tr_b16)
 //
-// bf16: mfma_f32_16x16x32_bf16, LDS tiles filled by global_load_lds (16 B/lane, swizzle on
-// the SOURCE address, linear LDS image), two buffers, one barrier per K-step.
+// bf16: mfma_f32_16x16x32_bf16, LDS ring filled by global_load_lds (16 B/lane, swizzle on
+// the SOURCE address, linear LDS image), persistent 256x256-tile kernels.
 // f32 : mfma_f32_16x16x4f32 (exact f32 FMA chain), register staged.  The f32 path exists
 // for the fp32 parity contract (1e-4 vs the CPU oracle); bf16 is the throughput path.
 #include "common.h"
@@ -52,101 +52,11 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M,
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16 NT GEMM: 128x128 tile, 256 threads (2x2 waves, 64x64 per wave = 4x4 MFMA tiles), BK = 64.
-// LDS image per operand tile: [128 rows][64 k] bf16, 128-B rows, 16-B chunk c of row r stored at
-// chunk position c ^ ((r >> 1) & 7)  -> ds_read_b128 fragment reads are bank-conflict free.
-// ------------------------------------------------------------------------------------------------
-constexpr int NT_BM = 128, NT_BN = 128, NT_BK = 64;
-constexpr int NT_TILE_BYTES = NT_BM * NT_BK * 2;   // 16 KiB per operand tile
-
-template <int EPI, typename OutT>
-__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
-                                                           int M, int N, int K, int lda, int ldb, EpiArgs e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buf][A 16K | B 16K]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const unsigned tiles_n = (N + NT_BN - 1) / NT_BN;
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (lid / tiles_n) * NT_BM, n0 = (lid % tiles_n) * NT_BN;
-
-  // staging: each wave issues 4 A pieces + 4 B pieces per K-step; piece = 8 rows x 128 B
-  const bf16* asrc[4];
-  const bf16* bsrc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave * 4 + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    asrc[i] = A + (size_t)min(m0 + r, M - 1) * lda + c * 8;
-    bsrc[i] = B + (size_t)min(n0 + r, N - 1) * ldb + c * 8;
-  }
-  auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * 2 * NT_TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + kt * NT_BK), LDS_PTR(void, base + (wave * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(bsrc[i] + kt * NT_BK), LDS_PTR(void, base + NT_TILE_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offsets (bytes) inside a tile for kk = 0; kk = 1 flips chunk bit 2 (c += 4)
-  int aoff[4], boff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = wm * 64 + i * 16 + (lane & 15), rb = wn * 64 + i * 16 + (lane & 15);
-    aoff[i] = ra * 128 + (((lane >> 4) ^ ((ra >> 1) & 7)) << 4);
-    boff[i] = rb * 128 + (((lane >> 4) ^ ((rb >> 1) & 7)) << 4);
-  }
-
-  const int nk = K / NT_BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* ta = smem + cur * 2 * NT_TILE_BYTES;
-    const char* tb = ta + NT_TILE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *(const bf16x8*)(ta + (aoff[i] ^ (kk << 6)));
-        bfr[i] = *(const bf16x8*)(tb + (boff[i] ^ (kk << 6)));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-  }
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        epi_store<EPI, OutT>(e, m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r, n0 + wn * 64 + j * 16 + (lane & 15), M, N, acc[i][j][r]);
-}
-
-// ------------------------------------------------------------------------------------------------
-// bf16 NT GEMM, ring-pipelined: BM x BN tile, WM x WN waves, BK = 32, STAGES LDS buffers filled by
-// global_load_lds that stay in flight ACROSS the per-K-step barrier (raw s_barrier + counted vmcnt, never
-// __syncthreads in the loop), so L2/HBM latency is covered by STAGES-2 K-steps of MFMA work.
-// LDS stage image: [BM + BN rows][32 k] bf16 = 64-B rows; 16-B chunk c of row r sits at position
+// bf16 NT GEMM building blocks.  256 x 256 output tile, 8 waves (2 x 4, 128 x 64 per wave = 8 x 4 MFMA
+// tiles), BK = 32, a 3-deep LDS ring filled by global_load_lds that stays in flight ACROSS the barriers
+// (raw s_barrier + counted vmcnt, never __syncthreads in the loop).
+// LDS stage image: [256 A rows + 256 B rows][32 k] bf16 = 64-B rows; 16-B chunk c of row r sits at position
 // c ^ F[(r >> 2) & 3], F = {0,2,3,1}: conflict-free for the ds_read_b128 lane groups of the 16x16x32 operands.
-// Epilogue: accumulators -> per-wave f32 LDS tile -> row-contiguous 16-B global accesses (fused bias /
-// gated residual / pos / GELU).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int ring_f(int g) { return (0x78 >> (2 * g)) & 3; }
 
@@ -212,195 +122,13 @@ template <int EPI, typename OutT> struct Epi4 {
   }
 };
 
-template <int BM, int BN, int WM, int WN, int STAGES, int EPI, typename OutT, bool PREFETCH = false, int DBG = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N,
-                                                                  int K, int lda, int ldb, EpiArgs e) {
-  constexpr int NW = WM * WN, TM = BM / WM, TNn = BN / WN, MI = TM / 16, NI = TNn / 16;
-  constexpr int STAGE_BYTES = (BM + BN) * 64, PIECES = (BM + BN) / 16, PPW = PIECES / NW;
-  static_assert(PIECES % NW == 0, "pieces must divide over waves");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const unsigned tiles_n = (N + BN - 1) / BN;
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
-
-  const bf16* src[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int piece = wave * PPW + i;                        // 0 .. PIECES-1 ; A pieces first
-    const int row = piece * 16 + (lane >> 2);                // row inside the stage image
-    const int c = (lane & 3) ^ ring_f((lane >> 4) & 3);      // global chunk stored at LDS position lane&3
-    int brow = n0 + row - BM;
-    if constexpr (EPI == LDMAE_EPI_SWIGLU) {   // wave slice of 64 B-rows = 32 rows of x1 | the matching 32 rows of x2 (N = 2*Hs)
-      const int rl = row - BM;
-      brow = ((rl & 32) ? (N >> 1) : 0) + (n0 >> 1) + (rl >> 6) * 32 + (rl & 31);
-    }
-    src[i] = row < BM ? A + (size_t)min(m0 + row, M - 1) * lda + c * 8 : B + (size_t)min(brow, N - 1) * ldb + c * 8;
-  }
-  auto issue = [&](int kt) {
-    char* base = smem + (kt % STAGES) * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + kt * 32), LDS_PTR(void, base + (wave * PPW + i) * 1024), 16, 0, 0);
-  };
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int fpos = ((lane >> 4) ^ ring_f((lane >> 2) & 3)) << 4;
-  const int a_off = (wm * TM + (lane & 15)) * 64 + fpos, b_off = (BM + wn * TNn + (lane & 15)) * 64 + fpos;
-
-  const int nk = K / 32;
-  if constexpr (DBG == 5) {
-    // Two wave groups (upper / lower half of the M waves; they share the SIMDs pairwise) run half a K-step apart: while one
-    // group issues its global_load_lds + fragment ds_reads (L phase) the other runs its 32 MFMAs (M phase), a barrier at every
-    // phase boundary is the metronome.  Every wave waits for its own pieces of stage kt+1 one phase before anyone reads them.
-    const bool grpB = wm >= WM / 2;
-    auto wait_next = [&](int kt) {                       // own pieces of stage kt+1 landed; later stages may stay in flight
-      const int ahead = min(STAGES - 2, nk - 2 - kt);
-      if (ahead >= 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-      else if (ahead == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-      if (s < nk) issue(s);
-    wait_next(-1);                                       // stage 0
-    __builtin_amdgcn_s_barrier();
-    if (grpB) __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);
-      const char* st = smem + (kt % STAGES) * STAGE_BYTES;
-      bf16x8 af[MI], bfr[NI];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
-      if (grpB) wait_next(kt);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      if (!grpB) wait_next(kt);
-      __builtin_amdgcn_s_barrier();
-    }
-    if (!grpB) __builtin_amdgcn_s_barrier();
-  } else if constexpr (DBG == 4) {
-    // two K-steps per barrier: stages (2t, 2t+1) are consumed while (2t+2, 2t+3) are in flight (4 buffers)
-    static_assert(DBG != 4 || STAGES == 4, "double-step variant uses 4 stages");
-    const int nd = nk / 2;                                   // host guarantees K % 64 == 0
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      if (s < nk) issue(s);
-    for (int t = 0; t < nd; ++t) {
-      if (t + 1 < nd) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (t >= 1 && 2 * t + 2 < nk) { issue(2 * t + 2); issue(2 * t + 3); }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const char* st = smem + ((2 * t + h) % STAGES) * STAGE_BYTES;
-        bf16x8 af[MI], bfr[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      }
-    }
-  } else {
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue(s);
-  }
-  if constexpr (DBG == 4 || DBG == 5) {
-  } else if constexpr (!PREFETCH) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const int ahead = min(STAGES - 2, nk - 1 - kt);          // stages allowed to stay in flight
-      if (ahead >= 2) { if constexpr (STAGES >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory"); }
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if constexpr (DBG != 2) { if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1); }
-      const char* st = smem + (kt % STAGES) * STAGE_BYTES;
-      bf16x8 af[MI], bfr[NI];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
-      if constexpr (DBG == 1) {        // ablation: everything but the MFMAs (fragments kept live)
-#pragma unroll
-        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
-#pragma unroll
-        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
-      } else {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      }
-    }
-  } else {
-    // register double-buffered fragments: the ds_reads of K-step kt+1 are issued beside the MFMAs of K-step kt
-    // (needs stage kt+1 landed at the barrier of iteration kt -> STAGES = 4, one stage less in flight)
-    static_assert(!PREFETCH || STAGES == 4, "prefetch variant uses 4 stages");
-    bf16x8 fa[2][MI], fb[2][NI];
-    auto rd = [&](int kt, bf16x8 (&a)[MI], bf16x8 (&b)[NI]) {
-      const char* st = smem + (kt % STAGES) * STAGE_BYTES;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = *(const bf16x8*)(st + b_off + j * 1024);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8*)(st + a_off + i * 1024);
-    };
-    auto step = [&](int kt, bf16x8 (&ca)[MI], bf16x8 (&cb)[NI], bf16x8 (&na)[MI], bf16x8 (&nb)[NI]) {
-      const int ahead = min(1, nk - 2 - kt);                   // stages beyond kt+1 allowed in flight
-      if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 3 < nk) issue(kt + 3);
-      if (kt + 1 < nk) rd(kt + 1, na, nb);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    rd(0, fa[0], fb[0]);
-    for (int kt = 0; kt < nk; kt += 2) {
-      step(kt, fa[0], fb[0], fa[1], fb[1]);
-      if (kt + 1 < nk) step(kt + 1, fa[1], fb[1], fa[0], fb[0]);
-    }
-  }
-  if constexpr (DBG == 3) {          // ablation: no epilogue at all (accumulators kept live)
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
-  }
-  // ---- epilogue: accumulators -> per-wave f32 LDS strip [16 rows][68] -> row-contiguous 16-B global accesses.
-  // One strip per MFMA row-block i (16 output rows x 64 columns); strips of 4.25 KiB keep the LDS footprint at the
-  // ring size, so two workgroups can share a CU where the register budget allows.
-  __syncthreads();
+// Epilogue shared by the NT kernels: accumulators -> per-wave f32 LDS strip [16 rows][68] (`ew`, private to the wave, so no
+// workgroup barrier is needed) -> row-contiguous 16-B global accesses with the fused bias / gated residual / pos / GELU /
+// SwiGLU forms.
+template <int EPI, typename OutT, int TM, int TNn, int MI, int NI>
+__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, const EpiArgs& e, int m0, int n0, int wm, int wn, int lane,
+                                            int M, int N) {
   constexpr int ELD = 68;
-  float* ew = (float*)smem + wave * (16 * ELD);
   auto fill = [&](int i, int cblk) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -414,26 +142,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
     const int Hs = N >> 1, hc = (n0 >> 1) + wn * 32 + (lane & 7) * 4;
     bf16* h12 = (bf16*)e.C;
     bf16* hid = (bf16*)e.xout;
-    const float4 b1 = e.bias ? *(const float4*)(e.bias + hc) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 b2 = e.bias ? *(const float4*)(e.bias + Hs + hc) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    const int hcl = min(hc, Hs - 4);
+    const float4 b1 = e.bias ? *(const float4*)(e.bias + hcl) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b2 = e.bias ? *(const float4*)(e.bias + Hs + hcl) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // wave-uniform in-range test: the straight-line form lets the compiler count vmcnt over the stores (a per-lane guard
+    // around them made it drain every store before the next strip: 8 us per tile instead of 4)
+    const bool whole = m0 + wm * TM + TM <= M && (n0 >> 1) + wn * 32 + 32 <= Hs;
+    auto strip = [&](int i, bool guard) {
       fill(i, 0);
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int row = it * 8 + (lane >> 3), m = m0 + wm * TM + i * 16 + row;
         const float4 u = *(const float4*)(ew + row * ELD + (lane & 7) * 4), v = *(const float4*)(ew + row * ELD + 32 + (lane & 7) * 4);
-        if (m < M && hc < Hs) {
+        if (!guard || (m < M && hc < Hs)) {
           bf16x4 x1, x2, ho;
           x1[0] = (bf16)(u.x + b1.x); x1[1] = (bf16)(u.y + b1.y); x1[2] = (bf16)(u.z + b1.z); x1[3] = (bf16)(u.w + b1.w);
           x2[0] = (bf16)(v.x + b2.x); x2[1] = (bf16)(v.y + b2.y); x2[2] = (bf16)(v.z + b2.z); x2[3] = (bf16)(v.w + b2.w);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { const float a = (float)x1[j]; ho[j] = (bf16)(a / (1.f + __expf(-a)) * (float)x2[j]); }
+          for (int j = 0; j < 4; ++j) { const float a = (float)x1[j]; ho[j] = (bf16)(a * fast_sigmoid(a) * (float)x2[j]); }
           *(bf16x4*)(h12 + (size_t)m * N + hc) = x1;
           *(bf16x4*)(h12 + (size_t)m * N + Hs + hc) = x2;
           *(bf16x4*)(hid + (size_t)m * Hs + hc) = ho;
         }
       }
+    };
+    if (whole) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) strip(i, false);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) strip(i, true);
     }
     return;
   }
@@ -445,20 +183,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
 #pragma unroll
     for (int cblk = 0; cblk < TNn / 64; ++cblk) {
       const int n = n0 + wn * TNn + cblk * 64 + (lane & 15) * 4;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        fill(i, cblk);
+      const int mw = m0 + wm * TM;
+      const bool inr = n < Hs;
+      // h12 rows of strip i+1 are requested before the stores of strip i (see the note on vmcnt order below)
+      bf16x4 hv[MI + 1][4][2];
+      auto ldh = [&](int i) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          const int row = it * 4 + (lane >> 4), m = m0 + wm * TM + i * 16 + row;
-          const float4 gv = *(const float4*)(ew + row * ELD + (lane & 15) * 4);
-          if (m < M && n < Hs) {
-            const bf16x4 av = *(const bf16x4*)(h12 + (size_t)m * 2 * Hs + n), bv = *(const bf16x4*)(h12 + (size_t)m * 2 * Hs + Hs + n);
+          const int m = min(mw + i * 16 + it * 4 + (lane >> 4), M - 1);
+          const bf16* hp = h12 + (size_t)m * 2 * Hs + (inr ? n : 0);
+          hv[i][it][0] = *(const bf16x4*)hp; hv[i][it][1] = *(const bf16x4*)(hp + Hs);
+        }
+      };
+      const bool whole = mw + TM <= M && n0 + wn * TNn + cblk * 64 + 64 <= Hs;     // wave-uniform: straight-line stores (see SwiGLU fwd)
+      auto strip = [&](int i, bool guard) {
+        fill(i, cblk);
+        float4 gvv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) gvv[it] = *(const float4*)(ew + (it * 4 + (lane >> 4)) * ELD + (lane & 15) * 4);
+        if (i + 1 < MI) ldh(i + 1);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row = it * 4 + (lane >> 4), m = mw + i * 16 + row;
+          const float4 gv = gvv[it];
+          if (!guard || (m < M && inr)) {
+            const bf16x4 av = hv[i][it][0], bv = hv[i][it][1];
             const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
             bf16x4 da, db;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float g = (float)(bf16)gg[j], a = (float)av[j], b = (float)bv[j], sg = 1.f / (1.f + __expf(-a));
+              const float g = (float)(bf16)gg[j], a = (float)av[j], b = (float)bv[j], sg = fast_sigmoid(a);
               da[j] = (bf16)(g * b * sg * (1.f + a * (1.f - sg)));
               db[j] = (bf16)(g * a * sg);
             }
@@ -466,22 +220,93 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
             *(bf16x4*)(dh12 + (size_t)m * 2 * Hs + Hs + n) = db;
           }
         }
+      };
+      ldh(0);
+      if (whole) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) strip(i, false);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) strip(i, true);
       }
     }
     return;
   }
   const bool nfast = (N % 8 == 0) && (e.ldc % 8 == 0) && (EPI != LDMAE_EPI_GATE_RES || e.rows_per_batch % 16 == 0);
+  auto put8 = [&](void* base, size_t oc, float4 a, float4 b) {
+    if constexpr (sizeof(OutT) == 4) { *(float4*)((float*)base + oc) = a; *(float4*)((float*)base + oc + 4) = b; }
+    else {
+      bf16x8 o;
+      o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w; o[4] = (bf16)b.x; o[5] = (bf16)b.y; o[6] = (bf16)b.z; o[7] = (bf16)b.w;
+      *(bf16x8*)((bf16*)base + oc) = o;
+    }
+  };
 #pragma unroll
   for (int cblk = 0; cblk < TNn / 64; ++cblk) {
-    const int nb = n0 + wn * TNn + cblk * 64, col = (lane & 15) * 4;
+    const int nb = n0 + wn * TNn + cblk * 64, col = (lane & 15) * 4, c8 = (lane & 7) * 8;
+    const int mw = m0 + wm * TM;
+    // Whole wave slice in range (and, gated form, inside one sample): per-column constants are loaded ONCE and the only loads
+    // between the stores are the next strip's residual rows, issued BEFORE the current strip's stores.  vmcnt retires in
+    // issue order, so a load issued after a store cannot be waited for without draining that store: a per-strip bias load
+    // used to serialise the whole store tail (5.6 us per 256x256 tile instead of ~2).
+    bool hoist = nfast && mw + TM <= M && nb + 64 <= N && EPI != LDMAE_EPI_BIAS_POS && (EPI != LDMAE_EPI_BIAS || e.beta == 0.f);
+    if (EPI == LDMAE_EPI_GATE_RES && hoist) hoist = (mw / e.rows_per_batch) == ((mw + TM - 1) / e.rows_per_batch);
+    if (hoist) {
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 b0 = e.bias ? *(const float4*)(e.bias + nb + c8) : z4, b1 = e.bias ? *(const float4*)(e.bias + nb + c8 + 4) : z4;
+      float4 g0 = o4, g1 = o4;
+      if (EPI == LDMAE_EPI_GATE_RES && e.gate) {
+        const float* gp = e.gate + (size_t)(mw / e.rows_per_batch) * e.gate_ld + nb + c8;
+        g0 = *(const float4*)gp; g1 = *(const float4*)(gp + 4);
+      }
+      float4 xi[MI + 1][2][2];                       // fully unrolled: only two strips' worth are live at a time
+      auto ldx = [&](int i) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const size_t o = (size_t)(mw + i * 16 + it * 8 + (lane >> 3)) * N + nb + c8;
+          xi[i][it][0] = *(const float4*)(e.xin + o); xi[i][it][1] = *(const float4*)(e.xin + o + 4);
+        }
+      };
+      if constexpr (EPI == LDMAE_EPI_GATE_RES) ldx(0);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        fill(i, cblk);
+        float4 a[2][2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 8 + (lane >> 3);
+          float4 u = *(const float4*)(ew + row * ELD + c8), v = *(const float4*)(ew + row * ELD + c8 + 4);
+          a[it][0] = make_float4(u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w);
+          a[it][1] = make_float4(v.x + b1.x, v.y + b1.y, v.z + b1.z, v.w + b1.w);
+        }
+        if constexpr (EPI == LDMAE_EPI_GATE_RES) { if (i + 1 < MI) ldx(i + 1); }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int m = mw + i * 16 + it * 8 + (lane >> 3);
+          const size_t oc = (size_t)m * e.ldc + nb + c8;
+          const float4 p = a[it][0], q = a[it][1];
+          if constexpr (EPI == LDMAE_EPI_GATE_RES) {
+            const size_t o = (size_t)m * N + nb + c8;
+            const float4 x0 = xi[i][it][0], x1 = xi[i][it][1];
+            *(float4*)(e.xout + o) = make_float4(x0.x + g0.x * p.x, x0.y + g0.y * p.y, x0.z + g0.z * p.z, x0.w + g0.w * p.w);
+            *(float4*)(e.xout + o + 4) = make_float4(x1.x + g1.x * q.x, x1.y + g1.y * q.y, x1.z + g1.z * q.z, x1.w + g1.w * q.w);
+            if (e.C) put8(e.C, oc, p, q);
+          } else if constexpr (EPI == LDMAE_EPI_BIAS_GELU) {
+            auto g = [](float y) { return 0.5f * y * (1.f + erff(y * 0.70710678118654752f)); };
+            put8(e.C, oc, make_float4(g(p.x), g(p.y), g(p.z), g(p.w)), make_float4(g(q.x), g(q.y), g(q.z), g(q.w)));
+            if (e.C2) put8(e.C2, oc, p, q);
+          } else {
+            put8(e.C, oc, p, q);
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       fill(i, cblk);
-      const int mb = m0 + wm * TM + i * 16;
+      const int mb = mw + i * 16;
       if (nfast && mb + 16 <= M && nb + 64 <= N) {
-        // 8 consecutive columns per lane, 8 lanes per row: one 16-B store per lane for bf16 outputs (the store tail is
-        // issue-bound: half the store instructions of the 8-B form), full 128-B lines per row
-        const int c8 = (lane & 7) * 8;
         const Epi4<EPI, OutT> ep0(e, mb, nb + c8, N), ep1(e, mb, nb + c8 + 4, N);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -490,16 +315,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
           ep0.compute(m, *(const float4*)(ew + row * ELD + c8), y0, z0);
           ep1.compute(m, *(const float4*)(ew + row * ELD + c8 + 4), y1, z1);
           const size_t oc = (size_t)m * e.ldc + nb + c8;
-          auto put8 = [&](void* base, float4 a, float4 b) {
-            if constexpr (sizeof(OutT) == 4) { *(float4*)((float*)base + oc) = a; *(float4*)((float*)base + oc + 4) = b; }
-            else {
-              bf16x8 o;
-              o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w; o[4] = (bf16)b.x; o[5] = (bf16)b.y; o[6] = (bf16)b.z; o[7] = (bf16)b.w;
-              *(bf16x8*)((bf16*)base + oc) = o;
-            }
-          };
-          if (e.C) put8(e.C, y0, y1);
-          if (EPI == LDMAE_EPI_BIAS_GELU && e.C2) put8(e.C2, z0, z1);
+          if (e.C) put8(e.C, oc, y0, y1);
+          if (EPI == LDMAE_EPI_BIAS_GELU && e.C2) put8(e.C2, oc, z0, z1);
         }
       } else {
         for (int it = 0; it < 4; ++it) {
@@ -510,6 +327,228 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_ring_kernel(const bf16* _
         }
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 NT GEMM kernel: persistent, one 512-thread workgroup per CU walks the 256x256 output tiles t = b, b + grid, ...
+// Main loop: the two M wave groups (which share the SIMDs pairwise) run half a K-step apart -- while one group issues its
+// global_load_lds + fragment ds_reads, the other runs its 32 MFMAs; a barrier at every phase boundary is the metronome, and
+// every wave waits for its own pieces of stage kt+1 one phase before anyone reads them.
+// The first STAGES-1 K-steps of the NEXT tile are put in flight before the epilogue of the current one
+// (its LDS strips live beside the ring, not in it), so the L2/HBM fill latency and the workgroup relaunch disappear behind
+// the store tail, and no workgroup barrier separates main loop and epilogue: the wave group that finishes half a phase
+// earlier starts storing while the other still multiplies.  `delay` (units of 8128 clocks) holds back every other workgroup of
+// an XCD once, at start: a GEMM whose tiles all take the same time otherwise runs all 256 CUs in lockstep -- everyone
+// loads, then everyone multiplies, then everyone stores 32 MiB into HBM at once.
+// ------------------------------------------------------------------------------------------------
+template <int STAGES, int EPI, typename OutT, int SPLIT = 0, bool TL = false>
+__global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
+                                                              int lda, int ldb, EpiArgs e, int ntiles, int delay,
+                                                              unsigned long long* stamps) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NW = 8, TM = 128, TNn = 64, MI = 8, NI = 4;
+  constexpr int STAGE_BYTES = (BM + BN) * 64, PPW = (BM + BN) / 16 / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const unsigned tiles_n = (N + BN - 1) / BN;
+  float* ew = (float*)(smem + STAGES * STAGE_BYTES) + wave * (16 * 68);
+  // workgroup b sits on XCD b % 8 (256 workgroups, one per CU): give each XCD a contiguous run of 32 tiles per round so the
+  // workgroups that share an A row-block (and the whole of B) share an L2
+  // (gridDim.x == ntiles: one tile per workgroup, the classic launch -- the hardware then overlaps a finished workgroup's store
+  // drain with the next workgroup's fill, which a persistent workgroup cannot do: vmcnt retires loads and stores in one order)
+  const bool persistent = (int)gridDim.x != ntiles;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int first = persistent ? xcd * per_xcd + slot : (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int tstride = persistent ? (int)gridDim.x : ntiles;
+  if (delay > 0 && (slot & 1) && persistent)
+    for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(127);
+
+  const bf16* src[PPW];
+  int m0 = 0, n0 = 0;
+  auto set_tile = [&](int t) {
+    m0 = (t / tiles_n) * BM; n0 = (t % tiles_n) * BN;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int piece = wave * PPW + i;
+      const int row = piece * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ring_f((lane >> 4) & 3);
+      int brow = n0 + row - BM;
+      if constexpr (EPI == LDMAE_EPI_SWIGLU) {
+        const int rl = row - BM;
+        brow = ((rl & 32) ? (N >> 1) : 0) + (n0 >> 1) + (rl >> 6) * 32 + (rl & 31);
+      }
+      src[i] = row < BM ? A + (size_t)min(m0 + row, M - 1) * lda + c * 8 : B + (size_t)min(brow, N - 1) * ldb + c * 8;
+    }
+  };
+  auto issue_part = [&](int kt, int lo, int hi) {
+    char* base = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+      if (i >= lo && i < hi)
+        glds16(src[i] + kt * 32, base + (wave * PPW + i) * 1024);
+  };
+  auto issue = [&](int kt) { issue_part(kt, 0, PPW); };
+  // SPLIT: how many of a wave's PPW pieces of stage kt+STAGES-1 are issued in the load phase; the rest go between the MFMAs
+  constexpr int PL = SPLIT == 0 ? PPW : (SPLIT == 1 ? PPW / 2 : 0);
+  const int fpos = ((lane >> 4) ^ ring_f((lane >> 2) & 3)) << 4;
+  const int a_off = (wm * TM + (lane & 15)) * 64 + fpos, b_off = (BM + wn * TNn + (lane & 15)) * 64 + fpos;
+  const int nk = K / 32;
+  const bool grpB = wm >= WM / 2;
+  static_assert(STAGES == 3, "wait accounting below is written for a 3-deep ring");
+  // own pieces of stage kt+1 landed; stage kt+2's may stay in flight (all PPW of them after the MFMA phase, only the PL issued
+  // so far when the wait sits between load and MFMA phase, i.e. for group B)
+  auto wait_next = [&](int kt, bool after_mfma) {
+    if (kt + 2 < nk) {
+      if (after_mfma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL) : "memory");
+    } else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  constexpr int PRO = SPLIT == 3 ? STAGES : STAGES - 1;   // K-steps put in flight ahead of a tile's main loop
+  int t = first;
+  if (t < ntiles) {
+    set_tile(t);
+#pragma unroll
+    for (int s = 0; s < PRO; ++s)
+      if (s < nk) issue(s);
+  }
+  int iter = 0;
+  auto stamp = [&](int k) {             // diagnostic timeline (tools/gemm_timeline.py); stamps == nullptr in product runs
+    if (stamps && lane == 0 && (wave & 3) == 0)
+      stamps[(((size_t)iter * gridDim.x + blockIdx.x) * 2 + (wave >> 2)) * 4 + k] = __builtin_amdgcn_s_memrealtime();
+  };
+  // TL (diagnostic build): per-K-step phase stamps (shader clock) of the second tile, kept in LDS beside the strips
+  unsigned long long* tl = (unsigned long long*)(smem + STAGES * STAGE_BYTES + 8 * 16 * 68 * 4);
+  auto tstamp = [&](int kt, int k2) {
+    if constexpr (TL) {
+      if (iter == 1 && (wave & 3) == 0 && lane == 0 && kt < 32) tl[((wave >> 2) * 32 + kt) * 4 + k2] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  while (t < ntiles) {
+    stamp(0);
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // vmcnt counts in issue order, and the previous tile's epilogue accesses are younger than this tile's prologue loads:
+    // the counted waits below can only over-wait (never under-wait) because of them
+    if constexpr (SPLIT == 3) {
+      // Register-pipelined loop, ONE barrier per K-step, no load phase: a K-step's MFMAs run in two halves (A rows 0-63 /
+      // 64-127 of the wave slice) and the LDS reads are always issued one half ahead of the MFMAs that consume them --
+      // the upper-half A fragments of step kt before the lower-half MFMAs, the lower-half A + B fragments of step kt+1
+      // before the upper-half MFMAs (B double-buffered in registers).  At the barrier every wave has finished with
+      // stage kt, so stage kt+3 is issued into its buffer: two stages stay in flight.
+      bf16x8 alo[4], ahi[4], bq[2][NI];
+      auto rd_a = [&](int kt, int half, bf16x8 (&a)[4]) {
+        const char* st = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(st + a_off + (half * 4 + i) * 1024);
+      };
+      auto rd_b = [&](int kt, bf16x8 (&bb)[NI]) {
+        const char* st = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bb[j] = *(const bf16x8*)(st + b_off + j * 1024);
+      };
+      auto mm = [&](int half, bf16x8 (&a)[4], bf16x8 (&bb)[NI]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bb[j], acc[half * 4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      };
+      auto step = [&](int kt, bf16x8 (&bc)[NI], bf16x8 (&bn)[NI]) {
+        tstamp(kt, 0);
+        rd_a(kt, 1, ahi);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0, alo, bc);
+        __builtin_amdgcn_sched_barrier(0);
+        tstamp(kt, 1);
+        // own pieces of stage kt+1 landed (stage kt+2 may stay in flight), own reads of stage kt landed
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        tstamp(kt, 2);
+        if (kt + 3 < nk) issue(kt + 3);
+        if (kt + 1 < nk) { rd_a(kt + 1, 0, alo); rd_b(kt + 1, bn); }
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1, ahi, bc);
+        __builtin_amdgcn_sched_barrier(0);
+        tstamp(kt, 3);
+      };
+      if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+      else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      rd_a(0, 0, alo); rd_b(0, bq[0]);
+      for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, bq[0], bq[1]);
+        if (kt + 1 < nk) step(kt + 1, bq[1], bq[0]);
+      }
+    } else {
+    // Tile start: vmcnt(0) through the BUILTIN, so that the compiler's waitcnt pass sees it.  It then knows that no load of the
+    // previous epilogue (bias, residual rows, h12) is pending when the K loop begins; otherwise it protects those registers,
+    // which the loop reuses, with vmcnt(0) waits INSIDE the loop -- and with the ring DMA hidden in asm such a wait drains
+    // the whole ring every K-step (seen: SwiGLU instantiations 35 % slower than the plain-bias one).  Cost: stage 1 must
+    // have landed too, and the previous tile's stores are drained (~0.2 us per tile).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    if (grpB) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      tstamp(kt, 0);
+      const bool more = kt + STAGES - 1 < nk;
+      if (more) issue_part(kt + STAGES - 1, 0, PL);
+      const char* st = smem + (kt % STAGES) * STAGE_BYTES;
+      bf16x8 af[MI], bfr[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+      if constexpr (TL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tstamp(kt, 1);
+      if (grpB) wait_next(kt, false);
+      __builtin_amdgcn_s_barrier();
+      tstamp(kt, 2);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if constexpr (PL < PPW) {                        // remaining pieces, spread over the MFMA phase
+          constexpr int REST = PPW - PL, GAP = MI / REST;
+          if (more && i % GAP == GAP / 2) issue_part(kt + STAGES - 1, PL + i / GAP, PL + i / GAP + 1);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      tstamp(kt, 3);
+      if (!grpB) wait_next(kt, true);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!grpB) __builtin_amdgcn_s_barrier();             // every wave is past its last fragment read: the ring is free
+    }
+    stamp(1);
+    const int em0 = m0, en0 = n0;
+    t += tstride;
+    if (t < ntiles) {
+      set_tile(t);
+#pragma unroll
+      for (int s = 0; s < PRO; ++s)
+        if (s < nk) issue(s);
+    }
+    nt_epilogue<EPI, OutT, TM, TNn, MI, NI>(acc, ew, e, em0, en0, wm, wn, lane, M, N);
+    if constexpr (TL) {
+      if (iter == 1 && stamps) {
+        __syncthreads();
+        if (tid < 256) stamps[(size_t)gridDim.x * 1024 + (size_t)blockIdx.x * 256 + tid] = tl[tid];
+      }
+    }
+    stamp(2);
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(3); }
+    ++iter;
   }
 }
 
@@ -609,8 +648,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restric
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const size_t m = (size_t)min(mt + arow[i], M - 1);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(A + m * lda + acol[i]), LDS_PTR(void, base + (wave * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(B + m * ldb + bcol[i]), LDS_PTR(void, base + TN_TILE_BYTES + (wave * 4 + i) * 1024), 16, 0, 0);
+      glds16(A + m * lda + acol[i], base + (wave * 4 + i) * 1024);
+      glds16(B + m * ldb + bcol[i], base + TN_TILE_BYTES + (wave * 4 + i) * 1024);
     }
   };
   f32x4 acc[4][4];
@@ -717,8 +756,7 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const bool isB = (wave * PPW + i) >= 16;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + (size_t)mbeg * (isB ? ldb : lda) + st * (isB ? bstep : astep)),
-                                       LDS_PTR(void, base + (wave * PPW + i) * 1024), 16, 0, 0);
+      glds16(src[i] + (size_t)mbeg * (isB ? ldb : lda) + st * (isB ? bstep : astep), base + (wave * PPW + i) * 1024);
     }
   };
   f32x4 acc[MI][NI], accb[MI];
@@ -945,113 +983,63 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, float* __restr
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+static void* g_nt_stamps = nullptr;
+// diagnostic: device buffer that receives s_memrealtime stamps of the persistent NT kernel (NULL = off, the default)
+extern "C" void ldmae_debug_nt_stamps(void* buf) { g_nt_stamps = buf; }
 template <typename OutT>
 static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
                      hipStream_t st) {
   const long pi = (ldmae_prof_is_on() && dtype == LDMAE_BF16) ? ldmae_prof_begin(st, 2.0 * M * N * K) : -1;
-  // default (variant 14): 256x256 tile, 8 waves (128x64 each), 3-stage ring, the two M wave groups staggered by half a K-step;
-  // tune value v selects variant v-1 for A/B runs
-  const int variant = ldmae_tune_get(0) == 0 ? 14 : ldmae_tune_get(0) - 1;
-#define RING(E, BM_, BN_, WM_, WN_, ST_)                                                                                          \
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0, n = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    ncu = n >= 8 ? n / 8 * 8 : 8;
+  }
+  const int ntiles = cdiv(M, 256) * cdiv(N, 256);
+  // tune key 8: 2 = one tile per workgroup; otherwise persistent (one workgroup per CU), the default
+  const bool pers = ldmae_tune_get(8) != 2;
+  const int pgrid = (pers && ntiles != ncu) ? ncu : ntiles;
+  // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup, key 6 = how
+  // many of a wave's ring pieces are issued between the MFMAs (A/B knobs), key 7 = diagnostic per-K-step stamp build.
+#define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048)
+#define PERS_GO(...)                                                                                                             \
+  hipLaunchKernelGGL((gemm_nt_persist_kernel<__VA_ARGS__>), dim3(pgrid), dim3(512), lds + 2048, st, (const bf16*)A, (const bf16*)B, \
+                     M, N, K, lda, ldb, e, ntiles, ldmae_tune_get(5), (unsigned long long*)g_nt_stamps)
+#define PERS(E)                                                                                                                  \
   {                                                                                                                               \
-    constexpr int lds_ring = ST_ * (BM_ + BN_) * 64, lds_epi = WM_ * WN_ * 16 * 68 * 4;                                           \
-    constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;                                                                   \
+    constexpr int lds = 3 * 512 * 64 + 8 * 16 * 68 * 4;                                                                           \
     static bool attr_done = false;                                                                                                 \
     if (!attr_done) {                                                                                                              \
-      hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BM_, BN_, WM_, WN_, ST_, E, OutT>,                                      \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                        \
+      PERS_ATTR(3, E, OutT); PERS_ATTR(3, E, OutT, 3);                                                                              \
+      if (E == LDMAE_EPI_BIAS) { PERS_ATTR(3, LDMAE_EPI_BIAS, OutT, 0, true); PERS_ATTR(3, LDMAE_EPI_BIAS, OutT, 3, true); }            \
+      if (E == LDMAE_EPI_SWIGLU) PERS_ATTR(3, LDMAE_EPI_SWIGLU, OutT, 0, true);                                                        \
       attr_done = true;                                                                                                            \
     }                                                                                                                              \
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<BM_, BN_, WM_, WN_, ST_, E, OutT>), dim3(cdiv(M, BM_) * cdiv(N, BN_)),                \
-                       dim3(WM_ * WN_ * 64), lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                      \
-  }
-#define RINGP(E)                                                                                                                  \
-  {                                                                                                                               \
-    constexpr int lds = 4 * 512 * 64;                                                                                             \
-    static bool attr_done = false;                                                                                                 \
-    if (!attr_done) {                                                                                                              \
-      hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, E, OutT, true>,                                      \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                        \
-      attr_done = true;                                                                                                            \
-    }                                                                                                                              \
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, E, OutT, true>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512),     \
-                       lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                                            \
-  }
-#define RINGD(E, D, S)                                                                                                            \
-  {                                                                                                                               \
-    constexpr int lds = 3 * 512 * 64;                                                                                             \
-    hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 3, E, OutT, false, D>,                                    \
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                          \
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 3, E, OutT, false, D>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512), \
-                       lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                                            \
-  }
-#define RING2(E)                                                                                                                  \
-  {                                                                                                                               \
-    constexpr int lds = 4 * 512 * 64;                                                                                             \
-    static bool attr_done = false;                                                                                                 \
-    if (!attr_done) {                                                                                                              \
-      hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, 2, 4, 4, E, OutT, false, 4>,                                  \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                        \
-      attr_done = true;                                                                                                            \
-    }                                                                                                                              \
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, 2, 4, 4, E, OutT, false, 4>), dim3(cdiv(M, 256) * cdiv(N, 256)), dim3(512), \
-                       lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                                            \
-  }
-#define RINGS(E, WM_, WN_, ST_)                                                                                                    \
-  {                                                                                                                               \
-    constexpr int lds = ST_ * 512 * 64;                                                                                           \
-    static bool attr_done = false;                                                                                                 \
-    if (!attr_done) {                                                                                                              \
-      hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<256, 256, WM_, WN_, ST_, E, OutT, false, 5>,                            \
-                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                                        \
-      attr_done = true;                                                                                                            \
-    }                                                                                                                              \
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<256, 256, WM_, WN_, ST_, E, OutT, false, 5>), dim3(cdiv(M, 256) * cdiv(N, 256)),      \
-                       dim3(WM_ * WN_ * 64), lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                      \
+    if (E == LDMAE_EPI_BIAS && ldmae_tune_get(7) == 1 && ldmae_tune_get(6) == 3) PERS_GO(3, LDMAE_EPI_BIAS, OutT, 3, true);        \
+    else if (E == LDMAE_EPI_BIAS && ldmae_tune_get(7) == 1) PERS_GO(3, LDMAE_EPI_BIAS, OutT, 0, true);                             \
+    else if (E == LDMAE_EPI_SWIGLU && ldmae_tune_get(7) == 1) PERS_GO(3, LDMAE_EPI_SWIGLU, OutT, 0, true);                             \
+    else if (ldmae_tune_get(6) == 3) PERS_GO(3, E, OutT, 3);                                                                       \
+    else PERS_GO(3, E, OutT);                                                                                                      \
   }
 #define NT_LAUNCH(E)                                                                                                             \
-  if (dtype == LDMAE_BF16 && variant == 14 && K % 32 == 0) RINGS(E, 2, 4, 3)                                                      \
-  else if (dtype == LDMAE_BF16 && variant == 15 && K % 32 == 0) RINGS(E, 2, 4, 4)                                                 \
-  else if (dtype == LDMAE_BF16 && variant == 16 && K % 32 == 0) RINGS(E, 4, 4, 4)                                                 \
-  else if (dtype == LDMAE_BF16 && variant == 11 && K % 64 == 0) RING2(E)                                                               \
-  else if (dtype == LDMAE_BF16 && variant == 8 && K % 32 == 0) RINGP(E)                                                                \
-  else if (dtype == LDMAE_BF16 && variant == 12 && K % 32 == 0) RING(E, 256, 256, 4, 4, 3)                                        \
-  else if (dtype == LDMAE_BF16 && variant == 13 && K % 32 == 0) RING(E, 256, 256, 4, 4, 4)                                        \
-  else if (dtype == LDMAE_BF16 && variant == 9 && K % 32 == 0) RING(E, 256, 128, 4, 2, 3)                                         \
-  else if (dtype == LDMAE_BF16 && variant == 10 && K % 32 == 0) RING(E, 128, 256, 2, 4, 3)                                        \
-  else if (dtype == LDMAE_BF16 && variant == 1 && K % 32 == 0) RING(E, 128, 128, 2, 2, 4)                                              \
-  else if (dtype == LDMAE_BF16 && variant == 2 && K % 32 == 0) RING(E, 256, 128, 4, 2, 4)                                         \
-  else if (dtype == LDMAE_BF16 && variant == 3 && K % 32 == 0) RING(E, 256, 256, 2, 4, 4)                                         \
-  else if (dtype == LDMAE_BF16 && variant == 4 && K % 32 == 0) RING(E, 256, 256, 2, 4, 3)                                         \
-  else if (dtype == LDMAE_BF16 && variant == 5 && K % 32 == 0) RING(E, 128, 256, 2, 2, 3)                                         \
-  else if (dtype == LDMAE_BF16 && variant == 6 && K % 32 == 0) RING(E, 256, 128, 2, 2, 3)                                         \
-  else if (dtype == LDMAE_BF16 && variant == 7 && K % 32 == 0) RING(E, 128, 256, 2, 2, 4)                                         \
-  else if (dtype == LDMAE_BF16)                                                                                                   \
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<E, OutT>), dim3(cdiv(M, NT_BM) * cdiv(N, NT_BN)), dim3(256), 4 * NT_TILE_BYTES, st, \
-                       (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e);                                                    \
+  if (dtype == LDMAE_BF16) PERS(E)                                                                                                \
   else                                                                                                                           \
     hipLaunchKernelGGL((gemm_nt_f32_kernel<E, OutT>), dim3(cdiv(M, F_BM) * cdiv(N, F_BN)), dim3(256), 0, st, (const float*)A,    \
                        (const float*)B, M, N, K, lda, ldb, e)
-  if (dtype == LDMAE_BF16 && epi == LDMAE_EPI_BIAS && (variant >= 20 && variant <= 22)) {   // diagnostic ablations (tools/ablate_gemm.py)
-    if (variant == 20) RINGD(LDMAE_EPI_BIAS, 1, 3) else if (variant == 21) RINGD(LDMAE_EPI_BIAS, 2, 3) else RINGD(LDMAE_EPI_BIAS, 3, 3)
-    if (pi >= 0) ldmae_prof_end(pi, st);
-    LDMAE_CHECK_LAUNCH("gemm_nt");
-    return LDMAE_OK;
-  }
   switch (epi) {
     case LDMAE_EPI_BIAS: NT_LAUNCH(LDMAE_EPI_BIAS); break;
     case LDMAE_EPI_GATE_RES: NT_LAUNCH(LDMAE_EPI_GATE_RES); break;
     case LDMAE_EPI_BIAS_POS: NT_LAUNCH(LDMAE_EPI_BIAS_POS); break;
-    case LDMAE_EPI_SWIGLU: RINGS(LDMAE_EPI_SWIGLU, 2, 4, 3); break;
-    case LDMAE_EPI_SWIGLU_BWD: RINGS(LDMAE_EPI_SWIGLU_BWD, 2, 4, 3); break;
+    case LDMAE_EPI_SWIGLU: PERS(LDMAE_EPI_SWIGLU); break;
+    case LDMAE_EPI_SWIGLU_BWD: PERS(LDMAE_EPI_SWIGLU_BWD); break;
     default: NT_LAUNCH(LDMAE_EPI_BIAS_GELU); break;
   }
 #undef NT_LAUNCH
-#undef RING
-#undef RINGP
-#undef RING2
-#undef RINGS
-#undef RINGD
+#undef PERS
+#undef PERS_GO
+#undef PERS_ATTR
   if (pi >= 0) ldmae_prof_end(pi, st);
   LDMAE_CHECK_LAUNCH("gemm_nt");
   return LDMAE_OK;
@@ -1064,7 +1052,7 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
   LDMAE_REQUIRE(out_dtype == LDMAE_F32 || out_dtype == LDMAE_BF16, "gemm_nt: bad out_dtype %d", out_dtype);
   LDMAE_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   LDMAE_REQUIRE(A && B, "gemm_nt: null operand");
-  const int kq = dtype == LDMAE_BF16 ? NT_BK : F_BK, al = dtype == LDMAE_BF16 ? 8 : 4;
+  const int kq = dtype == LDMAE_BF16 ? 64 : F_BK, al = dtype == LDMAE_BF16 ? 8 : 4;
   LDMAE_REQUIRE(K % kq == 0, "gemm_nt: K=%d must be a multiple of %d", K, kq);
   LDMAE_REQUIRE(lda % al == 0 && ldb % al == 0 && lda >= K && ldb >= K, "gemm_nt: lda=%d ldb=%d need 16-B aligned rows >= K", lda, ldb);
   LDMAE_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_nt: operands must be 16-B aligned");

@@ -31,8 +31,10 @@ def main():
     ap.add_argument("--m", type=int, default=262144)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--skip-tn", action="store_true")
+    ap.add_argument("--tune5", type=int, default=0, help="start delay of every other workgroup (persistent NT kernel)")
     args = ap.parse_args()
     lib = _lib.load()
+    lib.ldmae_tune(5, args.tune5)
     M = args.m
     variants = [int(v) for v in args.variants.split(",")]
     shapes = [("qkv", 2304, 768, False), ("proj", 768, 768, True), ("w12", 4096, 768, False), ("w3", 768, 2048, True),
@@ -49,7 +51,7 @@ def main():
         xin = torch.randn(M, N, device="cuda", generator=g) if gated else None
         gate = torch.randn(M // 1024, N, device="cuda", generator=g) if gated else None
         for v in variants:
-            lib.ldmae_tune(0, v)
+            lib.ldmae_tune(6, v)
             out = ops.gemm_nt(a, w, bias)
             err = float((out[:512].float() - ref).norm() / ref.norm())
             if gated:
@@ -59,7 +61,7 @@ def main():
             res[v] = [err]
         for _ in range(args.rounds):
             for v in variants:
-                lib.ldmae_tune(0, v)
+                lib.ldmae_tune(6, v)
                 res[v].append(timed(lambda: ops.gemm_nt(a, w, bias)))
                 if gated:
                     res[v].append(timed(lambda: ops.gemm_nt_gate_res(a, w, bias, xin, gate, 1024)))
@@ -74,7 +76,7 @@ def main():
                 line += f" | gate_res: {gt:7.3f} ms {flops / gt / 1e9:7.1f} TF/s"
             print(line)
         del a, w, xin, gate
-    lib.ldmae_tune(0, 0)
+    lib.ldmae_tune(6, 0)
     if args.skip_tn:
         return
     for name, N, K in [("dW_qkv", 2304, 768), ("dW_proj", 768, 768), ("dW_w12", 4096, 768), ("dW_w3", 768, 2048)]:
