@@ -117,6 +117,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)
     if (st < nt) stage(st);
+  // vmcnt(0) through the BUILTIN (visible to the compiler's waitcnt pass): the register fragments above are then known to have
+  // landed, so no compiler-counted wait for them ends up inside the tile loop, where -- the ring DMA being hidden in asm -- it
+  // would drain the ring at every tile.  The prologue stages are in flight beside those loads, so this costs one round trip.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   auto body = [&](auto ST, int kt) {
     constexpr int st = decltype(ST)::value;
     ring_wait<PPW, ATT_STAGES>(min(ATT_STAGES - 2, nt - 1 - kt));
@@ -249,6 +253,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)
     if (st < nt) stage(st);
+  // vmcnt(0) through the BUILTIN (visible to the compiler's waitcnt pass): the register fragments above are then known to have
+  // landed, so no compiler-counted wait for them ends up inside the tile loop, where -- the ring DMA being hidden in asm -- it
+  // would drain the ring at every tile.  The prologue stages are in flight beside those loads, so this costs one round trip.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   auto body = [&](auto ST, int qt) {
     constexpr int st = decltype(ST)::value;
     ring_wait<PPW, ATT_STAGES>(min(ATT_STAGES - 2, nt - 1 - qt));
@@ -345,6 +353,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)
     if (st < nt) stage(st);
+  // vmcnt(0) through the BUILTIN (visible to the compiler's waitcnt pass): the register fragments above are then known to have
+  // landed, so no compiler-counted wait for them ends up inside the tile loop, where -- the ring DMA being hidden in asm -- it
+  // would drain the ring at every tile.  The prologue stages are in flight beside those loads, so this costs one round trip.
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   auto body = [&](auto ST, int kt) {
     constexpr int st = decltype(ST)::value;
     ring_wait<PPW, ATT_STAGES>(min(ATT_STAGES - 2, nt - 1 - kt));
