@@ -64,7 +64,7 @@ def measured_traffic():
     WRITE_SIZE in separate passes over this same bench, FETCH_SIZE doubled per the gfx950 note); None if the file is absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_bench.json")) as f:
-            return round(json.load(f)["gemm_nt_ring"]["hbm_bytes_per_launch"])
+            return round(json.load(f)["gemm_nt"]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
@@ -176,7 +176,7 @@ def main():
                                    "latents 32x32x16", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "loss": round(final_loss, 5)},
             "step_mfma_frac": round(FLOPS_PER_IMAGE * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (all Linear fwd + dX GEMMs)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_persist_kernel (bf16 NT GEMM: every Linear fwd + dX)",
                          "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(),
                          "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_bench.json)",

@@ -259,7 +259,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, con
         const float* gp = e.gate + (size_t)(mw / e.rows_per_batch) * e.gate_ld + nb + c8;
         g0 = *(const float4*)gp; g1 = *(const float4*)(gp + 4);
       }
-      float4 xi[MI + 1][2][2];                       // fully unrolled: only two strips' worth are live at a time
+      constexpr int XPF = 1;                         // residual rows are requested XPF strips ahead of their use
+      float4 xi[MI + XPF][2][2];                     // fully unrolled: only XPF + 1 strips' worth are live at a time
       auto ldx = [&](int i) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -267,7 +268,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, con
           xi[i][it][0] = *(const float4*)(e.xin + o); xi[i][it][1] = *(const float4*)(e.xin + o + 4);
         }
       };
-      if constexpr (EPI == LDMAE_EPI_GATE_RES) ldx(0);
+      if constexpr (EPI == LDMAE_EPI_GATE_RES) {
+#pragma unroll
+        for (int i = 0; i < XPF; ++i) ldx(i);
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         fill(i, cblk);
@@ -279,7 +283,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, con
           a[it][0] = make_float4(u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w);
           a[it][1] = make_float4(v.x + b1.x, v.y + b1.y, v.z + b1.z, v.w + b1.w);
         }
-        if constexpr (EPI == LDMAE_EPI_GATE_RES) { if (i + 1 < MI) ldx(i + 1); }
+        if constexpr (EPI == LDMAE_EPI_GATE_RES) { if (i + XPF < MI) ldx(i + XPF); }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int m = mw + i * 16 + it * 8 + (lane >> 3);
@@ -360,8 +364,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
   // drain with the next workgroup's fill, which a persistent workgroup cannot do: vmcnt retires loads and stores in one order)
   const bool persistent = (int)gridDim.x != ntiles;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-  const int first = persistent ? xcd * per_xcd + slot : (int)xcd_remap(blockIdx.x, gridDim.x);
-  const int tstride = persistent ? (int)gridDim.x : ntiles;
+  // persistent: XCD x owns a contiguous range of A row-blocks for the whole launch and deals its tiles (all N tiles of a row-block
+  // are consecutive) round-robin to its CUs: a row-block is never split across two L2s, and the next round finds it in L2
+  const int rbx = (((M + BM - 1) / BM) + 7) / 8;
+  const int first = persistent ? xcd * rbx * (int)tiles_n + slot : (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int tend = persistent ? min(ntiles, (xcd + 1) * rbx * (int)tiles_n) : ntiles;
+  const int tstride = persistent ? per_xcd : ntiles;
   if (delay > 0 && (slot & 1) && persistent)
     for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(127);
 
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
 
   constexpr int PRO = SPLIT == 3 ? STAGES : STAGES - 1;   // K-steps put in flight ahead of a tile's main loop
   int t = first;
-  if (t < ntiles) {
+  if (t < tend) {
     set_tile(t);
 #pragma unroll
     for (int s = 0; s < PRO; ++s)
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
       if (iter == 1 && (wave & 3) == 0 && lane == 0 && kt < 32) tl[((wave >> 2) * 32 + kt) * 4 + k2] = __builtin_amdgcn_s_memtime();
     }
   };
-  while (t < ntiles) {
+  while (t < tend) {
     stamp(0);
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
     stamp(1);
     const int em0 = m0, en0 = n0;
     t += tstride;
-    if (t < ntiles) {
+    if (t < tend) {
       set_tile(t);
 #pragma unroll
       for (int s = 0; s < PRO; ++s)

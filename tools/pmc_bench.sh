@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of the dominant kernel (gemm_nt_ring_kernel, all epilogues) during bench.py, per MI355X_MICROARCH.md "HBM":
+# HBM traffic of the dominant kernel (gemm_nt_persist_kernel, all epilogues) during bench.py, per MI355X_MICROARCH.md "HBM":
 # separate --pmc passes for FETCH_SIZE and WRITE_SIZE (KB units; FETCH_SIZE doubled: gfx950 reports half of wide streaming reads).
 # Writes gpurun_out/pmc_bench.json (copy to profiles/ to have bench.py report it as roofline.traffic).
 cd /tmp && export TMPDIR=/tmp
@@ -15,7 +15,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = {}
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] == c:
-            key = "gemm_nt_ring" if "gemm_nt_ring" in r["Kernel_Name"] else ("gemm_tn_ring" if "gemm_tn_ring" in r["Kernel_Name"] else None)
+            key = "gemm_nt" if "gemm_nt_persist" in r["Kernel_Name"] else ("gemm_tn" if "gemm_tn_ring" in r["Kernel_Name"] else None)
             if key: vals.setdefault(key, []).append(float(r["Counter_Value"]))
     for k, v in vals.items():
         out.setdefault(k, {})[c + "_KB_avg"] = sum(v) / len(v); out[k]["launches"] = len(v)
