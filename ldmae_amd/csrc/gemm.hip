@@ -1134,38 +1134,25 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   float* P = workspace;
   float* Pb = workspace + (size_t)splits * N * K;
   if (ring) {
-    constexpr int lds = 5 * 32768;   // 5 stages x 32 KiB = all 160 KiB of LDS (the 139 KiB epilogue region re-uses it)
+    constexpr int lds = 5 * 32768;   // ring (4 x 32 KiB) and the 139 KiB epilogue region share it
     static bool attr_done = false;
     if (!attr_done) {
-      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_done = true;
     }
     const unsigned grid = cdiv(N, 256) * cdiv(K, 256) * splits;
-    if (ldmae_tune_get(4) == 11 || ldmae_tune_get(4) == 12) {
-      if (ldmae_tune_get(4) == 11) { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 1>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows); }
-      else { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 2>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows); }
-    } else if (ldmae_tune_get(4) == 5 || ldmae_tune_get(4) == 4) {     // staggered wave groups (measured slower for TN: 650 vs 730 TF/s)
-      static bool as_ = false;
-      if (!as_) { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                  hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); as_ = true; }
-      if (ldmae_tune_get(4) == 5)
-        hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 2, true>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
-      else
-        hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 4, true>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
-    } else if (ldmae_tune_get(4) == 0) {     // default: 16 waves (64x64 each), 4 stages
-      static bool a16 = false;
-      if (!a16) { hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 64 * 68 * 4 > lds ? lds : lds); a16 = true; }
-      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 4>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
-    } else if (ldmae_tune_get(4) == 2)
-      hipLaunchKernelGGL(gemm_tn_ring_kernel<5>, dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
-    else if (ldmae_tune_get(4) == 1)
-      hipLaunchKernelGGL(gemm_tn_ring_kernel<3>, dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+    // default: 8 waves (128x64 each), 4-deep ring, the two wave groups half a step apart (1115-1135 TF/s with the fused bias
+    // gradient vs 965-1030 for 16 lock-step waves); tune key 4: 3 = 16 lock-step waves, 4 = 16 staggered waves.
+    // The bias-gradient MFMAs stay on the wk == 0 waves: spreading them over all waves (a wave-uniform switch on wk, or one
+    // slot per K-tile workgroup) measured 8-15 % SLOWER -- every wave's MFMA phase is on the staggered loop's critical path.
+    if (ldmae_tune_get(4) == 3)
+      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 4, false>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+    else if (ldmae_tune_get(4) == 4)
+      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 4, true>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
     else
-      hipLaunchKernelGGL(gemm_tn_ring_kernel<4>, dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 2, true>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
   } else if (dtype == LDMAE_BF16) {
     const unsigned grid = cdiv(N, TN_BN) * cdiv(K, TN_BK) * splits;
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 4 * TN_TILE_BYTES, st, (const bf16*)A, (const bf16*)B, P, M, N, K, lda, ldb, rows);
