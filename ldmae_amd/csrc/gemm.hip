@@ -346,7 +346,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, con
 // an XCD once, at start: a GEMM whose tiles all take the same time otherwise runs all 256 CUs in lockstep -- everyone
 // loads, then everyone multiplies, then everyone stores 32 MiB into HBM at once.
 // ------------------------------------------------------------------------------------------------
-template <int STAGES, int EPI, typename OutT, int SPLIT = 0, bool TL = false>
+template <int STAGES, int EPI, typename OutT, bool TL = false>
 __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
                                                               int lda, int ldb, EpiArgs e, int ntiles, int delay,
                                                               unsigned long long* stamps) {
@@ -390,16 +390,13 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
       src[i] = row < BM ? A + (size_t)min(m0 + row, M - 1) * lda + c * 8 : B + (size_t)min(brow, N - 1) * ldb + c * 8;
     }
   };
-  auto issue_part = [&](int kt, int lo, int hi) {
+  auto issue = [&](int kt) {
     char* base = smem + (kt % STAGES) * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
-      if (i >= lo && i < hi)
         glds16(src[i] + kt * 32, base + (wave * PPW + i) * 1024);
   };
-  auto issue = [&](int kt) { issue_part(kt, 0, PPW); };
-  // SPLIT: how many of a wave's PPW pieces of stage kt+STAGES-1 are issued in the load phase; the rest go between the MFMAs
-  constexpr int PL = SPLIT == 0 ? PPW : (SPLIT == 1 ? PPW / 2 : 0);
+  constexpr int PL = PPW;      // all of a wave's pieces of stage kt+STAGES-1 are issued in its load phase
   const int fpos = ((lane >> 4) ^ ring_f((lane >> 2) & 3)) << 4;
   const int a_off = (wm * TM + (lane & 15)) * 64 + fpos, b_off = (BM + wn * TNn + (lane & 15)) * 64 + fpos;
   const int nk = K / 32;
@@ -414,7 +411,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
     } else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
-  constexpr int PRO = SPLIT == 3 ? STAGES : STAGES - 1;   // K-steps put in flight ahead of a tile's main loop
+  constexpr int PRO = STAGES - 1;   // K-steps put in flight ahead of a tile's main loop
   int t = first;
   if (t < tend) {
     set_tile(t);
@@ -443,61 +440,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
       for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // vmcnt counts in issue order, and the previous tile's epilogue accesses are younger than this tile's prologue loads:
     // the counted waits below can only over-wait (never under-wait) because of them
-    if constexpr (SPLIT == 3) {
-      // Register-pipelined loop, ONE barrier per K-step, no load phase: a K-step's MFMAs run in two halves (A rows 0-63 /
-      // 64-127 of the wave slice) and the LDS reads are always issued one half ahead of the MFMAs that consume them --
-      // the upper-half A fragments of step kt before the lower-half MFMAs, the lower-half A + B fragments of step kt+1
-      // before the upper-half MFMAs (B double-buffered in registers).  At the barrier every wave has finished with
-      // stage kt, so stage kt+3 is issued into its buffer: two stages stay in flight.
-      bf16x8 alo[4], ahi[4], bq[2][NI];
-      auto rd_a = [&](int kt, int half, bf16x8 (&a)[4]) {
-        const char* st = smem + (kt % STAGES) * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(st + a_off + (half * 4 + i) * 1024);
-      };
-      auto rd_b = [&](int kt, bf16x8 (&bb)[NI]) {
-        const char* st = smem + (kt % STAGES) * STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bb[j] = *(const bf16x8*)(st + b_off + j * 1024);
-      };
-      auto mm = [&](int half, bf16x8 (&a)[4], bf16x8 (&bb)[NI]) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bb[j], acc[half * 4 + i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      };
-      auto step = [&](int kt, bf16x8 (&bc)[NI], bf16x8 (&bn)[NI]) {
-        tstamp(kt, 0);
-        rd_a(kt, 1, ahi);
-        __builtin_amdgcn_sched_barrier(0);
-        mm(0, alo, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        tstamp(kt, 1);
-        // own pieces of stage kt+1 landed (stage kt+2 may stay in flight), own reads of stage kt landed
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        tstamp(kt, 2);
-        if (kt + 3 < nk) issue(kt + 3);
-        if (kt + 1 < nk) { rd_a(kt + 1, 0, alo); rd_b(kt + 1, bn); }
-        __builtin_amdgcn_sched_barrier(0);
-        mm(1, ahi, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        tstamp(kt, 3);
-      };
-      if (nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-      else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      rd_a(0, 0, alo); rd_b(0, bq[0]);
-      for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, bq[0], bq[1]);
-        if (kt + 1 < nk) step(kt + 1, bq[1], bq[0]);
-      }
-    } else {
+    {
     // Tile start: vmcnt(0) through the BUILTIN, so that the compiler's waitcnt pass sees it.  It then knows that no load of the
     // previous epilogue (bias, residual rows, h12) is pending when the K loop begins; otherwise it protects those registers,
     // which the loop reuses, with vmcnt(0) waits INSIDE the loop -- and with the ring DMA hidden in asm such a wait drains
@@ -509,7 +452,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
     for (int kt = 0; kt < nk; ++kt) {
       tstamp(kt, 0);
       const bool more = kt + STAGES - 1 < nk;
-      if (more) issue_part(kt + STAGES - 1, 0, PL);
+      if (more) issue(kt + STAGES - 1);
       const char* st = smem + (kt % STAGES) * STAGE_BYTES;
       bf16x8 af[MI], bfr[NI];
 #pragma unroll
@@ -523,14 +466,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
       tstamp(kt, 2);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        if constexpr (PL < PPW) {                        // remaining pieces, spread over the MFMA phase
-          constexpr int REST = PPW - PL, GAP = MI / REST;
-          if (more && i % GAP == GAP / 2) issue_part(kt + STAGES - 1, PL + i / GAP, PL + i / GAP + 1);
-        }
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      }
       __builtin_amdgcn_s_setprio(0);
       tstamp(kt, 3);
       if (!grpB) wait_next(kt, true);
@@ -1009,8 +947,8 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
   // tune key 8: 2 = one tile per workgroup; otherwise persistent (one workgroup per CU), the default
   const bool pers = ldmae_tune_get(8) != 2;
   const int pgrid = (pers && ntiles != ncu) ? ncu : ntiles;
-  // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup, key 6 = how
-  // many of a wave's ring pieces are issued between the MFMAs (A/B knobs), key 7 = diagnostic per-K-step stamp build.
+  // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup (A/B knob),
+  // key 7 = diagnostic per-K-step stamp build.
 #define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048)
 #define PERS_GO(...)                                                                                                             \
   hipLaunchKernelGGL((gemm_nt_persist_kernel<__VA_ARGS__>), dim3(pgrid), dim3(512), lds + 2048, st, (const bf16*)A, (const bf16*)B, \
@@ -1020,15 +958,13 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
     constexpr int lds = 3 * 512 * 64 + 8 * 16 * 68 * 4;                                                                           \
     static bool attr_done = false;                                                                                                 \
     if (!attr_done) {                                                                                                              \
-      PERS_ATTR(3, E, OutT); PERS_ATTR(3, E, OutT, 3);                                                                              \
-      if (E == LDMAE_EPI_BIAS) { PERS_ATTR(3, LDMAE_EPI_BIAS, OutT, 0, true); PERS_ATTR(3, LDMAE_EPI_BIAS, OutT, 3, true); }            \
-      if (E == LDMAE_EPI_SWIGLU) PERS_ATTR(3, LDMAE_EPI_SWIGLU, OutT, 0, true);                                                        \
+      PERS_ATTR(3, E, OutT);                                                                              \
+      if (E == LDMAE_EPI_BIAS) PERS_ATTR(3, LDMAE_EPI_BIAS, OutT, true);            \
+      if (E == LDMAE_EPI_SWIGLU) PERS_ATTR(3, LDMAE_EPI_SWIGLU, OutT, true);                                                        \
       attr_done = true;                                                                                                            \
     }                                                                                                                              \
-    if (E == LDMAE_EPI_BIAS && ldmae_tune_get(7) == 1 && ldmae_tune_get(6) == 3) PERS_GO(3, LDMAE_EPI_BIAS, OutT, 3, true);        \
-    else if (E == LDMAE_EPI_BIAS && ldmae_tune_get(7) == 1) PERS_GO(3, LDMAE_EPI_BIAS, OutT, 0, true);                             \
-    else if (E == LDMAE_EPI_SWIGLU && ldmae_tune_get(7) == 1) PERS_GO(3, LDMAE_EPI_SWIGLU, OutT, 0, true);                             \
-    else if (ldmae_tune_get(6) == 3) PERS_GO(3, E, OutT, 3);                                                                       \
+    if (E == LDMAE_EPI_BIAS && ldmae_tune_get(7) == 1) PERS_GO(3, LDMAE_EPI_BIAS, OutT, true);                             \
+    else if (E == LDMAE_EPI_SWIGLU && ldmae_tune_get(7) == 1) PERS_GO(3, LDMAE_EPI_SWIGLU, OutT, true);                             \
     else PERS_GO(3, E, OutT);                                                                                                      \
   }
 #define NT_LAUNCH(E)                                                                                                             \
