@@ -26,28 +26,33 @@ __device__ __forceinline__ float hsum(float4 a) { return (a.x + a.y) + (a.z + a.
 
 // out[o*out_ld + c] = beta*out + sum_{r<group} P[(o*group + r)*p_ld + c]; 8 row-lanes per column stride the group,
 // partial sums are combined in a fixed order (bitwise reproducible).
-__global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restrict__ P, int p_ld, int nout, int cols, int group,
-                                                           float* __restrict__ out, int out_ld, float beta) {
-  __shared__ float red[8][33];
+template <int RL>
+__global__ __launch_bounds__(32 * RL) void group_reduce_kernel(const float* __restrict__ P, int p_ld, int nout, int cols, int group,
+                                                              float* __restrict__ out, int out_ld, float beta) {
+  __shared__ float red[RL][33];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, o = blockIdx.y;
   float s = 0.f;
   if (c < cols) {
     const float* p = P + (size_t)o * group * p_ld + c;
-    for (int r = rl; r < group; r += 8) s += p[(size_t)r * p_ld];
+    for (int r = rl; r < group; r += RL) s += p[(size_t)r * p_ld];
   }
   red[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < cols) {
     float t = red[0][cl];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += red[k][cl];
+    for (int k = 1; k < RL; ++k) t += red[k][cl];
     float* q = out + (size_t)o * out_ld + c;
     *q = (beta != 0.f ? beta * *q : 0.f) + t;
   }
 }
 static void group_reduce(const float* P, int p_ld, int nout, int cols, int group, float* out, int out_ld, float beta, hipStream_t st) {
-  hipLaunchKernelGGL(group_reduce_kernel, dim3(cdiv(cols, 32), nout), dim3(256), 0, st, P, p_ld, nout, cols, group, out, out_ld, beta);
+  // long groups (thousands of per-workgroup partial rows into one output row): 32 row lanes, otherwise 8
+  if (group >= 256)
+    hipLaunchKernelGGL(group_reduce_kernel<32>, dim3(cdiv(cols, 32), nout), dim3(1024), 0, st, P, p_ld, nout, cols, group, out, out_ld, beta);
+  else
+    hipLaunchKernelGGL(group_reduce_kernel<8>, dim3(cdiv(cols, 32), nout), dim3(256), 0, st, P, p_ld, nout, cols, group, out, out_ld, beta);
 }
 
 // rows per workgroup for the per-sample reductions: largest of 64/32/16/8/4 dividing rows_per_batch
@@ -491,23 +496,31 @@ extern "C" int ldmae_gate_bwd(int dtype, const float* dxout, const void* y, cons
 }
 
 // ------------------------------------------------------------------ column sums (bias gradients)
-constexpr int CS_ROWS = 256;
+// rows summed by one workgroup: enough row groups for ~512 workgroups (the adaLN bias gradient is 256 rows x 4608 columns:
+// with a fixed 256 rows it ran on 5 workgroups, 65 us for 4.7 MB)
+static int colsum_rows(int M, int N) {
+  const long colblocks = cdiv(N, 1024);
+  long groups = 512 / colblocks; if (groups < 1) groups = 1;
+  long rows = (M + groups - 1) / groups;
+  int r = 8; while (r < rows && r < 256) r <<= 1;
+  return r;
+}
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ldx, int M, int N, float* __restrict__ P) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ldx, int M, int N, int rows, float* __restrict__ P) {
   const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c >= N) return;
-  const int m0 = blockIdx.y * CS_ROWS, m1 = min(M, m0 + CS_ROWS);
+  const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
   float4 s = f4(0.f);
   for (int m = m0; m < m1; ++m) s = s + load4<T>(X + (size_t)m * ldx + c);
   *(float4*)(P + (size_t)blockIdx.y * N + c) = s;
 }
-extern "C" long ldmae_colsum_workspace_bytes(int M, int N) { return (long)cdiv(M, CS_ROWS) * N * 4; }
+extern "C" long ldmae_colsum_workspace_bytes(int M, int N) { return (long)cdiv(M, colsum_rows(M, N)) * N * 4; }
 extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, float beta, float* workspace, void* stream) {
   LDMAE_REQUIRE(X && out && workspace && M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0, "colsum: bad arguments (N=%d ldx=%d multiples of 4)", N, ldx);
   hipStream_t st = as_stream(stream);
-  const int G = cdiv(M, CS_ROWS);
-  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(cdiv(N, 1024), G), dim3(256), 0, st, (const bf16*)X, ldx, M, N, workspace);
-  else hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(N, 1024), G), dim3(256), 0, st, (const float*)X, ldx, M, N, workspace);
+  const int rows = colsum_rows(M, N), G = cdiv(M, rows);
+  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(cdiv(N, 1024), G), dim3(256), 0, st, (const bf16*)X, ldx, M, N, rows, workspace);
+  else hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(N, 1024), G), dim3(256), 0, st, (const float*)X, ldx, M, N, rows, workspace);
   group_reduce(workspace, N, 1, N, G, out, N, beta, st);
   LDMAE_CHECK_LAUNCH("colsum");
   return LDMAE_OK;
