@@ -317,8 +317,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
 // ================================================================================================ backward dQ, bf16
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
-                                                               const bf16* __restrict__ dO, const float* __restrict__ LSE,
-                                                               const float* __restrict__ DELTA, bf16* __restrict__ dQ, int H, int N, float scale) {
+                                                               const bf16* __restrict__ O, const bf16* __restrict__ dO,
+                                                               const float* __restrict__ LSE, float* __restrict__ DELTA,
+                                                               bf16* __restrict__ dQ, int H, int N, float scale) {
   constexpr int KS = HD / 16, DB = HD / 32, TB = 64 * HD * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -332,12 +333,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   const bf16* kp = K + (size_t)bh * N * HD;
   const bf16* vp = V + (size_t)bh * N * HD;
   bf16x8 qf[KS], dof[KS];
+  // delta_i = sum_d dO[i,d] * O[i,d] is formed here from the dO fragments this lane holds anyway (its half of the row; the other
+  // half sits on lane ^ 32) and published for the dK/dV kernel, which runs after this one: no separate pass over O and dO.
+  float dpart = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     qf[ks] = *(const bf16x8*)(Q + ((size_t)bh * N + qrow) * HD + ks * 16 + 8 * h);
-    dof[ks] = *(const bf16x8*)(dO + (((size_t)b * N + qrow) * H + hh) * HD + ks * 16 + 8 * h);
+    const size_t oo = (((size_t)b * N + qrow) * H + hh) * HD + ks * 16 + 8 * h;
+    dof[ks] = *(const bf16x8*)(dO + oo);
+    const bf16x8 of = *(const bf16x8*)(O + oo);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dpart += (float)dof[ks][j] * (float)of[j];
   }
-  const float lse2 = LSE[(size_t)bh * N + qrow] * 1.4426950408889634f, dl = DELTA[(size_t)bh * N + qrow];
+  const float dl = dpart + __shfl_xor(dpart, 32);
+  if (h == 0 && q0 + r < N) DELTA[(size_t)bh * N + qrow] = dl;
+  const float lse2 = LSE[(size_t)bh * N + qrow] * 1.4426950408889634f;
   f32x16 dqacc[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d)
@@ -669,10 +679,10 @@ extern "C" int ldmae_attention_bwd(int dtype, const void* q, const void* k, cons
   const long items = (long)B * N * H;
   const unsigned dgrid = (unsigned)((items * 8 + 255) / 256 < 8192 ? (items * 8 + 255) / 256 : 8192);
   if (dtype == LDMAE_BF16) {
-    hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(dgrid), dim3(256), 0, st, (const bf16*)o, (const bf16*)do_, delta, B, H, N, hd);
+    // dQ first: it forms delta = rowsum(dO * O) from its own fragments and publishes it for the dK/dV kernel
 #define L(HD) { \
-    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), ATT_STAGES * (2 * 64 * HD * 2 + 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale); \
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), ATT_STAGES * 2 * 64 * HD * 2, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale); }
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), ATT_STAGES * 2 * 64 * HD * 2, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale); \
+    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), ATT_STAGES * (2 * 64 * HD * 2 + 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale); }
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {

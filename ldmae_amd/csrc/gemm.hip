@@ -503,31 +503,46 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
 // ------------------------------------------------------------------------------------------------
 constexpr int F_BM = 64, F_BN = 64, F_BK = 16, F_LD = 20;   // LDS row stride (floats), 80 B keeps 16-B alignment
 
-template <int EPI, typename OutT>
-__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                          int M, int N, int K, int lda, int ldb, EpiArgs e) {
-  __shared__ __attribute__((aligned(16))) float As[2][F_BM * F_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][F_BN * F_LD];
+template <int EPI, typename OutT, int TW = 2>
+__global__ __launch_bounds__(64 * TW * TW) void gemm_nt_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                                  int M, int N, int K, int lda, int ldb, EpiArgs e) {
+  // TW x TW waves of 32x32: TW = 2 -> 64x64 tile / 256 threads.  (TW = 1, 32x32 tiles of one wave, was tried for the small-M
+  // adaLN GEMMs: 4x the workgroups but 2x slower -- a lone wave cannot overlap its loads with its MFMAs.)
+  constexpr int BT = 32 * TW, NT = 64 * TW * TW, RPP = NT / 4, PASSES = BT / RPP;
+  __shared__ __attribute__((aligned(16))) float As[2][BT * F_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BT * F_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const unsigned tiles_n = (N + F_BN - 1) / F_BN;
-  const int m0 = (blockIdx.x / tiles_n) * F_BM, n0 = (blockIdx.x % tiles_n) * F_BN;
+  const int wm = wave / TW, wn = wave % TW;
+  const unsigned tiles_n = (N + BT - 1) / BT;
+  const int m0 = (blockIdx.x / tiles_n) * BT, n0 = (blockIdx.x % tiles_n) * BT;
   const int lr = tid >> 2, lc = (tid & 3) * 4;
-  const float* ap = A + (size_t)min(m0 + lr, M - 1) * lda + lc;
-  const float* bp = B + (size_t)min(n0 + lr, N - 1) * ldb + lc;
+  const float* ap[PASSES];
+  const float* bp[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    ap[p] = A + (size_t)min(m0 + lr + p * RPP, M - 1) * lda + lc;
+    bp[p] = B + (size_t)min(n0 + lr + p * RPP, N - 1) * ldb + lc;
+  }
   f32x4 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nk = K / F_BK;
-  float4 ra = *(const float4*)ap, rb = *(const float4*)bp;
-  *(float4*)&As[0][lr * F_LD + lc] = ra;
-  *(float4*)&Bs[0][lr * F_LD + lc] = rb;
+  float4 ra[PASSES], rb[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    ra[p] = *(const float4*)ap[p]; rb[p] = *(const float4*)bp[p];
+    *(float4*)&As[0][(lr + p * RPP) * F_LD + lc] = ra[p];
+    *(float4*)&Bs[0][(lr + p * RPP) * F_LD + lc] = rb[p];
+  }
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) { ra = *(const float4*)(ap + (kt + 1) * F_BK); rb = *(const float4*)(bp + (kt + 1) * F_BK); }
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) { ra[p] = *(const float4*)(ap[p] + (kt + 1) * F_BK); rb[p] = *(const float4*)(bp[p] + (kt + 1) * F_BK); }
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       float af[2], bfr[2];
@@ -542,8 +557,11 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const float* __restric
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      *(float4*)&As[cur ^ 1][lr * F_LD + lc] = ra;
-      *(float4*)&Bs[cur ^ 1][lr * F_LD + lc] = rb;
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        *(float4*)&As[cur ^ 1][(lr + p * RPP) * F_LD + lc] = ra[p];
+        *(float4*)&Bs[cur ^ 1][(lr + p * RPP) * F_LD + lc] = rb[p];
+      }
     }
     __syncthreads();
     cur ^= 1;
