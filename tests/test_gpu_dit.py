@@ -123,6 +123,30 @@ def test_patch2_learn_sigma_variant_vs_oracle():
     assert rel_err(out.cpu(), odit.dit_forward(sd, x, t, y, cfg, train=False)) < 1e-4
 
 
+def test_xl_head_dim_72_geometry_fp32_and_bf16():
+    """LightningDiT-XL geometry in small: head_dim 72 (hidden 576 = 8 heads, XL is 1152 = 16 heads), SwiGLU hidden
+    int(2/3*4*576) = 1536; forward and every parameter gradient vs the oracle in fp32; bf16 autocast (attention zero-padded
+    to 128 columns) close to it."""
+    cfg = odit.DiTConfig(input_size=8, patch_size=1, in_channels=16, hidden_size=576, depth=1, num_heads=8, num_classes=10,
+                         class_dropout_prob=0.5)
+    sd = det_weights(odit.param_shapes(cfg), 5)
+    sd.update(odit.fixed_tables(cfg))
+    torch.manual_seed(0)
+    np.random.seed(0)
+    x1, y, t, x0, drop = otrain.draw_batch(4, cfg)
+    oloss, ograds, _ = otrain.loss_and_grads(sd, cfg, x1, y, t, x0, drop)
+    _, xt, ut = otr.plan(t, x0, x1)
+    for prec, ltol, gtol in ((torch.float32, 1e-4, 1e-4), (torch.bfloat16, 5e-3, 6e-2)):
+        m = build(cfg, sd, prec)
+        force_drop(m, drop)
+        pred = m(xt.cuda(), t.cuda(), y.cuda())
+        loss = ((pred - ut.cuda()) ** 2).mean()
+        loss.backward()
+        assert abs(float(loss) - float(oloss)) / float(oloss) < ltol
+        worst = max(rel_err(p.grad.cpu(), ograds[n]) for n, p in m.named_parameters() if p.requires_grad and n in ograds)
+        assert worst < gtol, (prec, worst)
+
+
 def test_real_width_b1_forward_and_checkpointing():
     """DiT-B/1 at the real width / sequence length, batch 2, fp32: vs oracle; activation checkpointing gives the same grads."""
     cfg = odit.DiTConfig(**odit.DIT_B_1)

@@ -165,7 +165,7 @@ def _attn_ref(qq, kk, vv, scale):
 
 
 @pytest.mark.parametrize("dtype,hd,N", [(F32, 64, 64), (F32, 64, 192), (F32, 16, 256), (F32, 72, 128), (BF16, 64, 64), (BF16, 64, 192),
-                                        (BF16, 64, 1024)])
+                                        (BF16, 64, 1024), (BF16, 72, 256), (BF16, 128, 128)])
 def test_attention(ops, dtype, hd, N):
     B, H = 2, 3
     mk = lambda s: q(rnd(B, H, N, hd, seed=s), dtype).double().requires_grad_(True)
