@@ -102,10 +102,11 @@ int ldmae_attention_bwd(int dtype, const void* q, const void* k, const void* v, 
 int ldmae_swiglu_fwd(int dtype, const void* h12, void* hid, int M, int Hs, void* stream);
 int ldmae_swiglu_bwd(int dtype, const void* dhid, const void* h12, void* dh12, int M, int Hs, void* stream);
 
-/* ---- gated residual backward (lightningdit.py:248-249): dy = dxout * gate[b]; dgate[b] = sum_n dxout*y */
+/* ---- gated residual backward (lightningdit.py:248-249): dy = dxout * gate[b]; dgate[b] = sum_n dxout*y;
+   dbias (optional, [D]) = column sums of dy as stored = bias gradient of the branch's output Linear (proj / w3) */
 long ldmae_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch);
 int ldmae_gate_bwd(int dtype, const float* dxout, const void* y, const float* gate, int gate_ld, void* dy, float* dgate,
-                   int dgate_ld, int M, int D, int rows_per_batch, float* workspace, void* stream);
+                   int dgate_ld, float* dbias, int M, int D, int rows_per_batch, float* workspace, void* stream);
 
 /* ---- embedders (lightningdit.py:109-137, 152-169) -------------------------------------------- */
 int ldmae_timestep_embedding(const float* t, float* out, int B, int dim, float max_period, void* stream);

@@ -42,7 +42,7 @@ SIGNATURES = {
     "ldmae_swiglu_fwd": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "ldmae_swiglu_bwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
     "ldmae_gate_bwd_workspace_bytes": (_l, [_i, _i, _i]),
-    "ldmae_gate_bwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ldmae_gate_bwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "ldmae_timestep_embedding": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "ldmae_silu_fwd": (_i, [_i, _vp, _vp, _l, _vp]),
     "ldmae_silu_bwd": (_i, [_vp, _vp, _vp, _l, _vp]),

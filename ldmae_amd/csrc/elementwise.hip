@@ -434,17 +434,17 @@ extern "C" int ldmae_swiglu_bwd(int dtype, const void* dhid, const void* h12, vo
 // ------------------------------------------------------------------ gated residual backward
 template <int NCH, typename T>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dxo, const T* __restrict__ y, const float* __restrict__ gate,
-                                                       int gate_ld, T* __restrict__ dy, float* __restrict__ P, int M, int D, int rpb,
-                                                       int rows_per_wg) {
+                                                       int gate_ld, T* __restrict__ dy, float* __restrict__ P, float* __restrict__ Pb,
+                                                       int M, int D, int rpb, int rows_per_wg) {
   extern __shared__ float red[];   // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nch = D >> 2;
   const int m_base = blockIdx.x * rows_per_wg, b = m_base / rpb;
-  float4 gv[NCH], acc[NCH];
+  float4 gv[NCH], acc[NCH], accb[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     gv[i] = (c < nch && gate) ? *(const float4*)(gate + (size_t)b * gate_ld + 4 * c) : f4(1.f);
-    acc[i] = f4(0.f);
+    acc[i] = f4(0.f); accb[i] = f4(0.f);
   }
   for (int r = wave; r < rows_per_wg; r += 4) {
     const int m = m_base + r;
@@ -455,43 +455,58 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       if (c < nch) {
         const float4 g = *(const float4*)(dxo + (size_t)m * D + 4 * c);
         if (P) acc[i] = acc[i] + g * load4<T>(y + (size_t)m * D + 4 * c);
-        store4<T>(dy + (size_t)m * D + 4 * c, g * gv[i]);
+        const float4 d = g * gv[i];
+        store4<T>(dy + (size_t)m * D + 4 * c, d);
+        // bias gradient of the Linear that produced the branch = column sums of dy AS STORED (rounded to T: what the weight-
+        // gradient GEMM reads), formed here while the values are in registers instead of inside the TN GEMM
+        if (Pb) accb[i] = accb[i] + make_float4(to_f<T>(from_f<T>(d.x)), to_f<T>(from_f<T>(d.y)), to_f<T>(from_f<T>(d.z)), to_f<T>(from_f<T>(d.w)));
       }
     }
   }
-  if (!P) return;
+  if (P) {
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) { const int c = lane + 64 * i; if (c < nch) *(float4*)(red + wave * D + 4 * c) = acc[i]; }
-  __syncthreads();
-  for (int i = threadIdx.x; i < D; i += 256) P[(size_t)blockIdx.x * D + i] = (red[i] + red[D + i]) + (red[2 * D + i] + red[3 * D + i]);
+    for (int i = 0; i < NCH; ++i) { const int c = lane + 64 * i; if (c < nch) *(float4*)(red + wave * D + 4 * c) = acc[i]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) P[(size_t)blockIdx.x * D + i] = (red[i] + red[D + i]) + (red[2 * D + i] + red[3 * D + i]);
+    __syncthreads();
+  }
+  if (Pb) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { const int c = lane + 64 * i; if (c < nch) *(float4*)(red + wave * D + 4 * c) = accb[i]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) Pb[(size_t)blockIdx.x * D + i] = (red[i] + red[D + i]) + (red[2 * D + i] + red[3 * D + i]);
+  }
 }
-
+extern "C" long ldmae_colsum_workspace_bytes(int M, int N);
+extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, float beta, float* workspace, void* stream);
 extern "C" long ldmae_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch) {
   const int rw = pick_rows_per_wg(rows_per_batch);
-  return rw ? (long)(M / rw) * D * 4 : -1;
+  if (rw <= 0) return 0;
+  const int G = M / rw;                                // dgate partials + bias-gradient partials + their column-sum scratch
+  return 2L * G * D * 4 + ldmae_colsum_workspace_bytes(G, D);
 }
-
 extern "C" int ldmae_gate_bwd(int dtype, const float* dxout, const void* y, const float* gate, int gate_ld, void* dy, float* dgate,
-                              int dgate_ld, int M, int D, int rows_per_batch, float* workspace, void* stream) {
+                              int dgate_ld, float* dbias, int M, int D, int rows_per_batch, float* workspace, void* stream) {
   LDMAE_REQUIRE(dxout && dy && M > 0 && D % 4 == 0, "gate_bwd: null pointer or D=%d not a multiple of 4", D);
   LDMAE_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0, "gate_bwd: M=%d %% rows_per_batch=%d != 0", M, rows_per_batch);
   LDMAE_REQUIRE(!dgate || (y && gate && workspace), "gate_bwd: dgate requested without y/gate/workspace");
+  LDMAE_REQUIRE(!dbias || workspace, "gate_bwd: dbias requested without workspace");
   const int rw = pick_rows_per_wg(rows_per_batch);
   LDMAE_REQUIRE(rw > 0, "gate_bwd: rows_per_batch=%d must be a multiple of 4", rows_per_batch);
   hipStream_t st = as_stream(stream);
   const int G = M / rw;
   float* P = dgate ? workspace : nullptr;
+  float* Pb = dbias ? workspace + (size_t)G * D : nullptr;
   const size_t lds = (size_t)4 * D * sizeof(float);
   if (dtype == LDMAE_BF16) {
-    DISPATCH_NCH(D, hipLaunchKernelGGL((gate_bwd_kernel<NCH, bf16>), dim3(G), dim3(256), lds, st, dxout, (const bf16*)y, gate, gate_ld, (bf16*)dy, P, M, D, rows_per_batch, rw));
+    DISPATCH_NCH(D, hipLaunchKernelGGL((gate_bwd_kernel<NCH, bf16>), dim3(G), dim3(256), lds, st, dxout, (const bf16*)y, gate, gate_ld, (bf16*)dy, P, Pb, M, D, rows_per_batch, rw));
   } else {
-    DISPATCH_NCH(D, hipLaunchKernelGGL((gate_bwd_kernel<NCH, float>), dim3(G), dim3(256), lds, st, dxout, (const float*)y, gate, gate_ld, (float*)dy, P, M, D, rows_per_batch, rw));
+    DISPATCH_NCH(D, hipLaunchKernelGGL((gate_bwd_kernel<NCH, float>), dim3(G), dim3(256), lds, st, dxout, (const float*)y, gate, gate_ld, (float*)dy, P, Pb, M, D, rows_per_batch, rw));
   }
   LDMAE_CHECK_LAUNCH("gate_bwd");
-  if (dgate) {
-    group_reduce(P, D, M / rows_per_batch, D, rows_per_batch / rw, dgate, dgate_ld, 0.f, st);
-    LDMAE_CHECK_LAUNCH("gate_bwd reduce");
-  }
+  if (dgate) group_reduce(P, D, M / rows_per_batch, D, rows_per_batch / rw, dgate, dgate_ld, 0.f, st);
+  if (dbias) return ldmae_colsum(LDMAE_F32, Pb, D, G, D, dbias, 0.f, Pb + (size_t)G * D, stream);   // two-stage column sum of the G partial rows
+  LDMAE_CHECK_LAUNCH("gate_bwd reduce");
   return LDMAE_OK;
 }
 

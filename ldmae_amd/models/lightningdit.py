@@ -164,15 +164,15 @@ class _DiTBlockFn(torch.autograd.Function):
         dmod = torch.empty_like(mod)
         s1, g1, s2, g2 = mod[:, D:2 * D], mod[:, 2 * D:3 * D], mod[:, 4 * D:5 * D], mod[:, 5 * D:6 * D]
         # ---- MLP branch
-        dy2 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype)
-        dW3, db3 = ops.gemm_tn(dy2, hid, with_bias=True)
+        dy2, db3 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype, with_bias=True)   # bias grads where dy is produced
+        dW3 = ops.gemm_tn(dy2, hid)
         dh12 = ops.gemm_nt_swiglu_bwd(dy2, W3T, h12)
         dW12, db12 = ops.gemm_tn(dh12, xm2, with_bias=True)
         dxm2 = ops.gemm_nt(dh12, W12T)
         dn2 = ops.rmsnorm_modulate_bwd(dxm2, xmid, n2w, s2, rstd2, dx, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D], N)
         # ---- attention branch
-        dy1 = ops.gate_bwd(dx, y1, g1, dmod[:, 2 * D:3 * D], N, dtype)
-        dWp, dbp = ops.gemm_tn(dy1, o.view(M, D), with_bias=True)
+        dy1, dbp = ops.gate_bwd(dx, y1, g1, dmod[:, 2 * D:3 * D], N, dtype, with_bias=True)
+        dWp = ops.gemm_tn(dy1, o.view(M, D))
         do = ops.gemm_nt(dy1, WpT)
         dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
         dqkv, dqn, dkn = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, B, N, H, hd, eps)

@@ -237,14 +237,17 @@ def swiglu_bwd(dhid, h12):
     return dh12
 
 
-def gate_bwd(dxout, y, gate, dgate, rows_per_batch, act_dtype):
-    """dy = dxout * gate[b] (act dtype);  dgate view [B,D] <- sum_n dxout*y (skipped when dgate is None)."""
+def gate_bwd(dxout, y, gate, dgate, rows_per_batch, act_dtype, with_bias=False):
+    """dy = dxout * gate[b] (act dtype);  dgate view [B,D] <- sum_n dxout*y (skipped when dgate is None).
+    with_bias: also return the column sums of dy (the bias gradient of the Linear that produced the branch)."""
     M, D = dxout.shape
     dy = torch.empty(M, D, dtype=act_dtype, device=dxout.device)
-    ws = workspace(L.load().ldmae_gate_bwd_workspace_bytes(M, D, rows_per_batch), dxout.device) if dgate is not None else None
+    dbias = torch.empty(D, dtype=torch.float32, device=dxout.device) if with_bias else None
+    need_ws = dgate is not None or with_bias
+    ws = workspace(L.load().ldmae_gate_bwd_workspace_bytes(M, D, rows_per_batch), dxout.device) if need_ws else None
     call("ldmae_gate_bwd", dt(act_dtype), ptr(dxout), ptr(y), ptr(gate), gate.stride(0) if gate is not None else 0, ptr(dy), ptr(dgate),
-         dgate.stride(0) if dgate is not None else 0, M, D, rows_per_batch, ptr(ws), stream())
-    return dy
+         dgate.stride(0) if dgate is not None else 0, ptr(dbias), M, D, rows_per_batch, ptr(ws), stream())
+    return (dy, dbias) if with_bias else dy
 
 
 def timestep_embedding(t, dim=256, max_period=10000.0):

@@ -215,6 +215,9 @@ def test_swiglu_gate_silu(ops, dtype):
     gate = mod[:, 5 * D:].repeat_interleave(T, 0)
     assert rel_err(dy.float().cpu(), dxo * gate) < tol
     assert rel_err(dmod[:, 5 * D:].cpu(), (dxo * y).view(B, T, D).sum(1)) < 1e-5
+    dy2, db = ops.gate_bwd(dev(dxo), dev(y, dtype), modd[:, 5 * D:], None, T, dtype, with_bias=True)     # producer-side bias gradient
+    assert torch.equal(dy2, dy)
+    assert rel_err(db.cpu(), dy.float().cpu().sum(0)) < 1e-5          # column sums of dy exactly as stored
     if dtype == F32:
         c = rnd(5, 192, seed=6).requires_grad_(True)
         torch.nn.functional.silu(c).backward(g[:5, :192])
