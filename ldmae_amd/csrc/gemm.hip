@@ -126,8 +126,8 @@ template <int EPI, typename OutT> struct Epi4 {
 // workgroup barrier is needed) -> row-contiguous 16-B global accesses with the fused bias / gated residual / pos / GELU /
 // SwiGLU forms.
 template <int EPI, typename OutT, int TM, int TNn, int MI, int NI>
-__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, const EpiArgs& e, int m0, int n0, int wm, int wn, int lane,
-                                            int M, int N) {
+__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, float* ex, const EpiArgs& e, int m0, int n0, int wm, int wn,
+                                            int lane, int M, int N) {   // ew: strip [16][68]; ex: 512 more private floats
   constexpr int ELD = 68;
   auto fill = [&](int i, int cblk) {
 #pragma unroll
@@ -196,16 +196,19 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, con
         }
       };
       const bool whole = mw + TM <= M && n0 + wn * TNn + cblk * 64 + 64 <= Hs;     // wave-uniform: straight-line stores (see SwiGLU fwd)
+      // bias gradient of w12 = column sums of dh12 AS STORED (bf16), formed here while the values are in registers: per wave the
+      // sums over its 128 rows go to e.xout[(m0 / 128 + wm)][2 * Hs] (one partial row per 128 output rows; summed by the caller)
+      // (kept in the wave's LDS scratch ex[row group q = lane >> 4][da 64 | db 64]: eight more live registers spilled the kernel)
+      float* exq = ex + (lane >> 4) * 128 + (lane & 15) * 4;
+      const bool sums = e.xout != nullptr;
+      if (sums) { *(float4*)exq = make_float4(0.f, 0.f, 0.f, 0.f); *(float4*)(exq + 64) = make_float4(0.f, 0.f, 0.f, 0.f); }
       auto strip = [&](int i, bool guard) {
         fill(i, cblk);
-        float4 gvv[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) gvv[it] = *(const float4*)(ew + (it * 4 + (lane >> 4)) * ELD + (lane & 15) * 4);
         if (i + 1 < MI) ldh(i + 1);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int row = it * 4 + (lane >> 4), m = mw + i * 16 + row;
-          const float4 gv = gvv[it];
+          const float4 gv = *(const float4*)(ew + row * ELD + (lane & 15) * 4);
           if (!guard || (m < M && inr)) {
             const bf16x4 av = hv[i][it][0], bv = hv[i][it][1];
             const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -215,6 +218,12 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, con
               const float g = (float)(bf16)gg[j], a = (float)av[j], b = (float)bv[j], sg = fast_sigmoid(a);
               da[j] = (bf16)(g * b * sg * (1.f + a * (1.f - sg)));
               db[j] = (bf16)(g * a * sg);
+            }
+            if (sums) {
+              float4 ua = *(float4*)exq, ub = *(float4*)(exq + 64);
+              ua.x += (float)da[0]; ua.y += (float)da[1]; ua.z += (float)da[2]; ua.w += (float)da[3];
+              ub.x += (float)db[0]; ub.y += (float)db[1]; ub.z += (float)db[2]; ub.w += (float)db[3];
+              *(float4*)exq = ua; *(float4*)(exq + 64) = ub;
             }
             *(bf16x4*)(dh12 + (size_t)m * 2 * Hs + n) = da;
             *(bf16x4*)(dh12 + (size_t)m * 2 * Hs + Hs + n) = db;
@@ -228,6 +237,13 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, con
       } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i) strip(i, true);
+      }
+      if (sums && lane < 32 && inr && mw < M) {          // lanes 0-15 sum the da halves of the 4 row groups, lanes 16-31 the db halves
+        const float* src = ex + (lane >> 4) * 64 + (lane & 15) * 4;
+        float4 t = *(const float4*)src;
+#pragma unroll
+        for (int qg = 1; qg < 4; ++qg) { const float4 u = *(const float4*)(src + qg * 128); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        *(float4*)(e.xout + (size_t)(mw / TM) * 2 * Hs + (lane >> 4) * Hs + n) = t;
       }
     }
     return;
@@ -358,6 +374,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
   const int wm = wave / WN, wn = wave % WN;
   const unsigned tiles_n = (N + BN - 1) / BN;
   float* ew = (float*)(smem + STAGES * STAGE_BYTES) + wave * (16 * 68);
+  float* ex = (float*)(smem + STAGES * STAGE_BYTES + 8 * 16 * 68 * 4 + 2048) + wave * 512;    // per-wave column-sum scratch (SwiGLU-bwd)
   // workgroup b sits on XCD b % 8 (256 workgroups, one per CU): give each XCD a contiguous run of 32 tiles per round so the
   // workgroups that share an A row-block (and the whole of B) share an L2
   // (gridDim.x == ntiles: one tile per workgroup, the classic launch -- the hardware then overlaps a finished workgroup's store
@@ -485,7 +502,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
       for (int s = 0; s < PRO; ++s)
         if (s < nk) issue(s);
     }
-    nt_epilogue<EPI, OutT, TM, TNn, MI, NI>(acc, ew, e, em0, en0, wm, wn, lane, M, N);
+    nt_epilogue<EPI, OutT, TM, TNn, MI, NI>(acc, ew, ex, e, em0, en0, wm, wn, lane, M, N);
     if constexpr (TL) {
       if (iter == 1 && stamps) {
         __syncthreads();
@@ -967,9 +984,9 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
   const int pgrid = (pers && ntiles != ncu) ? ncu : ntiles;
   // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup (A/B knob),
   // key 7 = diagnostic per-K-step stamp build.
-#define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048)
+#define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048 + 16384)
 #define PERS_GO(...)                                                                                                             \
-  hipLaunchKernelGGL((gemm_nt_persist_kernel<__VA_ARGS__>), dim3(pgrid), dim3(512), lds + 2048, st, (const bf16*)A, (const bf16*)B, \
+  hipLaunchKernelGGL((gemm_nt_persist_kernel<__VA_ARGS__>), dim3(pgrid), dim3(512), lds + 2048 + 16384, st, (const bf16*)A, (const bf16*)B, \
                      M, N, K, lda, ldb, e, ntiles, ldmae_tune_get(5), (unsigned long long*)g_nt_stamps)
 #define PERS(E)                                                                                                                  \
   {                                                                                                                               \
@@ -1041,6 +1058,7 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
     LDMAE_REQUIRE(dtype == LDMAE_BF16 && out_dtype == LDMAE_BF16, "gemm_nt: swiglu-bwd epilogue is bf16 only");
     LDMAE_REQUIRE(C && xin && N % 4 == 0 && K % 32 == 0, "gemm_nt: swiglu-bwd epilogue needs dh12 (C) and h12 (xin)");
     e.xin = xin;
+    e.xout = xout;   /* optional: [ceil(M/128)][2*Hs] f32 partial column sums of dh12 (bias gradient of w12) */
   } else {
     LDMAE_FAIL(LDMAE_ERR_INVALID, "gemm_nt: unknown epilogue %d", epi);
   }

@@ -166,8 +166,8 @@ class _DiTBlockFn(torch.autograd.Function):
         # ---- MLP branch
         dy2, db3 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype, with_bias=True)   # bias grads where dy is produced
         dW3 = ops.gemm_tn(dy2, hid)
-        dh12 = ops.gemm_nt_swiglu_bwd(dy2, W3T, h12)
-        dW12, db12 = ops.gemm_tn(dh12, xm2, with_bias=True)
+        dh12, db12 = ops.gemm_nt_swiglu_bwd(dy2, W3T, h12, with_bias=True)
+        dW12 = ops.gemm_tn(dh12, xm2)
         dxm2 = ops.gemm_nt(dh12, W12T)
         dn2 = ops.rmsnorm_modulate_bwd(dxm2, xmid, n2w, s2, rstd2, dx, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D], N)
         # ---- attention branch

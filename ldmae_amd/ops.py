@@ -91,16 +91,19 @@ def gemm_nt_swiglu(a, w12, b12):
     return h12, swiglu_fwd(h12)
 
 
-def gemm_nt_swiglu_bwd(dy, w3t, h12):
-    """dh12 = swiglu_bwd(dy @ w3t^T, h12)   (w3t = [Hs, D] transposed copy of w3)."""
+def gemm_nt_swiglu_bwd(dy, w3t, h12, with_bias=False):
+    """dh12 = swiglu_bwd(dy @ w3t^T, h12)   (w3t = [Hs, D] transposed copy of w3).  with_bias: also the column sums of dh12 (the
+    bias gradient of w12), formed in the GEMM epilogue as per-128-row partials and summed here."""
     M, K = dy.shape
     Hs = w3t.shape[0]
     if dy.dtype == torch.bfloat16 and Hs % 4 == 0 and K % 64 == 0:
         dh12 = torch.empty_like(h12)
+        part = torch.zeros((M + 127) // 128, 2 * Hs, dtype=torch.float32, device=dy.device) if with_bias else None
         call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU_BWD, ptr(dy), dy.stride(0), ptr(w3t), w3t.stride(0), ptr(dh12), 2 * Hs, M, Hs, K, None, 0.0,
-             ptr(h12), None, None, 0, 0, stream())
-        return dh12
-    return swiglu_bwd(gemm_nt(dy, w3t), h12)
+             ptr(h12), ptr(part), None, 0, 0, stream())
+        return (dh12, colsum(part)) if with_bias else dh12
+    dh12 = swiglu_bwd(gemm_nt(dy, w3t), h12)
+    return (dh12, colsum(dh12)) if with_bias else dh12
 
 
 def gemm_tn(a, b, out=None, beta=0.0, with_bias=False):

@@ -233,6 +233,8 @@ def test_fused_swiglu_gemm_epilogues_match_unfused(ops):
     assert torch.equal(h12, h12_ref) and torch.equal(hid, ops.swiglu_fwd(h12_ref))
     dy, w3t = dev(rnd(M, D, seed=4), BF16), dev(rnd(Hs, D, seed=5, scale=D ** -0.5), BF16)
     assert torch.equal(ops.gemm_nt_swiglu_bwd(dy, w3t, h12), ops.swiglu_bwd(ops.gemm_nt(dy, w3t), h12))
+    dh12, db12 = ops.gemm_nt_swiglu_bwd(dy, w3t, h12, with_bias=True)          # epilogue-side bias gradient of w12
+    assert rel_err(db12.cpu(), dh12.float().sum(0).cpu()) < 1e-5
     # f32 path: unfused kernels behind the same entry points
     a32, w32 = dev(rnd(64, D, seed=1)), dev(rnd(2 * Hs, D, seed=2, scale=D ** -0.5))
     h32, hid32 = ops.gemm_nt_swiglu(a32, w32, b12)
