@@ -87,9 +87,10 @@ int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const float* x, cons
 int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq, const float* wk, const float* cos, const float* sin,
                           void* q, void* k, void* v, int B, int N, int H, int hd, float eps, void* stream);
 long ldmae_qknorm_rope_bwd_workspace_bytes(int B, int N, int H, int hd);
+/* dbias_hqd (optional, [H][3][hd] f32): column sums of dqkv as stored = bias gradient of the qkv Linear, in (head, q|k|v, d) order */
 int ldmae_qknorm_rope_bwd(int dtype, const void* dq, const void* dk, const void* dv, const void* qkv, const float* wq,
                           const float* wk, const float* cos, const float* sin, void* dqkv, float* dwq, float* dwk, float beta_w,
-                          int B, int N, int H, int hd, float eps, float* workspace, void* stream);
+                          float* dbias_hqd, int B, int N, int H, int hd, float eps, float* workspace, void* stream);
 
 /* ---- attention core (F.scaled_dot_product_attention, lightningdit.py:76-80; manual softmax attention
  *      models_mae.py:135-141).  q,k,v [B,H,N,hd]; o [B,N,H*hd]; lse [B,H,N] f32 (natural log). */

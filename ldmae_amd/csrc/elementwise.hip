@@ -281,7 +281,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
                                                               const T* __restrict__ qkv, const float* __restrict__ wq,
                                                               const float* __restrict__ wk, const float* __restrict__ cosT,
                                                               const float* __restrict__ sinT, T* __restrict__ dqkv, float* __restrict__ P,
-                                                              int B, int N, int H, int hd, float eps) {
+                                                              float* __restrict__ Pb, int B, int N, int H, int hd, float eps) {
+  // Pb (optional): bias gradient of the qkv Linear = column sums of dqkv AS STORED.  The host makes the group stride a multiple of
+  // H, so a lane group keeps one head for all its items and its lanes own fixed columns: three float4 running sums per lane,
+  // written as row `gid` of Pb[groups][3*hd] (q | k | v of head gid % H); the host sums the rows of each head.
   __shared__ float4 red[256][2];
   const int sub = threadIdx.x % LPR, c4 = sub * 4;
   const bool act = c4 < hd;
@@ -289,16 +292,19 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / LPR, gstride = (long)gridDim.x * 256 / LPR;
   const bool plain = wq == nullptr;
   const float4 wqv = (act && !plain) ? *(const float4*)(wq + c4) : f4(0.f), wkv = (act && !plain) ? *(const float4*)(wk + c4) : f4(0.f);
-  float4 awq = f4(0.f), awk = f4(0.f);
+  float4 awq = f4(0.f), awk = f4(0.f), bq = f4(0.f), bk = f4(0.f), bv = f4(0.f);
+  auto rnd = [](float4 v) { return make_float4(to_f<T>(from_f<T>(v.x)), to_f<T>(from_f<T>(v.y)), to_f<T>(from_f<T>(v.z)), to_f<T>(from_f<T>(v.w))); };
   for (long it = gid; it < items; it += gstride) {
     const int h = it % H, n = (it / H) % N, b = it / ((long)H * N);
     const size_t so = ((size_t)(b * N + n) * 3 * H + h) * hd + c4;
     const size_t go = ((size_t)(b * H + h) * N + n) * hd + c4;
     if (plain) {
       if (act) {
-        store4<T>(dqkv + so, load4<T>(dq + go));
-        store4<T>(dqkv + so + (size_t)H * hd, load4<T>(dk + go));
-        store4<T>(dqkv + so + (size_t)2 * H * hd, load4<T>(dv + go));
+        const float4 a = load4<T>(dq + go), bb = load4<T>(dk + go), c = load4<T>(dv + go);
+        store4<T>(dqkv + so, a);
+        store4<T>(dqkv + so + (size_t)H * hd, bb);
+        store4<T>(dqkv + so + (size_t)2 * H * hd, c);
+        if (Pb) { bq = bq + a; bk = bk + bb; bv = bv + c; }
       }
       continue;
     }
@@ -316,10 +322,16 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
     const float4 dnq = tq * wqv, dnk = tk * wkv;
     const float mq = group_sum<LPR>(hsum(dnq * nq)) / (float)hd, mk = group_sum<LPR>(hsum(dnk * nk)) / (float)hd;
     if (act) {
-      store4<T>(dqkv + so, (dnq - nq * mq) * rq);
-      store4<T>(dqkv + so + (size_t)H * hd, (dnk - nk * mk) * rk);
+      const float4 oq = (dnq - nq * mq) * rq, ok = (dnk - nk * mk) * rk;
+      store4<T>(dqkv + so, oq);
+      store4<T>(dqkv + so + (size_t)H * hd, ok);
       store4<T>(dqkv + so + (size_t)2 * H * hd, gv);
+      if (Pb) { bq = bq + rnd(oq); bk = bk + rnd(ok); bv = bv + gv; }
     }
+  }
+  if (Pb && act) {
+    float* row = Pb + (size_t)gid * 3 * hd + c4;
+    *(float4*)row = bq; *(float4*)(row + hd) = bk; *(float4*)(row + 2 * hd) = bv;
   }
   if (plain) return;
   red[threadIdx.x][0] = awq; red[threadIdx.x][1] = awk;
@@ -352,30 +364,50 @@ extern "C" int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq
   return LDMAE_OK;
 }
 
+// backward grid: like qk_grid, rounded down so that the lane-group stride (grid * 256 / lpr) is a multiple of H -- every lane group
+// then serves ONE head (needed for the fused bias-gradient sums)
+static unsigned qk_bwd_grid(long items, int lpr, int H) {
+  unsigned g = qk_grid(items, lpr);
+  const int gpw = 256 / lpr;
+  int a = H, bb = gpw;
+  while (bb) { const int t = a % bb; a = bb; bb = t; }       // gcd(H, groups per workgroup)
+  const unsigned m = (unsigned)(H / a);
+  return g >= m ? g / m * m : m;
+}
+extern "C" long ldmae_colsum_workspace_bytes(int M, int N);
+extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, float beta, float* workspace, void* stream);
 extern "C" long ldmae_qknorm_rope_bwd_workspace_bytes(int B, int N, int H, int hd) {
   const int lpr = hd <= 64 ? 16 : 32;
-  return (long)qk_grid((long)B * N * H, lpr) * 2 * hd * 4;
+  const long grid = qk_bwd_grid((long)B * N * H, lpr, H), groups = grid * (256 / lpr);
+  // dwq/dwk partials + bias partial rows [groups][3*hd] + their column-sum scratch
+  return grid * 2 * hd * 4 + groups * 3 * hd * 4 + ldmae_colsum_workspace_bytes((int)(groups / H), 3 * H * hd);
 }
 
 extern "C" int ldmae_qknorm_rope_bwd(int dtype, const void* dq, const void* dk, const void* dv, const void* qkv, const float* wq,
                                      const float* wk, const float* cos, const float* sin, void* dqkv, float* dwq, float* dwk, float beta_w,
-                                     int B, int N, int H, int hd, float eps, float* workspace, void* stream) {
+                                     float* dbias_hqd, int B, int N, int H, int hd, float eps, float* workspace, void* stream) {
   LDMAE_REQUIRE(dq && dk && dv && dqkv, "qknorm_rope_bwd: null pointer");
   LDMAE_REQUIRE((qkv && wq && wk && cos && sin && dwq && dwk && workspace) || (!wq && !wk), "qknorm_rope_bwd: pass all norm/rope arguments, or none of wq/wk (plain relayout)");
+  LDMAE_REQUIRE(!dbias_hqd || workspace, "qknorm_rope_bwd: dbias requested without workspace");
   LDMAE_REQUIRE(hd % 8 == 0 && hd <= 128 && B > 0 && N > 0 && H > 0, "qknorm_rope_bwd: head_dim=%d must be a multiple of 8 and <= 128", hd);
   hipStream_t st = as_stream(stream);
   const long items = (long)B * N * H;
   const int lpr = hd <= 64 ? 16 : 32;
-  const unsigned grid = qk_grid(items, lpr);
-#define QK_BWD(LPR, T) hipLaunchKernelGGL((qknorm_rope_bwd_kernel<LPR, T>), dim3(grid), dim3(256), 0, st, (const T*)dq, (const T*)dk, (const T*)dv, (const T*)qkv, wq, wk, cos, sin, (T*)dqkv, workspace, B, N, H, hd, eps)
+  const unsigned grid = qk_bwd_grid(items, lpr, H);
+  const long groups = (long)grid * (256 / lpr);
+  float* Pb = dbias_hqd ? workspace + (size_t)grid * 2 * hd : nullptr;
+#define QK_BWD(LPR, T) hipLaunchKernelGGL((qknorm_rope_bwd_kernel<LPR, T>), dim3(grid), dim3(256), 0, st, (const T*)dq, (const T*)dk, (const T*)dv, (const T*)qkv, wq, wk, cos, sin, (T*)dqkv, workspace, Pb, B, N, H, hd, eps)
   if (hd <= 64) { if (dtype == LDMAE_BF16) QK_BWD(16, bf16); else QK_BWD(16, float); }
   else { if (dtype == LDMAE_BF16) QK_BWD(32, bf16); else QK_BWD(32, float); }
 #undef QK_BWD
   LDMAE_CHECK_LAUNCH("qknorm_rope_bwd");
-  if (!wq) return LDMAE_OK;
-  group_reduce(workspace, 2 * hd, 1, hd, grid, dwq, hd, beta_w, st);
-  group_reduce(workspace + hd, 2 * hd, 1, hd, grid, dwk, hd, beta_w, st);
-  LDMAE_CHECK_LAUNCH("qknorm_rope_bwd reduce");
+  if (wq) {
+    group_reduce(workspace, 2 * hd, 1, hd, grid, dwq, hd, beta_w, st);
+    group_reduce(workspace + hd, 2 * hd, 1, hd, grid, dwk, hd, beta_w, st);
+    LDMAE_CHECK_LAUNCH("qknorm_rope_bwd reduce");
+  }
+  // rows g of Pb belong to head g % H: as a [groups/H][H*3*hd] matrix its column sums are the bias gradient in (head, q|k|v, d) order
+  if (dbias_hqd) return ldmae_colsum(LDMAE_F32, Pb, 3 * H * hd, (int)(groups / H), 3 * H * hd, dbias_hqd, 0.f, Pb + (size_t)groups * 3 * hd, stream);
   return LDMAE_OK;
 }
 

@@ -175,9 +175,9 @@ class _DiTBlockFn(torch.autograd.Function):
         dWp = ops.gemm_tn(dy1, o.view(M, D))
         do = ops.gemm_nt(dy1, WpT)
         dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
-        dqkv, dqn, dkn = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
+        dqkv, dqn, dkn, dbqkv = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, B, N, H, hd, eps, with_bias=True)
         dqkv = dqkv.view(M, 3 * D)
-        dWqkv, dbqkv = ops.gemm_tn(dqkv, xm1, with_bias=True)
+        dWqkv = ops.gemm_tn(dqkv, xm1)
         dxm1 = ops.gemm_nt(dqkv, WqkvT)
         dn1 = ops.rmsnorm_modulate_bwd(dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N)
         # ---- adaLN (f32 in both modes)

@@ -180,13 +180,18 @@ def qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6):
     return q, k, v
 
 
-def qknorm_rope_bwd(dq, dk, dv, qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6):
+def qknorm_rope_bwd(dq, dk, dv, qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6, with_bias=False):
+    """Backward of qknorm_rope_fwd: (dqkv [B,N,3,H,hd], dwq, dwk[, dbias [3*H*hd]]).  with_bias: the bias gradient of the qkv Linear
+    (column sums of dqkv as stored), formed in the same pass."""
     dqkv = torch.empty_like(qkv)
     dwq = torch.empty(hd, dtype=torch.float32, device=qkv.device)
     dwk = torch.empty_like(dwq)
+    db = torch.empty(H, 3, hd, dtype=torch.float32, device=qkv.device) if with_bias else None
     ws = workspace(L.load().ldmae_qknorm_rope_bwd_workspace_bytes(B, N, H, hd), qkv.device)
     call("ldmae_qknorm_rope_bwd", dt(qkv.dtype), ptr(dq), ptr(dk), ptr(dv), ptr(qkv), ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(dqkv),
-         ptr(dwq), ptr(dwk), 0.0, B, N, H, hd, eps, ptr(ws), stream())
+         ptr(dwq), ptr(dwk), 0.0, ptr(db), B, N, H, hd, eps, ptr(ws), stream())
+    if with_bias:
+        return dqkv, dwq, dwk, db.permute(1, 0, 2).reshape(-1)          # (head, q|k|v, d) -> the Linear's (q|k|v, head, d) order
     return dqkv, dwq, dwk
 
 
@@ -330,7 +335,7 @@ def heads_merge(dq, dk, dv, B, N, H, hd):
     """inverse of heads_split for the gradients: -> [B*N, 3*H*hd]."""
     dqkv = torch.empty(B * N, 3 * H * hd, dtype=dq.dtype, device=dq.device)
     call("ldmae_qknorm_rope_bwd", dt(dq.dtype), ptr(dq), ptr(dk), ptr(dv), None, None, None, None, None, ptr(dqkv), None, None, 0.0,
-         B, N, H, hd, 0.0, None, stream())
+         None, B, N, H, hd, 0.0, None, stream())
     return dqkv
 
 

@@ -155,6 +155,10 @@ def test_qknorm_rope(ops, dtype, hd, H):
                                          dev(wk.detach()), dev(cos), dev(sin), B, N, H, hd)
     assert rel_err(dqkv.float().cpu(), qkv.grad) < tol
     assert rel_err(dwq.cpu(), wq.grad) < 1e-4 and rel_err(dwk.cpu(), wk.grad) < 1e-4
+    dqkv2, _, _, db = ops.qknorm_rope_bwd(dev(gq_, dtype), dev(gk_, dtype), dev(gv_, dtype), dev(qkv.detach(), dtype), dev(wq.detach()),
+                                          dev(wk.detach()), dev(cos), dev(sin), B, N, H, hd, with_bias=True)     # fused qkv bias gradient
+    assert torch.equal(dqkv2, dqkv)
+    assert rel_err(db.cpu(), dqkv.float().cpu().reshape(B * N, 3 * H * hd).sum(0)) < 1e-5
 
 
 def _attn_ref(qq, kk, vv, scale):
