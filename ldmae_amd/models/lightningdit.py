@@ -163,26 +163,28 @@ class _DiTBlockFn(torch.autograd.Function):
         dx = gout.view(M, D) if gout.is_contiguous() else gout.contiguous().view(M, D)
         dmod = torch.empty_like(mod)
         s1, g1, s2, g2 = mod[:, D:2 * D], mod[:, 2 * D:3 * D], mod[:, 4 * D:5 * D], mod[:, 5 * D:6 * D]
+        sg = ops.SideGemms(dx.device, enabled=dtype == torch.bfloat16)      # weight gradients: off the critical path
         # ---- MLP branch
         dy2, db3 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype, with_bias=True)   # bias grads where dy is produced
-        dW3 = ops.gemm_tn(dy2, hid)
+        dW3 = sg.tn(dy2, hid)
         dh12, db12 = ops.gemm_nt_swiglu_bwd(dy2, W3T, h12, with_bias=True)
-        dW12 = ops.gemm_tn(dh12, xm2)
+        dW12 = sg.tn(dh12, xm2)
         dxm2 = ops.gemm_nt(dh12, W12T)
         dn2 = ops.rmsnorm_modulate_bwd(dxm2, xmid, n2w, s2, rstd2, dx, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D], N)
         # ---- attention branch
         dy1, dbp = ops.gate_bwd(dx, y1, g1, dmod[:, 2 * D:3 * D], N, dtype, with_bias=True)
-        dWp = ops.gemm_tn(dy1, o.view(M, D))
+        dWp = sg.tn(dy1, o.view(M, D))
         do = ops.gemm_nt(dy1, WpT)
         dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
         dqkv, dqn, dkn, dbqkv = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, B, N, H, hd, eps, with_bias=True)
         dqkv = dqkv.view(M, 3 * D)
-        dWqkv = ops.gemm_tn(dqkv, xm1)
+        dWqkv = sg.tn(dqkv, xm1)
         dxm1 = ops.gemm_nt(dqkv, WqkvT)
         dn1 = ops.rmsnorm_modulate_bwd(dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N)
         # ---- adaLN (f32 in both modes)
         dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
         dsc = ops.gemm_nt(dmod, ops.cast_weight(adaw, torch.float32, True, False)[1])
+        sg.join()
         return (dx.view(B, N, D), dsc, None, None, None, None, None,
                 dn1, dWqkv, dbqkv, dqn, dkn, dWp, dbp, dn2, dW12, db12, dW3, db3, dadaw, dadab)
 
