@@ -7,7 +7,7 @@ from ldmae_amd import _lib, ops
 kind, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 v = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 M = 262144
-_lib.load().ldmae_tune(6 if kind == "nt" else 4, v)
+_lib.load().ldmae_tune(8 if kind == "nt" else 4, v)      # nt: 2 = one tile per workgroup; tn: 3 / 4 = 16-wave variants
 g = torch.Generator(device="cuda").manual_seed(0)
 if kind == "nt":
     a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)

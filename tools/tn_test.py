@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""bf16 TN (weight-gradient) GEMM variants on the LightningDiT-B/1 bs=256 shapes, with and without the fused bias gradient."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ldmae_amd import _lib, ops
