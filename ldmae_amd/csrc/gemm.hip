@@ -469,13 +469,13 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
     for (int kt = 0; kt < nk; ++kt) {
       tstamp(kt, 0);
       const bool more = kt + STAGES - 1 < nk;
-      if (more) issue(kt + STAGES - 1);
       const char* st = smem + (kt % STAGES) * STAGE_BYTES;
       bf16x8 af[MI], bfr[NI];
 #pragma unroll
       for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
 #pragma unroll
       for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+      if (more) issue(kt + STAGES - 1);      // after the fragment reads: their LDS latency runs under the DMA issue (+0.5 %)
       if constexpr (TL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       tstamp(kt, 1);
       if (grpB) wait_next(kt, false);
