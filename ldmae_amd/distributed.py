@@ -11,6 +11,8 @@ step) rather than DDP's 25 MiB.  Works unchanged on CPU tensors with the gloo ba
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -46,6 +48,12 @@ class GradBucketReducer:
         if self.world > 1:
             for n, p in flat.trainable:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(n)))
+            if self.is_cuda and os.environ.get("LDMAE_TUNE") is None:
+                # RCCL's collective kernels hold some CUs while the all-reduce of a bucket overlaps backward.  A persistent GEMM
+                # (exactly one workgroup per CU for the whole launch) would then run its displaced workgroups as a second round;
+                # one-tile-per-workgroup launches (1 % slower alone) refill whatever CUs are free at tile granularity.
+                from . import _lib
+                _lib.load().ldmae_tune(8, 2)
 
     def _make_hook(self, name):
         def hook(_p):
