@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64 * TW * TW) void gemm_nt_f32_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16 TN GEMM (weight gradient): P[s][N,K] = sum over rows m in split s of A[m,n] * B[m,k].
+// bf16 TN GEMM (weight gradient), fallback form for ragged M: P[s][N,K] = sum over rows m in split s of A[m,n] * B[m,k].
 // 128(n) x 128(k) output tile, 256 threads (2x2 waves, 64x64 per wave), 64 rows of M per step.
 // LDS image per operand: [64 m][128 cols] bf16, 256-B rows, 16-B chunk ch of row r stored at
 // ch ^ sw(r), sw(r) = ((r&3)<<2) | ((r>>2)&3)  -> conflict-free ds_read_b64_tr_b16 (guide T10 (b)).
@@ -694,8 +694,9 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// bf16 TN GEMM, ring-pipelined: 256(n) x 256(k) output tile, 8 waves (2 x 4, 128 x 64 per wave), 32 token rows per
-// step, STAGES LDS buffers in flight across the per-step barrier (same protocol as gemm_nt_ring_kernel).
+// bf16 TN GEMM, ring-pipelined (the product kernel; the 128x128 one above is the fallback for M % 32 != 0): 256(n) x 256(k)
+// output tile, WNn x 4 waves (default 2 x 4: 128 x 64 per wave), 32 token rows per step, STAGES LDS buffers in flight across the
+// barriers (same protocol as gemm_nt_persist_kernel; STAG = the two wave groups run half a step apart).
 // Stage image: A rows then B rows, [32 m][256 cols] bf16 = 512-B rows; 16-B chunk ch of row r sits at
 // ch ^ sw(r), sw(r) = ((r&3)<<1) | (((r>>3)&1)<<3): the 32 lanes of a ds_read_b64_tr_b16 half hit 32 distinct
 // 8-B bank pairs.  Optional fused bias gradient: waves of the k-tile-0 column also run one MFMA per A fragment
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restric
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tnr_sw(int r) { return ((r & 3) << 1) | (((r >> 3) & 1) << 3); }
 
-template <int STAGES, int DBG = 0, int WNn = 2, bool STAG = false>
+template <int STAGES, int WNn = 2, bool STAG = false>
 __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, float* __restrict__ P,
                                                            float* __restrict__ Pb, int M, int N, int K, int lda, int ldb,
                                                            int rows_per_split) {
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nsteps) issue(s);
   if constexpr (STAG) {
-    // two wave groups half a step apart (see gemm_nt_ring_kernel, DBG == 5 path): loads + transposed fragment reads of one group
+    // two wave groups half a step apart (as in gemm_nt_persist_kernel): loads + transposed fragment reads of one group
     // run beside the MFMAs of the other on every SIMD
     const bool grpB = wn >= WNn / 2;
     auto wait_next = [&](int st) {
@@ -811,7 +812,7 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (DBG != 2) { if (st + STAGES - 1 < nsteps) issue(st + STAGES - 1); }
+    if (st + STAGES - 1 < nsteps) issue(st + STAGES - 1);
     const char* ta = smem + (st % STAGES) * STAGE_BYTES;
     const char* tb = ta + OP_BYTES;
     bf16x8 af[MI], bfr[NI];
@@ -819,13 +820,6 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
     for (int j = 0; j < NI; ++j) bfr[j] = frag(tb, wk * 64 + j * 16);
 #pragma unroll
     for (int i = 0; i < MI; ++i) af[i] = frag(ta, wn * (MI * 16) + i * 16);
-    if constexpr (DBG == 1) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
-#pragma unroll
-      for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
-      continue;
-    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -1109,9 +1103,9 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
     constexpr int lds = 5 * 32768;   // ring (4 x 32 KiB) and the 139 KiB epilogue region share it
     static bool attr_done = false;
     if (!attr_done) {
-      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 0, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_done = true;
     }
     const unsigned grid = cdiv(N, 256) * cdiv(K, 256) * splits;
@@ -1120,11 +1114,11 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
     // The bias-gradient MFMAs stay on the wk == 0 waves: spreading them over all waves (a wave-uniform switch on wk, or one
     // slot per K-tile workgroup) measured 8-15 % SLOWER -- every wave's MFMA phase is on the staggered loop's critical path.
     if (ldmae_tune_get(4) == 3)
-      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 4, false>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 4, false>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
     else if (ldmae_tune_get(4) == 4)
-      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 4, true>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 4, true>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
     else
-      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 0, 2, true>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 2, true>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
   } else if (dtype == LDMAE_BF16) {
     const unsigned grid = cdiv(N, TN_BN) * cdiv(K, TN_BK) * splits;
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 4 * TN_TILE_BYTES, st, (const bf16*)A, (const bf16*)B, P, M, N, K, lda, ldb, rows);
