@@ -136,8 +136,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
       for (int r = 0; r < 4; ++r) ew[((lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[i][cblk * 4 + j][r];
   };
   if constexpr (EPI == LDMAE_EPI_SWIGLU) {
-    // strip cols 0..31 = x1 (hid columns hc..), 32..63 = x2.  Values are rounded to bf16 BEFORE silu so the result is
-    // bit-identical to the unfused ldmae_swiglu_fwd on the stored h12.
+    // strip cols 0..31 = x1 (hid columns hc..), 32..63 = x2.  Values are rounded to bf16 BEFORE silu so the result
+    // matches the unfused ldmae_swiglu_fwd on the stored h12 (same formula; last-bit FMA-contraction differences are possible).
     static_assert(EPI != LDMAE_EPI_SWIGLU || TNn == 64, "swiglu epilogue needs 64-column wave slices");
     const int Hs = N >> 1, hc = (n0 >> 1) + wn * 32 + (lane & 7) * 4;
     bf16* h12 = (bf16*)e.C;

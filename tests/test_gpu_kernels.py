@@ -80,6 +80,43 @@ def test_gemm_nt_gate_res_pos_gelu(ops, dtype):
     assert rel_err(g.float().cpu(), torch.nn.functional.gelu(y)) < TOL[dtype]
 
 
+def test_gemm_nt_persistent_multi_tile_ragged(ops):
+    """More 256x256 tiles than CUs with ragged edges: every persistent workgroup walks several tiles (next-tile prefetch before
+    the epilogue, XCD-owned row-block ranges with an uneven tail).  Checked against an f32 torch product of the same bf16 data;
+    plain-bias, gated-residual, SwiGLU and SwiGLU-bwd epilogues, and the one-tile-per-workgroup launch mode."""
+    from ldmae_amd import _lib
+    M, N, K, T = 256 * 41 + 100, 2304 + 64, 192, 4
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a = torch.randn(M, K, device="cuda", generator=g).to(BF16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(BF16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    ref = a.float() @ w.float().T + bias
+    for mode in (0, 2):
+        _lib.load().ldmae_tune(8, mode)
+        out = ops.gemm_nt(a, w, bias)
+        assert rel_err(out.float().cpu(), ref.cpu()) < TOL[BF16]
+        assert torch.equal(out[-1].float(), ops.gemm_nt(a[-1:].contiguous().expand(8, K).contiguous(), w, bias)[0].float())
+        xin = torch.randn(M, N, device="cuda", generator=g)
+        gate = torch.randn(M // T, N, device="cuda", generator=g)
+        xo, y = ops.gemm_nt_gate_res(a, w, bias, xin, gate, T)
+        assert torch.equal(y, out)
+        assert rel_err(xo.cpu(), (xin + gate.repeat_interleave(T, 0) * ref).cpu()) < 1e-5      # residual uses the unrounded f32 product
+    _lib.load().ldmae_tune(8, 0)
+    Hs = 1280                                        # N = 2560 = 10 tile columns, 420 tiles
+    w12 = (torch.randn(2 * Hs, K, device="cuda", generator=g) * K ** -0.5).to(BF16)
+    b12 = torch.randn(2 * Hs, device="cuda", generator=g)
+    h12, hid = ops.gemm_nt_swiglu(a, w12, b12)
+    h12_ref = ops.gemm_nt(a, w12, b12)
+    assert torch.equal(h12, h12_ref) and torch.equal(hid, ops.swiglu_fwd(h12_ref))
+    w3t = (torch.randn(Hs, K, device="cuda", generator=g) * K ** -0.5).to(BF16)
+    dh12, db12 = ops.gemm_nt_swiglu_bwd(a, w3t, h12, with_bias=True)
+    unf = ops.swiglu_bwd(ops.gemm_nt(a, w3t), h12)
+    # same formula in both kernels; the compiler may contract an FMA differently: at most a last-bit difference in a few of 27 M values
+    nbad = int((dh12 != unf).sum())
+    assert nbad <= 1e-6 * dh12.numel() and rel_err(dh12.float().cpu(), unf.float().cpu()) < 1e-6, nbad
+    assert rel_err(db12.cpu(), dh12.float().sum(0).cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("M,N,K", [(128, 384, 192), (4096, 16, 768), (8192, 576, 192), (256, 1152, 200), (16384, 768, 2048), (32768, 2304, 768)])
 def test_gemm_tn(ops, dtype, M, N, K):
