@@ -6,16 +6,16 @@
 
 // ------------------------------------------------------------------ small vector helpers
 template <typename T> __device__ __forceinline__ float4 load4(const T* p);
-template <> __device__ __forceinline__ float4 load4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ __forceinline__ float4 load4<float>(const float* p) { const f32x4 v = __builtin_nontemporal_load((const f32x4*)p); return make_float4(v[0], v[1], v[2], v[3]); }
 template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* p) {
-  bf16x4 v = *(const bf16x4*)p;
+  bf16x4 v = __builtin_nontemporal_load((const bf16x4*)p);
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 template <typename T> __device__ __forceinline__ void store4(T* p, float4 v);
-template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) { *(float4*)p = v; }
+template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) { f32x4 o = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(o, (f32x4*)p); }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, float4 v) {
   bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
-  *(bf16x4*)p = o;
+  __builtin_nontemporal_store(o, (bf16x4*)p);
 }
 __device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
