@@ -225,8 +225,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
               ub.x += (float)db[0]; ub.y += (float)db[1]; ub.z += (float)db[2]; ub.w += (float)db[3];
               *(float4*)exq = ua; *(float4*)(exq + 64) = ub;
             }
-            *(bf16x4*)(dh12 + (size_t)m * 2 * Hs + n) = da;
-            *(bf16x4*)(dh12 + (size_t)m * 2 * Hs + Hs + n) = db;
+            __builtin_nontemporal_store(da, (bf16x4*)(dh12 + (size_t)m * 2 * Hs + n));
+            __builtin_nontemporal_store(db, (bf16x4*)(dh12 + (size_t)m * 2 * Hs + Hs + n));
           }
         }
       };
@@ -254,7 +254,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
     else {
       bf16x8 o;
       o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w; o[4] = (bf16)b.x; o[5] = (bf16)b.y; o[6] = (bf16)b.z; o[7] = (bf16)b.w;
-      *(bf16x8*)((bf16*)base + oc) = o;
+      __builtin_nontemporal_store(o, (bf16x8*)((bf16*)base + oc));      // streamed output: keeps the B tiles in L2 (+0.5..2 %)
     }
   };
 #pragma unroll
