@@ -85,6 +85,31 @@ template <int I> struct IC { static constexpr int value = I; };
 constexpr float RESCALE_THR = 6.0f;
 
 // ================================================================================================ forward, bf16
+// Epilogue store of a wave's [32 rows][HD] result held as (result)^T accumulators (lane = row r + 32 h; element t of block d is
+// column d*32 + 8*(t/4) + 4h + t%4).  Per-lane stores would put 8 B into 32 different rows per instruction (the store tail of a
+// workgroup then costs ~9k cycles, MI355X_MICROARCH 'attention epilogue store tail'); instead the tile goes through a wave-private
+// LDS image (144-B row pitch) and leaves as whole 128-B rows, 16 B per lane, 8 rows per instruction.  `mul` is per lane (= per row).
+template <int HD>
+__device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[HD / 32], float mul, char* lds_wave, bf16* gbase, long gstride, int lane) {
+  constexpr int PITCH = HD * 2 + 16, CPR = HD / 8;            // bytes per LDS row; 16-B chunks per row
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      bf16x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (bf16)(acc[d][4 * t4 + j] * mul);
+      *(bf16x4*)(lds_wave + r * PITCH + (d * 32 + 8 * t4 + 4 * h) * 2) = w;
+    }
+#pragma unroll
+  for (int it = 0; it < 32 * CPR / 64; ++it) {
+    const int idx = it * 64 + lane, row = idx / CPR, ch = idx % CPR;
+    const bf16x8 v = *(const bf16x8*)(lds_wave + row * PITCH + ch * 16);
+    *(bf16x8*)(gbase + (long)row * gstride + ch * 8) = v;
+  }
+}
+
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                             bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c) {
@@ -170,19 +195,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     if (kt + 2 < nt) body(IC<2>{}, kt + 2);
   }
   l += __shfl_xor(l, 32, 64);
+  __syncthreads();                                   // every wave is past its last K/V read: the ring becomes store scratch
   if (!active) return;
   const float inv = 1.f / l;
   const int b = bh / H, hh = bh % H;
-  bf16* op = O + ((size_t)(b * N + q0 + r) * H + hh) * HD;
-#pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-      bf16x4 w;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = (bf16)(oacc[d][4 * t4 + j] * inv);
-      *(bf16x4*)(op + d * 32 + 8 * t4 + 4 * h) = w;
-    }
+  store_rows_t<HD>(oacc, inv, smem + wave * 32 * (HD * 2 + 16), O + ((size_t)(b * N + q0) * H + hh) * HD, (long)H * HD, lane);
   if (h == 0) LSE[(size_t)bh * N + q0 + r] = (ms + log2f(l)) * 0.6931471805599453f;
 }
 
@@ -299,19 +316,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
     if (qt + 1 < nt) body(IC<1>{}, qt + 1);
     if (qt + 2 < nt) body(IC<2>{}, qt + 2);
   }
+  __syncthreads();                                   // ring -> store scratch
   if (!active) return;
-  bf16* dkp = dK + ((size_t)bh * N + k0 + r) * HD;
-  bf16* dvp = dV + ((size_t)bh * N + k0 + r) * HD;
-#pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-      bf16x4 wk, wv;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { wk[j] = (bf16)(dkacc[d][4 * t4 + j] * scale); wv[j] = (bf16)dvacc[d][4 * t4 + j]; }
-      *(bf16x4*)(dkp + d * 32 + 8 * t4 + 4 * h) = wk;
-      *(bf16x4*)(dvp + d * 32 + 8 * t4 + 4 * h) = wv;
-    }
+  char* sw = smem + wave * 32 * (HD * 2 + 16);
+  store_rows_t<HD>(dkacc, scale, sw, dK + ((size_t)bh * N + k0) * HD, HD, lane);
+  store_rows_t<HD>(dvacc, 1.f, sw, dV + ((size_t)bh * N + k0) * HD, HD, lane);       // same wave, same scratch: LDS ops stay in order
 }
 
 // ================================================================================================ backward dQ, bf16
@@ -399,17 +408,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
     if (kt + 1 < nt) body(IC<1>{}, kt + 1);
     if (kt + 2 < nt) body(IC<2>{}, kt + 2);
   }
+  __syncthreads();                                   // ring -> store scratch
   if (!active) return;
-  bf16* dqp = dQ + ((size_t)bh * N + q0 + r) * HD;
-#pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-      bf16x4 w;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = (bf16)(dqacc[d][4 * t4 + j] * scale);
-      *(bf16x4*)(dqp + d * 32 + 8 * t4 + 4 * h) = w;
-    }
+  store_rows_t<HD>(dqacc, scale, smem + wave * 32 * (HD * 2 + 16), dQ + ((size_t)bh * N + q0) * HD, HD, lane);
 }
 
 // ================================================================================================ f32 path (parity)
