@@ -16,11 +16,11 @@ for N, K in [(2304, 768), (768, 768), (4096, 768), (768, 2048)]:
     a = torch.randn(M, N, device='cuda', generator=g).to(torch.bfloat16)
     b = torch.randn(M, K, device='cuda', generator=g).to(torch.bfloat16)
     ref = a[:, :64].float().T @ b[:, :64].float()
-    for st, name in [(0, '8w-stag'), (3, '16w'), (4, '16w-stag')]:
-        lib.ldmae_tune(4, st)
+    for st, name in [(0, 'target256'), (512, 'target512'), (192, 'target192'), (128, 'target128')]:
+        lib.ldmae_tune(9, st)
         out, db = ops.gemm_tn(a, b, with_bias=True)
         err = float((out[:64, :64] - ref).norm() / ref.norm())
         t = min(timed(lambda: ops.gemm_tn(a, b, with_bias=True)) for _ in range(3))
         t0 = min(timed(lambda: ops.gemm_tn(a, b, with_bias=False)) for _ in range(3))
         print(f"TN N={N} K={K} {name:9s}: with bias {t:.3f} ms {2.0 * M * N * K / t / 1e9:.0f} TF/s | no bias {t0:.3f} ms {2.0 * M * N * K / t0 / 1e9:.0f} TF/s err={err:.1e}")
-lib.ldmae_tune(4, 0)
+lib.ldmae_tune(9, 0)
