@@ -471,6 +471,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
       const bool more = kt + STAGES - 1 < nk;
       const char* st = smem + (kt % STAGES) * STAGE_BYTES;
       bf16x8 af[MI], bfr[NI];
+      __builtin_amdgcn_s_setprio(1);      // load phase at raised priority
 #pragma unroll
       for (int j = 0; j < NI; ++j) bfr[j] = *(const bf16x8*)(st + b_off + j * 1024);
 #pragma unroll
@@ -478,15 +479,14 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
       if (more) issue(kt + STAGES - 1);      // after the fragment reads: their LDS latency runs under the DMA issue (+0.5 %)
       if constexpr (TL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       tstamp(kt, 1);
+      __builtin_amdgcn_s_setprio(0);
       if (grpB) wait_next(kt, false);
       __builtin_amdgcn_s_barrier();
       tstamp(kt, 2);
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
       tstamp(kt, 3);
       if (!grpB) wait_next(kt, true);
       __builtin_amdgcn_s_barrier();
@@ -790,7 +790,6 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
       for (int i = 0; i < MI; ++i) af[i] = frag(ta, wn * (MI * 16) + i * 16);
       if (grpB) wait_next(st);
       __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -799,7 +798,6 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
 #pragma unroll
         for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
       }
-      __builtin_amdgcn_s_setprio(0);
       if (!grpB) wait_next(st);
       __builtin_amdgcn_s_barrier();
     }
