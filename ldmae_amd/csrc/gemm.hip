@@ -11,344 +11,7 @@
 // for the fp32 parity contract (1e-4 vs the CPU oracle); bf16 is the throughput path.
 #include "common.h"
 
-// ------------------------------------------------------------------------------------------------
-// Epilogue shared by all NT kernels.  Accumulator tile layout (16x16 MFMA C/D map):
-//   col = lane & 15 ; row = (lane >> 4) * 4 + reg
-// ------------------------------------------------------------------------------------------------
-struct EpiArgs {
-  void* C;              // output [M,N] (dtype out_dt)      -- EPI_BIAS: result; EPI_GATE_RES: y (may be null)
-  void* C2;             // EPI_BIAS_GELU: pre-activation copy (may be null)
-  const float* bias;    // [N] or null
-  // EPI_GATE_RES: xout[m,n] = xin[m,n] + gate[m / rows_per_batch, n] * (acc + bias)
-  const float* xin;     // [M,N] f32
-  float* xout;          // [M,N] f32 (may alias xin)
-  const float* gate;    // [B, gate_ld] f32 (a column slice of the adaLN output)
-  int gate_ld;
-  int rows_per_batch;
-  int ldc;              // row stride of C in elements
-  float beta;           // EPI_BIAS with f32 out: C = acc + bias + beta*C   (beta 0 or 1: gradient accumulation)
-};
-
-template <int EPI, typename OutT>
-__device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M, int N, float acc) {
-  if (m >= M || n >= N) return;
-  float y = acc + (e.bias ? e.bias[n] : 0.f);
-  if (EPI == LDMAE_EPI_BIAS) {
-    OutT* C = (OutT*)e.C;
-    if (e.beta != 0.f) y += e.beta * to_f<OutT>(C[(size_t)m * e.ldc + n]);
-    C[(size_t)m * e.ldc + n] = from_f<OutT>(y);
-  } else if (EPI == LDMAE_EPI_BIAS_POS) {
-    y += e.xin[(size_t)(m % e.rows_per_batch) * N + n];
-    ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
-  } else if (EPI == LDMAE_EPI_BIAS_GELU) {
-    if (e.C2) ((OutT*)e.C2)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
-    ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(0.5f * y * (1.f + erff(y * 0.70710678118654752f)));
-  } else {  // LDMAE_EPI_GATE_RES
-    if (e.C) ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
-    const size_t o = (size_t)m * N + n;
-    const float gt = e.gate ? e.gate[(size_t)(m / e.rows_per_batch) * e.gate_ld + n] : 1.f;
-    e.xout[o] = e.xin[o] + gt * y;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// bf16 NT GEMM building blocks.  256 x 256 output tile, 8 waves (2 x 4, 128 x 64 per wave = 8 x 4 MFMA
-// tiles), BK = 32, a 3-deep LDS ring filled by global_load_lds that stays in flight ACROSS the barriers
-// (raw s_barrier + counted vmcnt, never __syncthreads in the loop).
-// LDS stage image: [256 A rows + 256 B rows][32 k] bf16 = 64-B rows; 16-B chunk c of row r sits at position
-// c ^ F[(r >> 2) & 3], F = {0,2,3,1}: conflict-free for the ds_read_b128 lane groups of the 16x16x32 operands.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int ring_f(int g) { return (0x78 >> (2 * g)) & 3; }
-
-// Vector epilogue for a 64-row x 4-column strip: per-column constants (bias, gate) are loaded once, then
-// one 16-B access per row.  `fast` = the whole strip is in range and (for the gated form) inside one sample.
-template <int EPI, typename OutT> struct Epi4 {
-  const EpiArgs& e;
-  int n, N;
-  float4 bias, gate;
-  __device__ __forceinline__ Epi4(const EpiArgs& e_, int m_first, int n_, int N_) : e(e_), n(n_), N(N_) {
-    bias = e.bias ? *(const float4*)(e.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    gate = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (EPI == LDMAE_EPI_GATE_RES && e.gate) gate = *(const float4*)(e.gate + (size_t)(m_first / e.rows_per_batch) * e.gate_ld + n);
-  }
-  static __device__ __forceinline__ void put(void* base, size_t off, float4 v) {
-    OutT* p = (OutT*)base + off;
-    if constexpr (sizeof(OutT) == 4) *(float4*)p = v;
-    else { bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w; *(bf16x4*)p = o; }
-  }
-  // value destined for C (and C2 for GELU) without storing them; side outputs (xout) are stored here
-  __device__ __forceinline__ void compute(int m, float4 a, float4& c, float4& c2) const {
-    a.x += bias.x; a.y += bias.y; a.z += bias.z; a.w += bias.w;
-    c = a; c2 = a;
-    if (EPI == LDMAE_EPI_BIAS) {
-      if (e.beta != 0.f) {
-        const OutT* p = (const OutT*)e.C + (size_t)m * e.ldc + n;
-        c.x += e.beta * to_f<OutT>(p[0]); c.y += e.beta * to_f<OutT>(p[1]); c.z += e.beta * to_f<OutT>(p[2]); c.w += e.beta * to_f<OutT>(p[3]);
-      }
-    } else if (EPI == LDMAE_EPI_BIAS_POS) {
-      const float4 q = *(const float4*)(e.xin + (size_t)(m % e.rows_per_batch) * N + n);
-      c = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
-    } else if (EPI == LDMAE_EPI_BIAS_GELU) {
-      auto g = [](float y) { return 0.5f * y * (1.f + erff(y * 0.70710678118654752f)); };
-      c = make_float4(g(a.x), g(a.y), g(a.z), g(a.w));
-    } else if (EPI == LDMAE_EPI_GATE_RES) {
-      const size_t o = (size_t)m * N + n;
-      const float4 xi = *(const float4*)(e.xin + o);
-      *(float4*)(e.xout + o) = make_float4(xi.x + gate.x * a.x, xi.y + gate.y * a.y, xi.z + gate.z * a.z, xi.w + gate.w * a.w);
-    }
-  }
-  __device__ __forceinline__ void apply(int m, float4 a) const {
-    a.x += bias.x; a.y += bias.y; a.z += bias.z; a.w += bias.w;
-    const size_t oc = (size_t)m * e.ldc + n;
-    if (EPI == LDMAE_EPI_BIAS) {
-      if (e.beta != 0.f) {
-        const OutT* p = (const OutT*)e.C + oc;
-        a.x += e.beta * to_f<OutT>(p[0]); a.y += e.beta * to_f<OutT>(p[1]); a.z += e.beta * to_f<OutT>(p[2]); a.w += e.beta * to_f<OutT>(p[3]);
-      }
-      put(e.C, oc, a);
-    } else if (EPI == LDMAE_EPI_BIAS_POS) {
-      const float4 q = *(const float4*)(e.xin + (size_t)(m % e.rows_per_batch) * N + n);
-      put(e.C, oc, make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w));
-    } else if (EPI == LDMAE_EPI_BIAS_GELU) {
-      if (e.C2) put(e.C2, oc, a);
-      auto g = [](float y) { return 0.5f * y * (1.f + erff(y * 0.70710678118654752f)); };
-      put(e.C, oc, make_float4(g(a.x), g(a.y), g(a.z), g(a.w)));
-    } else {
-      if (e.C) put(e.C, oc, a);
-      const size_t o = (size_t)m * N + n;
-      const float4 xi = *(const float4*)(e.xin + o);
-      *(float4*)(e.xout + o) = make_float4(xi.x + gate.x * a.x, xi.y + gate.y * a.y, xi.z + gate.z * a.z, xi.w + gate.w * a.w);
-    }
-  }
-};
-
-// Epilogue shared by the NT kernels: accumulators -> per-wave f32 LDS strip [16 rows][68] (`ew`, private to the wave, so no
-// workgroup barrier is needed) -> row-contiguous 16-B global accesses with the fused bias / gated residual / pos / GELU /
-// SwiGLU forms.
-template <int EPI, typename OutT, int TM, int TNn, int MI, int NI>
-__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, float* ex, const EpiArgs& e, int m0, int n0, int wm, int wn,
-                                            int lane, int M, int N) {   // ew: strip [16][68]; ex: 512 more private floats
-  constexpr int ELD = 68;
-  auto fill = [&](int i, int cblk) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ew[((lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[i][cblk * 4 + j][r];
-  };
-  if constexpr (EPI == LDMAE_EPI_SWIGLU) {
-    // strip cols 0..31 = x1 (hid columns hc..), 32..63 = x2.  Values are rounded to bf16 BEFORE silu so the result
-    // matches the unfused ldmae_swiglu_fwd on the stored h12 (same formula; last-bit FMA-contraction differences are possible).
-    static_assert(EPI != LDMAE_EPI_SWIGLU || TNn == 64, "swiglu epilogue needs 64-column wave slices");
-    const int Hs = N >> 1, hc = (n0 >> 1) + wn * 32 + (lane & 7) * 4;
-    bf16* h12 = (bf16*)e.C;
-    bf16* hid = (bf16*)e.xout;
-    const int hcl = min(hc, Hs - 4);
-    const float4 b1 = e.bias ? *(const float4*)(e.bias + hcl) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 b2 = e.bias ? *(const float4*)(e.bias + Hs + hcl) : make_float4(0.f, 0.f, 0.f, 0.f);
-    // wave-uniform in-range test: the straight-line form lets the compiler count vmcnt over the stores (a per-lane guard
-    // around them made it drain every store before the next strip: 8 us per tile instead of 4)
-    const bool whole = m0 + wm * TM + TM <= M && (n0 >> 1) + wn * 32 + 32 <= Hs;
-    auto strip = [&](int i, bool guard) {
-      fill(i, 0);
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int row = it * 8 + (lane >> 3), m = m0 + wm * TM + i * 16 + row;
-        const float4 u = *(const float4*)(ew + row * ELD + (lane & 7) * 4), v = *(const float4*)(ew + row * ELD + 32 + (lane & 7) * 4);
-        if (!guard || (m < M && hc < Hs)) {
-          bf16x4 x1, x2, ho;
-          x1[0] = (bf16)(u.x + b1.x); x1[1] = (bf16)(u.y + b1.y); x1[2] = (bf16)(u.z + b1.z); x1[3] = (bf16)(u.w + b1.w);
-          x2[0] = (bf16)(v.x + b2.x); x2[1] = (bf16)(v.y + b2.y); x2[2] = (bf16)(v.z + b2.z); x2[3] = (bf16)(v.w + b2.w);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { const float a = (float)x1[j]; ho[j] = (bf16)(a * fast_sigmoid(a) * (float)x2[j]); }
-          *(bf16x4*)(h12 + (size_t)m * N + hc) = x1;
-          *(bf16x4*)(h12 + (size_t)m * N + Hs + hc) = x2;
-          *(bf16x4*)(hid + (size_t)m * Hs + hc) = ho;
-        }
-      }
-    };
-    if (whole) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) strip(i, false);
-    } else {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) strip(i, true);
-    }
-    return;
-  }
-  if constexpr (EPI == LDMAE_EPI_SWIGLU_BWD) {
-    // acc = dhid (N = Hs columns); a,b = h12[:, n], h12[:, Hs+n]; dh12 = (g*b*s*(1+a(1-s)), g*a*s) with g rounded to bf16 first
-    const int Hs = N;
-    const bf16* h12 = (const bf16*)e.xin;
-    bf16* dh12 = (bf16*)e.C;
-#pragma unroll
-    for (int cblk = 0; cblk < TNn / 64; ++cblk) {
-      const int n = n0 + wn * TNn + cblk * 64 + (lane & 15) * 4;
-      const int mw = m0 + wm * TM;
-      const bool inr = n < Hs;
-      // h12 rows of strip i+1 are requested before the stores of strip i (see the note on vmcnt order below)
-      bf16x4 hv[MI + 1][4][2];
-      auto ldh = [&](int i) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int m = min(mw + i * 16 + it * 4 + (lane >> 4), M - 1);
-          const bf16* hp = h12 + (size_t)m * 2 * Hs + (inr ? n : 0);
-          hv[i][it][0] = *(const bf16x4*)hp; hv[i][it][1] = *(const bf16x4*)(hp + Hs);
-        }
-      };
-      const bool whole = mw + TM <= M && n0 + wn * TNn + cblk * 64 + 64 <= Hs;     // wave-uniform: straight-line stores (see SwiGLU fwd)
-      // bias gradient of w12 = column sums of dh12 AS STORED (bf16), formed here while the values are in registers: per wave the
-      // sums over its 128 rows go to e.xout[(m0 / 128 + wm)][2 * Hs] (one partial row per 128 output rows; summed by the caller)
-      // (kept in the wave's LDS scratch ex[row group q = lane >> 4][da 64 | db 64]: eight more live registers spilled the kernel)
-      float* exq = ex + (lane >> 4) * 128 + (lane & 15) * 4;
-      const bool sums = e.xout != nullptr;
-      if (sums) { *(float4*)exq = make_float4(0.f, 0.f, 0.f, 0.f); *(float4*)(exq + 64) = make_float4(0.f, 0.f, 0.f, 0.f); }
-      auto strip = [&](int i, bool guard) {
-        fill(i, cblk);
-        if (i + 1 < MI) ldh(i + 1);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int row = it * 4 + (lane >> 4), m = mw + i * 16 + row;
-          const float4 gv = *(const float4*)(ew + row * ELD + (lane & 15) * 4);
-          if (!guard || (m < M && inr)) {
-            const bf16x4 av = hv[i][it][0], bv = hv[i][it][1];
-            const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
-            bf16x4 da, db;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float g = (float)(bf16)gg[j], a = (float)av[j], b = (float)bv[j], sg = fast_sigmoid(a);
-              da[j] = (bf16)(g * b * sg * (1.f + a * (1.f - sg)));
-              db[j] = (bf16)(g * a * sg);
-            }
-            if (sums) {
-              float4 ua = *(float4*)exq, ub = *(float4*)(exq + 64);
-              ua.x += (float)da[0]; ua.y += (float)da[1]; ua.z += (float)da[2]; ua.w += (float)da[3];
-              ub.x += (float)db[0]; ub.y += (float)db[1]; ub.z += (float)db[2]; ub.w += (float)db[3];
-              *(float4*)exq = ua; *(float4*)(exq + 64) = ub;
-            }
-            __builtin_nontemporal_store(da, (bf16x4*)(dh12 + (size_t)m * 2 * Hs + n));
-            __builtin_nontemporal_store(db, (bf16x4*)(dh12 + (size_t)m * 2 * Hs + Hs + n));
-          }
-        }
-      };
-      ldh(0);
-      if (whole) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) strip(i, false);
-      } else {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) strip(i, true);
-      }
-      if (sums && lane < 32 && inr && mw < M) {          // lanes 0-15 sum the da halves of the 4 row groups, lanes 16-31 the db halves
-        const float* src = ex + (lane >> 4) * 64 + (lane & 15) * 4;
-        float4 t = *(const float4*)src;
-#pragma unroll
-        for (int qg = 1; qg < 4; ++qg) { const float4 u = *(const float4*)(src + qg * 128); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-        *(float4*)(e.xout + (size_t)(mw / TM) * 2 * Hs + (lane >> 4) * Hs + n) = t;
-      }
-    }
-    return;
-  }
-  const bool nfast = (N % 8 == 0) && (e.ldc % 8 == 0) && (EPI != LDMAE_EPI_GATE_RES || e.rows_per_batch % 16 == 0);
-  auto put8 = [&](void* base, size_t oc, float4 a, float4 b) {
-    if constexpr (sizeof(OutT) == 4) { *(float4*)((float*)base + oc) = a; *(float4*)((float*)base + oc + 4) = b; }
-    else {
-      bf16x8 o;
-      o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w; o[4] = (bf16)b.x; o[5] = (bf16)b.y; o[6] = (bf16)b.z; o[7] = (bf16)b.w;
-      __builtin_nontemporal_store(o, (bf16x8*)((bf16*)base + oc));      // streamed output: keeps the B tiles in L2 (+0.5..2 %)
-    }
-  };
-#pragma unroll
-  for (int cblk = 0; cblk < TNn / 64; ++cblk) {
-    const int nb = n0 + wn * TNn + cblk * 64, col = (lane & 15) * 4, c8 = (lane & 7) * 8;
-    const int mw = m0 + wm * TM;
-    // Whole wave slice in range (and, gated form, inside one sample): per-column constants are loaded ONCE and the only loads
-    // between the stores are the next strip's residual rows, issued BEFORE the current strip's stores.  vmcnt retires in
-    // issue order, so a load issued after a store cannot be waited for without draining that store: a per-strip bias load
-    // used to serialise the whole store tail (5.6 us per 256x256 tile instead of ~2).
-    bool hoist = nfast && mw + TM <= M && nb + 64 <= N && EPI != LDMAE_EPI_BIAS_POS && (EPI != LDMAE_EPI_BIAS || e.beta == 0.f);
-    if (EPI == LDMAE_EPI_GATE_RES && hoist) hoist = (mw / e.rows_per_batch) == ((mw + TM - 1) / e.rows_per_batch);
-    if (hoist) {
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f), o4 = make_float4(1.f, 1.f, 1.f, 1.f);
-      const float4 b0 = e.bias ? *(const float4*)(e.bias + nb + c8) : z4, b1 = e.bias ? *(const float4*)(e.bias + nb + c8 + 4) : z4;
-      float4 g0 = o4, g1 = o4;
-      if (EPI == LDMAE_EPI_GATE_RES && e.gate) {
-        const float* gp = e.gate + (size_t)(mw / e.rows_per_batch) * e.gate_ld + nb + c8;
-        g0 = *(const float4*)gp; g1 = *(const float4*)(gp + 4);
-      }
-      constexpr int XPF = 1;                         // residual rows are requested XPF strips ahead of their use
-      float4 xi[MI + XPF][2][2];                     // fully unrolled: only XPF + 1 strips' worth are live at a time
-      auto ldx = [&](int i) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const size_t o = (size_t)(mw + i * 16 + it * 8 + (lane >> 3)) * N + nb + c8;
-          xi[i][it][0] = *(const float4*)(e.xin + o); xi[i][it][1] = *(const float4*)(e.xin + o + 4);
-        }
-      };
-      if constexpr (EPI == LDMAE_EPI_GATE_RES) {
-#pragma unroll
-        for (int i = 0; i < XPF; ++i) ldx(i);
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        fill(i, cblk);
-        float4 a[2][2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int row = it * 8 + (lane >> 3);
-          float4 u = *(const float4*)(ew + row * ELD + c8), v = *(const float4*)(ew + row * ELD + c8 + 4);
-          a[it][0] = make_float4(u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w);
-          a[it][1] = make_float4(v.x + b1.x, v.y + b1.y, v.z + b1.z, v.w + b1.w);
-        }
-        if constexpr (EPI == LDMAE_EPI_GATE_RES) { if (i + XPF < MI) ldx(i + XPF); }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int m = mw + i * 16 + it * 8 + (lane >> 3);
-          const size_t oc = (size_t)m * e.ldc + nb + c8;
-          const float4 p = a[it][0], q = a[it][1];
-          if constexpr (EPI == LDMAE_EPI_GATE_RES) {
-            const size_t o = (size_t)m * N + nb + c8;
-            const float4 x0 = xi[i][it][0], x1 = xi[i][it][1];
-            *(float4*)(e.xout + o) = make_float4(x0.x + g0.x * p.x, x0.y + g0.y * p.y, x0.z + g0.z * p.z, x0.w + g0.w * p.w);
-            *(float4*)(e.xout + o + 4) = make_float4(x1.x + g1.x * q.x, x1.y + g1.y * q.y, x1.z + g1.z * q.z, x1.w + g1.w * q.w);
-            if (e.C) put8(e.C, oc, p, q);
-          } else if constexpr (EPI == LDMAE_EPI_BIAS_GELU) {
-            auto g = [](float y) { return 0.5f * y * (1.f + erff(y * 0.70710678118654752f)); };
-            put8(e.C, oc, make_float4(g(p.x), g(p.y), g(p.z), g(p.w)), make_float4(g(q.x), g(q.y), g(q.z), g(q.w)));
-            if (e.C2) put8(e.C2, oc, p, q);
-          } else {
-            put8(e.C, oc, p, q);
-          }
-        }
-      }
-      continue;
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      fill(i, cblk);
-      const int mb = mw + i * 16;
-      if (nfast && mb + 16 <= M && nb + 64 <= N) {
-        const Epi4<EPI, OutT> ep0(e, mb, nb + c8, N), ep1(e, mb, nb + c8 + 4, N);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int row = it * 8 + (lane >> 3), m = mb + row;
-          float4 y0, y1, z0, z1;
-          ep0.compute(m, *(const float4*)(ew + row * ELD + c8), y0, z0);
-          ep1.compute(m, *(const float4*)(ew + row * ELD + c8 + 4), y1, z1);
-          const size_t oc = (size_t)m * e.ldc + nb + c8;
-          if (e.C) put8(e.C, oc, y0, y1);
-          if (EPI == LDMAE_EPI_BIAS_GELU && e.C2) put8(e.C2, oc, z0, z1);
-        }
-      } else {
-        for (int it = 0; it < 4; ++it) {
-          const int row = it * 4 + (lane >> 4);
-          const float4 v = *(const float4*)(ew + row * ELD + col);
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-          for (int j = 0; j < 4; ++j) epi_store<EPI, OutT>(e, mb + row, nb + col + j, M, N, vv[j]);
-        }
-      }
-    }
-  }
-}
+#include "gemm_nt_common.h"
 
 // ------------------------------------------------------------------------------------------------
 // bf16 NT GEMM kernel: persistent, one 512-thread workgroup per CU walks the 256x256 output tiles t = b, b + grid, ...
