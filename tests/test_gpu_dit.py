@@ -147,6 +147,41 @@ def test_xl_head_dim_72_geometry_fp32_and_bf16():
         assert worst < gtol, (prec, worst)
 
 
+def test_full_size_bs256_bf16_properties():
+    """BASELINE config 2 (DiT-B/1, bs = 256, bf16 autocast) is too big for the CPU oracle; checked through size-independent properties:
+    (1) two identical forward+backward passes give bitwise identical outputs and gradients (fixed-order reductions, no atomics);
+    (2) samples are independent: the first 128 rows of the bs-256 forward equal the bs-128 forward on those samples;
+    (3) the mean-loss gradient of the full batch is the mean of the two half-batch gradients."""
+    cfg = odit.DiTConfig(**odit.DIT_B_1)
+    sd = det_weights(odit.param_shapes(cfg), 5)
+    sd.update(odit.fixed_tables(cfg))
+    m = build(cfg, sd).eval()                                   # eval: no label drop -> deterministic labels
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(256, 16, 32, 32, device="cuda", generator=g)
+    t = torch.rand(256, device="cuda", generator=g)
+    y = torch.randint(0, 1000, (256,), device="cuda", generator=g)
+    tgt = torch.randn(256, 16, 32, 32, device="cuda", generator=g)
+
+    def run(sl, scale=1.0):
+        for p in m.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(x[sl], t[sl], y[sl])
+        loss = ((out.float() - tgt[sl]) ** 2).mean() * scale
+        loss.backward()
+        return out.detach().float(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    full = slice(0, 256)
+    o1, g1 = run(full)
+    o2, g2 = run(full)
+    assert torch.equal(o1, o2) and all(torch.equal(g1[n], g2[n]) for n in g1), "bs-256 step is not bitwise reproducible"
+    oa, ga = run(slice(0, 128))
+    ob, gb = run(slice(128, 256))
+    assert rel_err(o1[:128].cpu(), oa.cpu()) < 1e-6 and rel_err(o1[128:].cpu(), ob.cpu()) < 1e-6
+    worst = max(rel_err(g1[n].cpu(), (0.5 * (ga[n] + gb[n])).cpu()) for n in g1)
+    assert worst < 2e-2, worst                                   # bf16 activations: only the reduction order differs
+
+
 def test_real_width_b1_forward_and_checkpointing():
     """DiT-B/1 at the real width / sequence length, batch 2, fp32: vs oracle; activation checkpointing gives the same grads."""
     cfg = odit.DiTConfig(**odit.DIT_B_1)
