@@ -45,6 +45,11 @@ class GradBucketReducer:
         self._pending = [len(ns) for _, _, ns in self.buckets]
         self._works = []
         self._hooks = []
+        self._exposed = []
+        # DDP.no_sync() equivalent: with gradient accumulation the slab holds the LOCAL sum of the micro-step gradients and is
+        # all-reduced once, on the last micro-step (`sync = True` before that backward).  All-reducing the accumulating slab on
+        # every micro-step would re-sum earlier micro-steps across ranks (world * g1 + g2).
+        self.sync = True
         if self.world > 1:
             for n, p in flat.trainable:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(n)))
@@ -57,6 +62,8 @@ class GradBucketReducer:
 
     def _make_hook(self, name):
         def hook(_p):
+            if not self.sync:
+                return
             bi = self.param_bucket[name]
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
@@ -78,17 +85,34 @@ class GradBucketReducer:
     def finish(self) -> float:
         """Call after backward: launches buckets whose hooks did not all fire (unused parameters), waits for the
         collectives, re-arms the counters.  Returns the grad scale (1/world) to hand to ``AdamWEMA.step``."""
-        if self.world > 1:
+        if self.world > 1 and self.sync:
             for bi, pend in enumerate(self._pending):
                 if pend > 0:
                     self._launch(bi)
+            ev0 = ev1 = None
+            if self.is_cuda:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(torch.cuda.current_stream())
             for w in self._works:
                 w.wait()
             if self.overlap:
                 torch.cuda.current_stream().wait_stream(self.stream)
+            if ev0 is not None:
+                ev1.record(torch.cuda.current_stream())
+                self._exposed.append((ev0, ev1))
         self._works = []
         self._pending = [len(ns) for _, _, ns in self.buckets]
         return 1.0 / self.world
+
+    def exposed_comm_ms(self) -> float:
+        """Sum over the steps since the last call of the time the compute stream waited for the gradient all-reduce after backward
+        had finished (HIP events around the wait in finish(); synchronises).  0 on CPU / world 1."""
+        tot = 0.0
+        for e0, e1 in self._exposed:
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        self._exposed = []
+        return tot
 
     def broadcast_params(self, src: int = 0):
         """DDP-constructor equivalent: replicate rank `src` parameters (and nothing else) to every rank."""

@@ -133,7 +133,7 @@ class _DiTBlockFn(torch.autograd.Function):
     """LightningDiTBlock.forward (:239-250) with RMSNorm, QK-norm, RoPE, SwiGLU, shift."""
 
     @staticmethod
-    def forward(ctx, x, sc, cos, sin, H, eps, dtype,
+    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace,
                 n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12, b12, w3, b3, adaw, adab):
         B, N, D = x.shape
         M, hd = B * N, D // H
@@ -158,6 +158,7 @@ class _DiTBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2, sc, cos, sin, mod, rstd1, xm1, qkv, q, k, v, o, lse, y1, xmid, rstd2, xm2, h12, hid, y2,
                               n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T)
         ctx.dims = (B, N, D, H, hd, eps, dtype)
+        ctx.inplace = bool(inplace)
         return xout.view(B, N, D)
 
     @staticmethod
@@ -166,9 +167,13 @@ class _DiTBlockFn(torch.autograd.Function):
          n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T) = ctx.saved_tensors
         B, N, D, H, hd, eps, dtype = ctx.dims
         M = B * N
-        # f32 residual-stream gradient: accumulated IN PLACE in the buffer the engine hands us (block outputs feed
-        # only the next block / final layer, whose backward allocates that buffer) -- no 805 MB copy per block.
-        dx = gout.view(M, D) if gout.is_contiguous() else gout.contiguous().view(M, D)
+        # f32 residual-stream gradient.  `inplace` (set by LightningDiT.forward for its own block chain, where a block output
+        # feeds only the next block / final layer, whose backward allocates the buffer handed to us): accumulate IN PLACE in
+        # that buffer -- no 805 MB copy per block.  Otherwise (a block called on its own, or with hooks tapping its output) the
+        # incoming gradient may be shared with another consumer and must not be modified: work on a private copy.
+        dx = gout.contiguous().view(M, D)
+        if not ctx.inplace and dx.data_ptr() == gout.data_ptr():
+            dx = dx.clone()
         dmod = torch.empty_like(mod)
         s1, g1, s2, g2 = mod[:, D:2 * D], mod[:, 2 * D:3 * D], mod[:, 4 * D:5 * D], mod[:, 5 * D:6 * D]
         sg = ops.SideGemms(dx.device, enabled=dtype == torch.bfloat16)      # weight gradients: off the critical path
@@ -193,7 +198,7 @@ class _DiTBlockFn(torch.autograd.Function):
         dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
         dsc = _dmod_times_w(dmod, adaw)
         sg.join()
-        return (dx.view(B, N, D), dsc, None, None, None, None, None,
+        return (dx.view(B, N, D), dsc, None, None, None, None, None, None,
                 dn1, dWqkv, dbqkv, dqn, dkn, dWp, dbp, dn2, dW12, db12, dW3, db3, dadaw, dadab)
 
 
@@ -337,13 +342,14 @@ class LightningDiTBlock(nn.Module):
         self.wo_shift = wo_shift
         self.precision = None
 
-    def forward(self, x, c, feat_rope=None, _silu_c=None, _dtype=None):
+    def forward(self, x, c, feat_rope=None, _silu_c=None, _dtype=None, _inplace_grad=False):
         if feat_rope is None:
             raise NotImplementedError("ldmae_amd LightningDiTBlock needs feat_rope (use_rope=True)")
         sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
         a, m = self.attn, self.mlp
         return _DiTBlockFn.apply(
             x.float(), sc, feat_rope.freqs_cos, feat_rope.freqs_sin, a.num_heads, self.norm1.eps, _dtype or _act_dtype(self.precision),
+            _inplace_grad,
             self.norm1.weight, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.k_norm.weight, a.proj.weight, a.proj.bias,
             self.norm2.weight, m.w12.weight, m.w12.bias, m.w3.weight, m.w3.bias,
             self.adaLN_modulation[1].weight, self.adaLN_modulation[1].bias)
@@ -453,10 +459,13 @@ class LightningDiT(nn.Module):
             c = t + y
             sc = _SiluFn.apply(c)
             for block in self.blocks:
+                # a block output of this chain has exactly one consumer (the next block / the final layer) unless someone
+                # taps it with a module hook: only then may the block's backward re-use the incoming gradient buffer
+                inpl = not (block._forward_hooks or block._forward_pre_hooks or block._backward_hooks)
                 if self.use_checkpoint:
-                    x = checkpoint(block, x, c, self.feat_rope, sc, dtype, use_reentrant=True)
+                    x = checkpoint(block, x, c, self.feat_rope, sc, dtype, inpl, use_reentrant=True)
                 else:
-                    x = block(x, c, self.feat_rope, sc, dtype)
+                    x = block(x, c, self.feat_rope, sc, dtype, inpl)
             x = self.final_layer(x, c, sc, dtype)
             x = self.unpatchify(x)
             if self.learn_sigma:

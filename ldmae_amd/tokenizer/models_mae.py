@@ -55,7 +55,7 @@ class _ViTBlockFn(torch.autograd.Function):
     """Block.forward (:176-187): x += proj(attn(LN1(x))); x += fc2(gelu(fc1(LN2(x))))."""
 
     @staticmethod
-    def forward(ctx, x, H, eps, dtype, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
+    def forward(ctx, x, H, eps, dtype, inplace, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
         B, N, D = x.shape
         M, hd = B * N, D // H
         x2 = x.contiguous().view(M, D)
@@ -74,6 +74,7 @@ class _ViTBlockFn(torch.autograd.Function):
         xout, _ = ops.gemm_nt_gate_res(act, W2, f2b, xmid, None, N, save_y=False)
         ctx.save_for_backward(x2, h1, mu1, rs1, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T)
         ctx.dims = (B, N, D, H, hd, dtype)
+        ctx.inplace = bool(inplace)
         return xout.view(B, N, D)
 
     @staticmethod
@@ -81,7 +82,9 @@ class _ViTBlockFn(torch.autograd.Function):
         x2, h1, mu1, rs1, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T = ctx.saved_tensors
         B, N, D, H, hd, dtype = ctx.dims
         M = B * N
-        dx = gout.view(M, D) if gout.is_contiguous() else gout.contiguous().view(M, D)
+        dx = gout.contiguous().view(M, D)
+        if not ctx.inplace and dx.data_ptr() == gout.data_ptr():
+            dx = dx.clone()                   # the incoming gradient may have other consumers: never modify it (see _DiTBlockFn)
         # MLP branch
         dy2 = ops.cast(dx, dtype)
         dW2, db2 = ops.gemm_tn(dy2, act, with_bias=True)
@@ -96,7 +99,7 @@ class _ViTBlockFn(torch.autograd.Function):
         dqkv = ops.cast(ops.heads_merge(dq, dk, dv, B, N, H, hd), dtype)
         dWqkv, dbqkv = ops.gemm_tn(dqkv, h1, with_bias=True)
         dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT), x2, n1w, mu1, rs1, dx)
-        return (dx.view(B, N, D), None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
+        return (dx.view(B, N, D), None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -186,9 +189,9 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
         self.precision = None
 
-    def forward(self, x):
+    def forward(self, x, _inplace_grad=False):
         a, m = self.attn, self.mlp
-        return _ViTBlockFn.apply(x.float(), a.num_heads, self.norm1.eps, _act_dtype(self.precision),
+        return _ViTBlockFn.apply(x.float(), a.num_heads, self.norm1.eps, _act_dtype(self.precision), _inplace_grad,
                                  self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                  self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
 
@@ -309,9 +312,15 @@ class MaskedAutoencoderViT(nn.Module):
     def _embed(self, x):
         return self.patch_embed(x, self.pos_embed[0])
 
+    @staticmethod
+    def _chain_ok(blk):
+        """A block of the encoder / decoder chain feeds only the next block or the closing LayerNorm (whose backward allocates the
+        gradient buffer it hands on) unless a module hook taps it: only then may its backward re-use the incoming gradient."""
+        return not (blk._forward_hooks or blk._forward_pre_hooks or blk._backward_hooks)
+
     def _run(self, blocks, x):
         for blk in blocks:
-            x = blk(x)
+            x = blk(x, self._chain_ok(blk))
         return x
 
     def forward_encoder(self, x, mask_ratio, noise=None):
@@ -322,7 +331,7 @@ class MaskedAutoencoderViT(nn.Module):
             x, mask, ids_restore = self.random_masking(x, mask_ratio, noise)
             for blk in self.blocks:
                 blk.precision = dtype
-                x = blk(x)
+                x = blk(x, self._chain_ok(blk))
             x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x, mask, ids_restore
 
@@ -378,7 +387,7 @@ class MaskedAutoencoderViT(nn.Module):
             x = self._embed(x)
             for blk in self.blocks:
                 blk.precision = dtype
-                x = blk(x)
+                x = blk(x, self._chain_ok(blk))
             x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
             x = _LinearFn.apply(x, self.to_latent.weight, self.to_latent.bias)
         g = self.latent_resolution
@@ -398,7 +407,7 @@ class MaskedAutoencoderViT(nn.Module):
             x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias) + self.decoder_pos_embed
             for blk in self.decoder_blocks:
                 blk.precision = dtype
-                x = blk(x)
+                x = blk(x, self._chain_ok(blk))
             x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
             x = self.decoder_pred(x) if not isinstance(self.decoder_pred, nn.Linear) else \
                 _LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)

@@ -148,7 +148,11 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
     running = torch.zeros((), device=device)
     log_steps, micro, start = 0, 0, time()
     opt.zero_grad()
+    epoch = 0
     while train_steps < max_steps:
+        if getattr(loader, "sampler", None) is not None and hasattr(loader.sampler, "set_epoch"):
+            loader.sampler.set_epoch(epoch)              # reshuffle per epoch, as the reference's DataLoader(shuffle=True) does
+        epoch += 1
         for x, y in loader:
             x, y = x.to(device, non_blocking=True), y.to(device, non_blocking=True)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16"):
@@ -157,10 +161,12 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
             if 'cos_loss' in terms:
                 loss = loss + terms["cos_loss"].mean()
             running += terms["loss"].mean().detach()
+            # the slab accumulates the local micro-step gradients; ONE all-reduce on the last micro-step gives sum over ranks of
+            # the local sums = what the reference's per-micro-step DDP mean accumulates to (train_accum.py:223-244), times world
+            reducer.sync = micro + 1 == accum
             (loss / accum).backward()
             micro += 1
             if micro < accum:
-                reducer.finish()          # reference all-reduces on every micro-step (no no_sync); sums stay exact
                 continue
             clip = o.get('max_grad_norm', None)
             scale = reducer.finish()

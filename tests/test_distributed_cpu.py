@@ -47,6 +47,26 @@ def _worker(rank, world, port, out):
     dist.all_gather(gathered, local)
     expect = sum(gathered)
     ok = torch.allclose(flat.grads, expect, rtol=1e-6, atol=1e-7)
+    # gradient accumulation (accum = 2) as the train driver runs it: the slab accumulates both micro-steps locally and is
+    # all-reduced ONCE (sync only on the last micro-step) -> sum over ranks of (g1 + g2); the round-1 form (all-reduce of the
+    # accumulating slab on every micro-step) gave world * g1 + g2
+    torch.manual_seed(200 + rank)
+    x2 = torch.randn(8, 16)
+    own2 = torch.autograd.grad(net(x2).pow(2).mean(), [p for _, p in flat.trainable])
+    local2 = local.clone()
+    for (n, p), g in zip(flat.trainable, own2):
+        o, k = flat.offsets[n]
+        local2[o:o + k] += g.reshape(-1)
+    flat.grads.zero_()
+    for mi, xx in enumerate((x, x2)):
+        red.sync = mi == 1
+        net(xx).pow(2).mean().backward()
+        if mi == 0:
+            assert not red._works           # nothing launched on a non-final micro-step
+    red.finish()
+    gathered2 = [torch.zeros_like(local2) for _ in range(world)]
+    dist.all_gather(gathered2, local2)
+    ok = ok and torch.allclose(flat.grads, sum(gathered2), rtol=1e-6, atol=1e-7)
     params = [torch.zeros_like(flat.params) for _ in range(world)]
     dist.all_gather(params, flat.params)
     same = torch.equal(params[0], params[1])
