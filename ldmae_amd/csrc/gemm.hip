@@ -637,6 +637,14 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
   // tune key 8: 2 = one tile per workgroup; otherwise persistent (one workgroup per CU), the default
   const bool pers = ldmae_tune_get(8) != 2;
   const int pgrid = (pers && ntiles != ncu) ? ncu : ntiles;
+  // tune key 0: 1 = the one-wave-per-SIMD kernel of gemm_w4.hip (bf16; bias / gated residual / SwiGLU / SwiGLU-bwd epilogues)
+  if (dtype == LDMAE_BF16 && ldmae_tune_get(0) != 0 &&
+      (ldmae_tune_get(0) == 1 ? ldmae_launch_nt_w4(epi, sizeof(OutT) == 2, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st)
+                              : ldmae_launch_nt_p8(epi, sizeof(OutT) == 2, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st))) {
+    if (pi >= 0) ldmae_prof_end(pi, st);
+    LDMAE_CHECK_LAUNCH("gemm_nt_w4");
+    return LDMAE_OK;
+  }
   // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup (A/B knob),
   // key 7 = diagnostic per-K-step stamp build.
 #define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048 + 16384)

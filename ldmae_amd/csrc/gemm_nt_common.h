@@ -21,6 +21,12 @@ struct EpiArgs {
   float beta;           // EPI_BIAS with f32 out: C = acc + bias + beta*C   (beta 0 or 1: gradient accumulation)
 };
 
+// gemm_w4.hip: the one-wave-per-SIMD kernel (returns 0 if it has no instantiation for `epi`)
+int ldmae_launch_nt_w4(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
+                       int ntiles, hipStream_t st);
+int ldmae_launch_nt_p8(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
+                       int ntiles, hipStream_t st);
+
 template <int EPI, typename OutT>
 __device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M, int N, float acc) {
   if (m >= M || n >= N) return;
@@ -130,18 +136,21 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
   if constexpr (EPI == LDMAE_EPI_SWIGLU) {
     // strip cols 0..31 = x1 (hid columns hc..), 32..63 = x2.  Values are rounded to bf16 BEFORE silu so the result
     // matches the unfused ldmae_swiglu_fwd on the stored h12 (same formula; last-bit FMA-contraction differences are possible).
-    static_assert(EPI != LDMAE_EPI_SWIGLU || TNn == 64, "swiglu epilogue needs 64-column wave slices");
-    const int Hs = N >> 1, hc = (n0 >> 1) + wn * 32 + (lane & 7) * 4;
+    // a wave slice of TNn columns is TNn / 64 groups of [x1 32 | x2 32]
     bf16* h12 = (bf16*)e.C;
     bf16* hid = (bf16*)e.xout;
+    const int Hs = N >> 1;
+#pragma unroll
+    for (int cblk = 0; cblk < TNn / 64; ++cblk) {
+    const int hb = (n0 >> 1) + (wn * (TNn / 64) + cblk) * 32, hc = hb + (lane & 7) * 4;
     const int hcl = min(hc, Hs - 4);
     const float4 b1 = e.bias ? *(const float4*)(e.bias + hcl) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 b2 = e.bias ? *(const float4*)(e.bias + Hs + hcl) : make_float4(0.f, 0.f, 0.f, 0.f);
     // wave-uniform in-range test: the straight-line form lets the compiler count vmcnt over the stores (a per-lane guard
     // around them made it drain every store before the next strip: 8 us per tile instead of 4)
-    const bool whole = m0 + wm * TM + TM <= M && (n0 >> 1) + wn * 32 + 32 <= Hs;
+    const bool whole = m0 + wm * TM + TM <= M && hb + 32 <= Hs;
     auto strip = [&](int i, bool guard) {
-      fill(i, 0);
+      fill(i, cblk);
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int row = it * 8 + (lane >> 3), m = m0 + wm * TM + i * 16 + row;
@@ -164,6 +173,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
     } else {
 #pragma unroll
       for (int i = 0; i < MI; ++i) strip(i, true);
+    }
     }
     return;
   }

@@ -1,0 +1,340 @@
+// bf16 NT GEMM, one wave per SIMD: C[M,N] = A[M,K] . B[N,K]^T with the fused epilogues of gemm_nt_common.h.
+//
+// 256 x 256 output tile per 256-thread workgroup = 4 waves (2 x 2), each wave owns 128 x 128 = 8 x 8 tiles of
+// mfma_f32_16x16x32_bf16 and the whole 512-entry register file of its SIMD: 256 accumulator registers (the compiler keeps them
+// in the AGPR half: this file is built WITHOUT -amdgpu-mfma-vgpr-form) + two sets of operand fragments (2 x 64 VGPRs).
+// Compared with the 8-wave kernel of gemm.hip (128 x 64 per wave) every byte read from LDS feeds twice the MFMA work
+// (64 KiB instead of 96 KiB of fragment reads per 32-deep K-step), there is no second wave on the SIMD to arbitrate
+// against, and the wave interleaves its own loads with its own MFMAs:
+//   K-step kt:  64 MFMAs on the fragments of stage kt (in registers)
+//               || 16 ds_read_b128 of the fragments of stage kt+1 (other register set)
+//               || 8 global->LDS DMA pieces of stage kt+STAGES into the slot stage kt has just left
+//   ONE workgroup barrier per K-step; the DMA ring is STAGES deep and, with the fragments double-buffered in registers, a
+//   stage is requested STAGES-1 K-steps before its barrier.
+// DMA addressing: wave-uniform 64-bit base in SGPRs (advanced by scalar adds) + one 32-bit VGPR offset per piece that is
+// constant for the whole tile: no vector address arithmetic in the loop.
+// LDS stage image and swizzle: identical to gemm.hip (64-B rows, chunk c of row r at c ^ F[(r >> 2) & 3]).
+#include "common.h"
+
+#include "gemm_nt_common.h"
+
+#include <type_traits>
+
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+
+// accumulate in place in the AGPR file: the tied "+a" operand makes the register allocator give every accumulator tile one AGPR
+// quad for the whole loop (the MFMA builtin lets it pick a different destination per instruction and shuffle the 256
+// accumulators through VGPRs: ~2000 v_accvgpr moves per K-step pair); volatile pins the MFMA / DMA / barrier order as written
+__device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// two waves per SIMD (256 registers per wave): accumulators in the VGPR half like everything else
+__device__ __forceinline__ void mfma_acc_v(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+template <int STAGES, int EPI, typename OutT>
+__global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
+                                                         int lda, int ldb, EpiArgs e, int ntiles) {
+  constexpr int BM = 256, BN = 256, TM = 128, TNn = 128, MI = 8, NI = 8, NW = 4, PPW = 8;
+  constexpr int STAGE_BYTES = (BM + BN) * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned tiles_n = (N + BN - 1) / BN;
+  float* ew = (float*)(smem + STAGES * STAGE_BYTES) + wave * (16 * 68);
+  float* ex = (float*)(smem + STAGES * STAGE_BYTES + NW * 16 * 68 * 4) + wave * 512;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(void, smem));
+
+  // tile ownership as in gemm_nt_persist_kernel: XCD x (= blockIdx % 8) owns a contiguous range of A row-blocks
+  const bool persistent = (int)gridDim.x != ntiles;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int rbx = (((M + BM - 1) / BM) + 7) / 8;
+  const int first = persistent ? xcd * rbx * (int)tiles_n + slot : (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int tend = persistent ? min(ntiles, (xcd + 1) * rbx * (int)tiles_n) : ntiles;
+  const int tstride = persistent ? per_xcd : ntiles;
+
+  // waves 0,1 bring the A rows (pieces 0..15), waves 2,3 the B rows (pieces 16..31): one uniform base per wave
+  const bool isB = wave >= 2;
+  unsigned voff[PPW];
+  const bf16* sbase = A;
+  int m0 = 0, n0 = 0;
+  auto set_tile = [&](int t) {
+    m0 = (t / tiles_n) * BM; n0 = (t % tiles_n) * BN;
+    const int c = (lane & 3) ^ ring_f((lane >> 4) & 3);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = ((wave & 1) * PPW + i) * 16 + (lane >> 2);        // 0..255 inside the operand's tile rows
+      if (!isB) voff[i] = (unsigned)(min(row, M - 1 - m0) * lda + c * 8) * 2u;
+      else {
+        int brow = n0 + row;
+        if constexpr (EPI == LDMAE_EPI_SWIGLU) brow = ((row & 32) ? (N >> 1) : 0) + (n0 >> 1) + (row >> 6) * 32 + (row & 31);
+        voff[i] = (unsigned)(min(brow, N - 1) * ldb + c * 8) * 2u;
+      }
+    }
+    sbase = isB ? B : A + (size_t)m0 * lda;
+  };
+  auto issue = [&](int kt) {
+    const unsigned dst = lds0 + (kt % STAGES) * STAGE_BYTES + wave * (PPW * 1024);
+    const bf16* sb = sbase + kt * 32;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16_s(sb, voff[i], dst + i * 1024);
+  };
+  const int fpos = ((lane >> 4) ^ ring_f((lane >> 2) & 3)) << 4;
+  const int a_off = (wm * TM + (lane & 15)) * 64 + fpos, b_off = (BM + wn * TNn + (lane & 15)) * 64 + fpos;
+  const int nk = K / 32;
+
+  int t = first;
+  if (t < tend) {
+    set_tile(t);
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s)
+      if (s < nk) issue(s);
+  }
+  while (t < tend) {
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
+    // tile start: everything this wave has in flight has landed (compiler-visible wait: see gemm.hip), every wave's pieces visible
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    {
+      const char* st = smem;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b0[j] = *(const bf16x8*)(st + b_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a0[i] = *(const bf16x8*)(st + a_off + i * 1024);
+    }
+    // one K-step: MFMAs on (ac, bc) while (an, bn) are read from stage kt+1 and stage kt+STAGES is requested.
+    // MAIN = steady state (both always happen, wait count constant); otherwise the drain steps at the end of the tile.
+    auto kstep = [&](auto main_tag, int kt, bf16x8 (&ac)[MI], bf16x8 (&bc)[NI], bf16x8 (&an)[MI], bf16x8 (&bn)[NI]) {
+      constexpr bool MAIN = decltype(main_tag)::value;
+      const bool nxt = MAIN || kt + 1 < nk;
+      if (nxt) {
+        // own pieces of stage kt+1 landed (stages kt+2 .. kt+STAGES-1 may stay in flight); own reads of stage kt done, so that
+        // after the barrier its slot may be overwritten
+        if constexpr (MAIN) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * PPW) : "memory");
+        else {
+          const int ahead = min(STAGES - 2, nk - 2 - kt);
+          if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPW) : "memory");
+          else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+      const char* st = smem + ((kt + 1) % STAGES) * STAGE_BYTES;
+      const unsigned dst = lds0 + (kt % STAGES) * STAGE_BYTES + wave * (PPW * 1024);
+      const bf16* sb = sbase + (kt + STAGES) * 32;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if (nxt) {
+          an[i] = *(const bf16x8*)(st + a_off + i * 1024);
+          bn[i] = *(const bf16x8*)(st + b_off + i * 1024);
+        }
+        if constexpr (MAIN) glds16_s(sb, voff[i], dst + i * 1024);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) mfma_acc(acc[i][j], ac[i], bc[j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    static_assert(STAGES == 4, "drain-step wait counts are written for a 4-deep ring");
+    const int kmain = max(nk - STAGES, 0);      // even: nk is even (K % 64 == 0, host check)
+    for (int kt = 0; kt < kmain; kt += 2) {
+      kstep(std::true_type{}, kt, a0, b0, a1, b1);
+      kstep(std::true_type{}, kt + 1, a1, b1, a0, b0);
+    }
+    for (int kt = kmain; kt < nk; kt += 2) {
+      kstep(std::false_type{}, kt, a0, b0, a1, b1);
+      kstep(std::false_type{}, kt + 1, a1, b1, a0, b0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // MFMA results -> ordinary reads of the accumulators (the compiler does not see MFMAs in asm)
+    __builtin_amdgcn_s_barrier();           // every wave has read its last fragments: the ring is free
+    const int em0 = m0, en0 = n0;
+    t += tstride;
+    if (t < tend) {
+      set_tile(t);
+#pragma unroll
+      for (int s = 0; s < STAGES; ++s)
+        if (s < nk) issue(s);
+    }
+    nt_epilogue<EPI, OutT, TM, TNn, MI, NI>(acc, ew, ex, e, em0, en0, wm, wn, lane, M, N);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same self-pipelined stream with TWO waves per SIMD: 8 waves (2 x 4), 128 x 64 per wave (8 x 4 MFMA tiles, 128 accumulator
+// registers), the geometry of gemm_nt_persist_kernel -- but no load / MFMA phases and no stagger: every wave interleaves its own
+// fragment reads (stage kt+1) and DMA pieces (stage kt+3) with its own MFMAs (stage kt, fragments in registers) and meets the
+// others at ONE barrier per K-step.  Whenever one wave of a SIMD stalls on a DMA issue or an LDS return, its partner's
+// MFMAs are there to fill the matrix pipe (with one wave per SIMD, above, every such stall is exposed).
+// ------------------------------------------------------------------------------------------------
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(512) void gemm_nt_p8_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K,
+                                                         int lda, int ldb, EpiArgs e, int ntiles) {
+  constexpr int STAGES = 3, BM = 256, BN = 256, TM = 128, TNn = 64, MI = 8, NI = 4, NW = 8, PPW = 4;
+  constexpr int STAGE_BYTES = (BM + BN) * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const unsigned tiles_n = (N + BN - 1) / BN;
+  float* ew = (float*)(smem + STAGES * STAGE_BYTES) + wave * (16 * 68);
+  float* ex = (float*)(smem + STAGES * STAGE_BYTES + NW * 16 * 68 * 4) + wave * 512;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(void, smem));
+
+  const bool persistent = (int)gridDim.x != ntiles;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const int rbx = (((M + BM - 1) / BM) + 7) / 8;
+  const int first = persistent ? xcd * rbx * (int)tiles_n + slot : (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int tend = persistent ? min(ntiles, (xcd + 1) * rbx * (int)tiles_n) : ntiles;
+  const int tstride = persistent ? per_xcd : ntiles;
+
+  // waves 0-3 bring the A rows (pieces 0..15), waves 4-7 the B rows (pieces 16..31): one uniform base per wave
+  const bool isB = wave >= 4;
+  unsigned voff[PPW];
+  const bf16* sbase = A;
+  int m0 = 0, n0 = 0;
+  auto set_tile = [&](int t) {
+    m0 = (t / tiles_n) * BM; n0 = (t % tiles_n) * BN;
+    const int c = (lane & 3) ^ ring_f((lane >> 4) & 3);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int row = ((wave & 3) * PPW + i) * 16 + (lane >> 2);        // 0..255 inside the operand's tile rows
+      if (!isB) voff[i] = (unsigned)(min(row, M - 1 - m0) * lda + c * 8) * 2u;
+      else {
+        int brow = n0 + row;
+        if constexpr (EPI == LDMAE_EPI_SWIGLU) brow = ((row & 32) ? (N >> 1) : 0) + (n0 >> 1) + (row >> 6) * 32 + (row & 31);
+        voff[i] = (unsigned)(min(brow, N - 1) * ldb + c * 8) * 2u;
+      }
+    }
+    sbase = isB ? B : A + (size_t)m0 * lda;
+  };
+  auto issue = [&](int kt) {
+    const unsigned dst = lds0 + (kt % STAGES) * STAGE_BYTES + wave * (PPW * 1024);
+    const bf16* sb = sbase + kt * 32;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) glds16_s(sb, voff[i], dst + i * 1024);
+  };
+  const int fpos = ((lane >> 4) ^ ring_f((lane >> 2) & 3)) << 4;
+  const int a_off = (wm * TM + (lane & 15)) * 64 + fpos, b_off = (BM + wn * TNn + (lane & 15)) * 64 + fpos;
+  const int nk = K / 32;
+
+  int t = first;
+  if (t < tend) {
+    set_tile(t);
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s)
+      if (s < nk) issue(s);
+  }
+  while (t < tend) {
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[MI], b0[NI], b1[NI];
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    {
+      const char* st = smem;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b0[j] = *(const bf16x8*)(st + b_off + j * 1024);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+    }
+    // one K-step.  B fragments are double-buffered (bc -> bn); an A fragment is dead after its row of MFMAs and is re-read for
+    // the next K-step right behind them (same registers): 64 fragment registers instead of 96.  ONE loop body for steady state
+    // and drain (wave-uniform branches around the DMA pieces and the wait flavours): with separate bodies the compiler moves
+    // the 128 accumulators between two register assignments at the seam.
+    auto kstep = [&](int kt, bf16x8 (&bc)[NI], bf16x8 (&bn)[NI]) {
+      const bool more = kt + STAGES < nk;
+      if (kt + 1 < nk) {
+        // own pieces of stage kt+1 landed (stage kt+2 may stay in flight), own reads of stage kt done (its slot is overwritten next)
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      const char* st = smem + ((kt + 1) % STAGES) * STAGE_BYTES;      // last K-step: reads a slot nobody needs (values unused)
+      const unsigned dst = lds0 + (kt % STAGES) * STAGE_BYTES + wave * (PPW * 1024);
+      const bf16* sb = sbase + (kt + STAGES) * 32;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if (i < NI) bn[i] = *(const bf16x8*)(st + b_off + i * 1024);
+        if ((i & 1) && more) glds16_s(sb, voff[i >> 1], dst + (i >> 1) * 1024);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) mfma_acc_v(acc[i][j], af[i], bc[j]);
+        af[i] = *(const bf16x8*)(st + a_off + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {            // nk is even (K % 64 == 0, host check)
+      kstep(kt, b0, b1);
+      kstep(kt + 1, b1, b0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int em0 = m0, en0 = n0;
+    t += tstride;
+    if (t < tend) {
+      set_tile(t);
+#pragma unroll
+      for (int s = 0; s < STAGES; ++s)
+        if (s < nk) issue(s);
+    }
+    nt_epilogue<EPI, OutT, TM, TNn, MI, NI>(acc, ew, ex, e, em0, en0, wm, wn, lane, M, N);
+  }
+}
+
+// host side: called from gemm.hip's launch_nt when tune key 0 selects this kernel
+template <int EPI, typename OutT>
+static void go_w4(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid, int ntiles, hipStream_t st) {
+  constexpr int ST = 4;
+  constexpr int lds = ST * 512 * 64 + 4 * 16 * 68 * 4 + 4 * 2048;
+  hipFuncSetAttribute((const void*)gemm_nt_w4_kernel<ST, EPI, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((gemm_nt_w4_kernel<ST, EPI, OutT>), dim3(grid), dim3(256), lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e, ntiles);
+}
+
+template <int EPI, typename OutT>
+static void go_p8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid, int ntiles, hipStream_t st) {
+  constexpr int lds = 3 * 512 * 64 + 8 * 16 * 68 * 4 + 8 * 2048;
+  hipFuncSetAttribute((const void*)gemm_nt_p8_kernel<EPI, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((gemm_nt_p8_kernel<EPI, OutT>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e, ntiles);
+}
+
+int ldmae_launch_nt_p8(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
+                       int ntiles, hipStream_t st) {
+#define P8(E)                                                                                        \
+  if (out_bf16) go_p8<E, bf16>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st);                        \
+  else go_p8<E, float>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st)
+  switch (epi) {
+    case LDMAE_EPI_BIAS: P8(LDMAE_EPI_BIAS); break;
+    case LDMAE_EPI_GATE_RES: P8(LDMAE_EPI_GATE_RES); break;
+    case LDMAE_EPI_SWIGLU: go_p8<LDMAE_EPI_SWIGLU, bf16>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st); break;
+    case LDMAE_EPI_SWIGLU_BWD: go_p8<LDMAE_EPI_SWIGLU_BWD, bf16>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st); break;
+    default: return 0;
+  }
+#undef P8
+  return 1;
+}
+
+int ldmae_launch_nt_w4(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
+                       int ntiles, hipStream_t st) {
+#define W4(E)                                                                                        \
+  if (out_bf16) go_w4<E, bf16>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st);                        \
+  else go_w4<E, float>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st)
+  switch (epi) {
+    case LDMAE_EPI_BIAS: W4(LDMAE_EPI_BIAS); break;
+    case LDMAE_EPI_GATE_RES: W4(LDMAE_EPI_GATE_RES); break;
+    case LDMAE_EPI_SWIGLU: go_w4<LDMAE_EPI_SWIGLU, bf16>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st); break;
+    case LDMAE_EPI_SWIGLU_BWD: go_w4<LDMAE_EPI_SWIGLU_BWD, bf16>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st); break;
+    default: return 0;
+  }
+#undef W4
+  return 1;
+}
