@@ -31,21 +31,37 @@ template <int HD> __device__ __forceinline__ void tile_inv(int off, int& row, in
   row = grp * 8 + r7;
   ch = sub * 4 + (pos ^ ((row >> 2) & 3));
 }
-// stage a [ROWS][HD] bf16 tile (global row stride ld elements) into LDS with global_load_lds; 256 threads
+// Head dims that are not a multiple of 32 (LightningDiT-XL: 72, VMAE: 16) are tiled with the LDS images and the register
+// fragments zero-padded to HDP = the next multiple of 32; global memory keeps the true HD (no padded copies in HBM).  Zero q/k
+// columns add 0 to every score, zero v / dO columns produce output columns that are never stored.  Padded 16-B chunks of an
+// LDS tile are fetched from this 16 zero bytes (the DMA source address is per lane).
+__device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+constexpr int hd_pad(int hd) { return (hd + 31) / 32 * 32; }
+
+// stage a [ROWS][HD] bf16 tile (global row stride ld elements) into the [ROWS][HDP] LDS image with global_load_lds; 256 threads
 template <int HD, int ROWS>
 __device__ __forceinline__ void stage_tile(const bf16* __restrict__ g, long ld, int row_limit, char* lds, int wave, int lane) {
-  constexpr int PIECES = ROWS * HD * 2 / 1024;
+  constexpr int HDP = hd_pad(HD), PIECES = ROWS * HDP * 2 / 1024;
   static_assert(PIECES % 4 == 0 || PIECES == 2 || PIECES == 1, "tile too small");
 #pragma unroll
   for (int i = 0; i < (PIECES + 3) / 4; ++i) {
     const int pi = wave * ((PIECES + 3) / 4) + i;
     if (pi < PIECES) {
       int row, ch;
-      tile_inv<HD>(pi * 1024 + lane * 16, row, ch);
+      tile_inv<HDP>(pi * 1024 + lane * 16, row, ch);
       row = min(row, row_limit);
-      glds16(g + (long)row * ld + ch * 8, lds + pi * 1024);
+      const void* src = (HD == HDP || ch * 8 < HD) ? (const void*)(g + (long)row * ld + ch * 8) : (const void*)g_zero16;
+      glds16(src, lds + pi * 1024);
     }
   }
+}
+// 8 bf16 of a row held in global memory at column c (a register fragment); zero past the true head dim
+template <int HD> __device__ __forceinline__ bf16x8 gfrag(const bf16* row, int c) {
+  if (HD % 16 == 0 || c < HD) return *(const bf16x8*)(row + c);
+  bf16x8 z;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = (bf16)0.f;
+  return z;
 }
 // A-operand fragment for a product that contracts over the tile's ROW index (transposed read):
 // rows r0 + {4h.. , 8+4h..} in the acc-as-operand k order, 32 columns starting at c0 (lane r = column)
@@ -90,11 +106,11 @@ constexpr float RESCALE_THR = 6.0f;
 // workgroup then costs ~9k cycles, MI355X_MICROARCH 'attention epilogue store tail'); instead the tile goes through a wave-private
 // LDS image (144-B row pitch) and leaves as whole 128-B rows, 16 B per lane, 8 rows per instruction.  `mul` is per lane (= per row).
 template <int HD>
-__device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[HD / 32], float mul, char* lds_wave, bf16* gbase, long gstride, int lane) {
-  constexpr int PITCH = HD * 2 + 16, CPR = HD / 8;            // bytes per LDS row; 16-B chunks per row
+__device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[hd_pad(HD) / 32], float mul, char* lds_wave, bf16* gbase, long gstride, int lane) {
+  constexpr int PITCH = hd_pad(HD) * 2 + 16, CPR = HD / 8;    // bytes per LDS row; 16-B chunks per (true) row
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int d = 0; d < HD / 32; ++d)
+  for (int d = 0; d < hd_pad(HD) / 32; ++d)
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
       bf16x4 w;
@@ -103,17 +119,19 @@ __device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[HD / 32], float
       *(bf16x4*)(lds_wave + r * PITCH + (d * 32 + 8 * t4 + 4 * h) * 2) = w;
     }
 #pragma unroll
-  for (int it = 0; it < 32 * CPR / 64; ++it) {
+  for (int it = 0; it < (32 * CPR + 63) / 64; ++it) {
     const int idx = it * 64 + lane, row = idx / CPR, ch = idx % CPR;
-    const bf16x8 v = *(const bf16x8*)(lds_wave + row * PITCH + ch * 16);
-    *(bf16x8*)(gbase + (long)row * gstride + ch * 8) = v;
+    if ((32 * CPR) % 64 == 0 || idx < 32 * CPR) {
+      const bf16x8 v = *(const bf16x8*)(lds_wave + row * PITCH + ch * 16);
+      *(bf16x8*)(gbase + (long)row * gstride + ch * 8) = v;
+    }
   }
 }
 
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                             bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c) {
-  constexpr int KS = HD / 16, DB = HD / 32, TB = 64 * HD * 2;
+  constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int qblocks = (N + 127) / 128;
@@ -125,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   const bf16* vp = V + (size_t)bh * N * HD;
   bf16x8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + (size_t)min(q0 + r, N - 1) * HD + ks * 16 + 8 * h);
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = gfrag<HD>(qp + (size_t)min(q0 + r, N - 1) * HD, ks * 16 + 8 * h);
   f32x16 oacc[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d)
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
 #pragma unroll
       for (int t = 0; t < 16; ++t) s[kb][t] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s[kb] = MFMA_BF16(frag_row<HD>(Kt, kb * 32, ks, lane), qf[ks], s[kb]);
+      for (int ks = 0; ks < KS; ++ks) s[kb] = MFMA_BF16(frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], s[kb]);
     }
     float mx = s[0][0];
 #pragma unroll
@@ -186,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pf = acc_frag(s[kb], s2);
 #pragma unroll
-        for (int d = 0; d < DB; ++d) oacc[d] = MFMA_BF16(frag_tr<HD>(Vt, kb * 32 + 16 * s2, d * 32, lane), pf, oacc[d]);
+        for (int d = 0; d < DB; ++d) oacc[d] = MFMA_BF16(frag_tr<HDP>(Vt, kb * 32 + 16 * s2, d * 32, lane), pf, oacc[d]);
       }
   };
   for (int kt = 0; kt < nt; kt += ATT_STAGES) {
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   if (!active) return;
   const float inv = 1.f / l;
   const int b = bh / H, hh = bh % H;
-  store_rows_t<HD>(oacc, inv, smem + wave * 32 * (HD * 2 + 16), O + ((size_t)(b * N + q0) * H + hh) * HD, (long)H * HD, lane);
+  store_rows_t<HD>(oacc, inv, smem + wave * 32 * (HDP * 2 + 16), O + ((size_t)(b * N + q0) * H + hh) * HD, (long)H * HD, lane);
   if (h == 0) LSE[(size_t)bh * N + q0 + r] = (ms + log2f(l)) * 0.6931471805599453f;
 }
 
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
                                                                  const bf16* __restrict__ dO, const float* __restrict__ LSE,
                                                                  const float* __restrict__ DELTA, bf16* __restrict__ dK, bf16* __restrict__ dV,
                                                                  int H, int N, float scale) {
-  constexpr int KS = HD / 16, DB = HD / 32, TB = 64 * HD * 2;
+  constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q tile | dO tile | lse2[64] delta[64]]
   constexpr int BUF = 2 * TB + 1024;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -248,9 +266,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const size_t o = ((size_t)bh * N + min(k0 + r, N - 1)) * HD + ks * 16 + 8 * h;
-    kf[ks] = *(const bf16x8*)(K + o);
-    vf[ks] = *(const bf16x8*)(V + o);
+    const size_t o = ((size_t)bh * N + min(k0 + r, N - 1)) * HD;
+    kf[ks] = gfrag<HD>(K + o, ks * 16 + 8 * h);
+    vf[ks] = gfrag<HD>(V + o, ks * 16 + 8 * h);
   }
   f32x16 dkacc[DB], dvacc[DB];
 #pragma unroll
@@ -290,8 +308,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
       for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s = MFMA_BF16(frag_row<HD>(Qt, qb * 32, ks, lane), kf[ks], s);
-        dp = MFMA_BF16(frag_row<HD>(dOt, qb * 32, ks, lane), vf[ks], dp);
+        s = MFMA_BF16(frag_row<HDP>(Qt, qb * 32, ks, lane), kf[ks], s);
+        dp = MFMA_BF16(frag_row<HDP>(dOt, qb * 32, ks, lane), vf[ks], dp);
       }
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
@@ -305,8 +323,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
         const bf16x8 pf = acc_frag(s, s2), dsf = acc_frag(dp, s2);
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
-          dvacc[d] = MFMA_BF16(frag_tr<HD>(dOt, qb * 32 + 16 * s2, d * 32, lane), pf, dvacc[d]);
-          dkacc[d] = MFMA_BF16(frag_tr<HD>(Qt, qb * 32 + 16 * s2, d * 32, lane), dsf, dkacc[d]);
+          dvacc[d] = MFMA_BF16(frag_tr<HDP>(dOt, qb * 32 + 16 * s2, d * 32, lane), pf, dvacc[d]);
+          dkacc[d] = MFMA_BF16(frag_tr<HDP>(Qt, qb * 32 + 16 * s2, d * 32, lane), dsf, dkacc[d]);
         }
       }
     }
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   }
   __syncthreads();                                   // ring -> store scratch
   if (!active) return;
-  char* sw = smem + wave * 32 * (HD * 2 + 16);
+  char* sw = smem + wave * 32 * (HDP * 2 + 16);
   store_rows_t<HD>(dkacc, scale, sw, dK + ((size_t)bh * N + k0) * HD, HD, lane);
   store_rows_t<HD>(dvacc, 1.f, sw, dV + ((size_t)bh * N + k0) * HD, HD, lane);       // same wave, same scratch: LDS ops stay in order
 }
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
                                                                const bf16* __restrict__ O, const bf16* __restrict__ dO,
                                                                const float* __restrict__ LSE, float* __restrict__ DELTA,
                                                                bf16* __restrict__ dQ, int H, int N, float scale) {
-  constexpr int KS = HD / 16, DB = HD / 32, TB = 64 * HD * 2;
+  constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const float c = scale * 1.4426950408889634f;
@@ -347,10 +365,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   float dpart = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    qf[ks] = *(const bf16x8*)(Q + ((size_t)bh * N + qrow) * HD + ks * 16 + 8 * h);
-    const size_t oo = (((size_t)b * N + qrow) * H + hh) * HD + ks * 16 + 8 * h;
-    dof[ks] = *(const bf16x8*)(dO + oo);
-    const bf16x8 of = *(const bf16x8*)(O + oo);
+    qf[ks] = gfrag<HD>(Q + ((size_t)bh * N + qrow) * HD, ks * 16 + 8 * h);
+    const size_t oo = (((size_t)b * N + qrow) * H + hh) * HD;
+    dof[ks] = gfrag<HD>(dO + oo, ks * 16 + 8 * h);
+    const bf16x8 of = gfrag<HD>(O + oo, ks * 16 + 8 * h);
 #pragma unroll
     for (int j = 0; j < 8; ++j) dpart += (float)dof[ks][j] * (float)of[j];
   }
@@ -390,8 +408,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
       for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s = MFMA_BF16(frag_row<HD>(Kt, kb * 32, ks, lane), qf[ks], s);
-        dp = MFMA_BF16(frag_row<HD>(Vt, kb * 32, ks, lane), dof[ks], dp);
+        s = MFMA_BF16(frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], s);
+        dp = MFMA_BF16(frag_row<HDP>(Vt, kb * 32, ks, lane), dof[ks], dp);
       }
 #pragma unroll
       for (int t = 0; t < 16; ++t) dp[t] = EXP2(s[t] * c - lse2) * (dp[t] - dl);
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 dsf = acc_frag(dp, s2);
 #pragma unroll
-        for (int d = 0; d < DB; ++d) dqacc[d] = MFMA_BF16(frag_tr<HD>(Kt, kb * 32 + 16 * s2, d * 32, lane), dsf, dqacc[d]);
+        for (int d = 0; d < DB; ++d) dqacc[d] = MFMA_BF16(frag_tr<HDP>(Kt, kb * 32 + 16 * s2, d * 32, lane), dsf, dqacc[d]);
       }
     }
   };
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   }
   __syncthreads();                                   // ring -> store scratch
   if (!active) return;
-  store_rows_t<HD>(dqacc, scale, smem + wave * 32 * (HD * 2 + 16), dQ + ((size_t)bh * N + q0) * HD, HD, lane);
+  store_rows_t<HD>(dqacc, scale, smem + wave * 32 * (HDP * 2 + 16), dQ + ((size_t)bh * N + q0) * HD, HD, lane);
 }
 
 // ================================================================================================ f32 path (parity)
@@ -636,10 +654,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __res
 
 // ================================================================================================ C ABI
 #define ATTN_HD_DISPATCH(hd, MACRO) \
-  switch (hd) { case 64: MACRO(64); break; case 128: MACRO(128); break; default: LDMAE_FAIL(LDMAE_ERR_INVALID, "attention(bf16): head_dim %d unsupported (64, 128)", hd); }
+  switch (hd) { case 16: MACRO(16); break; case 32: MACRO(32); break; case 64: MACRO(64); break; case 72: MACRO(72); break; case 128: MACRO(128); break; \
+    default: LDMAE_FAIL(LDMAE_ERR_INVALID, "attention(bf16): head_dim %d unsupported (16, 32, 64, 72, 128)", hd); }
 #define ATTN_HD_DISPATCH_F32(hd, MACRO) \
   switch (hd) { case 16: MACRO(16); break; case 32: MACRO(32); break; case 64: MACRO(64); break; case 72: MACRO(72); break; case 128: MACRO(128); break; \
     default: LDMAE_FAIL(LDMAE_ERR_INVALID, "attention(f32): head_dim %d unsupported (16, 32, 64, 72, 128)", hd); }
+
+// dynamic LDS of the bf16 kernels: the K/V (Q/dO) ring, and at least the 4 per-wave store images that re-use it at the end
+static int attn_lds(int hd, int extra) {
+  const int hdp = hd_pad(hd), ring = ATT_STAGES * (2 * 64 * hdp * 2 + extra), scratch = 4 * 32 * (hdp * 2 + 16);
+  return ring > scratch ? ring : scratch;
+}
 
 static int attn_check(const char* who, int dtype, int B, int H, int N, int hd) {
   LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "%s: bad dtype %d", who, dtype);
@@ -656,7 +681,8 @@ extern "C" int ldmae_attention_fwd(int dtype, const void* q, const void* k, cons
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const float c = scale * 1.4426950408889634f;
   if (dtype == LDMAE_BF16) {
-#define L(HD) hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(grid), dim3(256), ATT_STAGES * 2 * 64 * HD * 2, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c)
+#define L(HD) hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c)
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {
@@ -682,8 +708,10 @@ extern "C" int ldmae_attention_bwd(int dtype, const void* q, const void* k, cons
   if (dtype == LDMAE_BF16) {
     // dQ first: it forms delta = rowsum(dO * O) from its own fragments and publishes it for the dK/dV kernel
 #define L(HD) { \
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), ATT_STAGES * 2 * 64 * HD * 2, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale); \
-    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), ATT_STAGES * (2 * 64 * HD * 2 + 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale); }
+    hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
+    hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale); \
+    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale); }
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {

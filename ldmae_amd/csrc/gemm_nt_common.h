@@ -188,7 +188,11 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
       const int mw = m0 + wm * TM;
       const bool inr = n < Hs;
       // h12 rows of strip i+1 are requested before the stores of strip i (see the note on vmcnt order below)
-      bf16x4 hv[MI + 1][4][2];
+#ifndef NT_HPF
+#define NT_HPF 1
+#endif
+      constexpr int HPF = NT_HPF;                   // h12 rows are requested HPF strips ahead of their use
+      bf16x4 hv[MI + HPF][4][2];
       auto ldh = [&](int i) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -206,7 +210,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
       if (sums) { *(float4*)exq = make_float4(0.f, 0.f, 0.f, 0.f); *(float4*)(exq + 64) = make_float4(0.f, 0.f, 0.f, 0.f); }
       auto strip = [&](int i, bool guard) {
         fill(i, cblk);
-        if (i + 1 < MI) ldh(i + 1);
+        if (i + HPF < MI) ldh(i + HPF);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int row = it * 4 + (lane >> 4), m = mw + i * 16 + row;
@@ -232,7 +236,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
           }
         }
       };
-      ldh(0);
+#pragma unroll
+      for (int i = 0; i < HPF; ++i) ldh(i);
       if (whole) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) strip(i, false);
@@ -277,7 +282,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
         const float* gp = e.gate + (size_t)(mw / e.rows_per_batch) * e.gate_ld + nb + c8;
         g0 = *(const float4*)gp; g1 = *(const float4*)(gp + 4);
       }
-      constexpr int XPF = 1;                         // residual rows are requested XPF strips ahead of their use
+#ifndef NT_XPF
+#define NT_XPF 1
+#endif
+      constexpr int XPF = NT_XPF;                    // residual rows are requested XPF strips ahead of their use
       float4 xi[MI + XPF][2][2];                     // fully unrolled: only XPF + 1 strips' worth are live at a time
       auto ldx = [&](int i) {
 #pragma unroll

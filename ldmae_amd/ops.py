@@ -233,23 +233,11 @@ def qknorm_rope_bwd(dq, dk, dv, qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6, wi
     return dqkv, dwq, dwk
 
 
-_BF16_ATTN_HD = (64, 128)           # head dims the bf16 MFMA attention kernels are instantiated for
-
-
-def _pad_hd(t, hdp):
-    """[..., hd] -> [..., hdp] zero-padded (zero q/k columns add 0 to every score, zero v/dO columns produce columns that are cut)."""
-    return torch.nn.functional.pad(t, (0, hdp - t.shape[-1])).contiguous()
-
-
 def attention_fwd(q, k, v, scale):
     """softmax(q k^T * scale) v.  q, k, v: [B,H,N,hd]; returns (o [B,N,H*hd], lse [B,H,N] f32).
-    bf16 with a head dim the MFMA kernels do not tile (LightningDiT-XL: hd = 72) runs zero-padded to 128 columns: same numbers,
-    1.8x the attention FLOPs of that configuration."""
+    bf16 head dims that are not a multiple of 32 (LightningDiT-XL: 72, VMAE: 16) are zero-padded to the next multiple of 32
+    INSIDE the kernels (LDS images and register fragments); HBM tensors keep the true head dim."""
     B, H, N, hd = q.shape
-    if q.dtype == torch.bfloat16 and hd not in _BF16_ATTN_HD:
-        assert hd < 128, f"bf16 attention: head_dim {hd} > 128 unsupported"
-        op, lse = attention_fwd(_pad_hd(q, 128), _pad_hd(k, 128), _pad_hd(v, 128), scale)
-        return op.view(B, N, H, 128)[..., :hd].reshape(B, N, H * hd), lse
     o = torch.empty(B, N, H * hd, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
     call("ldmae_attention_fwd", dt(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, H, N, hd, float(scale), stream())
@@ -258,13 +246,9 @@ def attention_fwd(q, k, v, scale):
 
 def attention_bwd(q, k, v, o, do, lse, scale):
     B, H, N, hd = q.shape
-    if q.dtype == torch.bfloat16 and hd not in _BF16_ATTN_HD:
-        pt = lambda t: _pad_hd(t.view(B, N, H, hd), 128).view(B, N, H * 128)
-        dq, dk, dv = attention_bwd(_pad_hd(q, 128), _pad_hd(k, 128), _pad_hd(v, 128), pt(o), pt(do.contiguous()), lse, scale)
-        return dq[..., :hd].contiguous(), dk[..., :hd].contiguous(), dv[..., :hd].contiguous()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     delta = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
-    call("ldmae_attention_bwd", dt(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(do), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta),
+    call("ldmae_attention_bwd", dt(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(_c(do)), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta),
          B, H, N, hd, float(scale), stream())
     return dq, dk, dv
 

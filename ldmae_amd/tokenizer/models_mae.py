@@ -4,8 +4,8 @@
 Hot path = masked-token ENCODER: patch-embed GEMM(+pos) -> ``random_masking`` (in-LDS stable sort, bit-exact) -> gather
 kept tokens -> 12 pre-LN ViT blocks (LayerNorm, qkv GEMM, flash attention on the kept subset, proj GEMM + residual,
 fc1 GEMM + exact GELU, fc2 GEMM + residual) -> LayerNorm.  Each block is one autograd Function (forward + backward
-kernel sequences).  head_dim is 16: the attention core runs on the exact-f32 MFMA kernel in both precision modes
-(the bf16 flash kernel is tiled for head_dim 64/128); GEMMs follow the autocast mode.
+kernel sequences).  head_dim is 16: under bf16 autocast the attention core is the bf16 flash kernel with the K/V images and
+fragments zero-padded to 32 columns in LDS / registers (attention.hip); in f32 mode everything runs on the exact-f32 MFMA path.
 The decoder / ``encode`` / ``decode`` / ``decode_to_images`` docking functions re-use the same block kernels
 (inference only for the RGB smoothing conv).  Unshipped variants (gradual_resol, down_nonlinear, cls token,
 pred_with_conv, perceptual loss) raise NotImplementedError.
@@ -64,10 +64,10 @@ class _ViTBlockFn(torch.autograd.Function):
         W1, W1T = _wcopies(f1w, dtype)
         W2, W2T = _wcopies(f2w, dtype)
         h1, mu1, rs1 = ops.layernorm_fwd(x2, n1w, n1b, dtype, eps)
-        qkv = ops.gemm_nt(h1, Wqkv, qkvb, out_dtype=torch.float32)            # attention core in f32 (head_dim 16)
+        qkv = ops.gemm_nt(h1, Wqkv, qkvb)                                     # activation dtype: bf16 under autocast
         q, k, v = ops.heads_split(qkv, B, N, H, hd)
-        o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)                        # [B,N,D] f32
-        oa = ops.cast(o.view(M, D), dtype)
+        o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)                        # [B,N,D]; bf16: the flash kernel, head_dim 16 padded to 32 in LDS
+        oa = o.view(M, D)
         xmid, _ = ops.gemm_nt_gate_res(oa, Wp, pb, x2, None, N, save_y=False)
         h2, mu2, rs2 = ops.layernorm_fwd(xmid, n2w, n2b, dtype, eps)
         act, pre = ops.gemm_nt_gelu(h2, W1, f1b)
@@ -94,9 +94,9 @@ class _ViTBlockFn(torch.autograd.Function):
         # attention branch
         dy1 = ops.cast(dx, dtype)
         dWp, dbp = ops.gemm_tn(dy1, oa, with_bias=True)
-        do = ops.gemm_nt(dy1, WpT, out_dtype=torch.float32)
+        do = ops.gemm_nt(dy1, WpT)
         dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
-        dqkv = ops.cast(ops.heads_merge(dq, dk, dv, B, N, H, hd), dtype)
+        dqkv = ops.heads_merge(dq, dk, dv, B, N, H, hd)
         dWqkv, dbqkv = ops.gemm_tn(dqkv, h1, with_bias=True)
         dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT), x2, n1w, mu1, rs1, dx)
         return (dx.view(B, N, D), None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
