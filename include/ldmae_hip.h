@@ -100,6 +100,13 @@ int ldmae_attention_fwd(int dtype, const void* q, const void* k, const void* v, 
 int ldmae_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
                         void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, void* stream);
 
+/* The same on the PACKED token-major qkv [B,N,3,H,hd] that the qkv Linear writes (bf16 only): the VMAE blocks have no QK-norm / RoPE
+ * between the Linear and the attention (models_mae.py:133-141), so q / k / v are read, and dq / dk / dv written, in place (no head-major
+ * relayout passes).  dqkv [B,N,3,H,hd]. */
+int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream);
+int ldmae_attention_bwd_qkv(int dtype, const void* qkv, const void* o, const void* do_, const float* lse, void* dqkv, float* delta,
+                            int B, int H, int N, int hd, float scale, void* stream);
+
 /* ---- SwiGLU (swiglu_ffn.py:34-35) ------------------------------------------------------------ */
 int ldmae_swiglu_fwd(int dtype, const void* h12, void* hid, int M, int Hs, void* stream);
 int ldmae_swiglu_bwd(int dtype, const void* dhid, const void* h12, void* dh12, int M, int Hs, void* stream);

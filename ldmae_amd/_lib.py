@@ -40,6 +40,8 @@ SIGNATURES = {
     "ldmae_qknorm_rope_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "ldmae_attention_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ldmae_attention_fwd_qkv": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ldmae_attention_bwd_qkv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_swiglu_fwd": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "ldmae_swiglu_bwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
     "ldmae_gate_bwd_workspace_bytes": (_l, [_i, _i, _i]),

@@ -128,9 +128,14 @@ __device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[hd_pad(HD) / 32
   }
 }
 
+// where q / k / v (and dq / dk / dv) live: element offsets of (batch b, head h, row n) = b * sb + h * sh + n * ld.
+// Head-major [B,H,N,hd]: sb = H*N*hd, sh = N*hd, ld = hd.  Packed token-major qkv [B,N,3,H,hd] (what the qkv Linear writes, used as is
+// by the VMAE blocks, which have no QK-norm / RoPE between the Linear and the attention): sb = N*3*H*hd, sh = hd, ld = 3*H*hd.
+struct QkvLayout { long sb, sh, ld; };
+
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
-                                                            bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c) {
+                                                            bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -138,12 +143,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = lid / qblocks, q0 = (lid % qblocks) * 128 + wave * 32;
   const bool active = q0 < N;
-  const bf16* qp = Q + (size_t)bh * N * HD;
-  const bf16* kp = K + (size_t)bh * N * HD;
-  const bf16* vp = V + (size_t)bh * N * HD;
+  const size_t hb = (size_t)(bh / H) * L.sb + (size_t)(bh % H) * L.sh;
+  const bf16* qp = Q + hb;
+  const bf16* kp = K + hb;
+  const bf16* vp = V + hb;
+  const long ld = L.ld;
   bf16x8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = gfrag<HD>(qp + (size_t)min(q0 + r, N - 1) * HD, ks * 16 + 8 * h);
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = gfrag<HD>(qp + (size_t)min(q0 + r, N - 1) * ld, ks * 16 + 8 * h);
   f32x16 oacc[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d)
@@ -154,8 +161,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   constexpr int PPW = 2 * (TB / 1024) / 4;
   auto stage = [&](int kt) {
     char* base = smem + (kt % ATT_STAGES) * 2 * TB;
-    stage_tile<HD, 64>(kp + (size_t)kt * 64 * HD, HD, 63, base, wave, lane);
-    stage_tile<HD, 64>(vp + (size_t)kt * 64 * HD, HD, 63, base + TB, wave, lane);
+    stage_tile<HD, 64>(kp + (size_t)kt * 64 * ld, ld, 63, base, wave, lane);
+    stage_tile<HD, 64>(vp + (size_t)kt * 64 * ld, ld, 63, base + TB, wave, lane);
   };
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)
@@ -249,7 +256,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                  const bf16* __restrict__ dO, const float* __restrict__ LSE,
                                                                  const float* __restrict__ DELTA, bf16* __restrict__ dK, bf16* __restrict__ dV,
-                                                                 int H, int N, float scale) {
+                                                                 int H, int N, float scale, QkvLayout L) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q tile | dO tile | lse2[64] delta[64]]
   constexpr int BUF = 2 * TB + 1024;
@@ -260,13 +267,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   const int bh = lid / kblocks, k0 = (lid % kblocks) * 128 + wave * 32;
   const bool active = k0 < N;
   const int b = bh / H, hh = bh % H;
-  const bf16* qp = Q + (size_t)bh * N * HD;
+  const size_t hb = (size_t)b * L.sb + (size_t)hh * L.sh;
+  const long ld = L.ld;
+  const bf16* qp = Q + hb;
   const bf16* dop = dO + ((size_t)b * N * H + hh) * HD;     // row stride H*HD
   const long dold = (long)H * HD;
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const size_t o = ((size_t)bh * N + min(k0 + r, N - 1)) * HD;
+    const size_t o = hb + (size_t)min(k0 + r, N - 1) * ld;
     kf[ks] = gfrag<HD>(K + o, ks * 16 + 8 * h);
     vf[ks] = gfrag<HD>(V + o, ks * 16 + 8 * h);
   }
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   const float* rowc = (wave & 1) ? DELTA + (size_t)bh * N : LSE + (size_t)bh * N;     // wave 0/2: lse, wave 1/3: delta
   auto stage = [&](int qt) {
     char* base = smem + (qt % ATT_STAGES) * BUF;
-    stage_tile<HD, 64>(qp + (size_t)qt * 64 * HD, HD, 63, base, wave, lane);
+    stage_tile<HD, 64>(qp + (size_t)qt * 64 * ld, ld, 63, base, wave, lane);
     stage_tile<HD, 64>(dop + (size_t)qt * 64 * dold, dold, 63, base + TB, wave, lane);
     // 64 floats of lse (slot 0) / delta (slot 1); waves 2,3 fill scratch slots so every wave issues PPW loads
     glds4(rowc + qt * 64 + lane, base + 2 * TB + wave * 256);
@@ -337,8 +346,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   __syncthreads();                                   // ring -> store scratch
   if (!active) return;
   char* sw = smem + wave * 32 * (HDP * 2 + 16);
-  store_rows_t<HD>(dkacc, scale, sw, dK + ((size_t)bh * N + k0) * HD, HD, lane);
-  store_rows_t<HD>(dvacc, 1.f, sw, dV + ((size_t)bh * N + k0) * HD, HD, lane);       // same wave, same scratch: LDS ops stay in order
+  store_rows_t<HD>(dkacc, scale, sw, dK + hb + (size_t)k0 * ld, ld, lane);
+  store_rows_t<HD>(dvacc, 1.f, sw, dV + hb + (size_t)k0 * ld, ld, lane);       // same wave, same scratch: LDS ops stay in order
 }
 
 // ================================================================================================ backward dQ, bf16
@@ -346,7 +355,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                const bf16* __restrict__ O, const bf16* __restrict__ dO,
                                                                const float* __restrict__ LSE, float* __restrict__ DELTA,
-                                                               bf16* __restrict__ dQ, int H, int N, float scale) {
+                                                               bf16* __restrict__ dQ, int H, int N, float scale, QkvLayout L) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -357,15 +366,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   const bool active = q0 < N;
   const int b = bh / H, hh = bh % H;
   const int qrow = min(q0 + r, N - 1);
-  const bf16* kp = K + (size_t)bh * N * HD;
-  const bf16* vp = V + (size_t)bh * N * HD;
+  const size_t hb = (size_t)b * L.sb + (size_t)hh * L.sh;
+  const long ld = L.ld;
+  const bf16* kp = K + hb;
+  const bf16* vp = V + hb;
   bf16x8 qf[KS], dof[KS];
   // delta_i = sum_d dO[i,d] * O[i,d] is formed here from the dO fragments this lane holds anyway (its half of the row; the other
   // half sits on lane ^ 32) and published for the dK/dV kernel, which runs after this one: no separate pass over O and dO.
   float dpart = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    qf[ks] = gfrag<HD>(Q + ((size_t)bh * N + qrow) * HD, ks * 16 + 8 * h);
+    qf[ks] = gfrag<HD>(Q + hb + (size_t)qrow * ld, ks * 16 + 8 * h);
     const size_t oo = (((size_t)b * N + qrow) * H + hh) * HD;
     dof[ks] = gfrag<HD>(dO + oo, ks * 16 + 8 * h);
     const bf16x8 of = gfrag<HD>(O + oo, ks * 16 + 8 * h);
@@ -384,8 +395,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   constexpr int PPW = 2 * (TB / 1024) / 4;
   auto stage = [&](int kt) {
     char* base = smem + (kt % ATT_STAGES) * 2 * TB;
-    stage_tile<HD, 64>(kp + (size_t)kt * 64 * HD, HD, 63, base, wave, lane);
-    stage_tile<HD, 64>(vp + (size_t)kt * 64 * HD, HD, 63, base + TB, wave, lane);
+    stage_tile<HD, 64>(kp + (size_t)kt * 64 * ld, ld, 63, base, wave, lane);
+    stage_tile<HD, 64>(vp + (size_t)kt * 64 * ld, ld, 63, base + TB, wave, lane);
   };
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   }
   __syncthreads();                                   // ring -> store scratch
   if (!active) return;
-  store_rows_t<HD>(dqacc, scale, smem + wave * 32 * (HDP * 2 + 16), dQ + ((size_t)bh * N + q0) * HD, HD, lane);
+  store_rows_t<HD>(dqacc, scale, smem + wave * 32 * (HDP * 2 + 16), dQ + hb + (size_t)q0 * ld, ld, lane);
 }
 
 // ================================================================================================ f32 path (parity)
@@ -673,19 +684,17 @@ static int attn_check(const char* who, int dtype, int B, int H, int N, int hd) {
   return LDMAE_OK;
 }
 
-extern "C" int ldmae_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N, int hd,
-                                   float scale, void* stream) {
-  LDMAE_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
-  if (int e = attn_check("attention_fwd", dtype, B, H, N, hd)) return e;
-  hipStream_t st = as_stream(stream);
+static int attention_fwd_core(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N, int hd,
+                              float scale, QkvLayout Lq, hipStream_t st) {
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const float c = scale * 1.4426950408889634f;
   if (dtype == LDMAE_BF16) {
 #define L(HD) hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c)
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq)
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {
+    LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd, "attention_fwd(f32): head-major q/k/v only");
 #define L(HD) { const size_t lds = (size_t)(128 + 64 + 64) * (HD + 1) * 4; \
     hipFuncSetAttribute((const void*)attn_fwd_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(attn_fwd_f32_kernel<HD>, dim3(grid), dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, H, N, c); }
@@ -696,12 +705,25 @@ extern "C" int ldmae_attention_fwd(int dtype, const void* q, const void* k, cons
   return LDMAE_OK;
 }
 
-extern "C" int ldmae_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
-                                   void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, void* stream) {
-  LDMAE_REQUIRE(q && k && v && o && do_ && lse && dq && dk && dv && delta, "attention_bwd: null pointer");
-  if (int e = attn_check("attention_bwd", dtype, B, H, N, hd)) return e;
-  LDMAE_REQUIRE(hd % 8 == 0, "attention_bwd: head_dim %d must be a multiple of 8", hd);
-  hipStream_t st = as_stream(stream);
+extern "C" int ldmae_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N, int hd,
+                                   float scale, void* stream) {
+  LDMAE_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
+  if (int e = attn_check("attention_fwd", dtype, B, H, N, hd)) return e;
+  return attention_fwd_core(dtype, q, k, v, o, lse, B, H, N, hd, scale, QkvLayout{(long)H * N * hd, (long)N * hd, (long)hd}, as_stream(stream));
+}
+
+extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream) {
+  LDMAE_REQUIRE(qkv && o && lse, "attention_fwd_qkv: null pointer");
+  LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_fwd_qkv: bf16 only (the f32 path takes head-major q/k/v)");
+  if (int e = attn_check("attention_fwd_qkv", dtype, B, H, N, hd)) return e;
+  LDMAE_REQUIRE(hd % 8 == 0, "attention_fwd_qkv: head_dim %d must be a multiple of 8", hd);
+  const bf16* p = (const bf16*)qkv;
+  const long hw = (long)H * hd;
+  return attention_fwd_core(dtype, p, p + hw, p + 2 * hw, o, lse, B, H, N, hd, scale, QkvLayout{(long)N * 3 * hw, (long)hd, 3 * hw}, as_stream(stream));
+}
+
+static int attention_bwd_core(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                              void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, QkvLayout Lq, hipStream_t st) {
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const long items = (long)B * N * H;
   const unsigned dgrid = (unsigned)((items * 8 + 255) / 256 < 8192 ? (items * 8 + 255) / 256 : 8192);
@@ -710,11 +732,12 @@ extern "C" int ldmae_attention_bwd(int dtype, const void* q, const void* k, cons
 #define L(HD) { \
     hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
     hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale); \
-    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale); }
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale, Lq); \
+    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, Lq); }
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {
+    LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd, "attention_bwd(f32): head-major q/k/v only");
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(dgrid), dim3(256), 0, st, (const float*)o, (const float*)do_, delta, B, H, N, hd);
 #define L(HD) { const size_t l1 = (size_t)(128 + 128 + 64 + 64) * (HD + 1) * 4 + 512; \
     hipFuncSetAttribute((const void*)attn_bwd_dkdv_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
@@ -726,4 +749,26 @@ extern "C" int ldmae_attention_bwd(int dtype, const void* q, const void* k, cons
   }
   LDMAE_CHECK_LAUNCH("attention_bwd");
   return LDMAE_OK;
+}
+
+extern "C" int ldmae_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
+                                   void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, void* stream) {
+  LDMAE_REQUIRE(q && k && v && o && do_ && lse && dq && dk && dv && delta, "attention_bwd: null pointer");
+  if (int e = attn_check("attention_bwd", dtype, B, H, N, hd)) return e;
+  LDMAE_REQUIRE(hd % 8 == 0, "attention_bwd: head_dim %d must be a multiple of 8", hd);
+  return attention_bwd_core(dtype, q, k, v, o, do_, lse, dq, dk, dv, delta, B, H, N, hd, scale,
+                            QkvLayout{(long)H * N * hd, (long)N * hd, (long)hd}, as_stream(stream));
+}
+
+extern "C" int ldmae_attention_bwd_qkv(int dtype, const void* qkv, const void* o, const void* do_, const float* lse, void* dqkv, float* delta,
+                                       int B, int H, int N, int hd, float scale, void* stream) {
+  LDMAE_REQUIRE(qkv && o && do_ && lse && dqkv && delta, "attention_bwd_qkv: null pointer");
+  LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_bwd_qkv: bf16 only");
+  if (int e = attn_check("attention_bwd_qkv", dtype, B, H, N, hd)) return e;
+  LDMAE_REQUIRE(hd % 8 == 0, "attention_bwd_qkv: head_dim %d must be a multiple of 8", hd);
+  const bf16* p = (const bf16*)qkv;
+  bf16* g = (bf16*)dqkv;
+  const long hw = (long)H * hd;
+  return attention_bwd_core(dtype, p, p + hw, p + 2 * hw, o, do_, lse, g, g + hw, g + 2 * hw, delta, B, H, N, hd, scale,
+                            QkvLayout{(long)N * 3 * hw, (long)hd, 3 * hw}, as_stream(stream));
 }

@@ -79,87 +79,169 @@ extern "C" int ldmae_scatter_rows(const float* dout, const long long* ids, float
   return LDMAE_OK;
 }
 
-// ------------------------------------------------------------------ LayerNorm (affine), one wave per row
-template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = from_f<T>(v); }
+// ------------------------------------------------------------------ LayerNorm (affine)
+// 16 lanes per row, 16 B per lane and access (float4 / 4 x bf16): a 256-thread workgroup streams 16 rows at a time.  A lane owns
+// the same columns {4 * (sub + 16 * i)} in every row it visits, so w / b live in registers and the dw / db partial sums of the
+// backward are per-lane register accumulators (reduced across the 16 row groups through LDS once per workgroup, fixed order).
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&v)[4]) { const float4 a = *(const float4*)p; v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+template <> __device__ __forceinline__ void ld4<bf16>(const bf16* p, float (&v)[4]) { const bf16x4 a = *(const bf16x4*)p; for (int j = 0; j < 4; ++j) v[j] = (float)a[j]; }
+template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+template <> __device__ __forceinline__ void st4<bf16>(bf16* p, const float (&v)[4]) { bf16x4 a; for (int j = 0; j < 4; ++j) a[j] = (bf16)v[j]; *(bf16x4*)p = a; }
 
-template <typename OutT>
+template <typename OutT, int NV>     // NV = ceil(D / 64): 16-B chunks per lane
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                             OutT* __restrict__ out, float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m = blockIdx.x * 4 + wave;
-  if (m >= M) return;
-  const float* xr = x + (size_t)m * D;
-  float s = 0.f;
-  for (int d = lane; d < D; d += 64) s += xr[d];
-  const float mu = wave_sum(s) / (float)D;
-  float v = 0.f;
-  for (int d = lane; d < D; d += 64) { const float c = xr[d] - mu; v += c * c; }
-  const float rs = rsqrtf(wave_sum(v) / (float)D + eps);
-  if (lane == 0) { if (mean) mean[m] = mu; if (rstd) rstd[m] = rs; }
-  for (int d = lane; d < D; d += 64) st1<OutT>(out + (size_t)m * D + d, (xr[d] - mu) * rs * w[d] + b[d]);
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  float wv[NV][4], bv[NV][4];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (sub + 16 * i);
+    if (c < D) { ld4<float>(w + c, wv[i]); ld4<float>(b + c, bv[i]); }
+  }
+  const float invD = 1.f / (float)D;
+  for (int m = blockIdx.x * 16 + grp; m < M; m += gridDim.x * 16) {
+    const float* xr = x + (size_t)m * D;
+    float xv[NV][4], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (sub + 16 * i);
+      if (c < D) { ld4<float>(xr + c, xv[i]); s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]); }
+    }
+    const float mu = group_sum<16>(s) * invD;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (4 * (sub + 16 * i) < D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float cdev = xv[i][j] - mu; v += cdev * cdev; }
+      }
+    const float rs = rsqrtf(group_sum<16>(v) * invD + eps);
+    if (sub == 0) { if (mean) mean[m] = mu; if (rstd) rstd[m] = rs; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (sub + 16 * i);
+      if (c < D) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (xv[i][j] - mu) * rs * wv[i][j] + bv[i][j];
+        st4<OutT>(out + (size_t)m * D + c, o);
+      }
+    }
+  }
 }
 
-// dx_accum += dLN/dx ; partial dw/db per workgroup (4 rows) -> reduced in fixed order
-template <typename T>
+// dx_accum += dLN/dx ; partial dw/db per workgroup -> reduced in fixed order by ln_reduce_kernel
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
                                                             float* __restrict__ P, int M, int D, int rows_per_wg) {
-  extern __shared__ float red[];   // [4][2][D]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 8 * D; i += 256) red[i] = 0.f;
-  __syncthreads();
-  float* rw = red + wave * 2 * D;
-  for (int r = wave; r < rows_per_wg; r += 4) {
-    const int m = blockIdx.x * rows_per_wg + r;
-    if (m >= M) break;
+  extern __shared__ float red[];   // [16 row groups][2][D]
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  float wv[NV][4], aw[NV][4], ab[NV][4];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (sub + 16 * i);
+    if (c < D) ld4<float>(w + c, wv[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { aw[i][j] = 0.f; ab[i][j] = 0.f; }
+  }
+  const float invD = 1.f / (float)D;
+  const int mend = min(M, (int)(blockIdx.x + 1) * rows_per_wg);
+  for (int m = blockIdx.x * rows_per_wg + grp; m < mend; m += 16) {
     const float mu = mean[m], rs = rstd[m];
     const float* xr = x + (size_t)m * D;
     const T* gr = dout + (size_t)m * D;
-    float s1 = 0.f, s2 = 0.f;
-    for (int d = lane; d < D; d += 64) {
-      const float g = to_f<T>(gr[d]), xh = (xr[d] - mu) * rs, gy = g * w[d];
-      s1 += gy; s2 += gy * xh;
-      rw[d] += g * xh; rw[D + d] += g;
+    float* dxr = dx + (size_t)m * D;
+    float g[NV][4], xh[NV][4], dxo[NV][4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (sub + 16 * i);
+      if (c < D) {
+        float xv[4];
+        ld4<T>(gr + c, g[i]); ld4<float>(xr + c, xv); ld4<float>(dxr + c, dxo[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[i][j] = (xv[j] - mu) * rs;
+          const float gy = g[i][j] * wv[i][j];
+          s1 += gy; s2 += gy * xh[i][j];
+          aw[i][j] += g[i][j] * xh[i][j]; ab[i][j] += g[i][j];
+        }
+      }
     }
-    s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
-    for (int d = lane; d < D; d += 64) {
-      const float g = to_f<T>(gr[d]), xh = (xr[d] - mu) * rs;
-      dx[(size_t)m * D + d] += rs * (g * w[d] - s1 - xh * s2);
+    s1 = group_sum<16>(s1) * invD; s2 = group_sum<16>(s2) * invD;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (sub + 16 * i);
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dxo[i][j] += rs * (g[i][j] * wv[i][j] - s1 - xh[i][j] * s2);
+        st4<float>(dxr + c, dxo[i]);
+      }
     }
   }
+  float* rw = red + grp * 2 * D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (sub + 16 * i);
+    if (c < D) { st4<float>(rw + c, aw[i]); st4<float>(rw + D + c, ab[i]); }
+  }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * D; i += 256)
-    P[(size_t)blockIdx.x * 2 * D + i] = (red[i] + red[2 * D + i]) + (red[4 * D + i] + red[6 * D + i]);
+  for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 16; ++gq) t += red[gq * 2 * D + i];
+    P[(size_t)blockIdx.x * 2 * D + i] = t;
+  }
 }
 
-__global__ void ln_reduce_kernel(const float* __restrict__ P, int G, int D, float* __restrict__ dw, float* __restrict__ db, float beta) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
-  float a = 0.f, c = 0.f;
-  for (int g = 0; g < G; ++g) { a += P[(size_t)g * 2 * D + d]; c += P[(size_t)g * 2 * D + D + d]; }
-  dw[d] = (beta != 0.f ? beta * dw[d] : 0.f) + a;
-  db[d] = (beta != 0.f ? beta * db[d] : 0.f) + c;
+// column sums of the G partial rows [G][2D] in fixed order: 4 row slices per 64-column block, combined through LDS
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ P, int G, int D, float* __restrict__ dw, float* __restrict__ db, float beta) {
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  float a = 0.f;
+  if (col < 2 * D)
+    for (int g = sl; g < G; g += 4) a += P[(size_t)g * 2 * D + col];
+  part[sl][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (sl == 0 && col < 2 * D) {
+    const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    float* dst = col < D ? dw + col : db + (col - D);
+    *dst = (beta != 0.f ? beta * *dst : 0.f) + t;
+  }
 }
 
-constexpr int LN_ROWS = 64;
+constexpr int LN_ROWS = 128;
+#define LN_NV_DISPATCH(D, MACRO) \
+  { const int nv_ = (D + 63) / 64; \
+    if (nv_ <= 3) MACRO(3) else if (nv_ <= 6) MACRO(6) else if (nv_ <= 12) MACRO(12) else MACRO(16) }
 extern "C" int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w, const float* b, void* out, float* mean, float* rstd,
                                    int M, int D, float eps, void* stream) {
-  LDMAE_REQUIRE(x && w && b && out && M > 0 && D > 0, "layernorm_fwd: bad arguments");
-  if (out_dtype == LDMAE_BF16) hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), x, w, b, (bf16*)out, mean, rstd, M, D, eps);
-  else hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), x, w, b, (float*)out, mean, rstd, M, D, eps);
+  LDMAE_REQUIRE(x && w && b && out && M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_fwd: bad arguments (D=%d: multiple of 4, <= 1024)", D);
+  const unsigned grid = cdiv(M, 16) < 4096 ? cdiv(M, 16) : 4096;
+#define LN_F(NV) { if (out_dtype == LDMAE_BF16) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, NV>), dim3(grid), dim3(256), 0, as_stream(stream), x, w, b, (bf16*)out, mean, rstd, M, D, eps); \
+                   else hipLaunchKernelGGL((layernorm_fwd_kernel<float, NV>), dim3(grid), dim3(256), 0, as_stream(stream), x, w, b, (float*)out, mean, rstd, M, D, eps); }
+  LN_NV_DISPATCH(D, LN_F);
+#undef LN_F
   LDMAE_CHECK_LAUNCH("layernorm_fwd");
   return LDMAE_OK;
 }
 extern "C" long ldmae_layernorm_bwd_workspace_bytes(int M, int D) { return (long)cdiv(M, LN_ROWS) * 2 * D * 4; }
 extern "C" int ldmae_layernorm_bwd(int dtype, const void* dout, const float* x, const float* w, const float* mean, const float* rstd,
                                    float* dx_accum, float* dw, float* db, float beta_w, int M, int D, float* workspace, void* stream) {
-  LDMAE_REQUIRE(dout && x && w && mean && rstd && dx_accum && dw && db && workspace && M > 0 && D > 0, "layernorm_bwd: bad arguments");
+  LDMAE_REQUIRE(dout && x && w && mean && rstd && dx_accum && dw && db && workspace && M > 0 && D > 0 && D % 4 == 0 && D <= 1024,
+                "layernorm_bwd: bad arguments (D=%d: multiple of 4, <= 1024)", D);
   hipStream_t st = as_stream(stream);
   const int G = cdiv(M, LN_ROWS);
-  const size_t lds = (size_t)8 * D * 4;
-  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(G), dim3(256), lds, st, (const bf16*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS);
-  else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(G), dim3(256), lds, st, (const float*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS);
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, workspace, G, D, dw, db, beta_w);
+  const size_t lds = (size_t)32 * D * 4;
+#define LN_B(NV) { if (dtype == LDMAE_BF16) { hipFuncSetAttribute((const void*)layernorm_bwd_kernel<bf16, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                     hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NV>), dim3(G), dim3(256), lds, st, (const bf16*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS); } \
+                   else { hipFuncSetAttribute((const void*)layernorm_bwd_kernel<float, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                     hipLaunchKernelGGL((layernorm_bwd_kernel<float, NV>), dim3(G), dim3(256), lds, st, (const float*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS); } }
+  LN_NV_DISPATCH(D, LN_B);
+#undef LN_B
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, st, workspace, G, D, dw, db, beta_w);
   LDMAE_CHECK_LAUNCH("layernorm_bwd");
   return LDMAE_OK;
 }

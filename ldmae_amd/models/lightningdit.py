@@ -108,8 +108,16 @@ class _PatchEmbedFn(torch.autograd.Function):
     """tokens @ W^T + b + pos_embed (timm PatchEmbed as used at :309,402 then + pos_embed)."""
 
     @staticmethod
-    def forward(ctx, tok, w2d, b, pos, T):
+    def forward(ctx, tok, w2d, b, pos, T, dtype=torch.float32):
         tok = tok.contiguous()
+        # under bf16 autocast the conv runs in bf16 (f32 accumulate, f32 output) like the reference's autocast conv2d; the bf16
+        # MFMA GEMM needs K = C*p*p to be a multiple of 64 (VMAE 8x8x3 = 192; the DiT's K = 16 stays on the f32 kernel)
+        lowp = dtype == torch.bfloat16 and tok.shape[1] % 64 == 0 and tok.shape[0] % 64 == 0
+        ctx.lowp = lowp
+        if lowp:
+            tok = ops.cast(tok, torch.bfloat16)
+            ctx.save_for_backward(tok, w2d)
+            return ops.gemm_nt_pos(tok, ops.cast(w2d.contiguous(), torch.bfloat16), b, pos, T)
         ctx.save_for_backward(tok, w2d)
         return ops.gemm_nt_pos(tok, w2d, b, pos, T)
 
@@ -118,7 +126,8 @@ class _PatchEmbedFn(torch.autograd.Function):
         tok, w2d = ctx.saved_tensors
         g = g.contiguous()
         dtok = ops.gemm_nt(g, ops.cast_weight(w2d, torch.float32, True, False)[1]) if ctx.needs_input_grad[0] else None
-        return dtok, ops.gemm_tn(g, tok), ops.colsum(g), None, None
+        dw = ops.gemm_tn(ops.cast(g, torch.bfloat16), tok) if ctx.lowp else ops.gemm_tn(g, tok)
+        return dtok, dw, ops.colsum(g), None, None, None
 
 
 def _dmod_times_w(dmod, adaw):
@@ -258,12 +267,13 @@ class PatchEmbed(nn.Module):
         x = x.float().reshape(B, C, Hh // p, p, Ww // p, p).permute(0, 2, 4, 1, 3, 5)
         return x.reshape(B * (Hh // p) * (Ww // p), C * p * p)
 
-    def forward(self, x, pos=None):
+    def forward(self, x, pos=None, dtype=None):
         B = x.shape[0]
         w2d = self.proj.weight.view(self.proj.weight.shape[0], -1)
         if pos is None:
             pos = torch.zeros(self.num_patches, w2d.shape[0], device=x.device)
-        return _PatchEmbedFn.apply(self.tokens(x), w2d, self.proj.bias, pos, self.num_patches).view(B, self.num_patches, -1)
+        return _PatchEmbedFn.apply(self.tokens(x), w2d, self.proj.bias, pos, self.num_patches,
+                                   dtype or torch.float32).view(B, self.num_patches, -1)
 
 
 class TimestepEmbedder(nn.Module):

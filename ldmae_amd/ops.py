@@ -253,6 +253,22 @@ def attention_bwd(q, k, v, o, do, lse, scale):
     return dq, dk, dv
 
 
+def attention_fwd_qkv(qkv, B, N, H, hd, scale):
+    """Attention straight on the packed token-major qkv [B*N, 3*H*hd] (bf16): no head-major relayout.  -> (o [B,N,H*hd], lse)."""
+    o = torch.empty(B, N, H * hd, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    call("ldmae_attention_fwd_qkv", dt(qkv.dtype), ptr(qkv), ptr(o), ptr(lse), B, H, N, hd, float(scale), stream())
+    return o, lse
+
+
+def attention_bwd_qkv(qkv, o, do, lse, B, N, H, hd, scale):
+    """-> dqkv [B*N, 3*H*hd] (dq / dk / dv written in the packed layout)."""
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    call("ldmae_attention_bwd_qkv", dt(qkv.dtype), ptr(qkv), ptr(o), ptr(_c(do)), ptr(lse), ptr(dqkv), ptr(delta), B, H, N, hd, float(scale), stream())
+    return dqkv
+
+
 def swiglu_fwd(h12):
     M, H2 = h12.shape
     hid = torch.empty(M, H2 // 2, dtype=h12.dtype, device=h12.device)

@@ -65,21 +65,26 @@ class _ViTBlockFn(torch.autograd.Function):
         W2, W2T = _wcopies(f2w, dtype)
         h1, mu1, rs1 = ops.layernorm_fwd(x2, n1w, n1b, dtype, eps)
         qkv = ops.gemm_nt(h1, Wqkv, qkvb)                                     # activation dtype: bf16 under autocast
-        q, k, v = ops.heads_split(qkv, B, N, H, hd)
-        o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)                        # [B,N,D]; bf16: the flash kernel, head_dim 16 padded to 32 in LDS
+        if dtype == torch.bfloat16:      # flash kernel on the packed qkv as the Linear wrote it (head_dim 16 padded to 32 in LDS)
+            q = k = v = None
+            o, lse = ops.attention_fwd_qkv(qkv, B, N, H, hd, hd ** -0.5)
+        else:
+            q, k, v = ops.heads_split(qkv, B, N, H, hd)
+            o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)                    # [B,N,D]
+            qkv = None
         oa = o.view(M, D)
         xmid, _ = ops.gemm_nt_gate_res(oa, Wp, pb, x2, None, N, save_y=False)
         h2, mu2, rs2 = ops.layernorm_fwd(xmid, n2w, n2b, dtype, eps)
         act, pre = ops.gemm_nt_gelu(h2, W1, f1b)
         xout, _ = ops.gemm_nt_gate_res(act, W2, f2b, xmid, None, N, save_y=False)
-        ctx.save_for_backward(x2, h1, mu1, rs1, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T)
+        ctx.save_for_backward(x2, h1, mu1, rs1, qkv, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T)
         ctx.dims = (B, N, D, H, hd, dtype)
         ctx.inplace = bool(inplace)
         return xout.view(B, N, D)
 
     @staticmethod
     def backward(ctx, gout):
-        x2, h1, mu1, rs1, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T = ctx.saved_tensors
+        x2, h1, mu1, rs1, qkv, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T = ctx.saved_tensors
         B, N, D, H, hd, dtype = ctx.dims
         M = B * N
         dx = gout.contiguous().view(M, D)
@@ -95,8 +100,11 @@ class _ViTBlockFn(torch.autograd.Function):
         dy1 = ops.cast(dx, dtype)
         dWp, dbp = ops.gemm_tn(dy1, oa, with_bias=True)
         do = ops.gemm_nt(dy1, WpT)
-        dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
-        dqkv = ops.heads_merge(dq, dk, dv, B, N, H, hd)
+        if qkv is not None:
+            dqkv = ops.attention_bwd_qkv(qkv, o, do, lse, B, N, H, hd, hd ** -0.5)
+        else:
+            dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
+            dqkv = ops.heads_merge(dq, dk, dv, B, N, H, hd)
         dWqkv, dbqkv = ops.gemm_tn(dqkv, h1, with_bias=True)
         dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT), x2, n1w, mu1, rs1, dx)
         return (dx.view(B, N, D), None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
@@ -309,8 +317,8 @@ class MaskedAutoencoderViT(nn.Module):
         ids_keep, mask, ids_restore = ops.random_masking(noise.float().contiguous(), len_keep)
         return _GatherFn.apply(x.float(), ids_keep), mask, ids_restore
 
-    def _embed(self, x):
-        return self.patch_embed(x, self.pos_embed[0])
+    def _embed(self, x, dtype=None):
+        return self.patch_embed(x, self.pos_embed[0], dtype)
 
     @staticmethod
     def _chain_ok(blk):
@@ -327,7 +335,7 @@ class MaskedAutoencoderViT(nn.Module):
         """:499-523."""
         dtype = _act_dtype(self.precision)
         with torch.autocast(device_type="cuda", enabled=False):
-            x = self._embed(x)
+            x = self._embed(x, dtype)
             x, mask, ids_restore = self.random_masking(x, mask_ratio, noise)
             for blk in self.blocks:
                 blk.precision = dtype
@@ -384,7 +392,7 @@ class MaskedAutoencoderViT(nn.Module):
     def _encode(self, x):
         dtype = _act_dtype(self.precision)
         with torch.autocast(device_type="cuda", enabled=False):
-            x = self._embed(x)
+            x = self._embed(x, dtype)
             for blk in self.blocks:
                 blk.precision = dtype
                 x = blk(x, self._chain_ok(blk))

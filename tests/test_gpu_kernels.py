@@ -227,6 +227,22 @@ def test_attention(ops, dtype, hd, N):
         assert rel_err(got.float().cpu(), ref) < (1e-4 if dtype == F32 else 3e-2)
 
 
+@pytest.mark.parametrize("hd,N", [(16, 256), (64, 128)])
+def test_attention_packed_qkv_equals_head_major(ops, hd, N):
+    """The VMAE path: flash attention straight on the packed token-major qkv [B,N,3,H,hd] (q / k / v read, dq / dk / dv written in
+    place) gives bitwise the results of the head-major path behind the relayout kernels."""
+    B, H = 2, 12
+    qkv = dev(rnd(B * N, 3 * H * hd, seed=1), BF16)
+    do = dev(rnd(B, N, H * hd, seed=2), BF16)
+    qh, kh, vh = ops.heads_split(qkv, B, N, H, hd)
+    o1, lse1 = ops.attention_fwd(qh, kh, vh, hd ** -0.5)
+    o2, lse2 = ops.attention_fwd_qkv(qkv, B, N, H, hd, hd ** -0.5)
+    assert torch.equal(o1, o2) and torch.equal(lse1, lse2)
+    dq, dk, dv = ops.attention_bwd(qh, kh, vh, o1, do, lse1, hd ** -0.5)
+    dqkv = ops.attention_bwd_qkv(qkv, o2, do, lse2, B, N, H, hd, hd ** -0.5)
+    assert torch.equal(dqkv, ops.heads_merge(dq, dk, dv, B, N, H, hd))
+
+
 def test_attention_softmax_rescale_branch(ops):
     """Force the running max to jump at a chosen key tile (guide rule 26): one huge score late in the sequence."""
     B, H, N, hd = 1, 1, 256, 64

@@ -14,11 +14,14 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--ratio", type=float, default=0.75)
+    ap.add_argument("--mode", default="both", choices=["both", "fp32", "bf16"])
     args = ap.parse_args()
     m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).cuda().eval()
     g = torch.Generator(device="cuda").manual_seed(0)
     x = (torch.rand(args.batch, 3, 256, 256, device="cuda", generator=g) * 2 - 1)
     for name, ctx in (("fp32", torch.autocast("cuda", enabled=False)), ("bf16 autocast", torch.autocast("cuda", dtype=torch.bfloat16))):
+        if args.mode != "both" and not name.startswith(args.mode):
+            continue
         with torch.no_grad(), ctx:
             for _ in range(3):
                 lat, mask, ids = m.forward_encoder(x, args.ratio)
