@@ -60,21 +60,37 @@ def train_step(model, opt, reducer, transport, x, y):
 
 
 def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC run (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate passes over this same bench, FETCH_SIZE doubled per the gfx950 note); None if the file is absent."""
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC run (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes over this same bench, FETCH_SIZE doubled per the gfx950 note).  Not measured in this run (PMC needs
+    rocprofv3 around the process): returns (bytes or None, source file or None)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                return round(json.load(fh)["gemm_nt"]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def cpu_model():
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_bench.json")) as f:
-            return round(json.load(f)["gemm_nt"]["hbm_bytes_per_launch"])
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
     except Exception:
-        return None
+        pass
+    return "unknown"
 
 
 def cpu_baseline(max_seconds=30.0):
-    """The CPU oracle (a port of the reference step; the reference itself cannot travel) on this box's host cores:
-    BASELINE config 1 -- LightningDiT-B/1, bs=4, fp32, AdamW + EMA, eager.  Bounded sample: 1 untimed + up to 3 timed steps."""
+    """The CPU oracle (a port of the reference step; the reference itself cannot travel) on this box's host cores, SURVEY 8(d):
+    BASELINE config 1 -- LightningDiT-B/1, bs=4, fp32, AdamW + EMA, eager, torch.set_num_threads(os.cpu_count()).
+    Bounded sample: 1 untimed step + as many timed steps (at most 8) as fit in `max_seconds` of CPU work."""
     from oracle import dit as odit, train as otrain
     cfg = odit.DiTConfig(**odit.DIT_B_1)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))       # a 1-GPU box's CPU share (16 cores)
+    torch.set_num_threads(os.cpu_count() or 1)
     torch.manual_seed(0)
     np.random.seed(0)
     sd = odit.init_weights(cfg)
@@ -83,7 +99,7 @@ def cpu_baseline(max_seconds=30.0):
             sd[k] = torch.randn(sd[k].shape) * 0.02
     times = []
     t_begin = time.perf_counter()
-    batches = [otrain.draw_batch(4, cfg) for _ in range(4)]
+    batches = [otrain.draw_batch(4, cfg) for _ in range(9)]
     keys = otrain.trainable_keys(cfg)
     st = otrain.AdamWState(keys, sd)
     ema = {k: sd[k].clone() for k in keys + ["pos_embed"]}
@@ -98,17 +114,188 @@ def cpu_baseline(max_seconds=30.0):
         if time.perf_counter() - t_begin > max_seconds and times:
             break
     sps = float(np.median(times))
-    return {"value": round(4.0 / sps, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"LightningDiT-B/1 bs=4 fp32 eager CPU step (fwd+bwd+AdamW+EMA), median of {len(times)} steps after 1 warm-up, "
-                      f"{sps:.2f} s/step, torch {torch.__version__} on {os.cpu_count()} visible CPUs"}
+    return {"value": round(4.0 / sps, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model(),
+            "sample": f"LightningDiT-B/1 bs=4 fp32 eager CPU step (fwd+bwd+AdamW+EMA), median of {len(times)} timed steps after 1 warm-up "
+                      f"(bounded to ~{max_seconds:.0f} s of CPU work), {sps:.2f} s/step, torch {torch.__version__}, "
+                      f"{torch.get_num_threads()} threads on {os.cpu_count()} visible CPUs"}
+
+
+def timed_loop(fn, steps, warmup, world):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, out
+
+
+def gemm_roofline(lib, fn, steps=2):
+    """Short profiled pass AFTER the timed region: every bf16 NT GEMM launch is bracketed by HIP events on its launch stream inside
+    the library (ldmae_prof_*); achieved = sum(2MNK) / sum(duration)."""
+    import ctypes as C
+    lib.ldmae_prof_enable(1)
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    lib.ldmae_prof_enable(0)
+    ms, fl, nl = C.c_double(), C.c_double(), C.c_long()
+    lib.ldmae_prof_collect(C.byref(ms), C.byref(fl), C.byref(nl))
+    tf = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+    traffic, src = measured_traffic()
+    return {"bound": "mfma", "kernel": "gemm_nt_persist_kernel (bf16 NT GEMM: every Linear fwd + dX)",
+            "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": (src + " (committed rocprofv3 --pmc run of this bench; not re-measured in this process)") if src else None,
+            "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4),
+            "avg_launch_gflop": round(fl.value / max(1, nl.value) / 1e9, 2),
+            "measured": f"{steps} profiled steps after the timed region (HIP events per launch on the launch stream)"}
+
+
+def bench_dit(args, world, rank, device, lib, backend):
+    model, opt, reducer, transport = build(device, args.batch)
+    seed = 0 * world + rank                      # inference.py:87 convention
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    x = torch.randn(args.batch, 16, 32, 32, device=device)     # latents are channel-normalised -> N(0,1) (img_latent_dataset.py:86-88)
+    y = torch.randint(0, 1000, (args.batch,), device=device)
+    step = lambda: train_step(model, opt, reducer, transport, x, y)
+    for _ in range(min(2, args.warmup)):
+        step()
+    reducer.exposed_comm_ms()                                  # drop warm-up samples
+    elapsed, loss = timed_loop(step, args.steps, max(0, args.warmup - 2), world)
+    exposed = reducer.exposed_comm_ms() / max(1, args.steps + max(0, args.warmup - 2))
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item())
+    if not np.isfinite(final_loss):
+        raise RuntimeError("non-finite loss in bench")
+    roof = gemm_roofline(lib, step)
+    if rank != 0:
+        return None
+    ips = args.batch * world * args.steps / elapsed
+    out = {
+        "metric": METRIC, "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "LightningDiT-B/1 f8d16 bf16 train step (fwd+bwd+AdamW+EMA), 1024 tokens x 768, synthetic ImageNet-256 "
+                               "latents 32x32x16", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                   "parallelism": f"dp{world}", "loss": round(final_loss, 5)},
+        "step_mfma_frac": round(FLOPS_PER_IMAGE * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "roofline": roof,
+    }
+    if world > 1:
+        out["comm"] = {"backend": "rccl" if backend == "nccl" else backend, "rccl_ranks": world if backend == "nccl" else 0,
+                       "grad_bytes_per_step": int(opt.flat.n_trainable) * 4, "buckets": len(reducer.buckets),
+                       "exposed_comm_ms_per_step_rank0": round(exposed, 3),
+                       "gemm_launch_mode": "one tile per workgroup" if lib.ldmae_tune_query(8) == 2 else "persistent"}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    return out
+
+
+def bench_vmae(args, world, rank, device, lib):
+    """BASELINE config 4: VMAE masked-token encoder (mae_for_ldmae_f8d16_prev, mask_ratio 0.75) on 256x256 random images, bf16 autocast,
+    forward_encoder (patch-embed -> random_masking -> gather -> 12 blocks on the kept tokens -> LayerNorm).  Replicas only for N > 1."""
+    from ldmae_amd.tokenizer import models_mae
+    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).to(device).eval()
+    g = torch.Generator(device=device).manual_seed(rank)
+    x = torch.rand(args.batch, 3, 256, 256, device=device, generator=g) * 2 - 1
+    noise = torch.rand(args.batch, 1024, device=device, generator=g)
+
+    def step():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return m.forward_encoder(x, 0.75, noise=noise)[0]
+    elapsed, lat = timed_loop(step, args.steps, args.warmup, world)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return None
+    kept = lat.shape[1]
+    ips = args.batch * world * args.steps / elapsed
+    flops = 3.395e9                      # SURVEY 8(d): 3.32 GFLOP/sample encoder @ keep 256 + 0.075 patch embed
+    # algorithmic HBM bytes per image if every block were perfectly fused (residual f32 in/out per branch, qkv + attention out + hidden
+    # bf16 written and read once): 12 * 256 tokens * (4*192*4 + (576+192+768)*2*2) B + the image itself
+    abytes = 12 * 256 * (4 * 192 * 4 + (576 + 192 + 768) * 2 * 2) + 3 * 256 * 256 * 4
+    return {
+        "metric": "VMAE encoder kept-tokens/sec (mask_ratio 0.75, 256x256 images) on MI355X", "value": round(ips * kept, 1), "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "images_per_s": round(ips, 1),
+        "config": {"workload": "VMAE mae_for_ldmae_f8d16_prev forward_encoder, mask_ratio 0.75, 256x256x3 random images (BASELINE config 4)",
+                   "per_gpu_batch": args.batch, "kept_tokens_per_image": int(kept), "parallelism": f"replicas{world}"},
+        "roofline": {"bound": "hbm", "kernel": "whole forward_encoder step (width 192 / head_dim 16: every kernel is HBM- or latency-bound)",
+                     "achieved": round(abytes * ips / world / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(abytes * ips / world / 8e12, 4), "traffic": None,
+                     "algorithmic_bytes_per_image": abytes, "mfma_frac_of_peak": round(flops * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4)},
+    }
+
+
+def bench_xl_sample(args, world, rank, device, lib):
+    """BASELINE config 5 kernel reuse: LightningDiT-XL/1 (depth 28, width 1152, 16 heads, head_dim 72) CFG forward in bf16, inference
+    only.  One step = one forward_with_cfg on a doubled batch (what every Euler step of run_inference.sh costs; 250 of them per image)."""
+    from ldmae_amd.models.lightningdit import LightningDiT_models
+    n = args.batch if args.batch != 256 else 64                  # per-GPU images per sampling batch (doubled for CFG)
+    model = LightningDiT_models["LightningDiT-XL/1"](input_size=32, num_classes=1000, use_qknorm=True, use_swiglu=True, use_rope=True,
+                                                      use_rmsnorm=True, wo_shift=False, in_channels=16, class_dropout_prob=0.1)
+    gsd = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for nm, p in model.named_parameters():
+            if "adaLN_modulation" in nm or nm.startswith("final_layer.linear"):
+                p.copy_(torch.randn(p.shape, generator=gsd) * 0.02)
+    model = model.to(device).eval()
+    g = torch.Generator(device=device).manual_seed(rank)
+    z = torch.randn(n, 16, 32, 32, device=device, generator=g)
+    z = torch.cat([z, z], 0)
+    y = torch.cat([torch.randint(0, 1000, (n,), device=device, generator=g), torch.full((n,), 1000, device=device)], 0)
+    t = torch.full((2 * n,), 0.5, device=device)
+
+    def step():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return model.forward_with_cfg(z, t, y, 10.0, True, 0.10)
+    elapsed, out = timed_loop(step, args.steps, args.warmup, world)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if not bool(torch.isfinite(out).all()):
+        raise RuntimeError("non-finite XL output")
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    fl = 1049.04e9 * 2 * n                                    # SURVEY 8(d): 1049.04 GFLOP per sample forward
+    return {
+        "metric": "LightningDiT-XL/1 CFG sampling samples/sec (Euler 250 steps) on MI355X", "value": round(n * world / (250 * ms / 1e3), 3),
+        "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "LightningDiT-XL/1 f8d16 bf16 forward_with_cfg (cfg 10.0, interval 0.10) on a doubled batch; samples/s "
+                               "implied for 250 Euler steps (BASELINE config 5, inference-only kernel reuse)",
+                   "per_gpu_images": n, "cfg_batch": 2 * n, "parallelism": f"replicas{world}"},
+        "roofline": {"bound": "mfma", "kernel": "whole CFG forward (algorithmic 1049.04 GFLOP per sample)", "achieved": round(fl / (ms / 1e3) / 1e12, 1),
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (ms / 1e3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None},
+    }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
+    ap.add_argument("--workload", default="dit", choices=["dit", "vmae", "xl_sample"],
+                    help="dit = the headline train step (BASELINE config 2/3); vmae = config 4 encoder; xl_sample = config 5 CFG forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -131,60 +318,13 @@ def main():
 
     from ldmae_amd import _lib
     lib = _lib.load()
-    model, opt, reducer, transport = build(device, args.batch)
-    seed = 0 * world + rank                      # inference.py:87 convention
-    torch.manual_seed(seed)
-    np.random.seed(seed)
-    x = torch.randn(args.batch, 16, 32, 32, device=device)     # latents are channel-normalised -> N(0,1) (img_latent_dataset.py:86-88)
-    y = torch.randint(0, 1000, (args.batch,), device=device)
-
-    for _ in range(args.warmup):
-        train_step(model, opt, reducer, transport, x, y)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    lib.ldmae_prof_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step(model, opt, reducer, transport, x, y)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    lib.ldmae_prof_enable(0)
-    import ctypes as C
-    ms, fl, nl = C.c_double(), C.c_double(), C.c_long()
-    lib.ldmae_prof_collect(C.byref(ms), C.byref(fl), C.byref(nl))
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    final_loss = float(loss.item())
-    if not np.isfinite(final_loss):
-        raise RuntimeError("non-finite loss in bench")
-
+    if args.workload == "dit":
+        out = bench_dit(args, world, rank, device, lib, backend)
+    elif args.workload == "vmae":
+        out = bench_vmae(args, world, rank, device, lib)
+    else:
+        out = bench_xl_sample(args, world, rank, device, lib)
     if rank == 0:
-        ips = args.batch * world * args.steps / elapsed
-        gemm_tflops = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
-        out = {
-            "metric": METRIC, "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "LightningDiT-B/1 f8d16 bf16 train step (fwd+bwd+AdamW+EMA), 1024 tokens x 768, synthetic ImageNet-256 "
-                                   "latents 32x32x16", "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}", "loss": round(final_loss, 5)},
-            "step_mfma_frac": round(FLOPS_PER_IMAGE * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_persist_kernel (bf16 NT GEMM: every Linear fwd + dX)",
-                         "achieved": round(gemm_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": measured_traffic(),
-                         "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_bench.json)",
-                         "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4),
-                         "avg_launch_gflop": round(fl.value / max(1, nl.value) / 1e9, 2)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

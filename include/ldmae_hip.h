@@ -9,9 +9,12 @@
  *
  * Conventions
  *  - plain device pointers + explicit sizes, no torch types; `stream` is a hipStream_t (NULL = default).
- *  - every call only ENQUEUES on `stream`: no allocation, no synchronisation, no global mutable state
- *    (callable from the Python main thread and the autograd thread concurrently).  Workspaces are
- *    caller-owned.
+ *  - every call only ENQUEUES on `stream`: no allocation, no synchronisation; compute entry points keep no state
+ *    between calls and are callable from the Python main thread and the autograd thread concurrently.
+ *    Workspaces are caller-owned.  The only process-wide mutable state is diagnostic and opt-in: the A/B knobs of
+ *    ldmae_tune() (plain ints read at launch time; 0 = shipped behaviour), the event list of the ldmae_prof_*
+ *    timing hook (mutex-protected, off by default) and the stamp buffer of ldmae_debug_nt_stamps(); per-device
+ *    launch attributes (CU count, dynamic-LDS opt-in) are looked up per call.
  *  - return 0 on success, negative on error; ldmae_last_error() gives the thread-local message.
  *  - dtype codes select the activation type: LDMAE_F32 (parity path, exact-f32 MFMA) or LDMAE_BF16
  *    (throughput path, bf16 MFMA with f32 accumulation).  Residual stream, norms' statistics,
@@ -162,6 +165,7 @@ int ldmae_prof_collect(double* total_ms, double* total_flops, long* launches);  
 
 /* kernel-variant selection for tuning / A-B measurements (key 0: bf16 NT GEMM variant, key 1: bf16 TN GEMM variant) */
 int ldmae_tune(int key, int value);
+int ldmae_tune_query(int key);   /* current value of a knob (0 = shipped default) */
 /* diagnostic: device buffer (>= 64 B x 256 workgroups x tiles-per-workgroup) that receives s_memrealtime stamps of the
    persistent NT GEMM (tile start / main loop end / epilogue issued / stores drained); NULL (default) = off */
 void ldmae_debug_nt_stamps(void* buf);

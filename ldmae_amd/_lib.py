@@ -63,6 +63,7 @@ SIGNATURES = {
     "ldmae_gelu_bwd": (_i, [_i, _vp, _vp, _vp, _l, _vp]),
     "ldmae_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_tune": (_i, [_i, _i]),
+    "ldmae_tune_query": (_i, [_i]),
     "ldmae_debug_nt_stamps": (None, [_vp]),
     "ldmae_prof_enable": (_i, [_i]),
     "ldmae_prof_collect": (_i, [C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),

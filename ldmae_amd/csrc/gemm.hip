@@ -626,8 +626,9 @@ template <typename OutT>
 static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
                      hipStream_t st) {
   const long pi = (ldmae_prof_is_on() && dtype == LDMAE_BF16) ? ldmae_prof_begin(st, 2.0 * M * N * K) : -1;
-  static int ncu = 0;
-  if (ncu == 0) {
+  // per call and per device (a process may drive several GPUs; the query is a cached driver attribute, ~100 ns)
+  int ncu = 0;
+  {
     int dev = 0, n = 0;
     hipGetDevice(&dev);
     hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -654,16 +655,10 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
 #define PERS(E)                                                                                                                  \
   {                                                                                                                               \
     constexpr int lds = 3 * 512 * 64 + 8 * 16 * 68 * 4;                                                                           \
-    static bool attr_done = false;                                                                                                 \
-    if (!attr_done) {                                                                                                              \
-      PERS_ATTR(3, E, OutT);                                                                              \
-      if (E == LDMAE_EPI_BIAS) PERS_ATTR(3, LDMAE_EPI_BIAS, OutT, true);            \
-      if (E == LDMAE_EPI_SWIGLU) PERS_ATTR(3, LDMAE_EPI_SWIGLU, OutT, true);                                                        \
-      attr_done = true;                                                                                                            \
-    }                                                                                                                              \
-    if (E == LDMAE_EPI_BIAS && ldmae_tune_get(7) == 1) PERS_GO(3, LDMAE_EPI_BIAS, OutT, true);                             \
-    else if (E == LDMAE_EPI_SWIGLU && ldmae_tune_get(7) == 1) PERS_GO(3, LDMAE_EPI_SWIGLU, OutT, true);                             \
-    else PERS_GO(3, E, OutT);                                                                                                      \
+    /* the LDS opt-in is per device and cheap: set it at every launch (no process-wide "done" flag) */                            \
+    if (E == LDMAE_EPI_BIAS && ldmae_tune_get(7) == 1) { PERS_ATTR(3, LDMAE_EPI_BIAS, OutT, true); PERS_GO(3, LDMAE_EPI_BIAS, OutT, true); }     \
+    else if (E == LDMAE_EPI_SWIGLU && ldmae_tune_get(7) == 1) { PERS_ATTR(3, LDMAE_EPI_SWIGLU, OutT, true); PERS_GO(3, LDMAE_EPI_SWIGLU, OutT, true); } \
+    else { PERS_ATTR(3, E, OutT); PERS_GO(3, E, OutT); }                                                                          \
   }
 #define NT_LAUNCH(E)                                                                                                             \
   if (dtype == LDMAE_BF16) PERS(E)                                                                                                \
@@ -772,13 +767,9 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   float* Pb = workspace + (size_t)splits * N * K;
   if (ring) {
     constexpr int lds = 5 * 32768;   // ring (4 x 32 KiB) and the 139 KiB epilogue region share it
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_done = true;
-    }
+    if (ldmae_tune_get(4) == 3) hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else if (ldmae_tune_get(4) == 4) hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const unsigned grid = cdiv(N, 256) * cdiv(K, 256) * splits;
     // default: 8 waves (128x64 each), 4-deep ring, the two wave groups half a step apart (1115-1135 TF/s with the fused bias
     // gradient vs 965-1030 for 16 lock-step waves); tune key 4: 3 = 16 lock-step waves, 4 = 16 staggered waves.

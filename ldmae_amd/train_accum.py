@@ -99,9 +99,15 @@ def make_loader(cfg, per_gpu, rank, world, synthetic):
 
 def do_train(cfg, synthetic=False, max_steps=None, precision=None):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    # LDMAE_DIST_BACKEND=gloo + LDMAE_DEVICE=0: several ranks share ONE GPU (rehearsal of the multi-rank launch on a 1-GPU box)
+    backend = os.environ.get("LDMAE_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("LDMAE_DEVICE", local))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     tr_cfg = cfg['train']
@@ -112,7 +118,8 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
     if world > 1:
         dist.barrier()
     logger = create_logger(exp_dir, rank)
-    precision = precision or os.environ.get("PRECISION", "bf16")
+    precision = precision or os.environ.get("PRECISION") or os.environ.get("ACCELERATE_MIXED_PRECISION") or "bf16"
+    precision = {"no": "fp32"}.get(precision, precision)
 
     model = build_model(cfg)
     if 'weight_init' in tr_cfg:

@@ -91,9 +91,11 @@ def test_gemm_nt_persistent_multi_tile_ragged(ops):
     w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(BF16)
     bias = torch.randn(N, device="cuda", generator=g)
     ref = a.float() @ w.float().T + bias
+    outs = {}
     for mode in (0, 2):
         _lib.load().ldmae_tune(8, mode)
         out = ops.gemm_nt(a, w, bias)
+        outs[mode] = out
         assert rel_err(out.float().cpu(), ref.cpu()) < TOL[BF16]
         assert torch.equal(out[-1].float(), ops.gemm_nt(a[-1:].contiguous().expand(8, K).contiguous(), w, bias)[0].float())
         xin = torch.randn(M, N, device="cuda", generator=g)
@@ -102,6 +104,7 @@ def test_gemm_nt_persistent_multi_tile_ragged(ops):
         assert torch.equal(y, out)
         assert rel_err(xo.cpu(), (xin + gate.repeat_interleave(T, 0) * ref).cpu()) < 1e-5      # residual uses the unrounded f32 product
     _lib.load().ldmae_tune(8, 0)
+    assert torch.equal(outs[0], outs[2])             # persistent and one-tile-per-workgroup launches (the multi-rank mode): bitwise equal
     Hs = 1280                                        # N = 2560 = 10 tile columns, 420 tiles
     w12 = (torch.randn(2 * Hs, K, device="cuda", generator=g) * K ** -0.5).to(BF16)
     b12 = torch.randn(2 * Hs, device="cuda", generator=g)
