@@ -86,7 +86,9 @@ int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const float* x, cons
 
 /* ---- attention front end (lightningdit.py:68-74; rmsnorm.py on head_dim; pos_embed.py:38-42,135) */
 /* qkv [B,N,3,H,hd] -> q,k = rope(rmsnorm(.)*w) and v, each [B,H,N,hd]. cos/sin [N,hd] f32.
- * wq = wk = cos = sin = NULL: plain head-major relayout (VMAE attention has no QK-norm / RoPE, models_mae.py:133-134). */
+ * wq = wk = cos = sin = NULL: plain head-major relayout (VMAE attention has no QK-norm / RoPE, models_mae.py:133-134).
+ * v = NULL (fwd) / dv = NULL (bwd), norm + rope form only: v stays in the packed buffer (see ldmae_attention_fwd_pv / _bwd_pv);
+ * the backward then reads dv from the v slot of dqkv for the bias-gradient sums and leaves it in place. */
 int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq, const float* wk, const float* cos, const float* sin,
                           void* q, void* k, void* v, int B, int N, int H, int hd, float eps, void* stream);
 long ldmae_qknorm_rope_bwd_workspace_bytes(int B, int N, int H, int hd);
@@ -109,6 +111,14 @@ int ldmae_attention_bwd(int dtype, const void* q, const void* k, const void* v, 
 int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream);
 int ldmae_attention_bwd_qkv(int dtype, const void* qkv, const void* o, const void* do_, const float* lse, void* dqkv, float* delta,
                             int B, int H, int N, int hd, float scale, void* stream);
+
+/* Mixed form for the LightningDiT block (bf16 only): q / k (dq / dk) head-major as QK-norm + RoPE produce them, v read from -- and dv
+ * written into -- the v slot of the packed token-major qkv / dqkv [B,N,3,H,hd].  Pair with ldmae_qknorm_rope_fwd(v = NULL) and
+ * ldmae_qknorm_rope_bwd(dv = NULL): v never gets a head-major copy. */
+int ldmae_attention_fwd_pv(int dtype, const void* q, const void* k, const void* qkv, void* o, float* lse, int B, int H, int N, int hd,
+                           float scale, void* stream);
+int ldmae_attention_bwd_pv(int dtype, const void* q, const void* k, const void* qkv, const void* o, const void* do_, const float* lse,
+                           void* dq, void* dk, void* dqkv, float* delta, int B, int H, int N, int hd, float scale, void* stream);
 
 /* ---- SwiGLU (swiglu_ffn.py:34-35) ------------------------------------------------------------ */
 int ldmae_swiglu_fwd(int dtype, const void* h12, void* hid, int M, int Hs, void* stream);

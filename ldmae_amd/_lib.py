@@ -42,6 +42,8 @@ SIGNATURES = {
     "ldmae_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_attention_fwd_qkv": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_attention_bwd_qkv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ldmae_attention_fwd_pv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ldmae_attention_bwd_pv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_swiglu_fwd": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "ldmae_swiglu_bwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
     "ldmae_gate_bwd_workspace_bytes": (_l, [_i, _i, _i]),

@@ -135,7 +135,7 @@ struct QkvLayout { long sb, sh, ld; };
 
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
-                                                            bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L) {
+                                                            bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L, QkvLayout Lv) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   const size_t hb = (size_t)(bh / H) * L.sb + (size_t)(bh % H) * L.sh;
   const bf16* qp = Q + hb;
   const bf16* kp = K + hb;
-  const bf16* vp = V + hb;
-  const long ld = L.ld;
+  const bf16* vp = V + (size_t)(bh / H) * Lv.sb + (size_t)(bh % H) * Lv.sh;
+  const long ld = L.ld, ldv = Lv.ld;
   bf16x8 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) qf[ks] = gfrag<HD>(qp + (size_t)min(q0 + r, N - 1) * ld, ks * 16 + 8 * h);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   auto stage = [&](int kt) {
     char* base = smem + (kt % ATT_STAGES) * 2 * TB;
     stage_tile<HD, 64>(kp + (size_t)kt * 64 * ld, ld, 63, base, wave, lane);
-    stage_tile<HD, 64>(vp + (size_t)kt * 64 * ld, ld, 63, base + TB, wave, lane);
+    stage_tile<HD, 64>(vp + (size_t)kt * 64 * ldv, ldv, 63, base + TB, wave, lane);
   };
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)
@@ -256,7 +256,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                  const bf16* __restrict__ dO, const float* __restrict__ LSE,
                                                                  const float* __restrict__ DELTA, bf16* __restrict__ dK, bf16* __restrict__ dV,
-                                                                 int H, int N, float scale, QkvLayout L) {
+                                                                 int H, int N, float scale, QkvLayout L, QkvLayout Lv) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q tile | dO tile | lse2[64] delta[64]]
   constexpr int BUF = 2 * TB + 1024;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   const int bh = lid / kblocks, k0 = (lid % kblocks) * 128 + wave * 32;
   const bool active = k0 < N;
   const int b = bh / H, hh = bh % H;
-  const size_t hb = (size_t)b * L.sb + (size_t)hh * L.sh;
+  const size_t hb = (size_t)b * L.sb + (size_t)hh * L.sh, hbv = (size_t)b * Lv.sb + (size_t)hh * Lv.sh;
   const long ld = L.ld;
   const bf16* qp = Q + hb;
   const bf16* dop = dO + ((size_t)b * N * H + hh) * HD;     // row stride H*HD
@@ -275,9 +275,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const size_t o = hb + (size_t)min(k0 + r, N - 1) * ld;
-    kf[ks] = gfrag<HD>(K + o, ks * 16 + 8 * h);
-    vf[ks] = gfrag<HD>(V + o, ks * 16 + 8 * h);
+    kf[ks] = gfrag<HD>(K + hb + (size_t)min(k0 + r, N - 1) * ld, ks * 16 + 8 * h);
+    vf[ks] = gfrag<HD>(V + hbv + (size_t)min(k0 + r, N - 1) * Lv.ld, ks * 16 + 8 * h);
   }
   f32x16 dkacc[DB], dvacc[DB];
 #pragma unroll
@@ -347,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   if (!active) return;
   char* sw = smem + wave * 32 * (HDP * 2 + 16);
   store_rows_t<HD>(dkacc, scale, sw, dK + hb + (size_t)k0 * ld, ld, lane);
-  store_rows_t<HD>(dvacc, 1.f, sw, dV + hb + (size_t)k0 * ld, ld, lane);       // same wave, same scratch: LDS ops stay in order
+  store_rows_t<HD>(dvacc, 1.f, sw, dV + hbv + (size_t)k0 * Lv.ld, Lv.ld, lane);       // same wave, same scratch: LDS ops stay in order
 }
 
 // ================================================================================================ backward dQ, bf16
@@ -355,7 +354,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                const bf16* __restrict__ O, const bf16* __restrict__ dO,
                                                                const float* __restrict__ LSE, float* __restrict__ DELTA,
-                                                               bf16* __restrict__ dQ, int H, int N, float scale, QkvLayout L) {
+                                                               bf16* __restrict__ dQ, int H, int N, float scale, QkvLayout L, QkvLayout Lv) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -367,9 +366,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   const int b = bh / H, hh = bh % H;
   const int qrow = min(q0 + r, N - 1);
   const size_t hb = (size_t)b * L.sb + (size_t)hh * L.sh;
-  const long ld = L.ld;
+  const long ld = L.ld, ldv = Lv.ld;
   const bf16* kp = K + hb;
-  const bf16* vp = V + hb;
+  const bf16* vp = V + (size_t)b * Lv.sb + (size_t)hh * Lv.sh;
   bf16x8 qf[KS], dof[KS];
   // delta_i = sum_d dO[i,d] * O[i,d] is formed here from the dO fragments this lane holds anyway (its half of the row; the other
   // half sits on lane ^ 32) and published for the dK/dV kernel, which runs after this one: no separate pass over O and dO.
@@ -396,7 +395,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   auto stage = [&](int kt) {
     char* base = smem + (kt % ATT_STAGES) * 2 * TB;
     stage_tile<HD, 64>(kp + (size_t)kt * 64 * ld, ld, 63, base, wave, lane);
-    stage_tile<HD, 64>(vp + (size_t)kt * 64 * ld, ld, 63, base + TB, wave, lane);
+    stage_tile<HD, 64>(vp + (size_t)kt * 64 * ldv, ldv, 63, base + TB, wave, lane);
   };
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)
@@ -685,16 +684,16 @@ static int attn_check(const char* who, int dtype, int B, int H, int N, int hd) {
 }
 
 static int attention_fwd_core(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N, int hd,
-                              float scale, QkvLayout Lq, hipStream_t st) {
+                              float scale, QkvLayout Lq, QkvLayout Lv, hipStream_t st) {
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const float c = scale * 1.4426950408889634f;
   if (dtype == LDMAE_BF16) {
 #define L(HD) hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq)
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq, Lv)
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {
-    LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd, "attention_fwd(f32): head-major q/k/v only");
+    LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd && Lv.ld == hd && Lv.sh == (long)N * hd, "attention_fwd(f32): head-major q/k/v only");
 #define L(HD) { const size_t lds = (size_t)(128 + 64 + 64) * (HD + 1) * 4; \
     hipFuncSetAttribute((const void*)attn_fwd_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(attn_fwd_f32_kernel<HD>, dim3(grid), dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, H, N, c); }
@@ -709,7 +708,8 @@ extern "C" int ldmae_attention_fwd(int dtype, const void* q, const void* k, cons
                                    float scale, void* stream) {
   LDMAE_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
   if (int e = attn_check("attention_fwd", dtype, B, H, N, hd)) return e;
-  return attention_fwd_core(dtype, q, k, v, o, lse, B, H, N, hd, scale, QkvLayout{(long)H * N * hd, (long)N * hd, (long)hd}, as_stream(stream));
+  const QkvLayout hm{(long)H * N * hd, (long)N * hd, (long)hd};
+  return attention_fwd_core(dtype, q, k, v, o, lse, B, H, N, hd, scale, hm, hm, as_stream(stream));
 }
 
 extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream) {
@@ -719,11 +719,12 @@ extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, floa
   LDMAE_REQUIRE(hd % 8 == 0, "attention_fwd_qkv: head_dim %d must be a multiple of 8", hd);
   const bf16* p = (const bf16*)qkv;
   const long hw = (long)H * hd;
-  return attention_fwd_core(dtype, p, p + hw, p + 2 * hw, o, lse, B, H, N, hd, scale, QkvLayout{(long)N * 3 * hw, (long)hd, 3 * hw}, as_stream(stream));
+  const QkvLayout pk{(long)N * 3 * hw, (long)hd, 3 * hw};
+  return attention_fwd_core(dtype, p, p + hw, p + 2 * hw, o, lse, B, H, N, hd, scale, pk, pk, as_stream(stream));
 }
 
 static int attention_bwd_core(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
-                              void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, QkvLayout Lq, hipStream_t st) {
+                              void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, QkvLayout Lq, QkvLayout Lv, hipStream_t st) {
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const long items = (long)B * N * H;
   const unsigned dgrid = (unsigned)((items * 8 + 255) / 256 < 8192 ? (items * 8 + 255) / 256 : 8192);
@@ -732,12 +733,12 @@ static int attention_bwd_core(int dtype, const void* q, const void* k, const voi
 #define L(HD) { \
     hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
     hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale, Lq); \
-    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, Lq); }
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale, Lq, Lv); \
+    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv); }
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {
-    LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd, "attention_bwd(f32): head-major q/k/v only");
+    LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd && Lv.ld == hd && Lv.sh == (long)N * hd, "attention_bwd(f32): head-major q/k/v only");
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(dgrid), dim3(256), 0, st, (const float*)o, (const float*)do_, delta, B, H, N, hd);
 #define L(HD) { const size_t l1 = (size_t)(128 + 128 + 64 + 64) * (HD + 1) * 4 + 512; \
     hipFuncSetAttribute((const void*)attn_bwd_dkdv_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \
@@ -756,8 +757,8 @@ extern "C" int ldmae_attention_bwd(int dtype, const void* q, const void* k, cons
   LDMAE_REQUIRE(q && k && v && o && do_ && lse && dq && dk && dv && delta, "attention_bwd: null pointer");
   if (int e = attn_check("attention_bwd", dtype, B, H, N, hd)) return e;
   LDMAE_REQUIRE(hd % 8 == 0, "attention_bwd: head_dim %d must be a multiple of 8", hd);
-  return attention_bwd_core(dtype, q, k, v, o, do_, lse, dq, dk, dv, delta, B, H, N, hd, scale,
-                            QkvLayout{(long)H * N * hd, (long)N * hd, (long)hd}, as_stream(stream));
+  const QkvLayout hm{(long)H * N * hd, (long)N * hd, (long)hd};
+  return attention_bwd_core(dtype, q, k, v, o, do_, lse, dq, dk, dv, delta, B, H, N, hd, scale, hm, hm, as_stream(stream));
 }
 
 extern "C" int ldmae_attention_bwd_qkv(int dtype, const void* qkv, const void* o, const void* do_, const float* lse, void* dqkv, float* delta,
@@ -769,6 +770,30 @@ extern "C" int ldmae_attention_bwd_qkv(int dtype, const void* qkv, const void* o
   const bf16* p = (const bf16*)qkv;
   bf16* g = (bf16*)dqkv;
   const long hw = (long)H * hd;
-  return attention_bwd_core(dtype, p, p + hw, p + 2 * hw, o, do_, lse, g, g + hw, g + 2 * hw, delta, B, H, N, hd, scale,
-                            QkvLayout{(long)N * 3 * hw, (long)hd, 3 * hw}, as_stream(stream));
+  const QkvLayout pk{(long)N * 3 * hw, (long)hd, 3 * hw};
+  return attention_bwd_core(dtype, p, p + hw, p + 2 * hw, o, do_, lse, g, g + hw, g + 2 * hw, delta, B, H, N, hd, scale, pk, pk, as_stream(stream));
+}
+
+// q, k (dq, dk) head-major [B,H,N,hd]; v read from -- and dv written into -- the v slot of a packed token-major [B,N,3,H,hd] buffer
+// (the LightningDiT block: QK-norm + RoPE produce new q / k, v is used exactly as the qkv Linear wrote it)
+extern "C" int ldmae_attention_fwd_pv(int dtype, const void* q, const void* k, const void* qkv, void* o, float* lse, int B, int H, int N, int hd,
+                                      float scale, void* stream) {
+  LDMAE_REQUIRE(q && k && qkv && o && lse, "attention_fwd_pv: null pointer");
+  LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_fwd_pv: bf16 only");
+  if (int e = attn_check("attention_fwd_pv", dtype, B, H, N, hd)) return e;
+  LDMAE_REQUIRE(hd % 8 == 0, "attention_fwd_pv: head_dim %d must be a multiple of 8", hd);
+  const long hw = (long)H * hd;
+  const QkvLayout hm{(long)H * N * hd, (long)N * hd, (long)hd}, pk{(long)N * 3 * hw, (long)hd, 3 * hw};
+  return attention_fwd_core(dtype, q, k, (const bf16*)qkv + 2 * hw, o, lse, B, H, N, hd, scale, hm, pk, as_stream(stream));
+}
+extern "C" int ldmae_attention_bwd_pv(int dtype, const void* q, const void* k, const void* qkv, const void* o, const void* do_, const float* lse,
+                                      void* dq, void* dk, void* dqkv, float* delta, int B, int H, int N, int hd, float scale, void* stream) {
+  LDMAE_REQUIRE(q && k && qkv && o && do_ && lse && dq && dk && dqkv && delta, "attention_bwd_pv: null pointer");
+  LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_bwd_pv: bf16 only");
+  if (int e = attn_check("attention_bwd_pv", dtype, B, H, N, hd)) return e;
+  LDMAE_REQUIRE(hd % 8 == 0, "attention_bwd_pv: head_dim %d must be a multiple of 8", hd);
+  const long hw = (long)H * hd;
+  const QkvLayout hm{(long)H * N * hd, (long)N * hd, (long)hd}, pk{(long)N * 3 * hw, (long)hd, 3 * hw};
+  return attention_bwd_core(dtype, q, k, (const bf16*)qkv + 2 * hw, o, do_, lse, dq, dk, (bf16*)dqkv + 2 * hw, delta, B, H, N, hd, scale, hm, pk,
+                            as_stream(stream));
 }

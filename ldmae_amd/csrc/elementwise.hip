@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const T* __restric
     const size_t dst = ((size_t)(b * H + h) * N + n) * hd + c4;
     float4 qv = f4(0.f), kv = f4(0.f), vv = f4(0.f), cs = f4(0.f), sn = f4(0.f);
     if (act) {
-      qv = load4<T>(src); kv = load4<T>(src + (size_t)H * hd); vv = load4<T>(src + (size_t)2 * H * hd);
+      qv = load4<T>(src); kv = load4<T>(src + (size_t)H * hd);
+      if (v) vv = load4<T>(src + (size_t)2 * H * hd);
       if (!plain) { cs = *(const float4*)(cosT + (size_t)n * hd + c4); sn = *(const float4*)(sinT + (size_t)n * hd + c4); }
     }
     if (plain) {
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const T* __restric
     if (act) {
       store4<T>(q + dst, rope_apply((qv * rq) * wqv, cs, sn));
       store4<T>(k + dst, rope_apply((kv * rk) * wkv, cs, sn));
-      store4<T>(v + dst, vv);
+      if (v) store4<T>(v + dst, vv);            // v == NULL: attention reads v from the packed qkv itself (ldmae_attention_fwd_pv)
     }
   }
 }
@@ -312,7 +313,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
     float4 qv = f4(0.f), kv = f4(0.f), gq = f4(0.f), gk = f4(0.f), gv = f4(0.f), cs = f4(0.f), sn = f4(0.f);
     if (act) {
       qv = load4<T>(qkv + so); kv = load4<T>(qkv + so + (size_t)H * hd);
-      gq = load4<T>(dq + go); gk = load4<T>(dk + go); gv = load4<T>(dv + go);
+      gq = load4<T>(dq + go); gk = load4<T>(dk + go);
+      // dv == NULL: the attention backward has already written dv into the v slot of dqkv (ldmae_attention_bwd_pv); it is only
+      // read back for the bias-gradient column sums
+      if (dv) gv = load4<T>(dv + go); else if (Pb) gv = load4<T>(dqkv + so + (size_t)2 * H * hd);
       cs = *(const float4*)(cosT + (size_t)n * hd + c4); sn = *(const float4*)(sinT + (size_t)n * hd + c4);
     }
     const float rq = rsqrtf(group_sum<LPR>(hsum(qv * qv)) / (float)hd + eps);
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
       const float4 oq = (dnq - nq * mq) * rq, ok = (dnk - nk * mk) * rk;
       store4<T>(dqkv + so, oq);
       store4<T>(dqkv + so + (size_t)H * hd, ok);
-      store4<T>(dqkv + so + (size_t)2 * H * hd, gv);
+      if (dv) store4<T>(dqkv + so + (size_t)2 * H * hd, gv);
       if (Pb) { bq = bq + rnd(oq); bk = bk + rnd(ok); bv = bv + gv; }
     }
   }
@@ -352,7 +356,7 @@ static unsigned qk_grid(long items, int lpr) {
 
 extern "C" int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq, const float* wk, const float* cos, const float* sin,
                                      void* q, void* k, void* v, int B, int N, int H, int hd, float eps, void* stream) {
-  LDMAE_REQUIRE(qkv && q && k && v, "qknorm_rope_fwd: null pointer");
+  LDMAE_REQUIRE(qkv && q && k && (v || wq), "qknorm_rope_fwd: null pointer (v may be NULL only with QK-norm / RoPE: v then stays in the packed qkv)");
   LDMAE_REQUIRE((wq && wk && cos && sin) || (!wq && !wk), "qknorm_rope_fwd: pass all of wq/wk/cos/sin, or none (plain head-major relayout)");
   LDMAE_REQUIRE(hd % 8 == 0 && hd <= 128 && B > 0 && N > 0 && H > 0, "qknorm_rope_fwd: head_dim=%d must be a multiple of 8 and <= 128", hd);
   hipStream_t st = as_stream(stream);
@@ -387,7 +391,7 @@ extern "C" long ldmae_qknorm_rope_bwd_workspace_bytes(int B, int N, int H, int h
 extern "C" int ldmae_qknorm_rope_bwd(int dtype, const void* dq, const void* dk, const void* dv, const void* qkv, const float* wq,
                                      const float* wk, const float* cos, const float* sin, void* dqkv, float* dwq, float* dwk, float beta_w,
                                      float* dbias_hqd, int B, int N, int H, int hd, float eps, float* workspace, void* stream) {
-  LDMAE_REQUIRE(dq && dk && dv && dqkv, "qknorm_rope_bwd: null pointer");
+  LDMAE_REQUIRE(dq && dk && dqkv && (dv || wq), "qknorm_rope_bwd: null pointer (dv may be NULL only with QK-norm / RoPE: dv is then already in dqkv)");
   LDMAE_REQUIRE((qkv && wq && wk && cos && sin && dwq && dwk && workspace) || (!wq && !wk), "qknorm_rope_bwd: pass all norm/rope arguments, or none of wq/wk (plain relayout)");
   LDMAE_REQUIRE(!dbias_hqd || workspace, "qknorm_rope_bwd: dbias requested without workspace");
   LDMAE_REQUIRE(hd % 8 == 0 && hd <= 128 && B > 0 && N > 0 && H > 0, "qknorm_rope_bwd: head_dim=%d must be a multiple of 8 and <= 128", hd);

@@ -157,8 +157,12 @@ class _DiTBlockFn(torch.autograd.Function):
         # attention branch (:248)
         xm1, rstd1 = ops.rmsnorm_modulate_fwd(x2, n1w, sh1, s1, N, dtype, eps)
         qkv = ops.gemm_nt(xm1, Wqkv, qkvb)                                               # [M, 3D] == [B,N,3,H,hd]
-        q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
-        o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)                                  # [B,N,D]
+        if dtype == torch.bfloat16:      # v is consumed where the qkv Linear wrote it: no head-major copy of v (nor of dv in backward)
+            q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps, copy_v=False)
+            o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5)                          # [B,N,D]
+        else:
+            q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
+            o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)
         xmid, y1 = ops.gemm_nt_gate_res(o.view(M, D), Wp, pb, x2, g1, N)
         # MLP branch (:249)
         xm2, rstd2 = ops.rmsnorm_modulate_fwd(xmid, n2w, sh2, s2, N, dtype, eps)
@@ -197,8 +201,12 @@ class _DiTBlockFn(torch.autograd.Function):
         dy1, dbp = ops.gate_bwd(dx, y1, g1, dmod[:, 2 * D:3 * D], N, dtype, with_bias=True)
         dWp = sg.tn(dy1, o.view(M, D))
         do = ops.gemm_nt(dy1, WpT)
-        dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
-        dqkv, dqn, dkn, dbqkv = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, B, N, H, hd, eps, with_bias=True)
+        if v is None:
+            dq, dk, dqkv = ops.attention_bwd_pv(q, k, qkv, o, do, lse, hd ** -0.5)          # dv lands in the v slot of dqkv
+            dqkv, dqn, dkn, dbqkv = ops.qknorm_rope_bwd(dq, dk, None, qkv, qnw, knw, cos, sin, B, N, H, hd, eps, with_bias=True, dqkv=dqkv)
+        else:
+            dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
+            dqkv, dqn, dkn, dbqkv = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, B, N, H, hd, eps, with_bias=True)
         dqkv = dqkv.view(M, 3 * D)
         dWqkv = sg.tn(dqkv, xm1)
         dxm1 = ops.gemm_nt(dqkv, WqkvT)

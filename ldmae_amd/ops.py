@@ -210,18 +210,20 @@ def rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx_accum, dshift, dscale, rows
     return dw
 
 
-def qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6):
+def qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6, copy_v=True):
+    """copy_v=False: v gets no head-major copy (returned as None); attention then reads it from the packed qkv (attention_fwd_pv)."""
     q = torch.empty(B, H, N, hd, dtype=qkv.dtype, device=qkv.device)
     k = torch.empty_like(q)
-    v = torch.empty_like(q)
+    v = torch.empty_like(q) if copy_v else None
     call("ldmae_qknorm_rope_fwd", dt(qkv.dtype), ptr(qkv), ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(q), ptr(k), ptr(v), B, N, H, hd, eps, stream())
     return q, k, v
 
 
-def qknorm_rope_bwd(dq, dk, dv, qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6, with_bias=False):
+def qknorm_rope_bwd(dq, dk, dv, qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6, with_bias=False, dqkv=None):
     """Backward of qknorm_rope_fwd: (dqkv [B,N,3,H,hd], dwq, dwk[, dbias [3*H*hd]]).  with_bias: the bias gradient of the qkv Linear
-    (column sums of dqkv as stored), formed in the same pass."""
-    dqkv = torch.empty_like(qkv)
+    (column sums of dqkv as stored), formed in the same pass.  dv=None with dqkv given: dv already sits in the v slot of dqkv
+    (attention_bwd_pv) and is left there."""
+    dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
     dwq = torch.empty(hd, dtype=torch.float32, device=qkv.device)
     dwk = torch.empty_like(dwq)
     db = torch.empty(H, 3, hd, dtype=torch.float32, device=qkv.device) if with_bias else None
@@ -251,6 +253,26 @@ def attention_bwd(q, k, v, o, do, lse, scale):
     call("ldmae_attention_bwd", dt(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(_c(do)), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta),
          B, H, N, hd, float(scale), stream())
     return dq, dk, dv
+
+
+def attention_fwd_pv(q, k, qkv, scale):
+    """q, k head-major [B,H,N,hd]; v read from the packed qkv [B*N, 3*H*hd] (bf16)."""
+    B, H, N, hd = q.shape
+    o = torch.empty(B, N, H * hd, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
+    call("ldmae_attention_fwd_pv", dt(q.dtype), ptr(q), ptr(k), ptr(qkv), ptr(o), ptr(lse), B, H, N, hd, float(scale), stream())
+    return o, lse
+
+
+def attention_bwd_pv(q, k, qkv, o, do, lse, scale):
+    """-> (dq, dk head-major, dqkv with ONLY its v slot written: dv in the packed layout)."""
+    B, H, N, hd = q.shape
+    dq, dk = torch.empty_like(q), torch.empty_like(q)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
+    call("ldmae_attention_bwd_pv", dt(q.dtype), ptr(q), ptr(k), ptr(qkv), ptr(o), ptr(_c(do)), ptr(lse), ptr(dq), ptr(dk), ptr(dqkv), ptr(delta),
+         B, H, N, hd, float(scale), stream())
+    return dq, dk, dqkv
 
 
 def attention_fwd_qkv(qkv, B, N, H, hd, scale):
