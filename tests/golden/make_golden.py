@@ -280,6 +280,38 @@ def gen_mae(out):
 
 
 # --------------------------------------------------------------------------- 100-step loss curve, B/1 bs=4
+def gen_dataset(out):
+    """the reference's own ``ImgLatentDataset`` (datasets/img_latent_dataset.py:16-93) on a tiny generated shard
+    directory: shard contents (inputs) + the stats it caches + the (feature, label) items it returns under a seeded numpy / torch
+    RNG, for both the moments-sampling configuration of the shipped YAML (latent_norm, sample, multiplier 1.0) and the plain one."""
+    import shutil
+    import tempfile
+    from safetensors.torch import save_file
+    from datasets.img_latent_dataset import ImgLatentDataset
+    g = torch.Generator().manual_seed(123)
+    shards = []
+    for s, n in enumerate((5, 3)):
+        shards.append({"latents": torch.randn(n, 8, 4, 4, generator=g), "latents_flip": torch.randn(n, 8, 4, 4, generator=g),
+                       "labels": torch.randint(0, 1000, (n,), generator=g)})
+        for k, v in shards[-1].items():
+            out[f"ds_shard{s}_{k}"] = v.numpy()
+    for tag, kw in (("a", dict(latent_norm=True, latent_multiplier=1.0, sample=True)), ("b", dict(latent_norm=False, latent_multiplier=0.18215, sample=False)),
+                    ("c", dict(latent_norm=True, latent_multiplier=0.5, sample=False))):
+        d = tempfile.mkdtemp()
+        for s, sh in enumerate(shards):
+            save_file(sh, os.path.join(d, f"latents_rank00_shard{s:03d}.safetensors"), metadata={"total_size": str(len(sh["labels"])), "dtype": "torch.float32", "device": "cpu"})
+        np.random.seed(7)
+        torch.manual_seed(7)
+        ds = ImgLatentDataset(d, **kw)
+        assert len(ds) == 8
+        if kw["latent_norm"]:
+            out[f"ds_{tag}_mean"], out[f"ds_{tag}_std"] = ds._latent_mean.numpy(), ds._latent_std.numpy()
+        order = [3, 0, 7, 5, 5, 1, 6, 2, 4, 0]
+        feats, labels = zip(*[ds[i] for i in order])
+        out[f"ds_{tag}_order"], out[f"ds_{tag}_feat"], out[f"ds_{tag}_label"] = np.array(order), torch.stack(feats).numpy(), torch.stack(labels).numpy()
+        shutil.rmtree(d)
+
+
 def ref_style_init(model, seed):
     """Reference init *scheme* (zero adaLN / final, Xavier Linears) with name-keyed
     values so the oracle / HIP side can rebuild the identical start point."""
@@ -353,12 +385,16 @@ def main():
     ap.add_argument("--curve", action="store_true", help="also run the 100-step B/1 bs=4 loss curve (~15 min)")
     ap.add_argument("--only-curve", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,dataset}")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     install_shims()
     sys.path.insert(0, REF)
     if not args.only_curve:
-        for name, fn in (("dit_tiny", gen_dit_tiny), ("kernels", gen_tables_and_kernels), ("mae", gen_mae)):
+        gens = (("dit_tiny", gen_dit_tiny), ("kernels", gen_tables_and_kernels), ("mae", gen_mae), ("dataset", gen_dataset))
+        for name, fn in gens:
+            if args.only and name not in args.only.split(","):
+                continue
             out = {}
             fn(out)
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)

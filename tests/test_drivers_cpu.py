@@ -41,6 +41,32 @@ def test_latent_dataset_roundtrip(tmp_path):
     assert torch.equal(a[0], b[0]) and a[0].shape == (16, 8, 8)
 
 
+def test_latent_dataset_matches_reference_golden(tmp_path):
+    """SURVEY 8(f)3 pinned: shards rebuilt from the golden inputs, then our ImgLatentDataset under the same numpy / torch seeds must
+    reproduce what the reference's class returned (tests/golden/make_golden.py:gen_dataset imports it): cached stats (np.random.choice
+    pick + posterior sample), the per-item flip pick (np.random.uniform), posterior sample (torch.randn), normalisation, multiplier."""
+    from safetensors.torch import save_file
+    sys.path.insert(0, os.path.join(ROOT, "ldmae_amd"))
+    from ldmae_amd.datasets.img_latent_dataset import ImgLatentDataset
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dataset.npz"))
+    for tag, kw in (("a", dict(latent_norm=True, latent_multiplier=1.0, sample=True)), ("b", dict(latent_norm=False, latent_multiplier=0.18215, sample=False)),
+                    ("c", dict(latent_norm=True, latent_multiplier=0.5, sample=False))):
+        d = tmp_path / tag
+        d.mkdir()
+        for s in range(2):
+            save_file({k: torch.from_numpy(g[f"ds_shard{s}_{k}"]) for k in ("latents", "latents_flip", "labels")},
+                      str(d / f"latents_rank00_shard{s:03d}.safetensors"))
+        np.random.seed(7)
+        torch.manual_seed(7)
+        ds = ImgLatentDataset(str(d), **kw)
+        assert len(ds) == 8
+        if kw["latent_norm"]:
+            assert np.array_equal(ds._latent_mean.numpy(), g[f"ds_{tag}_mean"]) and np.array_equal(ds._latent_std.numpy(), g[f"ds_{tag}_std"])
+        items = [ds[int(i)] for i in g[f"ds_{tag}_order"]]
+        assert np.array_equal(torch.stack([x for x, _ in items]).numpy(), g[f"ds_{tag}_feat"])
+        assert np.array_equal(torch.stack([y for _, y in items]).numpy(), g[f"ds_{tag}_label"])
+
+
 def test_weight_init_special_case():
     import ldmae_amd.train_accum as t
     from ldmae_amd.models.lightningdit import LightningDiT
