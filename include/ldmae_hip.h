@@ -165,8 +165,12 @@ int ldmae_layernorm_bwd(int dtype, const void* dout, const float* x, const float
 /* exact-erf GELU (timm Mlp act, models_mae.py:172) */
 int ldmae_gelu_fwd(int dtype, const void* x, void* out, long n, void* stream);
 int ldmae_gelu_bwd(int dtype, const void* dout, const void* x, void* dx, long n, void* stream);
-/* 3x3 / stride 1 / pad 1 convolution on [B,C,H,W] f32 (conv_decoder_pred.conv_smoother, models_mae.py:254,275), inference only */
+/* 3x3 / stride 1 / pad 1 convolution on [B,C,H,W] f32 (conv_decoder_pred.conv_smoother, models_mae.py:254,275) */
 int ldmae_conv3x3(const float* x, const float* w, const float* b, float* out, int B, int C, int H, int W, void* stream);
+/* its backward (VMAE pre-training trains the smoother, engine_pretrain.py:51-76): dx (optional) [B,C,H,W], dw [C,C,3,3], db [C]; C = 3 */
+long ldmae_conv3x3_bwd_workspace_bytes(int C);
+int ldmae_conv3x3_bwd(const float* dout, const float* x, const float* w, float* dx, float* dw, float* db, int B, int C, int H, int W,
+                      float* workspace, void* stream);
 
 /* ---- optional per-kernel timing hook used by bench.py for the roofline line ------------------- */
 /* When enabled, ldmae_gemm_nt brackets each launch with HIP events on the launch stream. */

@@ -64,6 +64,8 @@ SIGNATURES = {
     "ldmae_gelu_fwd": (_i, [_i, _vp, _vp, _l, _vp]),
     "ldmae_gelu_bwd": (_i, [_i, _vp, _vp, _vp, _l, _vp]),
     "ldmae_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ldmae_conv3x3_bwd_workspace_bytes": (_l, [_i]),
+    "ldmae_conv3x3_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldmae_tune": (_i, [_i, _i]),
     "ldmae_tune_query": (_i, [_i]),
     "ldmae_debug_nt_stamps": (None, [_vp]),

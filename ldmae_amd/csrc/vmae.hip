@@ -302,3 +302,84 @@ extern "C" int ldmae_conv3x3(const float* x, const float* w, const float* b, flo
   LDMAE_CHECK_LAUNCH("conv3x3");
   return LDMAE_OK;
 }
+
+// ------------------------------------------------------------------ backward of the 3x3 RGB smoothing conv (VMAE pre-training, engine_pretrain.py:51-76:
+// the decoder's conv_smoother is trained with everything else).  C = 3: dx is the correlation of dout with the transposed taps,
+// dw / db are 84 whole-tensor sums -> per-workgroup partials [G][C*C*9 + C] (registers -> wave shuffles -> LDS), summed in fixed order.
+__global__ void conv3x3_bwd_dx_kernel(const float* __restrict__ dout, const float* __restrict__ w, float* __restrict__ dx, int B, int C, int Hh, int Ww) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C * Hh * Ww) return;
+  const int xx = i % Ww, yy = (i / Ww) % Hh, ci = (i / ((long)Ww * Hh)) % C, n = i / ((long)Ww * Hh * C);
+  float s = 0.f;
+  for (int co = 0; co < C; ++co)
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int y2 = yy - ky + 1, x2 = xx - kx + 1;
+        if (y2 >= 0 && y2 < Hh && x2 >= 0 && x2 < Ww)
+          s += dout[(((size_t)n * C + co) * Hh + y2) * Ww + x2] * w[((co * C + ci) * 3 + ky) * 3 + kx];
+      }
+  dx[i] = s;
+}
+template <int C>
+__global__ __launch_bounds__(256) void conv3x3_bwd_dw_kernel(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ P,
+                                                             int B, int Hh, int Ww) {
+  constexpr int NA = C * C * 9 + C;
+  __shared__ float red[4][NA];
+  float acc[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acc[a] = 0.f;
+  const long npix = (long)B * Hh * Ww;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    const int xx = i % Ww, yy = (i / Ww) % Hh, n = i / ((long)Ww * Hh);
+    float g[C], xv[C][9];
+#pragma unroll
+    for (int co = 0; co < C; ++co) g[co] = dout[(((size_t)n * C + co) * Hh + yy) * Ww + xx];
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int y2 = yy + ky - 1, x2 = xx + kx - 1;
+          xv[ci][ky * 3 + kx] = (y2 >= 0 && y2 < Hh && x2 >= 0 && x2 < Ww) ? x[(((size_t)n * C + ci) * Hh + y2) * Ww + x2] : 0.f;
+        }
+#pragma unroll
+    for (int co = 0; co < C; ++co) {
+#pragma unroll
+      for (int ci = 0; ci < C; ++ci)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[(co * C + ci) * 9 + t] += g[co] * xv[ci][t];
+      acc[C * C * 9 + co] += g[co];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    const float v = wave_sum(acc[a]);
+    if (lane == 0) red[wave][a] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NA) P[(size_t)blockIdx.x * NA + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void conv3x3_bwd_reduce_kernel(const float* __restrict__ P, int G, int NA, int NW, float* __restrict__ dw, float* __restrict__ db) {
+  const int a = threadIdx.x;
+  if (a >= NA) return;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += P[(size_t)g * NA + a];
+  if (a < NW) dw[a] = s; else db[a - NW] = s;
+}
+constexpr int CONV_BWD_G = 1024;
+extern "C" long ldmae_conv3x3_bwd_workspace_bytes(int C) { return (long)CONV_BWD_G * (C * C * 9 + C) * 4; }
+extern "C" int ldmae_conv3x3_bwd(const float* dout, const float* x, const float* w, float* dx, float* dw, float* db, int B, int C, int H, int W,
+                                 float* workspace, void* stream) {
+  LDMAE_REQUIRE(dout && x && w && dw && db && workspace && B > 0 && H > 0 && W > 0, "conv3x3_bwd: bad arguments");
+  LDMAE_REQUIRE(C == 3, "conv3x3_bwd: C=%d unsupported (the RGB smoothing conv has 3 channels)", C);
+  hipStream_t st = as_stream(stream);
+  const long n = (long)B * C * H * W, npix = (long)B * H * W;
+  if (dx) hipLaunchKernelGGL(conv3x3_bwd_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, w, dx, B, C, H, W);
+  const int G = (int)((npix + 255) / 256 < CONV_BWD_G ? (npix + 255) / 256 : CONV_BWD_G);
+  hipLaunchKernelGGL(conv3x3_bwd_dw_kernel<3>, dim3(G), dim3(256), 0, st, dout, x, workspace, B, H, W);
+  hipLaunchKernelGGL(conv3x3_bwd_reduce_kernel, dim3(1), dim3(128), 0, st, workspace, G, C * C * 9 + C, C * C * 9, dw, db);
+  LDMAE_CHECK_LAUNCH("conv3x3_bwd");
+  return LDMAE_OK;
+}

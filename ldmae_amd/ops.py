@@ -406,6 +406,16 @@ def conv3x3(x, w, b):
     return out
 
 
+def conv3x3_bwd(dout, x, w, need_dx=True):
+    B, C, Hh, Ww = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty_like(w)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(L.load().ldmae_conv3x3_bwd_workspace_bytes(C), x.device, "conv")
+    call("ldmae_conv3x3_bwd", ptr(_c(dout)), ptr(_c(x)), ptr(_c(w)), ptr(dx), ptr(dw), ptr(db), B, C, Hh, Ww, ptr(ws), stream())
+    return dx, dw, db
+
+
 def layernorm_fwd(x, w, b, out_dtype, eps=1e-6):
     M, D = x.shape
     out = torch.empty(M, D, dtype=out_dtype, device=x.device)

@@ -145,6 +145,22 @@ class _LinearFn(torch.autograd.Function):
         return dx, ops.gemm_tn(g2, x2), ops.colsum(g2)
 
 
+class _Conv3x3Fn(torch.autograd.Function):
+    """conv_smoother (:254,275): 3x3 / stride 1 / pad 1 on the RGB prediction, f32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        return ops.conv3x3(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dx, dw, db = ops.conv3x3_bwd(g.contiguous(), x, w, need_dx=ctx.needs_input_grad[0])
+        return dx, dw, db
+
+
 class _GatherFn(torch.autograd.Function):
     """torch.gather(x, 1, ids_keep) on token rows (:486)."""
 
@@ -221,9 +237,7 @@ class conv_decoder_pred(nn.Module):
         x = _LinearFn.apply(x, self.linear_pred.weight, self.linear_pred.bias)
         x = x.reshape(x.shape[0], h, w, self.p, self.p, 3)
         x = torch.einsum('nhwpqc->nchpwq', x).reshape(x.shape[0], 3, h * self.p, w * self.p)
-        if x.requires_grad:
-            raise NotImplementedError("ldmae_amd: the RGB smoothing conv is inference-only (decoder fine-tuning is out of scope)")
-        x = ops.conv3x3(x, self.conv_smoother.weight, self.conv_smoother.bias)
+        x = _Conv3x3Fn.apply(x, self.conv_smoother.weight, self.conv_smoother.bias)
         x = x.reshape(x.shape[0], 3, h, self.p, w, self.p)
         return torch.einsum('nchpwq->nhwpqc', x).reshape(x.shape[0], h * w, self.p * self.p * 3)
 
@@ -366,12 +380,14 @@ class MaskedAutoencoderViT(nn.Module):
         mask_loss = (loss * mask).sum() / mask.sum()
         return (1 - visible_loss_ratio) * mask_loss + visible_loss_ratio * visible_loss, visible_loss, mask_loss
 
-    def forward(self, imgs, mask_ratio=0.75, visible_loss_ratio=0.5):
-        """forward_vanilla (:756-790).  The masked encoder runs on the kernels; the decoder's RGB smoothing conv has no backward
-        here, so end-to-end pre-training is out of scope -- this is usable under torch.no_grad()."""
+    def forward(self, imgs, mask_ratio=0.75, visible_loss_ratio=0.5, _noise=None, _eps=None):
+        """forward_vanilla (:756-790), trainable end to end on the kernels (the VMAE pre-training step of engine_pretrain.py:51-76):
+        masked encoder -> to_latent -> KL + posterior sample -> from_latent -> decoder (mask tokens, blocks, RGB smoothing conv) ->
+        masked / visible reconstruction loss.  `_noise` [B, L] / `_eps` [B, latent, kept] (tests): host-drawn masking noise and
+        posterior-sample noise instead of the device RNG draws the reference makes at the same two places."""
         if self.ldmae_mode:
             raise NotImplementedError("ldmae_amd: ldmae_mode (decoder fine-tuning with LPIPS) is out of scope")
-        latent, mask, ids_restore = self.forward_encoder(imgs, mask_ratio)
+        latent, mask, ids_restore = self.forward_encoder(imgs, mask_ratio, noise=_noise)
         with torch.autocast(device_type="cuda", enabled=False):
             latent = _LinearFn.apply(latent, self.to_latent.weight, self.to_latent.bias)
             kl_loss = None
@@ -380,7 +396,7 @@ class MaskedAutoencoderViT(nn.Module):
                 posterior = DiagonalGaussianDistribution(latent.permute(0, 2, 1))
                 kl = posterior.kl()
                 kl_loss = torch.sum(kl) / kl.shape[0] / N
-                latent = posterior.sample().permute(0, 2, 1)
+                latent = (posterior.sample() if _eps is None else posterior.mean + posterior.std * _eps).permute(0, 2, 1)
             latent = _LinearFn.apply(latent.contiguous(), self.from_latent.weight, self.from_latent.bias)
             pred = self.forward_decoder(latent, ids_restore)
             loss, vis_loss, mask_loss = self.forward_loss(imgs, pred, mask, visible_loss_ratio)

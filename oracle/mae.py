@@ -162,6 +162,42 @@ def decode(sd, z, cfg: MAEConfig):
     return torch.einsum("nhwpqc->nchpwq", x).reshape(B, 3, g * p, g * p)
 
 
+def patchify(imgs, cfg: MAEConfig):
+    """models_mae.py:449-460: [N,3,H,W] -> [N, L, p*p*3] in (p, q, c) order."""
+    p, g = cfg.patch_size, cfg.grid
+    x = imgs.reshape(imgs.shape[0], 3, g, p, g, p)
+    return torch.einsum("nchpwq->nhwpqc", x).reshape(imgs.shape[0], g * g, p * p * 3)
+
+
+def forward_vanilla(sd, imgs, noise, eps, mask_ratio, visible_loss_ratio, kl_loss_weight, cfg: MAEConfig):
+    """MaskedAutoencoderViT.forward_vanilla + forward_decoder + forward_loss (models_mae.py:756-790, 525-554, 733-754) with the two
+    random draws supplied by the caller: `noise` [B, L] (random_masking, :480) and `eps` [B, latent, kept] (posterior.sample,
+    util/misc.py:87-96).  Returns (loss, pred, mask, vis_loss, mask_loss, kl_loss)."""
+    latent, mask, ids_restore = forward_encoder(sd, imgs, noise, mask_ratio, cfg)
+    latent = F.linear(latent, sd["to_latent.weight"], sd["to_latent.bias"])
+    B, N, D = latent.shape
+    mom = latent.permute(0, 2, 1)                                     # B D HW
+    mean, logvar = torch.chunk(mom, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    kl = 0.5 * torch.sum(mean ** 2 + torch.exp(logvar) - 1.0 - logvar, dim=[1, 2])     # misc.py:98-107
+    kl_loss = torch.sum(kl) / kl.shape[0] / N
+    latent = (mean + torch.exp(0.5 * logvar) * eps).permute(0, 2, 1)
+    x = F.linear(latent, sd["from_latent.weight"], sd["from_latent.bias"])
+    x = F.linear(x, sd["decoder_embed.weight"], sd["decoder_embed.bias"])
+    mask_tokens = sd["mask_token"].repeat(x.shape[0], ids_restore.shape[1] - x.shape[1], 1)
+    x_ = torch.cat([x, mask_tokens], dim=1)
+    x = torch.gather(x_, 1, ids_restore.unsqueeze(-1).repeat(1, 1, x.shape[2])) + sd["decoder_pos_embed"]
+    for i in range(cfg.decoder_depth):
+        x = mae_block(sd, f"decoder_blocks.{i}.", x, cfg.decoder_num_heads, cfg.ln_eps)
+    x = F.layer_norm(x, (cfg.decoder_embed_dim,), sd["decoder_norm.weight"], sd["decoder_norm.bias"], cfg.ln_eps)
+    pred = decoder_pred(sd, x, cfg)
+    per_patch = ((pred - patchify(imgs, cfg)) ** 2).mean(dim=-1)
+    vis_loss = (per_patch * (1 - mask)).sum() / (1 - mask).sum()
+    mask_loss = (per_patch * mask).sum() / mask.sum()
+    loss = (1 - visible_loss_ratio) * mask_loss + visible_loss_ratio * vis_loss + kl_loss_weight * kl_loss
+    return loss, pred, mask, vis_loss, mask_loss, kl_loss
+
+
 def to_uint8_images(img):
     """models_mae.py:970-972 (decode_to_images tail)."""
     return torch.clamp(127.5 * img + 128.0, 0, 255).permute(0, 2, 3, 1).to(torch.uint8).numpy()

@@ -91,3 +91,47 @@ def test_masked_encoder_gradients_vs_oracle():
     params = dict(m.named_parameters())
     for k in enc_keys:
         assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 2e-4, k
+
+
+def test_pretraining_step_loss_and_all_grads_vs_oracle():
+    """SURVEY 8(f)4 minimal slice: the VMAE pre-training forward (masked encoder -> KL posterior -> decoder with mask tokens and the
+    RGB smoothing conv -> masked / visible loss, models_mae.py:733-790) and EVERY parameter gradient against torch autograd on the
+    oracle, 128-px images, encoder / decoder depth 2, f32, host-drawn masking noise and posterior noise."""
+    cfg = omae.MAEConfig(img_size=128, depth=2, decoder_depth=2)
+    sd = full_sd(cfg, seed=6)
+    from ldmae_amd.tokenizer import models_mae
+    m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192,
+                                        decoder_depth=2, decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16,
+                                        no_cls=True, kl_loss_weight=1e-3, smooth_output=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    imgs = det_randn("img128p", (2, 3, 128, 128), 4).clamp(-1, 1)
+    noise = torch.rand(2, 256, generator=torch.Generator().manual_seed(9))
+    eps = det_randn("peps", (2, 16, 64), 5)
+    keys = [k for k in omae.param_shapes(cfg)]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    osd = dict(sd)
+    osd.update(leaves)
+    ol, opred, omask, ovis, omsk, okl = omae.forward_vanilla(osd, imgs, noise, eps, 0.75, 0.5, 1e-3, cfg)
+    ol.backward()
+    loss, pred, mask, vis, msk, kl = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())
+    assert torch.equal(mask.cpu(), omask)
+    for a, b in ((loss, ol), (vis, ovis), (msk, omsk), (kl, okl)):
+        assert abs(float(a) - float(b)) < 1e-4 * abs(float(b)), (float(a), float(b))
+    assert rel_err(pred.detach().cpu(), opred.detach()) < 1e-4
+    loss.backward()
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for k in keys:
+        e = rel_err(params[k].grad.cpu(), leaves[k].grad)
+        worst = max(worst, e)
+        assert e < 2e-4, (k, e)
+    print("worst grad rel err", worst)
+    # the same step under bf16 autocast stays close (conv / loss stay f32)
+    m.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss16 = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())[0]
+    loss16.backward()
+    assert abs(float(loss16) - float(ol)) < 2e-2 * abs(float(ol))
+    g, r = params["decoder_pred.conv_smoother.weight"].grad.cpu(), leaves["decoder_pred.conv_smoother.weight"].grad
+    assert rel_err(g, r) < 5e-2
