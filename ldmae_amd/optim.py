@@ -22,12 +22,18 @@ class FlatParams:
     and gives trainable parameters ``.grad`` views into a second one.  Names / shapes / state_dict are
     unchanged; ``module.to(device)`` must happen BEFORE this."""
 
-    def __init__(self, module: torch.nn.Module):
+    def __init__(self, module: torch.nn.Module, group_fn=None):
+        """group_fn(name, param) -> int (optional): trainable parameters are laid out group by group (stable inside a group), so every
+        group is ONE contiguous slice ``self.groups[g] = (lo, hi)`` -- per-group optimizer hyper-parameters (timm-style weight-decay
+        groups of the VMAE pre-training) still cost one fused launch per group, not one per parameter."""
         named = [(n, p) for n, p in module.named_parameters()]
         self.trainable = [(n, p) for n, p in named if p.requires_grad]
+        gid = {n: (group_fn(n, p) if group_fn else 0) for n, p in self.trainable}
+        self.trainable.sort(key=lambda np_: gid[np_[0]])
         self.frozen = [(n, p) for n, p in named if not p.requires_grad]
         dev = named[0][1].device
         self.offsets = OrderedDict()
+        self.groups = {}
         off = 0
         for group in (self.trainable, self.frozen):
             for n, p in group:
@@ -35,6 +41,8 @@ class FlatParams:
                     raise RuntimeError(f"FlatParams: parameter {n} is {p.dtype}; master weights must be float32")
                 self.offsets[n] = (off, p.numel())
                 off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+                if group is self.trainable:
+                    self.groups[gid[n]] = (self.groups.get(gid[n], (self.offsets[n][0], 0))[0], off)
             if group is self.trainable:
                 self.n_trainable = off
         self.total = off
@@ -60,10 +68,13 @@ class AdamWEMA:
     """AdamW(lr, betas, eps, weight_decay) on the trainable slice + EMA(decay) over ALL parameters (the
     reference's EMA includes the frozen ``pos_embed``, train_accum.py:343-347)."""
 
-    def __init__(self, module, lr=2e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, ema_decay=0.9999, flat: FlatParams = None):
+    def __init__(self, module, lr=2e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, ema_decay=0.9999, flat: FlatParams = None,
+                 group_weight_decay=None):
+        """group_weight_decay: {group id: weight decay} for a ``FlatParams(module, group_fn)`` layout (default: `weight_decay` everywhere)."""
         self.module = module
         self.flat = flat or FlatParams(module)
         self.lr, self.betas, self.eps, self.weight_decay, self.ema_decay = lr, betas, eps, weight_decay, ema_decay
+        self.group_weight_decay = group_weight_decay
         f = self.flat
         self.m = torch.zeros_like(f.grads)
         self.v = torch.zeros_like(f.grads)
@@ -80,8 +91,11 @@ class AdamWEMA:
         f = self.flat
         self.step_count += 1
         n = f.n_trainable
-        ops.adamw_ema(f.params[:n], f.grads, self.m, self.v, self.ema[:n], self.step_count, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.weight_decay, self.ema_decay, grad_scale)
+        spans = [(0, n, self.weight_decay)] if not self.group_weight_decay else \
+            [(lo, hi, self.group_weight_decay.get(g, self.weight_decay)) for g, (lo, hi) in sorted(f.groups.items())]
+        for lo, hi, wd in spans:
+            ops.adamw_ema(f.params[lo:hi], f.grads[lo:hi], self.m[lo:hi], self.v[lo:hi], self.ema[lo:hi], self.step_count, self.lr,
+                          self.betas[0], self.betas[1], self.eps, wd, self.ema_decay, grad_scale)
         if f.total > n:
             ops.ema_only(self.ema[n:], f.params[n:], self.ema_decay)
 

@@ -77,3 +77,22 @@ def test_weight_init_special_case():
     t.load_weights_with_shape_check(small, ck, rank=1)
     assert torch.equal(small.x_embedder.proj.weight[:, :16], big.x_embedder.proj.weight[:, :16])
     assert torch.equal(small.blocks[0].attn.qkv.weight, big.blocks[0].attn.qkv.weight)
+
+
+def test_vmae_pretrain_schedule_and_param_groups():
+    """Host logic of the VMAE pre-training driver: the half-cycle cosine schedule with warm-up (reference VMAE/util/lr_sched.py:9-18) and
+    the timm weight-decay split as contiguous groups of the flat parameter slab."""
+    import math
+    from ldmae_amd.vmae_pretrain import cosine_lr, no_decay
+    from ldmae_amd.optim import FlatParams
+    assert cosine_lr(0.0, 1e-3, 0.0, 40, 400) == 0.0 and abs(cosine_lr(20.0, 1e-3, 0.0, 40, 400) - 5e-4) < 1e-12
+    assert abs(cosine_lr(40.0, 1e-3, 1e-5, 40, 400) - 1e-3) < 1e-12 and abs(cosine_lr(400.0, 1e-3, 1e-5, 40, 400) - 1e-5) < 1e-12
+    mid = cosine_lr(220.0, 1e-3, 0.0, 40, 400)
+    assert abs(mid - 0.5e-3 * (1 + math.cos(math.pi * 0.5))) < 1e-12 and cosine_lr(7.0, 3e-4, 0, 40, 400, fixed_lr=True) == 3e-4
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.LayerNorm(16), torch.nn.Linear(16, 4))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    flat = FlatParams(net, group_fn=no_decay)
+    assert set(flat.groups) == {0, 1} and flat.groups[0][0] == 0 and flat.groups[0][1] == flat.groups[1][0] and flat.groups[1][1] == flat.n_trainable
+    for n, p in net.named_parameters():
+        lo, hi = flat.groups[no_decay(n, p)]
+        assert lo <= flat.offsets[n][0] < hi and torch.equal(p.data, before[n])           # values unchanged, each name inside its group

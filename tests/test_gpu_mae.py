@@ -135,3 +135,25 @@ def test_pretraining_step_loss_and_all_grads_vs_oracle():
     assert abs(float(loss16) - float(ol)) < 2e-2 * abs(float(ol))
     g, r = params["decoder_pred.conv_smoother.weight"].grad.cpu(), leaves["decoder_pred.conv_smoother.weight"].grad
     assert rel_err(g, r) < 5e-2
+
+
+def test_vmae_pretrain_driver_steps():
+    """A few optimizer steps of the pre-training driver (engine_pretrain.py counterpart) on a small geometry: loss finite and falling on a
+    repeated batch, weight decay applied to matrices only."""
+    import argparse
+    from ldmae_amd import vmae_pretrain as vp
+    from ldmae_amd.tokenizer import models_mae
+    torch.manual_seed(0)
+    m = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192, decoder_depth=2,
+                                        decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
+                                        kl_loss_weight=1e-6, smooth_output=True).cuda()
+    opt = vp.build_optimizer(m, 1e-3, 0.05)
+    args = argparse.Namespace(accum_iter=2, lr=1e-3, min_lr=0.0, warmup_epochs=0, epochs=10, fixed_lr=False, precision="bf16", mask_ratio=0.75,
+                              visible_loss_ratio=0.5, print_freq=1000)
+    x = torch.rand(8, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    loader = [(x, 0)] * 24
+    ln_w = m.norm.weight.detach().clone()
+    first = vp.train_one_epoch(m, loader[:2], opt, 0, args, log=lambda s: None)
+    last = vp.train_one_epoch(m, loader, opt, 1, args, log=lambda s: None)
+    assert opt.step_count == 13 and np.isfinite(last["loss"]) and last["loss"] < first["loss"]
+    assert 0 < last["lr"] < 1e-3 and torch.isfinite(m.norm.weight).all() and not torch.equal(m.norm.weight, ln_w)
