@@ -144,13 +144,13 @@ def test_vmae_pretrain_driver_steps():
     from ldmae_amd import vmae_pretrain as vp
     from ldmae_amd.tokenizer import models_mae
     torch.manual_seed(0)
-    m = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192, decoder_depth=2,
+    m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192, decoder_depth=2,
                                         decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
                                         kl_loss_weight=1e-6, smooth_output=True).cuda()
     opt = vp.build_optimizer(m, 1e-3, 0.05)
     args = argparse.Namespace(accum_iter=2, lr=1e-3, min_lr=0.0, warmup_epochs=0, epochs=10, fixed_lr=False, precision="bf16", mask_ratio=0.75,
                               visible_loss_ratio=0.5, print_freq=1000)
-    x = torch.rand(8, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    x = torch.rand(8, 3, 128, 128, generator=torch.Generator().manual_seed(1)) * 2 - 1     # 256 patches -> 64 kept tokens (attention tiles: N % 64 == 0)
     loader = [(x, 0)] * 24
     ln_w = m.norm.weight.detach().clone()
     first = vp.train_one_epoch(m, loader[:2], opt, 0, args, log=lambda s: None)
