@@ -641,7 +641,7 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
   // tune key 0: 1 = the one-wave-per-SIMD kernel of gemm_w4.hip (bf16; bias / gated residual / SwiGLU / SwiGLU-bwd epilogues)
   if (dtype == LDMAE_BF16 && ldmae_tune_get(0) != 0 &&
       (ldmae_tune_get(0) == 1 ? ldmae_launch_nt_w4(epi, sizeof(OutT) == 2, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st)
-                              : ldmae_launch_nt_p8(epi, sizeof(OutT) == 2, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st))) {
+                                : ldmae_launch_nt_p8(epi, sizeof(OutT) == 2, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st))) {
     if (pi >= 0) ldmae_prof_end(pi, st);
     LDMAE_CHECK_LAUNCH("gemm_nt_w4");
     return LDMAE_OK;

@@ -123,15 +123,19 @@ template <int EPI, typename OutT> struct Epi4 {
 // Epilogue shared by the NT kernels: accumulators -> per-wave f32 LDS strip [16 rows][68] (`ew`, private to the wave, so no
 // workgroup barrier is needed) -> row-contiguous 16-B global accesses with the fused bias / gated residual / pos / GELU /
 // SwiGLU forms.
-template <int EPI, typename OutT, int TM, int TNn, int MI, int NI>
+struct NoHook { __device__ __forceinline__ void operator()(int, int) const {} };
+// `consumed(i, cblk)`: called once accumulator tiles acc[i][4*cblk .. 4*cblk+3] have been copied to the strip (they are dead from then
+// on): the one-wave-per-SIMD kernel re-zeroes them there on the idle matrix pipe instead of in a pass of its own.
+template <int EPI, typename OutT, int TM, int TNn, int MI, int NI, typename Hook = NoHook>
 __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, float* ex, const EpiArgs& e, int m0, int n0, int wm, int wn,
-                                            int lane, int M, int N) {   // ew: strip [16][68]; ex: 512 more private floats
+                                            int lane, int M, int N, Hook consumed = Hook()) {   // ew: strip [16][68]; ex: 512 more private floats
   constexpr int ELD = 68;
   auto fill = [&](int i, int cblk) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ew[((lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[i][cblk * 4 + j][r];
+    consumed(i, cblk);
   };
   if constexpr (EPI == LDMAE_EPI_SWIGLU) {
     // strip cols 0..31 = x1 (hid columns hc..), 32..63 = x2.  Values are rounded to bf16 BEFORE silu so the result

@@ -19,6 +19,7 @@
 #include "gemm_nt_common.h"
 
 #include <type_traits>
+#include <utility>
 
 __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
@@ -29,6 +30,12 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
 // accumulators through VGPRs: ~2000 v_accvgpr moves per K-step pair); volatile pins the MFMA / DMA / barrier order as written
 __device__ __forceinline__ void mfma_acc(f32x4& c, const bf16x8& a, const bf16x8& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// c = 0 on the matrix pipe (0 * 0 + 0): the accumulator is (re)defined by an asm output, so the compiler never materialises zeros in
+// the AGPR file itself (its own zero-init wanted a spare AGPR quad; with all 64 quads taken it moved an accumulator through VGPRs in
+// the K loop -- read right behind the asm MFMA that wrote it, i.e. stale)
+__device__ __forceinline__ void mfma_zero(f32x4& c, const bf16x8& z) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(c) : "v"(z));
 }
 // two waves per SIMD (256 registers per wave): accumulators in the VGPR half like everything else
 __device__ __forceinline__ void mfma_acc_v(f32x4& c, const bf16x8& a, const bf16x8& b) {
@@ -166,6 +173,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const bf16* __restrict_
     nt_epilogue<EPI, OutT, TM, TNn, MI, NI>(acc, ew, ex, e, em0, en0, wm, wn, lane, M, N);
   }
 }
+
+// (A register-staged form of this kernel -- global_load_dwordx4 -> VGPR -> ds_write_b128, continuous operand stream across tiles,
+// accumulators re-zeroed on the idle matrix pipe from an epilogue hook -- was built and measured this round: 979 TF/s at K = 4096
+// against 1137 for the DMA form above and 1259 for the phased 8-wave kernel; with 256 accumulators + 2 x 8 staging quads + fragments
+// the allocator spills inside the K loop.  Not kept; DESIGN.md section 9 has the numbers.)
 
 // ------------------------------------------------------------------------------------------------
 // The same self-pipelined stream with TWO waves per SIMD: 8 waves (2 x 4), 128 x 64 per wave (8 x 4 MFMA tiles, 128 accumulator

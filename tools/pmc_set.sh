@@ -19,5 +19,11 @@ for r in csv.DictReader(open(f[0])):
         acc[r["Kernel_Name"][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kn,d in acc.items():
     for k,v in d.items(): print(f"{kn:50s} {k:32s} {sum(v)/len(v):.6g}")
+t=glob.glob("/tmp/pmc/*/*kernel_trace.csv")
+if t:
+    dur=collections.defaultdict(list)
+    for r in csv.DictReader(open(t[0])):
+        if sys.argv[1] in r["Kernel_Name"]: dur[r["Kernel_Name"][:48]].append(float(r["End_Timestamp"])-float(r["Start_Timestamp"]))
+    for kn,v in dur.items(): print(f"{kn:50s} {'duration_ns (this pass)':32s} {sum(v)/len(v):.6g}")
 PY
 done
