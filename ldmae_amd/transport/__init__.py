@@ -8,16 +8,12 @@ from .transport import ModelType, PathType, Sampler, Transport, WeightType
 
 def create_transport(path_type='Linear', prediction="velocity", loss_weight=None, train_eps=None, sample_eps=None,
                      use_cosine_loss=None, use_lognorm=None, partitial_train=None, partial_ratio=1.0, shift_lg=False):
-    """Reference: transport/__init__.py:3-72 (same positional order and defaults)."""
-    model_type = {"noise": ModelType.NOISE, "score": ModelType.SCORE}.get(prediction, ModelType.VELOCITY)
-    loss_type = {"velocity": WeightType.VELOCITY, "likelihood": WeightType.LIKELIHOOD}.get(loss_weight, WeightType.NONE)
-    path = {"Linear": PathType.LINEAR, "GVP": PathType.GVP, "VP": PathType.VP}[path_type]
-    if path == PathType.VP:
-        train_eps, sample_eps = (1e-5 if train_eps is None else train_eps), (1e-3 if train_eps is None else sample_eps)
-    elif model_type != ModelType.VELOCITY:
-        train_eps, sample_eps = (1e-3 if train_eps is None else train_eps), (1e-3 if train_eps is None else sample_eps)
-    else:   # velocity on a linear / GVP path is stable on the whole interval
-        train_eps = sample_eps = 0
-    return Transport(model_type=model_type, path_type=path, loss_type=loss_type, train_eps=train_eps, sample_eps=sample_eps,
+    """Reference: transport/__init__.py:3-72 (same positional order and defaults).  The shipped configuration -- linear path, velocity
+    prediction, unweighted loss -- is the hot path; the other plans / parametrisations of the reference are out of scope."""
+    if path_type != "Linear" or prediction != "velocity" or loss_weight not in (None, "None", "none"):
+        raise NotImplementedError(f"ldmae_amd transport: only path_type='Linear', prediction='velocity', loss_weight=None are on the hot path "
+                                  f"(got {path_type!r}, {prediction!r}, {loss_weight!r}); SURVEY.md 2.1 #7")
+    # velocity on the linear path is stable on the whole interval (transport/__init__.py:60-62)
+    return Transport(model_type=ModelType.VELOCITY, path_type=PathType.LINEAR, loss_type=WeightType.NONE, train_eps=0, sample_eps=0,
                      use_cosine_loss=use_cosine_loss, use_lognorm=use_lognorm, partitial_train=partitial_train,
                      partial_ratio=partial_ratio, shift_lg=shift_lg)

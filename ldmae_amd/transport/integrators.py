@@ -1,5 +1,5 @@
-"""Fixed-grid ODE / SDE integrators (reference: LDMAE/transport/integrators.py; the reference delegates the
-ODE to torchdiffeq.odeint(method='euler') -- here the fixed-step solvers are written out, no torchdiffeq)."""
+"""Fixed-grid ODE integrator (reference: LDMAE/transport/integrators.py:77-125; the reference delegates the ODE to
+torchdiffeq.odeint(method='euler') -- here the fixed-step solvers are written out, no torchdiffeq)."""
 import torch as th
 
 
@@ -41,38 +41,3 @@ class ode:
                     x = x + dt / 2 * (k1 + f(t[k + 1], x + dt * k1))
                 xs.append(x)
         return th.stack(xs)
-
-
-class sde:
-    """Euler-Maruyama / Heun SDE sampler (integrators.py:8-75)."""
-
-    def __init__(self, drift, diffusion, *, t0, t1, num_steps, sampler_type):
-        assert t0 < t1, "SDE sampler has to be in forward time"
-        self.t = th.linspace(t0, t1, num_steps)
-        self.dt = self.t[1] - self.t[0]
-        self.drift, self.diffusion, self.sampler_type = drift, diffusion, sampler_type
-
-    def _euler(self, x, t, model, **kw):
-        w = th.randn(x.size()).to(x)
-        tv = th.ones(x.size(0)).to(x) * t
-        mean_x = x + self.drift(x, tv, model, **kw) * self.dt
-        return mean_x + th.sqrt(2 * self.diffusion(x, tv)) * w * th.sqrt(self.dt), mean_x
-
-    def _heun(self, x, t, model, **kw):
-        w = th.randn(x.size()).to(x)
-        tv = th.ones(x.size(0)).to(x) * t
-        xhat = x + th.sqrt(2 * self.diffusion(x, tv)) * w * th.sqrt(self.dt)
-        k1 = self.drift(xhat, tv, model, **kw)
-        k2 = self.drift(xhat + self.dt * k1, tv + self.dt, model, **kw)
-        return xhat + 0.5 * self.dt * (k1 + k2), xhat
-
-    def sample(self, init, model, **kw):
-        step = {"Euler": self._euler, "Heun": self._heun}.get(self.sampler_type)
-        if step is None:
-            raise NotImplementedError("Smapler type not implemented.")
-        x, out = init, []
-        for ti in self.t[:-1]:
-            with th.no_grad():
-                x, _ = step(x, ti, model, **kw)
-                out.append(x)
-        return out

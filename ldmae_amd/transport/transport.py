@@ -5,7 +5,7 @@ import numpy as np
 import torch as th
 
 from . import path
-from .integrators import ode, sde
+from .integrators import ode
 from .utils import mean_flat
 
 
@@ -31,7 +31,9 @@ class Transport:
     def __init__(self, *, model_type, path_type, loss_type, train_eps, sample_eps, use_cosine_loss=False, use_lognorm=False,
                  partitial_train=None, partial_ratio=1.0, shift_lg=False):
         self.loss_type, self.model_type = loss_type, model_type
-        self.path_sampler = {PathType.LINEAR: path.ICPlan, PathType.GVP: path.GVPCPlan, PathType.VP: path.VPCPlan}[path_type]()
+        if path_type != PathType.LINEAR or model_type != ModelType.VELOCITY:
+            raise NotImplementedError("ldmae_amd Transport: linear path + velocity prediction only (SURVEY.md 2.1 #7)")
+        self.path_sampler = path.ICPlan()
         self.train_eps, self.sample_eps = train_eps, sample_eps
         self.use_cosine_loss, self.use_lognorm = use_cosine_loss, use_lognorm
         self.partitial_train, self.partial_ratio, self.shift_lg = partitial_train, partial_ratio, shift_lg
@@ -42,17 +44,10 @@ class Transport:
 
     def check_interval(self, train_eps, sample_eps, *, diffusion_form="SBDM", sde=False, reverse=False, eval=False,
                        last_step_size=0.0):
-        """transport.py:84-111."""
-        t0, t1 = 0, 1
-        eps = train_eps if not eval else sample_eps
-        if isinstance(self.path_sampler, path.VPCPlan):
-            t1 = 1 - eps if (not sde or last_step_size == 0) else 1 - last_step_size
-        elif self.model_type != ModelType.VELOCITY or sde:
-            t0 = eps if (diffusion_form == "SBDM" and sde) or self.model_type != ModelType.VELOCITY else 0
-            t1 = 1 - eps if (not sde or last_step_size == 0) else 1 - last_step_size
-        if reverse:
-            t0, t1 = 1 - t0, 1 - t1
-        return t0, t1
+        """transport.py:84-111 for the velocity model on the linear path: the whole unit interval."""
+        if sde:
+            raise NotImplementedError("ldmae_amd Transport: SDE sampling is out of scope (SURVEY.md 2.1 #7)")
+        return (1, 0) if reverse else (0, 1)
 
     def sample_logit_normal(self, mu, sigma, size=1):
         """transport.py:113-123.  The reference calls scipy.stats.norm.rvs with no random_state, i.e.
@@ -97,64 +92,26 @@ class Transport:
         out = model(xt, t, **model_kwargs)
         assert out.size() == xt.size()
         terms = {'pred': out}
-        if self.model_type == ModelType.VELOCITY:
-            terms['loss'] = mean_flat((out - ut) ** 2)
-            if self.use_cosine_loss:
-                terms['cos_loss'] = mean_flat(1 - th.nn.functional.cosine_similarity(out, ut, dim=1))
-            return terms
-        _, drift_var = self.path_sampler.compute_drift(xt, t)
-        sigma_t, _ = self.path_sampler.compute_sigma_t(path.expand_t_like_x(t, xt))
-        if self.loss_type == WeightType.VELOCITY:
-            weight = (drift_var / sigma_t) ** 2
-        elif self.loss_type == WeightType.LIKELIHOOD:
-            weight = drift_var / (sigma_t ** 2)
-        else:
-            weight = 1
-        if self.model_type == ModelType.NOISE:
-            terms['loss'] = mean_flat(weight * ((out - x0) ** 2))
-        else:
-            terms['loss'] = mean_flat(weight * ((out * sigma_t + x0) ** 2))
+        terms['loss'] = mean_flat((out - ut) ** 2)
+        if self.use_cosine_loss:
+            terms['cos_loss'] = mean_flat(1 - th.nn.functional.cosine_similarity(out, ut, dim=1))
         return terms
 
     def get_drift(self):
-        ps = self.path_sampler
-
-        def velocity_ode(x, t, model, **kw):
-            return model(x, t, **kw)
-
-        def score_ode(x, t, model, **kw):
-            mean, var = ps.compute_drift(x, t)
-            return -mean + var * model(x, t, **kw)
-
-        def noise_ode(x, t, model, **kw):
-            mean, var = ps.compute_drift(x, t)
-            sigma_t, _ = ps.compute_sigma_t(path.expand_t_like_x(t, x))
-            return -mean + var * (model(x, t, **kw) / -sigma_t)
-
-        fn = {ModelType.NOISE: noise_ode, ModelType.SCORE: score_ode}.get(self.model_type, velocity_ode)
-
+        """transport.py:217-245, velocity model: the drift of the probability-flow ODE is the model output itself."""
         def body_fn(x, t, model, **kw):
-            out = fn(x, t, model, **kw)
+            out = model(x, t, **kw)
             assert out.shape == x.shape, "Output shape from ODE solver must match input shape"
             return out
         return body_fn
 
-    def get_score(self):
-        ps = self.path_sampler
-        if self.model_type == ModelType.NOISE:
-            return lambda x, t, model, **kw: model(x, t, **kw) / -ps.compute_sigma_t(path.expand_t_like_x(t, x))[0]
-        if self.model_type == ModelType.SCORE:
-            return lambda x, t, model, **kw: model(x, t, **kw)
-        return lambda x, t, model, **kw: ps.get_score_from_velocity(model(x, t, **kw), x, t)
-
 
 class Sampler:
-    """transport.py:270-443 (ODE and SDE samplers; likelihood evaluation is out of scope, SURVEY.md §2.1 #7)."""
+    """transport.py:270-443, ODE sampler (the SDE sampler and likelihood evaluation are out of scope, SURVEY.md 2.1 #7)."""
 
     def __init__(self, transport):
         self.transport = transport
         self.drift = transport.get_drift()
-        self.score = transport.get_score()
 
     def sample_ode(self, *, sampling_method="dopri5", num_steps=50, atol=1e-6, rtol=1e-3, reverse=False, timestep_shift=0.0):
         drift = (lambda x, t, model, **kw: self.drift(x, th.ones_like(t) * (1 - t), model, **kw)) if reverse else self.drift
@@ -163,37 +120,5 @@ class Sampler:
         return ode(drift=drift, t0=t0, t1=t1, sampler_type=sampling_method, num_steps=num_steps, atol=atol, rtol=rtol,
                    timestep_shift=timestep_shift).sample
 
-    def sample_sde(self, *, sampling_method="Euler", diffusion_form="SBDM", diffusion_norm=1.0, last_step="Mean",
-                   last_step_size=0.04, num_steps=250):
-        if last_step is None:
-            last_step_size = 0.0
-        ps = self.transport.path_sampler
-
-        def diffusion_fn(x, t):
-            return ps.compute_diffusion(x, t, form=diffusion_form, norm=diffusion_norm)
-
-        def sde_drift(x, t, model, **kw):
-            return self.drift(x, t, model, **kw) + diffusion_fn(x, t) * self.score(x, t, model, **kw)
-
-        t0, t1 = self.transport.check_interval(self.transport.train_eps, self.transport.sample_eps, diffusion_form=diffusion_form,
-                                               sde=True, eval=True, reverse=False, last_step_size=last_step_size)
-        solver = sde(sde_drift, diffusion_fn, t0=t0, t1=t1, num_steps=num_steps, sampler_type=sampling_method)
-        if last_step is None:
-            last = lambda x, t, model, **kw: x
-        elif last_step == "Mean":
-            last = lambda x, t, model, **kw: x + sde_drift(x, t, model, **kw) * last_step_size
-        elif last_step == "Euler":
-            last = lambda x, t, model, **kw: x + self.drift(x, t, model, **kw) * last_step_size
-        elif last_step == "Tweedie":
-            last = lambda x, t, model, **kw: x / ps.compute_alpha_t(t)[0][0] + (ps.compute_sigma_t(t)[0][0] ** 2) / \
-                ps.compute_alpha_t(t)[0][0] * self.score(x, t, model, **kw)
-        else:
-            raise NotImplementedError()
-
-        def _sample(init, model, **kw):
-            xs = solver.sample(init, model, **kw)
-            ts = th.ones(init.size(0), device=init.device) * t1
-            xs.append(last(xs[-1], ts, model, **kw))
-            assert len(xs) == num_steps, "Samples does not match the number of steps"
-            return xs
-        return _sample
+    def sample_sde(self, **_):
+        raise NotImplementedError("ldmae_amd Sampler: SDE sampling is out of scope (SURVEY.md 2.1 #7); run_inference.sh uses sample_ode")
