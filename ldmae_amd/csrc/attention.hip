@@ -10,6 +10,10 @@
 // 8-row x 32-col sub-tiles of 512 B with a 2-bit XOR on the 16-B chunk; filled by global_load_lds with
 // the permutation applied to the per-lane SOURCE address.
 //
+// The loops are bound by vector-instruction ISSUE, not by the matrix pipe (hd = 64: 16 MFMAs against 32 exponentials per 64-key tile
+// and wave), so everything around the exponential is folded away: the stationary operand carries scale*log2(e), the score chains start
+// from accumulators that already hold -(running max) / -lse / -delta, and tile addresses are scalar (SGPR-base LDS-DMA).
+//
 // Backward = two passes without atomics (bitwise reproducible):
 //   dKdV: a wave owns 32 keys (key on the lane), sweeps 64-query tiles: S, dP, then dV^T += dO^T P,
 //         dK^T += Q^T dS with Q / dO read both by rows and transposed from the same LDS image.
@@ -54,6 +58,45 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ g, long ld, 
       glds16(src, lds + pi * 1024);
     }
   }
+}
+// The same staging with the addressing hoisted out of the tile loop (head dims that need no padding): per-lane byte offsets of this
+// wave's pieces, computed once; a tile is then (uniform base pointer, uniform LDS address) + one LDS-DMA instruction per piece.  Head
+// dims with padded chunks keep the per-lane-pointer form above (their zero source is not base-relative).
+template <int HD, int ROWS> struct TileMap {
+  static constexpr int HDP = hd_pad(HD), PIECES = ROWS * HDP * 2 / 1024, NPW = (PIECES + 3) / 4;
+  unsigned voff[NPW];
+  __device__ __forceinline__ void init(long ld, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      int row, ch;
+      tile_inv<HDP>((wave * NPW + i) * 1024 + lane * 16, row, ch);
+      voff[i] = (unsigned)((row * ld + ch * 8) * 2);
+    }
+  }
+  // g: first element of the tile (wave-uniform); lds: the tile's LDS image; lds_addr: its LDS byte address (wave-uniform)
+  __device__ __forceinline__ void issue(const bf16* g, long ld, char* lds, unsigned lds_addr, int wave, int lane) const {
+    if constexpr (HD == HDP) {
+#pragma unroll
+      for (int i = 0; i < NPW; ++i)
+        if (wave * NPW + i < PIECES) glds16_s(g, voff[i], lds_addr + (wave * NPW + i) * 1024);
+    } else {
+      stage_tile<HD, ROWS>(g, ld, ROWS - 1, lds, wave, lane);
+    }
+  }
+};
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(void, p)); }
+// register fragment times a scalar, rounded back to bf16 (the stationary operand of a score product carries scale * log2(e))
+__device__ __forceinline__ bf16x8 frag_scale(const bf16x8& a, float c) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] * c);
+  return o;
+}
+__device__ __forceinline__ f32x16 splat16(float v) {
+  f32x16 o;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) o[t] = v;
+  return o;
 }
 // 8 bf16 of a row held in global memory at column c (a register fragment); zero past the true head dim
 template <int HD> __device__ __forceinline__ bf16x8 gfrag(const bf16* row, int c) {
@@ -133,12 +176,17 @@ __device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[hd_pad(HD) / 32
 // by the VMAE blocks, which have no QK-norm / RoPE between the Linear and the attention): sb = N*3*H*hd, sh = hd, ld = 3*H*hd.
 struct QkvLayout { long sb, sh, ld; };
 
+// VALU diet (the loop is bound by vector ISSUE, not by the matrix pipe: ~260 VALU instructions per 16 MFMAs before, profiles/r02):
+// (i) q carries scale*log2(e) (rounded once more to bf16 in registers) and every score chain starts from the accumulator block
+// nm = -(running max): the MFMA result is already the exponent, p = exp2(s) is ONE instruction per score; (ii) the running max only
+// moves in the (rare, wave-uniform) rescale branch, which shifts the tile's scores and refreshes nm; (iii) K / V tile addresses are scalar.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                             bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L, QkvLayout Lv) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  constexpr bool BATCH = HDP <= 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [STAGES][K tile | V tile]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
   const int qblocks = (N + 127) / 128;
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = lid / qblocks, q0 = (lid % qblocks) * 128 + wave * 32;
@@ -150,19 +198,22 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   const long ld = L.ld, ldv = Lv.ld;
   bf16x8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = gfrag<HD>(qp + (size_t)min(q0 + r, N - 1) * ld, ks * 16 + 8 * h);
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_scale(gfrag<HD>(qp + (size_t)min(q0 + r, N - 1) * ld, ks * 16 + 8 * h), c);
   f32x16 oacc[DB];
 #pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) oacc[d][t] = 0.f;
-  float ms = -1e30f, l = 0.f;
+  for (int d = 0; d < DB; ++d) oacc[d] = splat16(0.f);
+  f32x16 nm = splat16(0.f);                // -ms in every element: the C operand of the first MFMA of a score chain
+  float ms = 0.f, l = 0.f;                 // ms is set from the first tile (rescale branch), so 0 is never used as a maximum
   const int nt = N / 64;
   constexpr int PPW = 2 * (TB / 1024) / 4;
+  TileMap<HD, 64> mk, mv;
+  mk.init(ld, wave, lane);
+  mv.init(ldv, wave, lane);
+  const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int kt) {
-    char* base = smem + (kt % ATT_STAGES) * 2 * TB;
-    stage_tile<HD, 64>(kp + (size_t)kt * 64 * ld, ld, 63, base, wave, lane);
-    stage_tile<HD, 64>(vp + (size_t)kt * 64 * ldv, ldv, 63, base + TB, wave, lane);
+    const int so = (kt % ATT_STAGES) * 2 * TB;
+    mk.issue(kp + (size_t)kt * 64 * ld, ld, smem + so, lds0 + so, wave, lane);
+    mv.issue(vp + (size_t)kt * 64 * ldv, ldv, smem + so + TB, lds0 + so + TB, wave, lane);
   };
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)
@@ -178,32 +229,59 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     if (kt + ATT_STAGES - 1 < nt) stage(kt + ATT_STAGES - 1);
     const char* Kt = smem + st * 2 * TB;
     const char* Vt = Kt + TB;
+    // LDS reads are batched ahead of the MFMAs that consume them (left to itself the compiler keeps ONE fragment in flight and waits
+    // for it before every MFMA: 16 exposed LDS round trips per tile); the two 32-key chains are interleaved
+    // (head dims up to 64; wider ones would not fit the register file that way and read each fragment where it is used)
     f32x16 s[2];
+    bf16x8 kfr[KS][2];
+    if constexpr (BATCH) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) s[kb][t] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s[kb] = MFMA_BF16(frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], s[kb]);
+        for (int kb = 0; kb < 2; ++kb) kfr[ks][kb] = frag_row<HDP>(Kt, kb * 32, ks, lane);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    float mx = s[0][0];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) mx = fmaxf(mx, fmaxf(s[0][t], s[1][t]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;
-    if (__builtin_amdgcn_ballot_w64(mx > ms + RESCALE_THR) != 0) {      // wave-uniform: some query's max grew a lot
-      const float ms_new = fmaxf(ms, mx), alpha = EXP2(ms - ms_new);
-      ms = ms_new;
-      l *= alpha;
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int d = 0; d < DB; ++d)
+      for (int kb = 0; kb < 2; ++kb)
+        s[kb] = MFMA_BF16(BATCH ? kfr[ks][kb] : frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], ks == 0 ? nm : s[kb]);
+    bf16x8 vfr[2][2][DB];                              // V^T fragments: in flight under the softmax arithmetic
+    if constexpr (BATCH) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) oacc[d][t] *= alpha;
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int d = 0; d < DB; ++d) vfr[kb][s2][d] = frag_tr<HDP>(Vt, kb * 32 + 16 * s2, d * 32, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // s = score * scale * log2(e) - ms
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int t = 1; t < 16; ++t) mx = fmaxf(mx, fmaxf(s[0][t], s[1][t]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const bool first = kt == 0;
+    if (first || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0) {      // wave-uniform: first tile, or some query's max grew a lot
+      const float d = first ? mx : fmaxf(mx, 0.f);
+      ms += d;
+      if (!first) {
+        const float alpha = EXP2(-d);
+        l *= alpha;
+#pragma unroll
+        for (int dd = 0; dd < DB; ++dd)
+#pragma unroll
+          for (int t = 0; t < 16; ++t) oacc[dd][t] *= alpha;
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { s[0][t] -= d; s[1][t] -= d; }
+      nm = splat16(-ms);
     }
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) { const float p = EXP2(s[kb][t] * c - ms); s[kb][t] = p; rs += p; }
+      for (int t = 0; t < 16; ++t) { const float p = EXP2(s[kb][t]); s[kb][t] = p; rs += p; }
     l += rs;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -211,7 +289,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pf = acc_frag(s[kb], s2);
 #pragma unroll
-        for (int d = 0; d < DB; ++d) oacc[d] = MFMA_BF16(frag_tr<HDP>(Vt, kb * 32 + 16 * s2, d * 32, lane), pf, oacc[d]);
+        for (int d = 0; d < DB; ++d)
+          oacc[d] = MFMA_BF16(BATCH ? vfr[kb][s2][d] : frag_tr<HDP>(Vt, kb * 32 + 16 * s2, d * 32, lane), pf, oacc[d]);
       }
   };
   for (int kt = 0; kt < nt; kt += ATT_STAGES) {
@@ -252,15 +331,18 @@ __global__ void attn_delta_kernel(const T* __restrict__ O, const T* __restrict__
 }
 
 // ================================================================================================ backward dK/dV, bf16
+// ROWC = [2][B*H*N] f32 written by the dQ kernel (which runs first): slot 0 = -delta, slot 1 = -lse * log2(e).  They are the INITIAL
+// ACCUMULATORS of the dP and S chains (a query row = an accumulator element here, so they come from the LDS copy of the tile's 64 values
+// by ds_read_b128), k carries scale*log2(e): p = exp2(S) and dS = p * dP are one instruction per element each.
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
-                                                                 const bf16* __restrict__ dO, const float* __restrict__ LSE,
-                                                                 const float* __restrict__ DELTA, bf16* __restrict__ dK, bf16* __restrict__ dV,
+                                                                 const bf16* __restrict__ dO, const float* __restrict__ ROWC, long rc_stride,
+                                                                 bf16* __restrict__ dK, bf16* __restrict__ dV,
                                                                  int H, int N, float scale, QkvLayout L, QkvLayout Lv) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][Q tile | dO tile | lse2[64] delta[64]]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [STAGES][Q tile | dO tile | -lse2[64] -delta[64] scratch[128]]
   constexpr int BUF = 2 * TB + 1024;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
   const float c = scale * 1.4426950408889634f;
   const int kblocks = (N + 127) / 128;
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -275,23 +357,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    kf[ks] = gfrag<HD>(K + hb + (size_t)min(k0 + r, N - 1) * ld, ks * 16 + 8 * h);
+    kf[ks] = frag_scale(gfrag<HD>(K + hb + (size_t)min(k0 + r, N - 1) * ld, ks * 16 + 8 * h), c);
     vf[ks] = gfrag<HD>(V + hbv + (size_t)min(k0 + r, N - 1) * Lv.ld, ks * 16 + 8 * h);
   }
   f32x16 dkacc[DB], dvacc[DB];
 #pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) { dkacc[d][t] = 0.f; dvacc[d][t] = 0.f; }
+  for (int d = 0; d < DB; ++d) { dkacc[d] = splat16(0.f); dvacc[d] = splat16(0.f); }
   const int nt = N / 64;
   constexpr int PPW = 2 * (TB / 1024) / 4 + 1;
-  const float* rowc = (wave & 1) ? DELTA + (size_t)bh * N : LSE + (size_t)bh * N;     // wave 0/2: lse, wave 1/3: delta
+  const float* rowc = ROWC + (size_t)bh * N + ((wave & 1) ? 0 : rc_stride);     // wave 0/2: -lse2, wave 1/3: -delta
+  TileMap<HD, 64> mq, mo;
+  mq.init(ld, wave, lane);
+  mo.init(dold, wave, lane);
+  const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int qt) {
-    char* base = smem + (qt % ATT_STAGES) * BUF;
-    stage_tile<HD, 64>(qp + (size_t)qt * 64 * ld, ld, 63, base, wave, lane);
-    stage_tile<HD, 64>(dop + (size_t)qt * 64 * dold, dold, 63, base + TB, wave, lane);
-    // 64 floats of lse (slot 0) / delta (slot 1); waves 2,3 fill scratch slots so every wave issues PPW loads
-    glds4(rowc + qt * 64 + lane, base + 2 * TB + wave * 256);
+    const int so = (qt % ATT_STAGES) * BUF;
+    mq.issue(qp + (size_t)qt * 64 * ld, ld, smem + so, lds0 + so, wave, lane);
+    mo.issue(dop + (size_t)qt * 64 * dold, dold, smem + so + TB, lds0 + so + TB, wave, lane);
+    // 64 floats of -lse2 (slot 0) / -delta (slot 1); waves 2,3 fill scratch slots so every wave issues PPW loads
+    glds4_s(rowc + qt * 64, lane * 4, lds0 + so + 2 * TB + wave * 256);
   };
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)
@@ -307,13 +391,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
     if (qt + ATT_STAGES - 1 < nt) stage(qt + ATT_STAGES - 1);
     const char* Qt = smem + st * BUF;
     const char* dOt = Qt + TB;
-    const float* lse_t = (const float*)(Qt + 2 * TB);
-    const float* dl = lse_t + 64;
+    const float* nl = (const float*)(Qt + 2 * TB);
+    const float* nd = nl + 64;
+    // (fragments are read where they are used: batching them ahead, as the forward kernel does, costs this kernel its third wave per SIMD
+    // and measured slower: 1.64 vs 1.56 ms)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16 s, dp;
 #pragma unroll
-      for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
+      for (int g = 0; g < 4; ++g) {              // accumulator element 4g+j <-> query row qb*32 + 8g + 4h + j
+        const f32x4 a = *(const f32x4*)(nl + qb * 32 + 8 * g + 4 * h), e = *(const f32x4*)(nd + qb * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[4 * g + j] = a[j]; dp[4 * g + j] = e[j]; }
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         s = MFMA_BF16(frag_row<HDP>(Qt, qb * 32, ks, lane), kf[ks], s);
@@ -321,10 +411,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
       }
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        const int row = qb * 32 + acc_row(t, h);
-        const float p = EXP2(s[t] * c - lse_t[row] * 1.4426950408889634f);
+        const float p = EXP2(s[t]);
         s[t] = p;
-        dp[t] = p * (dp[t] - dl[row]);
+        dp[t] *= p;
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -353,11 +442,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                const bf16* __restrict__ O, const bf16* __restrict__ dO,
-                                                               const float* __restrict__ LSE, float* __restrict__ DELTA,
+                                                               const float* __restrict__ LSE, float* __restrict__ ROWC, long rc_stride,
                                                                bf16* __restrict__ dQ, int H, int N, float scale, QkvLayout L, QkvLayout Lv) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  constexpr bool BTR = HDP <= 64;     // transposed K fragments read ahead, under the exp / multiply arithmetic (fits 3 waves per SIMD)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [STAGES][K tile | V tile]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
   const float c = scale * 1.4426950408889634f;
   const int qblocks = (N + 127) / 128;
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -371,11 +461,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   const bf16* vp = V + (size_t)b * Lv.sb + (size_t)hh * Lv.sh;
   bf16x8 qf[KS], dof[KS];
   // delta_i = sum_d dO[i,d] * O[i,d] is formed here from the dO fragments this lane holds anyway (its half of the row; the other
-  // half sits on lane ^ 32) and published for the dK/dV kernel, which runs after this one: no separate pass over O and dO.
+  // half sits on lane ^ 32) and published (negated, with -lse*log2(e) beside it) for the dK/dV kernel, which runs after this one:
+  // no separate pass over O and dO.  Here the query sits on the lane, so both are lane constants: splat into the accumulator blocks
+  // the S and dP chains start from; q carries scale*log2(e).
   float dpart = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    qf[ks] = gfrag<HD>(Q + hb + (size_t)qrow * ld, ks * 16 + 8 * h);
+    qf[ks] = frag_scale(gfrag<HD>(Q + hb + (size_t)qrow * ld, ks * 16 + 8 * h), c);
     const size_t oo = (((size_t)b * N + qrow) * H + hh) * HD;
     dof[ks] = gfrag<HD>(dO + oo, ks * 16 + 8 * h);
     const bf16x8 of = gfrag<HD>(O + oo, ks * 16 + 8 * h);
@@ -383,19 +475,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
     for (int j = 0; j < 8; ++j) dpart += (float)dof[ks][j] * (float)of[j];
   }
   const float dl = dpart + __shfl_xor(dpart, 32);
-  if (h == 0 && q0 + r < N) DELTA[(size_t)bh * N + qrow] = dl;
   const float lse2 = LSE[(size_t)bh * N + qrow] * 1.4426950408889634f;
+  if (h == 0 && q0 + r < N) {
+    ROWC[(size_t)bh * N + qrow] = -dl;
+    ROWC[rc_stride + (size_t)bh * N + qrow] = -lse2;
+  }
+  const f32x16 nl = splat16(-lse2), nd = splat16(-dl);
   f32x16 dqacc[DB];
 #pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int t = 0; t < 16; ++t) dqacc[d][t] = 0.f;
+  for (int d = 0; d < DB; ++d) dqacc[d] = splat16(0.f);
   const int nt = N / 64;
   constexpr int PPW = 2 * (TB / 1024) / 4;
+  TileMap<HD, 64> mk, mv;
+  mk.init(ld, wave, lane);
+  mv.init(ldv, wave, lane);
+  const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int kt) {
-    char* base = smem + (kt % ATT_STAGES) * 2 * TB;
-    stage_tile<HD, 64>(kp + (size_t)kt * 64 * ld, ld, 63, base, wave, lane);
-    stage_tile<HD, 64>(vp + (size_t)kt * 64 * ldv, ldv, 63, base + TB, wave, lane);
+    const int so = (kt % ATT_STAGES) * 2 * TB;
+    mk.issue(kp + (size_t)kt * 64 * ld, ld, smem + so, lds0 + so, wave, lane);
+    mv.issue(vp + (size_t)kt * 64 * ldv, ldv, smem + so + TB, lds0 + so + TB, wave, lane);
   };
 #pragma unroll
   for (int st = 0; st < ATT_STAGES - 1; ++st)
@@ -415,19 +513,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s, dp;
 #pragma unroll
-      for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
-#pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s = MFMA_BF16(frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], s);
-        dp = MFMA_BF16(frag_row<HDP>(Vt, kb * 32, ks, lane), dof[ks], dp);
+        s = MFMA_BF16(frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], ks == 0 ? nl : s);
+        dp = MFMA_BF16(frag_row<HDP>(Vt, kb * 32, ks, lane), dof[ks], ks == 0 ? nd : dp);
+      }
+      bf16x8 ktr[2][DB];
+      if constexpr (BTR) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int d = 0; d < DB; ++d) ktr[s2][d] = frag_tr<HDP>(Kt, kb * 32 + 16 * s2, d * 32, lane);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int t = 0; t < 16; ++t) dp[t] = EXP2(s[t] * c - lse2) * (dp[t] - dl);
+      for (int t = 0; t < 16; ++t) dp[t] *= EXP2(s[t]);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 dsf = acc_frag(dp, s2);
 #pragma unroll
-        for (int d = 0; d < DB; ++d) dqacc[d] = MFMA_BF16(frag_tr<HDP>(Kt, kb * 32 + 16 * s2, d * 32, lane), dsf, dqacc[d]);
+        for (int d = 0; d < DB; ++d) dqacc[d] = MFMA_BF16(BTR ? ktr[s2][d] : frag_tr<HDP>(Kt, kb * 32 + 16 * s2, d * 32, lane), dsf, dqacc[d]);
       }
     }
   };
@@ -726,15 +830,15 @@ extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, floa
 static int attention_bwd_core(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
                               void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, QkvLayout Lq, QkvLayout Lv, hipStream_t st) {
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
-  const long items = (long)B * N * H;
+  const long items = (long)B * N * H, rcs = items;      // delta = [2][B*H*N] f32 workspace (bf16: -delta | -lse*log2e; f32: slot 0 = delta)
   const unsigned dgrid = (unsigned)((items * 8 + 255) / 256 < 8192 ? (items * 8 + 255) / 256 : 8192);
   if (dtype == LDMAE_BF16) {
     // dQ first: it forms delta = rowsum(dO * O) from its own fragments and publishes it for the dK/dV kernel
 #define L(HD) { \
     hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
     hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, (bf16*)dq, H, N, scale, Lq, Lv); \
-    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv); }
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, rcs, (bf16*)dq, H, N, scale, Lq, Lv); \
+    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, delta, rcs, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv); }
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {

@@ -32,6 +32,15 @@ __device__ __forceinline__ void glds4(const void* g, const void* lds) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(a) : "memory", "m0");
 }
 
+// SGPR-base forms: the 64-bit base and the LDS address are wave-uniform (scalar registers, advanced per tile by scalar adds), the lane
+// supplies only a 32-bit byte offset that is computed once per kernel: no per-piece 64-bit VALU address arithmetic in the main loops.
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void glds4_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+
 // ---------------------------------------------------------------- error plumbing
 void ldmae_set_error(const char* fmt, ...);
 #define LDMAE_FAIL(code, ...) do { ldmae_set_error(__VA_ARGS__); return (code); } while (0)

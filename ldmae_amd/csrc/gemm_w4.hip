@@ -21,10 +21,6 @@
 #include <type_traits>
 #include <utility>
 
-__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
-}
-
 // accumulate in place in the AGPR file: the tied "+a" operand makes the register allocator give every accumulator tile one AGPR
 // quad for the whole loop (the MFMA builtin lets it pick a different destination per instruction and shuffle the 256
 // accumulators through VGPRs: ~2000 v_accvgpr moves per K-step pair); volatile pins the MFMA / DMA / barrier order as written
