@@ -83,6 +83,14 @@ long ldmae_rmsnorm_modulate_bwd_workspace_bytes(int M, int D, int rows_per_batch
 int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
                                const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
                                float beta_w, int M, int D, int rows_per_batch, float* workspace, void* stream);
+/* The same followed by the gated-residual backward (ldmae_gate_bwd) of the updated dx_accum, in one pass over the rows (the block's
+ * norm2 backward feeds the attention branch's gate: lightningdit.py:247-248 read backwards): dy = dx_accum * gate[b] (in `dtype`),
+ * dgate [B, dgate_ld] = sum_n dx_accum * y, dbias [D] = column sums of dy. */
+long ldmae_rmsnorm_modulate_bwd_gate_workspace_bytes(int M, int D, int rows_per_batch);
+int ldmae_rmsnorm_modulate_bwd_gate(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
+                                    const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                                    float beta_w, const void* y, const float* gate, int gate_ld, void* dy, float* dgate, int dgate_ld,
+                                    float* dbias, int M, int D, int rows_per_batch, float* workspace, void* stream);
 
 /* ---- attention front end (lightningdit.py:68-74; rmsnorm.py on head_dim; pos_embed.py:38-42,135) */
 /* qkv [B,N,3,H,hd] -> q,k = rope(rmsnorm(.)*w) and v, each [B,H,N,hd]. cos/sin [N,hd] f32.

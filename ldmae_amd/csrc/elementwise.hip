@@ -62,6 +62,12 @@ static int pick_rows_per_wg(int rows_per_batch) {
   return 0;
 }
 
+// a product that is never contracted into a following add (HIP's __fmul_rn is a plain `*`): its consumers sum the value AS STORED
+__device__ __forceinline__ float4 mul_rn(float4 a, float4 b) {
+#pragma clang fp contract(off)
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+
 // ------------------------------------------------------------------ RMSNorm + modulate
 template <int NCH, typename OutT>
 __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -101,21 +107,33 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __res
 }
 
 // partials P[wg][3][D] = {sum dout, sum dout*y, sum dy*n} over the workgroup's rows (one sample)
-template <int NCH, typename T>
+// GATE: the gated-residual backward of the branch BELOW this norm (the attention branch under norm2) rides along: the updated residual
+// gradient is consumed while it is in registers -- dy = dx_new * gate[b] (rounded to T), dgate partials sum dx_new * y, bias-gradient
+// partials sum dy -- instead of being re-read by a separate gate_bwd pass (805 MB per block).  Same arithmetic, same partial layout
+// and same summation order as gate_bwd_kernel.
+struct GateBwdArgs { const void* y; const float* gate; int gate_ld; void* dy; float* Pg; float* Pb; };
+template <int NCH, typename T, bool GATE>
 __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x,
                                                               const float* __restrict__ w, const float* __restrict__ scale, int mod_ld,
                                                               const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ P,
-                                                              int M, int D, int rpb, int rows_per_wg) {
+                                                              int M, int D, int rpb, int rows_per_wg, GateBwdArgs ga) {
   extern __shared__ float red[];   // [4 waves][3][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nch = D >> 2;
   const int m_base = blockIdx.x * rows_per_wg, b = m_base / rpb;
   float4 wv[NCH], sc1[NCH], a_sh[NCH], a_sc[NCH], a_w[NCH];
+  float4 gv[GATE ? NCH : 1], a_g[GATE ? NCH : 1], a_b[GATE ? NCH : 1];
+  const T* gy = (const T*)ga.y;
+  T* gdy = (T*)ga.dy;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     wv[i] = c < nch ? *(const float4*)(w + 4 * c) : f4(0.f);
     sc1[i] = (c < nch && scale) ? f4(1.f) + *(const float4*)(scale + (size_t)b * mod_ld + 4 * c) : f4(1.f);
     a_sh[i] = a_sc[i] = a_w[i] = f4(0.f);
+    if constexpr (GATE) {
+      gv[i] = c < nch ? *(const float4*)(ga.gate + (size_t)b * ga.gate_ld + 4 * c) : f4(1.f);
+      a_g[i] = a_b[i] = f4(0.f);
+    }
   }
   for (int r = wave; r < rows_per_wg; r += 4) {
     const int m = m_base + r;
@@ -143,7 +161,14 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
       const int c = lane + 64 * i;
       if (c < nch) {
         float* p = dx + (size_t)m * D + 4 * c;
-        *(float4*)p = *(const float4*)p + (dn[i] - nv[i] * dot) * rs;
+        const float4 g = *(const float4*)p + (dn[i] - nv[i] * dot) * rs;
+        *(float4*)p = g;
+        if constexpr (GATE) {
+          a_g[i] = a_g[i] + g * load4<T>(gy + (size_t)m * D + 4 * c);
+          const float4 d = mul_rn(g, gv[i]);
+          store4<T>(gdy + (size_t)m * D + 4 * c, d);
+          a_b[i] = a_b[i] + make_float4(to_f<T>(from_f<T>(d.x)), to_f<T>(from_f<T>(d.y)), to_f<T>(from_f<T>(d.z)), to_f<T>(from_f<T>(d.w)));
+        }
       }
     }
   }
@@ -159,6 +184,19 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * D; i += 256)
     P[(size_t)blockIdx.x * 3 * D + i] = (red[i] + red[3 * D + i]) + (red[6 * D + i] + red[9 * D + i]);
+  if constexpr (GATE) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) { *(float4*)(red + (wave * 2 + 0) * D + 4 * c) = a_g[i]; *(float4*)(red + (wave * 2 + 1) * D + 4 * c) = a_b[i]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) {
+      ga.Pg[(size_t)blockIdx.x * D + i] = (red[i] + red[2 * D + i]) + (red[4 * D + i] + red[6 * D + i]);
+      ga.Pb[(size_t)blockIdx.x * D + i] = (red[D + i] + red[3 * D + i]) + (red[5 * D + i] + red[7 * D + i]);
+    }
+  }
 }
 
 // per-sample reduce of the partials: dshift/dscale [B, dmod_ld], dwb [B, D]
@@ -210,9 +248,14 @@ extern "C" long ldmae_rmsnorm_modulate_bwd_workspace_bytes(int M, int D, int row
   return ((long)(M / rw) * 3 * D + (long)(M / rows_per_batch) * D) * 4;
 }
 
-extern "C" int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
-                                          const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
-                                          float beta_w, int M, int D, int rows_per_batch, float* workspace, void* stream) {
+extern "C" long ldmae_colsum_workspace_bytes(int M, int N);
+extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, float beta, float* workspace, void* stream);
+extern "C" long ldmae_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch);
+
+static int rmsnorm_modulate_bwd_core(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
+                                     const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                                     float beta_w, int M, int D, int rows_per_batch, float* workspace, const GateBwdArgs* gate,
+                                     float* dgate, int dgate_ld, float* dbias, void* stream) {
   LDMAE_REQUIRE(dout && x && w && rstd && dx_accum && dw && workspace, "rmsnorm_modulate_bwd: null pointer");
   LDMAE_REQUIRE(D % 4 == 0 && M > 0 && rows_per_batch > 0 && M % rows_per_batch == 0, "rmsnorm_modulate_bwd: bad shape M=%d D=%d rpb=%d", M, D, rows_per_batch);
   const int rw = pick_rows_per_wg(rows_per_batch);
@@ -221,17 +264,48 @@ extern "C" int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const flo
   const int G = M / rw, B = M / rows_per_batch, gps = rows_per_batch / rw;
   float* P = workspace;
   float* dwb = workspace + (size_t)G * 3 * D;
+  float* gws = dwb + (size_t)B * D;                     // gate partials (fused form): [G][D] dgate, [G][D] bias, colsum scratch
   const size_t lds = (size_t)4 * 3 * D * sizeof(float);
-  if (dtype == LDMAE_BF16) {
-    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NCH, bf16>), dim3(G), dim3(256), lds, st, (const bf16*)dout, x, w, scale, mod_ld, rstd, dx_accum, P, M, D, rows_per_batch, rw));
-  } else {
-    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NCH, float>), dim3(G), dim3(256), lds, st, (const float*)dout, x, w, scale, mod_ld, rstd, dx_accum, P, M, D, rows_per_batch, rw));
-  }
+  GateBwdArgs ga{nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+  if (gate) { ga = *gate; ga.Pg = gws; ga.Pb = gws + (size_t)G * D; }
+#define LAUNCH(T, GATE) DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NCH, T, GATE>), dim3(G), dim3(256), lds, st, (const T*)dout, x, w, scale, mod_ld, rstd, dx_accum, P, M, D, rows_per_batch, rw, ga))
+  if (dtype == LDMAE_BF16) { if (gate) { LAUNCH(bf16, true); } else { LAUNCH(bf16, false); } }
+  else { if (gate) { LAUNCH(float, true); } else { LAUNCH(float, false); } }
+#undef LAUNCH
   LDMAE_CHECK_LAUNCH("rmsnorm_modulate_bwd");
   hipLaunchKernelGGL(mod_partials_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, P, D, gps, dshift, dscale, dmod_ld, dwb);
   group_reduce(dwb, D, 1, D, B, dw, D, beta_w, st);
   LDMAE_CHECK_LAUNCH("rmsnorm_modulate_bwd reduce");
+  if (gate) {
+    group_reduce(ga.Pg, D, B, D, gps, dgate, dgate_ld, 0.f, st);
+    LDMAE_CHECK_LAUNCH("rmsnorm_modulate_bwd gate reduce");
+    return ldmae_colsum(LDMAE_F32, ga.Pb, D, G, D, dbias, 0.f, ga.Pb + (size_t)G * D, stream);
+  }
   return LDMAE_OK;
+}
+
+extern "C" int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
+                                          const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                                          float beta_w, int M, int D, int rows_per_batch, float* workspace, void* stream) {
+  return rmsnorm_modulate_bwd_core(dtype, dout, x, w, scale, mod_ld, rstd, dx_accum, dshift, dscale, dmod_ld, dw, beta_w, M, D, rows_per_batch,
+                                   workspace, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" long ldmae_rmsnorm_modulate_bwd_gate_workspace_bytes(int M, int D, int rows_per_batch) {
+  const long a = ldmae_rmsnorm_modulate_bwd_workspace_bytes(M, D, rows_per_batch), b = ldmae_gate_bwd_workspace_bytes(M, D, rows_per_batch);
+  return a < 0 ? a : a + b;
+}
+// rmsnorm_modulate_bwd followed by gate_bwd of the updated dx_accum (dy = dx_accum * gate[b] in `dtype`; dgate [B, dgate_ld] = sum_n
+// dx_accum * y; dbias [D] = column sums of dy) in one pass over the rows.
+extern "C" int ldmae_rmsnorm_modulate_bwd_gate(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
+                                               const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                                               float beta_w, const void* y, const float* gate, int gate_ld, void* dy, float* dgate,
+                                               int dgate_ld, float* dbias, int M, int D, int rows_per_batch, float* workspace, void* stream) {
+  LDMAE_REQUIRE(y && gate && dy && dgate && dbias, "rmsnorm_modulate_bwd_gate: null pointer");
+  LDMAE_REQUIRE(gate_ld % 4 == 0, "rmsnorm_modulate_bwd_gate: gate_ld=%d must be a multiple of 4", gate_ld);
+  const GateBwdArgs ga{y, gate, gate_ld, dy, nullptr, nullptr};
+  return rmsnorm_modulate_bwd_core(dtype, dout, x, w, scale, mod_ld, rstd, dx_accum, dshift, dscale, dmod_ld, dw, beta_w, M, D, rows_per_batch,
+                                   workspace, &ga, dgate, dgate_ld, dbias, stream);
 }
 
 // ------------------------------------------------------------------ QK-RMSNorm + RoPE + head-major relayout
@@ -492,7 +566,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       if (c < nch) {
         const float4 g = *(const float4*)(dxo + (size_t)m * D + 4 * c);
         if (P) acc[i] = acc[i] + g * load4<T>(y + (size_t)m * D + 4 * c);
-        const float4 d = g * gv[i];
+        const float4 d = mul_rn(g, gv[i]);       // never contracted into the bias sum below: that sum is over the values AS STORED
         store4<T>(dy + (size_t)m * D + 4 * c, d);
         // bias gradient of the Linear that produced the branch = column sums of dy AS STORED (rounded to T: what the weight-
         // gradient GEMM reads), formed here while the values are in registers instead of inside the TN GEMM

@@ -196,9 +196,10 @@ class _DiTBlockFn(torch.autograd.Function):
         dh12, db12 = ops.gemm_nt_swiglu_bwd(dy2, W3T, h12, with_bias=True)
         dW12 = sg.tn(dh12, xm2)
         dxm2 = ops.gemm_nt(dh12, W12T)
-        dn2 = ops.rmsnorm_modulate_bwd(dxm2, xmid, n2w, s2, rstd2, dx, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D], N)
+        # norm2 backward and the attention branch's gate backward in one pass (the updated dx is consumed from registers)
+        dn2, dy1, dbp = ops.rmsnorm_modulate_bwd_gate(dxm2, xmid, n2w, s2, rstd2, dx, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D],
+                                                      y1, g1, dmod[:, 2 * D:3 * D], N, dtype)
         # ---- attention branch
-        dy1, dbp = ops.gate_bwd(dx, y1, g1, dmod[:, 2 * D:3 * D], N, dtype, with_bias=True)
         dWp = sg.tn(dy1, o.view(M, D))
         do = ops.gemm_nt(dy1, WpT)
         if v is None:

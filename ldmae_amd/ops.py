@@ -210,6 +210,20 @@ def rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx_accum, dshift, dscale, rows
     return dw
 
 
+def rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx_accum, dshift, dscale, y, gate, dgate, rows_per_batch, act_dtype):
+    """rmsnorm_modulate_bwd followed by gate_bwd(dx_accum, y, gate, dgate, with_bias=True) in one pass over the rows.
+    Returns (dw [D], dy [M,D] act dtype, dbias [D])."""
+    M, D = x.shape
+    dw = torch.empty(D, dtype=torch.float32, device=x.device)
+    dy = torch.empty(M, D, dtype=act_dtype, device=x.device)
+    dbias = torch.empty(D, dtype=torch.float32, device=x.device)
+    ws = workspace(L.load().ldmae_rmsnorm_modulate_bwd_gate_workspace_bytes(M, D, rows_per_batch), x.device)
+    call("ldmae_rmsnorm_modulate_bwd_gate", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(scale), scale.stride(0) if scale is not None else 0,
+         ptr(rstd), ptr(dx_accum), ptr(dshift), ptr(dscale), dshift.stride(0) if dshift is not None else 0, ptr(dw), 0.0,
+         ptr(y), ptr(gate), gate.stride(0), ptr(dy), ptr(dgate), dgate.stride(0), ptr(dbias), M, D, rows_per_batch, ptr(ws), stream())
+    return dw, dy, dbias
+
+
 def qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6, copy_v=True):
     """copy_v=False: v gets no head-major copy (returned as None); attention then reads it from the packed qkv (attention_fwd_pv)."""
     q = torch.empty(B, H, N, hd, dtype=qkv.dtype, device=qkv.device)

@@ -175,6 +175,27 @@ def test_rmsnorm_modulate(ops, dtype, D):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("D,T", [(768, 64), (192, 128), (1152, 64)])
+def test_rmsnorm_modulate_bwd_gate_fused(ops, dtype, D, T):
+    """The one-pass form (norm2 backward + the attention branch's gate backward) against the two separate entry points it replaces:
+    same arithmetic, same partial layout and summation order, so every output is bitwise equal."""
+    B = 3
+    M = B * T
+    x, w, g = dev(rnd(M, D, seed=1)), dev(1 + 0.1 * rnd(D, seed=2)), dev(rnd(M, D, seed=4), dtype)
+    mod = dev(0.3 * rnd(B, 6 * D, seed=3))
+    y = dev(rnd(M, D, seed=6), dtype)
+    _, rstd = ops.rmsnorm_modulate_fwd(x, w, mod[:, 3 * D:4 * D], mod[:, 4 * D:5 * D], T, dtype)
+    dx_a, dx_b = dev(rnd(M, D, seed=5)), dev(rnd(M, D, seed=5))
+    dmod_a, dmod_b = torch.zeros(B, 6 * D, device="cuda"), torch.zeros(B, 6 * D, device="cuda")
+    dw_a = ops.rmsnorm_modulate_bwd(g, x, w, mod[:, 4 * D:5 * D], rstd, dx_a, dmod_a[:, 3 * D:4 * D], dmod_a[:, 4 * D:5 * D], T)
+    dy_a, db_a = ops.gate_bwd(dx_a, y, mod[:, 2 * D:3 * D], dmod_a[:, 2 * D:3 * D], T, dtype, with_bias=True)
+    dw_b, dy_b, db_b = ops.rmsnorm_modulate_bwd_gate(g, x, w, mod[:, 4 * D:5 * D], rstd, dx_b, dmod_b[:, 3 * D:4 * D], dmod_b[:, 4 * D:5 * D],
+                                                     y, mod[:, 2 * D:3 * D], dmod_b[:, 2 * D:3 * D], T, dtype)
+    for name, a, b_ in (("dx", dx_a, dx_b), ("dmod", dmod_a, dmod_b), ("dw", dw_a, dw_b), ("dy", dy_a, dy_b), ("dbias", db_a, db_b)):
+        assert torch.equal(a, b_), name
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("hd,H", [(64, 3), (72, 2)])
 def test_qknorm_rope(ops, dtype, hd, H):
     B, grid = 2, 8
