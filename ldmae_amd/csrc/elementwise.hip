@@ -117,23 +117,35 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
                                                               const float* __restrict__ w, const float* __restrict__ scale, int mod_ld,
                                                               const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ P,
                                                               int M, int D, int rpb, int rows_per_wg, GateBwdArgs ga) {
-  extern __shared__ float red[];   // [4 waves][3][D]
+  extern __shared__ float red[];   // [4 waves][3][D]; GATE: the first 3*D floats hold the per-column constants during the row loop
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nch = D >> 2;
   const int m_base = blockIdx.x * rows_per_wg, b = m_base / rpb;
-  float4 wv[NCH], sc1[NCH], a_sh[NCH], a_sc[NCH], a_w[NCH];
-  float4 gv[GATE ? NCH : 1], a_g[GATE ? NCH : 1], a_b[GATE ? NCH : 1];
+  float4 wv[GATE ? 1 : NCH], sc1[GATE ? 1 : NCH], a_sh[NCH], a_sc[NCH], a_w[NCH];
+  float4 a_g[GATE ? NCH : 1], a_b[GATE ? NCH : 1];
   const T* gy = (const T*)ga.y;
   T* gdy = (T*)ga.dy;
+  // GATE: five accumulator sets live in registers, so the three per-column constants (norm weight, 1 + scale, gate) are kept in LDS
+  // and re-read per row instead (36 registers: 174 -> 3 waves per SIMD instead of 2 for a kernel that lives on bytes in flight)
+  float* cw = red;
+  float* cs = red + D;
+  float* cg = red + 2 * D;
+  if constexpr (GATE) {
+    for (int c = threadIdx.x; c < nch; c += 256) {
+      *(float4*)(cw + 4 * c) = *(const float4*)(w + 4 * c);
+      *(float4*)(cs + 4 * c) = scale ? f4(1.f) + *(const float4*)(scale + (size_t)b * mod_ld + 4 * c) : f4(1.f);
+      *(float4*)(cg + 4 * c) = *(const float4*)(ga.gate + (size_t)b * ga.gate_ld + 4 * c);
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    wv[i] = c < nch ? *(const float4*)(w + 4 * c) : f4(0.f);
-    sc1[i] = (c < nch && scale) ? f4(1.f) + *(const float4*)(scale + (size_t)b * mod_ld + 4 * c) : f4(1.f);
-    a_sh[i] = a_sc[i] = a_w[i] = f4(0.f);
-    if constexpr (GATE) {
-      gv[i] = c < nch ? *(const float4*)(ga.gate + (size_t)b * ga.gate_ld + 4 * c) : f4(1.f);
-      a_g[i] = a_b[i] = f4(0.f);
+    if constexpr (!GATE) {
+      wv[i] = c < nch ? *(const float4*)(w + 4 * c) : f4(0.f);
+      sc1[i] = (c < nch && scale) ? f4(1.f) + *(const float4*)(scale + (size_t)b * mod_ld + 4 * c) : f4(1.f);
     }
+    a_sh[i] = a_sc[i] = a_w[i] = f4(0.f);
+    if constexpr (GATE) a_g[i] = a_b[i] = f4(0.f);
   }
   for (int r = wave; r < rows_per_wg; r += 4) {
     const int m = m_base + r;
@@ -146,12 +158,13 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
       const int c = lane + 64 * i;
       if (c < nch) {
         const float4 g = load4<T>(dout + (size_t)m * D + 4 * c);
+        const float4 wc = GATE ? *(const float4*)(cw + 4 * c) : wv[i], sc = GATE ? *(const float4*)(cs + 4 * c) : sc1[i];
         nv[i] = *(const float4*)(x + (size_t)m * D + 4 * c) * rs;
-        const float4 dy = g * sc1[i];
+        const float4 dy = g * sc;
         a_sh[i] = a_sh[i] + g;
-        a_sc[i] = a_sc[i] + g * (nv[i] * wv[i]);
+        a_sc[i] = a_sc[i] + g * (nv[i] * wc);
         a_w[i] = a_w[i] + dy * nv[i];
-        dn[i] = dy * wv[i];
+        dn[i] = dy * wc;
         dot += hsum(dn[i] * nv[i]);
       } else { nv[i] = dn[i] = f4(0.f); }
     }
@@ -165,13 +178,14 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
         *(float4*)p = g;
         if constexpr (GATE) {
           a_g[i] = a_g[i] + g * load4<T>(gy + (size_t)m * D + 4 * c);
-          const float4 d = mul_rn(g, gv[i]);
+          const float4 d = mul_rn(g, *(const float4*)(cg + 4 * c));
           store4<T>(gdy + (size_t)m * D + 4 * c, d);
           a_b[i] = a_b[i] + make_float4(to_f<T>(from_f<T>(d.x)), to_f<T>(from_f<T>(d.y)), to_f<T>(from_f<T>(d.z)), to_f<T>(from_f<T>(d.w)));
         }
       }
     }
   }
+  if constexpr (GATE) __syncthreads();            // every wave is done with the constants: the region becomes reduction scratch
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;

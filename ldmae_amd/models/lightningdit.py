@@ -138,11 +138,36 @@ def _dmod_times_w(dmod, adaw):
     return ops.gemm_nt(dmod, ops.cast_weight(adaw, torch.float32, True, False)[1])
 
 
+class _GradChain:
+    """Hand-off between the backward passes of consecutive members of LightningDiT.forward's block chain (one object per forward).
+    Backward of member j+1 ends with norm1's backward, which finishes the residual-stream gradient dx that member j's backward starts
+    from with gate_bwd(dx, y2_j, gate_mlp_j): member j+1 runs both in one pass over the rows (ops.rmsnorm_modulate_bwd_gate, 805 MB
+    less traffic per block) and leaves (dy2_j, db3_j, dmod_j with the gate slot filled) here.  `up[j]` = (y2, mod) of member j,
+    registered in forward; `pre[j]` = what member j+1's backward prepared, keyed by the data pointer of the dx it belongs to so that
+    member j falls back to its own gate_bwd if it is ever handed a different gradient buffer."""
+
+    def __init__(self):
+        self.up, self.pre = {}, {}
+
+    def norm_bwd(self, j, dout, x, w, scale, rstd, dx, dshift, dscale, N, dtype):
+        """norm backward of member j (accumulating into dx); fused with member j-1's gate backward when that member is registered."""
+        D = x.shape[1]
+        prev = self.up.get(j - 1)
+        if prev is None:
+            return ops.rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx, dshift, dscale, N)
+        y2p, modp = prev
+        dmodp = torch.empty_like(modp)
+        dw, dy2p, db3p = ops.rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx, dshift, dscale, y2p, modp[:, 5 * D:6 * D],
+                                                       dmodp[:, 5 * D:6 * D], N, dtype)
+        self.pre[j - 1] = (dx.data_ptr(), dy2p, db3p, dmodp)
+        return dw
+
+
 class _DiTBlockFn(torch.autograd.Function):
     """LightningDiTBlock.forward (:239-250) with RMSNorm, QK-norm, RoPE, SwiGLU, shift."""
 
     @staticmethod
-    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace,
+    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace, chain, idx,
                 n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12, b12, w3, b3, adaw, adab):
         B, N, D = x.shape
         M, hd = B * N, D // H
@@ -172,6 +197,9 @@ class _DiTBlockFn(torch.autograd.Function):
                               n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T)
         ctx.dims = (B, N, D, H, hd, eps, dtype)
         ctx.inplace = bool(inplace)
+        ctx.chain, ctx.idx = chain, idx
+        if chain is not None:
+            chain.up[idx] = (y2, mod)
         return xout.view(B, N, D)
 
     @staticmethod
@@ -187,11 +215,16 @@ class _DiTBlockFn(torch.autograd.Function):
         dx = gout.contiguous().view(M, D)
         if not ctx.inplace and dx.data_ptr() == gout.data_ptr():
             dx = dx.clone()
-        dmod = torch.empty_like(mod)
+        chain, idx = ctx.chain, ctx.idx
         s1, g1, s2, g2 = mod[:, D:2 * D], mod[:, 2 * D:3 * D], mod[:, 4 * D:5 * D], mod[:, 5 * D:6 * D]
         sg = ops.SideGemms(dx.device, enabled=dtype == torch.bfloat16)      # weight gradients: off the critical path
         # ---- MLP branch
-        dy2, db3 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype, with_bias=True)   # bias grads where dy is produced
+        pre = chain.pre.pop(idx, None) if chain is not None else None
+        if pre is not None and pre[0] == dx.data_ptr():      # the next member's backward already gated this dx (see _GradChain)
+            _, dy2, db3, dmod = pre
+        else:
+            dmod = torch.empty_like(mod)
+            dy2, db3 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype, with_bias=True)   # bias grads where dy is produced
         dW3 = sg.tn(dy2, hid)
         dh12, db12 = ops.gemm_nt_swiglu_bwd(dy2, W3T, h12, with_bias=True)
         dW12 = sg.tn(dh12, xm2)
@@ -211,12 +244,15 @@ class _DiTBlockFn(torch.autograd.Function):
         dqkv = dqkv.view(M, 3 * D)
         dWqkv = sg.tn(dqkv, xm1)
         dxm1 = ops.gemm_nt(dqkv, WqkvT)
-        dn1 = ops.rmsnorm_modulate_bwd(dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N)
+        if chain is not None:
+            dn1 = chain.norm_bwd(idx, dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N, dtype)
+        else:
+            dn1 = ops.rmsnorm_modulate_bwd(dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N)
         # ---- adaLN (f32 in both modes)
         dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
         dsc = _dmod_times_w(dmod, adaw)
         sg.join()
-        return (dx.view(B, N, D), dsc, None, None, None, None, None, None,
+        return (dx.view(B, N, D), dsc, None, None, None, None, None, None, None, None,
                 dn1, dWqkv, dbqkv, dqn, dkn, dWp, dbp, dn2, dW12, db12, dW3, db3, dadaw, dadab)
 
 
@@ -224,11 +260,12 @@ class _FinalLayerFn(torch.autograd.Function):
     """FinalLayer.forward (:267-272): adaLN(2) -> RMSNorm -> modulate -> Linear."""
 
     @staticmethod
-    def forward(ctx, x, sc, eps, dtype, nw, lw, lb, adaw, adab):
+    def forward(ctx, x, sc, eps, dtype, chain, idx, nw, lw, lb, adaw, adab):
         B, N, D = x.shape
         M = B * N
         x2 = x.contiguous().view(M, D)
         sc = sc.contiguous()
+        ctx.chain, ctx.idx = chain, idx
         mod = ops.gemm_nt(sc, adaw, adab, out_dtype=torch.float32)
         xf, rstd = ops.rmsnorm_modulate_fwd(x2, nw, mod[:, :D], mod[:, D:], N, dtype, eps)
         out = ops.gemm_nt(xf, ops.cast(lw, dtype), lb, out_dtype=torch.float32)
@@ -247,10 +284,13 @@ class _FinalLayerFn(torch.autograd.Function):
         dxf = ops.gemm_nt(g, ops.cast_weight(lw, torch.float32, True, False)[1], out_dtype=dtype)     # K = p*p*C (16): f32 MFMA
         dx = torch.zeros(M, D, dtype=torch.float32, device=g.device)
         dmod = torch.empty_like(mod)
-        dnw = ops.rmsnorm_modulate_bwd(dxf, x2, nw, mod[:, D:], rstd, dx, dmod[:, :D], dmod[:, D:], N)
+        if ctx.chain is not None:
+            dnw = ctx.chain.norm_bwd(ctx.idx, dxf, x2, nw, mod[:, D:], rstd, dx, dmod[:, :D], dmod[:, D:], N, dtype)
+        else:
+            dnw = ops.rmsnorm_modulate_bwd(dxf, x2, nw, mod[:, D:], rstd, dx, dmod[:, :D], dmod[:, D:], N)
         dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
         dsc = _dmod_times_w(dmod, adaw)
-        return dx.view(B, N, D), dsc, None, None, dnw, dlw, dlb, dadaw, dadab
+        return dx.view(B, N, D), dsc, None, None, None, None, dnw, dlw, dlb, dadaw, dadab
 
 
 # ----------------------------------------------------------------------------- modules (reference names / keys)
@@ -361,14 +401,14 @@ class LightningDiTBlock(nn.Module):
         self.wo_shift = wo_shift
         self.precision = None
 
-    def forward(self, x, c, feat_rope=None, _silu_c=None, _dtype=None, _inplace_grad=False):
+    def forward(self, x, c, feat_rope=None, _silu_c=None, _dtype=None, _inplace_grad=False, _chain=None, _idx=0):
         if feat_rope is None:
             raise NotImplementedError("ldmae_amd LightningDiTBlock needs feat_rope (use_rope=True)")
         sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
         a, m = self.attn, self.mlp
         return _DiTBlockFn.apply(
             x.float(), sc, feat_rope.freqs_cos, feat_rope.freqs_sin, a.num_heads, self.norm1.eps, _dtype or _act_dtype(self.precision),
-            _inplace_grad,
+            _inplace_grad, _chain, _idx,
             self.norm1.weight, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.k_norm.weight, a.proj.weight, a.proj.bias,
             self.norm2.weight, m.w12.weight, m.w12.bias, m.w3.weight, m.w3.bias,
             self.adaLN_modulation[1].weight, self.adaLN_modulation[1].bias)
@@ -386,9 +426,10 @@ class FinalLayer(nn.Module):
         self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
         self.precision = None
 
-    def forward(self, x, c, _silu_c=None, _dtype=None):
+    def forward(self, x, c, _silu_c=None, _dtype=None, _chain=None, _idx=0):
         sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
-        return _FinalLayerFn.apply(x.float(), sc, self.norm_final.eps, _dtype or _act_dtype(self.precision), self.norm_final.weight,
+        return _FinalLayerFn.apply(x.float(), sc, self.norm_final.eps, _dtype or _act_dtype(self.precision), _chain, _idx,
+                                   self.norm_final.weight,
                                    self.linear.weight, self.linear.bias, self.adaLN_modulation[1].weight,
                                    self.adaLN_modulation[1].bias)
 
@@ -477,15 +518,21 @@ class LightningDiT(nn.Module):
             y = self.y_embedder(y, self.training)
             c = t + y
             sc = _SiluFn.apply(c)
-            for block in self.blocks:
-                # a block output of this chain has exactly one consumer (the next block / the final layer) unless someone
-                # taps it with a module hook: only then may the block's backward re-use the incoming gradient buffer
-                inpl = not (block._forward_hooks or block._forward_pre_hooks or block._backward_hooks)
+            # a block output of this chain has exactly one consumer (the next block / the final layer) unless someone taps it with a
+            # module hook: only then may a block's backward re-use the incoming gradient buffer, and only when that holds for the
+            # whole chain do consecutive backward passes hand work to each other (_GradChain)
+            hooked = [bool(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks) for m in self.blocks]
+            fl = self.final_layer
+            chain = None
+            if torch.is_grad_enabled() and not self.use_checkpoint and not any(hooked) and \
+                    not (fl._forward_hooks or fl._forward_pre_hooks or fl._backward_hooks):
+                chain = _GradChain()
+            for i, block in enumerate(self.blocks):
                 if self.use_checkpoint:
-                    x = checkpoint(block, x, c, self.feat_rope, sc, dtype, inpl, use_reentrant=True)
+                    x = checkpoint(block, x, c, self.feat_rope, sc, dtype, not hooked[i], use_reentrant=True)
                 else:
-                    x = block(x, c, self.feat_rope, sc, dtype, inpl)
-            x = self.final_layer(x, c, sc, dtype)
+                    x = block(x, c, self.feat_rope, sc, dtype, not hooked[i], chain, i)
+            x = self.final_layer(x, c, sc, dtype, chain, len(self.blocks))
             x = self.unpatchify(x)
             if self.learn_sigma:
                 x, _ = x.chunk(2, dim=1)
