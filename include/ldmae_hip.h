@@ -128,6 +128,13 @@ int ldmae_attention_fwd_pv(int dtype, const void* q, const void* k, const void* 
                            float scale, void* stream);
 int ldmae_attention_bwd_pv(int dtype, const void* q, const void* k, const void* qkv, const void* o, const void* do_, const float* lse,
                            void* dq, void* dk, void* dqkv, float* delta, int B, int H, int N, int hd, float scale, void* stream);
+/* ldmae_attention_bwd_pv + ldmae_qknorm_rope_bwd in one (bf16, head_dim 64 / 128): the QK-RMSNorm / RoPE backward (lightningdit.py:70-75
+ * read backwards) runs in the epilogues of the dQ and dK/dV kernels, dq / dk are never written head-major.  dqkv [B,N,3,H,hd] complete;
+ * dwq, dwk [hd] norm-weight gradients; dbias [3*H*hd] = column sums of dqkv (the qkv Linear's bias gradient). */
+long ldmae_attention_bwd_pv_qknorm_workspace_bytes(int B, int H, int N, int hd);
+int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const void* k, const void* qkv, const void* o, const void* do_, const float* lse,
+                                  const float* wq, const float* wk, const float* cos, const float* sin, float eps, void* dqkv, float* dwq,
+                                  float* dwk, float* dbias, float* workspace, int B, int H, int N, int hd, float scale, void* stream);
 
 /* ---- SwiGLU (swiglu_ffn.py:34-35) ------------------------------------------------------------ */
 int ldmae_swiglu_fwd(int dtype, const void* h12, void* hid, int M, int Hs, void* stream);

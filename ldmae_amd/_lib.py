@@ -47,6 +47,9 @@ SIGNATURES = {
     "ldmae_attention_bwd_qkv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_attention_fwd_pv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_attention_bwd_pv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ldmae_attention_bwd_pv_qknorm_workspace_bytes": (_l, [_i, _i, _i, _i]),
+    "ldmae_attention_bwd_pv_qknorm": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                           _f, _vp]),
     "ldmae_swiglu_fwd": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "ldmae_swiglu_bwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
     "ldmae_gate_bwd_workspace_bytes": (_l, [_i, _i, _i]),

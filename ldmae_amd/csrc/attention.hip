@@ -171,6 +171,158 @@ __device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[hd_pad(HD) / 32
   }
 }
 
+// ---- QK-RMSNorm + RoPE backward folded into the dQ / dK epilogues (LightningDiT block, head dims with 8 or 16 chunks per row).
+// The unfused chain wrote dq / dk head-major, then elementwise.hip's qknorm_rope_bwd read them back with the pre-norm q / k to produce
+// the packed dqkv (1.6 GB per layer at bs 256).  Here the dq (dk) tile goes through the same bf16 row image as store_rows_t and every
+// (row, 16-B chunk) lane finishes the job: rope^T, RMSNorm backward against the pre-norm row it loads from the packed qkv, the result
+// stored into the q (k) slot of dqkv as a whole 128-B line per row.  Same per-element formulas as qknorm_rope_bwd_kernel.
+// Partial sums for the norm-weight and qkv-bias gradients are left per workgroup (batch, 128-row block, head): Pw [B*NB*H][2*hd] (q | k),
+// Pb [B*NB][3*H*hd] (q | k | v) with NB = ceil(N / 128), summed over rows by the host (ldmae_colsum).
+struct QkNormBwd {
+  const bf16* qkv;
+  const float* wq; const float* wk; const float* cos; const float* sin;
+  bf16* dqkv;
+  float* Pw; float* Pb;
+  float eps;
+};
+// sum over the CPR (8 or 16) consecutive lanes that hold one row, by DPP moves (a few cycles each; __shfl_xor is a ds_bpermute round
+// trip, and two of these reductions sit in the dependent chain of every row): quad_perm xor 1, xor 2, then row_half_mirror joins the
+// two quads of an 8-lane group and row_mirror the two halves of a 16-lane row (the partial sums are uniform inside a group by then)
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CPR> __device__ __forceinline__ float row_sum(float v) {
+  v = dpp_add<0xB1>(v);            // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);            // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);           // row_half_mirror
+  if constexpr (CPR == 16) v = dpp_add<0x140>(v);      // row_mirror
+  return v;
+}
+template <int CPR> __device__ __forceinline__ float col_sum(float v) {      // over the 64 / CPR lanes that hold one chunk column
+#pragma unroll
+  for (int o = CPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// everything the epilogue reads from global memory (pre-norm rows: HBM; cos / sin rows: L2-resident tables) is requested BEFORE the
+// end-of-loop barrier, all iterations at once, so the latency hides under the barrier and the staging (the main loop's registers are dead)
+template <int HD> struct QkPref { bf16x8 x[32 * (HD / 8) / 64]; float4 cs[32 * (HD / 8) / 64][2], sn[32 * (HD / 8) / 64][2]; };
+template <int HD>
+__device__ __forceinline__ void qk_prefetch_cs(QkPref<HD>& p, const QkNormBwd& a, int n0, int lane) {
+  constexpr int CPR = HD / 8;
+#pragma unroll
+  for (int it = 0; it < 32 * CPR / 64; ++it) {
+    const size_t to = (size_t)(n0 + (it * 64 + lane) / CPR) * HD + (lane % CPR) * 8;
+    p.cs[it][0] = *(const float4*)(a.cos + to); p.cs[it][1] = *(const float4*)(a.cos + to + 4);
+    p.sn[it][0] = *(const float4*)(a.sin + to); p.sn[it][1] = *(const float4*)(a.sin + to + 4);
+  }
+}
+template <int HD>
+__device__ __forceinline__ void qk_prefetch(QkPref<HD>& p, const QkNormBwd& a, int which, int b, int hh, int H, int N, int n0, int lane) {
+  constexpr int CPR = HD / 8;
+#pragma unroll
+  for (int it = 0; it < 32 * CPR / 64; ++it) {
+    const int row = (it * 64 + lane) / CPR, ch = lane % CPR;
+    p.x[it] = *(const bf16x8*)(a.qkv + (((size_t)b * N + n0 + row) * 3 + which) * H * HD + (size_t)hh * HD + ch * 8);
+  }
+}
+// aw / ab: this wave's column sums (norm-weight gradient, bias gradient) for columns ch*8 .. +7, valid on lanes < CPR
+template <int HD>
+__device__ __forceinline__ void qknorm_rows_bwd(const f32x16 (&acc)[HD / 32], float mul, char* lds_wave, int lane, const QkNormBwd& a, int which,
+                                                int b, int hh, int H, int N, int n0, const QkPref<HD>& pf, float (&aw)[8], float (&ab)[8]) {
+  static_assert(HD == 64 || HD == 128, "fused QK-norm backward: 8 or 16 chunks per row");
+  constexpr int PITCH = HD * 2 + 16, CPR = HD / 8, NIT = 32 * CPR / 64;
+  const int r = lane & 31, h = lane >> 5;
+  const int ch = lane % CPR;                      // 64 % CPR == 0: a lane keeps its chunk column in every iteration
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      bf16x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (bf16)(acc[d][4 * t4 + j] * mul);
+      *(bf16x4*)(lds_wave + r * PITCH + (d * 32 + 8 * t4 + 4 * h) * 2) = w;
+    }
+  const float* wsrc = (which ? a.wk : a.wq) + ch * 8;
+  float w8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { w8[j] = wsrc[j]; aw[j] = 0.f; ab[j] = 0.f; }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = (it * 64 + lane) / CPR, n = n0 + row;
+    const bf16x8 gv = *(const bf16x8*)(lds_wave + row * PITCH + ch * 16);
+    const size_t so = (((size_t)b * N + n) * 3 + which) * H * HD + (size_t)hh * HD + ch * 8;
+    const float c8[8] = {pf.cs[it][0].x, pf.cs[it][0].y, pf.cs[it][0].z, pf.cs[it][0].w, pf.cs[it][1].x, pf.cs[it][1].y, pf.cs[it][1].z, pf.cs[it][1].w};
+    const float s8[8] = {pf.sn[it][0].x, pf.sn[it][0].y, pf.sn[it][0].z, pf.sn[it][0].w, pf.sn[it][1].x, pf.sn[it][1].y, pf.sn[it][1].z, pf.sn[it][1].w};
+    float x[8], g[8], ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = (float)pf.x[it][j]; g[j] = (float)gv[j]; ss += x[j] * x[j]; }
+    const float rs = rsqrtf(row_sum<CPR>(ss) / (float)HD + a.eps);
+    float nq[8], dn[8], dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {              // rope^T on the pair (j, j+1): elementwise.hip rope_apply_bwd
+      const float t0 = g[j] * c8[j] + g[j + 1] * s8[j + 1], t1 = g[j + 1] * c8[j + 1] - g[j] * s8[j];
+      nq[j] = x[j] * rs; nq[j + 1] = x[j + 1] * rs;
+      aw[j] += t0 * nq[j]; aw[j + 1] += t1 * nq[j + 1];
+      dn[j] = t0 * w8[j]; dn[j + 1] = t1 * w8[j + 1];
+      dot += dn[j] * nq[j] + dn[j + 1] * nq[j + 1];
+    }
+    const float m = row_sum<CPR>(dot) / (float)HD;
+    bf16x8 ov;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ov[j] = (bf16)((dn[j] - nq[j] * m) * rs); ab[j] += (float)ov[j]; }
+    *(bf16x8*)(a.dqkv + so) = ov;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { aw[j] = col_sum<CPR>(aw[j]); ab[j] = col_sum<CPR>(ab[j]); }
+}
+// store_rows_t that also returns the column sums of the rows AS STORED (the v part of the qkv bias gradient): ab, valid on lanes < CPR
+template <int HD>
+__device__ __forceinline__ void store_rows_t_colsum(const f32x16 (&acc)[HD / 32], float mul, char* lds_wave, bf16* gbase, long gstride, int lane,
+                                                    float (&ab)[8]) {
+  static_assert(HD == 64 || HD == 128, "8 or 16 chunks per row");
+  constexpr int PITCH = HD * 2 + 16, CPR = HD / 8;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      bf16x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (bf16)(acc[d][4 * t4 + j] * mul);
+      *(bf16x4*)(lds_wave + r * PITCH + (d * 32 + 8 * t4 + 4 * h) * 2) = w;
+    }
+  const int ch = lane % CPR;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ab[j] = 0.f;
+#pragma unroll
+  for (int it = 0; it < 32 * CPR / 64; ++it) {
+    const int row = (it * 64 + lane) / CPR;
+    const bf16x8 v = *(const bf16x8*)(lds_wave + row * PITCH + ch * 16);
+    *(bf16x8*)(gbase + (long)row * gstride + ch * 8) = v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ab[j] += (float)v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ab[j] = col_sum<CPR>(ab[j]);
+}
+// the four waves' column sums (NV vectors of HD floats each, lanes < CPR hold 8 columns) -> one row per workgroup, summed in wave order
+template <int HD, int NV>
+__device__ __forceinline__ void wg_colsums(const float (&v)[NV][8], float* red, int wave, int lane, bool active, int nact, float* const (&dst)[NV]) {
+  constexpr int CPR = HD / 8;
+  if (active && lane < CPR) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[(wave * NV + k) * HD + lane * 8 + j] = v[k][j];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < NV * HD; t += 256) {
+    float s = red[t];
+    for (int w = 1; w < nact; ++w) s += red[w * NV * HD + t];
+    dst[t / HD][t % HD] = s;
+  }
+}
+
 // where q / k / v (and dq / dk / dv) live: element offsets of (batch b, head h, row n) = b * sb + h * sh + n * ld.
 // Head-major [B,H,N,hd]: sb = H*N*hd, sh = N*hd, ld = hd.  Packed token-major qkv [B,N,3,H,hd] (what the qkv Linear writes, used as is
 // by the VMAE blocks, which have no QK-norm / RoPE between the Linear and the attention): sb = N*3*H*hd, sh = hd, ld = 3*H*hd.
@@ -334,11 +486,11 @@ __global__ void attn_delta_kernel(const T* __restrict__ O, const T* __restrict__
 // ROWC = [2][B*H*N] f32 written by the dQ kernel (which runs first): slot 0 = -delta, slot 1 = -lse * log2(e).  They are the INITIAL
 // ACCUMULATORS of the dP and S chains (a query row = an accumulator element here, so they come from the LDS copy of the tile's 64 values
 // by ds_read_b128), k carries scale*log2(e): p = exp2(S) and dS = p * dP are one instruction per element each.
-template <int HD>
+template <int HD, bool QKN = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                  const bf16* __restrict__ dO, const float* __restrict__ ROWC, long rc_stride,
                                                                  bf16* __restrict__ dK, bf16* __restrict__ dV,
-                                                                 int H, int N, float scale, QkvLayout L, QkvLayout Lv) {
+                                                                 int H, int N, float scale, QkvLayout L, QkvLayout Lv, QkNormBwd qn) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [STAGES][Q tile | dO tile | -lse2[64] -delta[64] scratch[128]]
   constexpr int BUF = 2 * TB + 1024;
@@ -431,19 +583,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
     if (qt + 1 < nt) body(IC<1>{}, qt + 1);
     if (qt + 2 < nt) body(IC<2>{}, qt + 2);
   }
-  __syncthreads();                                   // ring -> store scratch
-  if (!active) return;
-  char* sw = smem + wave * 32 * (HDP * 2 + 16);
-  store_rows_t<HD>(dkacc, scale, sw, dK + hb + (size_t)k0 * ld, ld, lane);
-  store_rows_t<HD>(dvacc, 1.f, sw, dV + hbv + (size_t)k0 * Lv.ld, Lv.ld, lane);       // same wave, same scratch: LDS ops stay in order
+  if constexpr (QKN) {       // dk -> k slot of dqkv through the QK-norm / RoPE backward; dv as before, plus its column sums for the qkv bias gradient
+    QkPref<HD> pf;
+    if (active) qk_prefetch<HD>(pf, qn, 1, b, hh, H, N, k0, lane);
+    __syncthreads();                                 // ring -> store scratch
+    char* sw = smem + wave * 32 * (HDP * 2 + 16);
+    float cs3[3][8];
+    if (active) {
+      qk_prefetch_cs<HD>(pf, qn, k0, lane);          // (two accumulator sets are still live before the barrier: no room there)
+      qknorm_rows_bwd<HD>(dkacc, scale, sw, lane, qn, 1, b, hh, H, N, k0, pf, cs3[0], cs3[1]);
+      store_rows_t_colsum<HD>(dvacc, 1.f, sw, dV + hbv + (size_t)k0 * Lv.ld, Lv.ld, lane, cs3[2]);
+    }
+    const int kb = lid % kblocks;
+    const size_t blk = (size_t)b * kblocks + kb;
+    float* const dst[3] = {qn.Pw + (blk * H + hh) * (2 * HD) + HD, qn.Pb + blk * (3 * H * HD) + ((size_t)H + hh) * HD,
+                           qn.Pb + blk * (3 * H * HD) + ((size_t)2 * H + hh) * HD};
+    wg_colsums<HD, 3>(cs3, (float*)(smem + 4 * 32 * (HDP * 2 + 16)), wave, lane, active, min(4, (N - kb * 128) / 32), dst);
+  } else {
+    __syncthreads();                                   // ring -> store scratch
+    if (!active) return;
+    char* sw = smem + wave * 32 * (HDP * 2 + 16);
+    store_rows_t<HD>(dkacc, scale, sw, dK + hb + (size_t)k0 * ld, ld, lane);
+    store_rows_t<HD>(dvacc, 1.f, sw, dV + hbv + (size_t)k0 * Lv.ld, Lv.ld, lane);       // same wave, same scratch: LDS ops stay in order
+  }
 }
 
 // ================================================================================================ backward dQ, bf16
-template <int HD>
+template <int HD, bool QKN = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                const bf16* __restrict__ O, const bf16* __restrict__ dO,
                                                                const float* __restrict__ LSE, float* __restrict__ ROWC, long rc_stride,
-                                                               bf16* __restrict__ dQ, int H, int N, float scale, QkvLayout L, QkvLayout Lv) {
+                                                               bf16* __restrict__ dQ, int H, int N, float scale, QkvLayout L, QkvLayout Lv, QkNormBwd qn) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   constexpr bool BTR = HDP <= 64;     // transposed K fragments read ahead, under the exp / multiply arithmetic (fits 3 waves per SIMD)
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [STAGES][K tile | V tile]
@@ -540,9 +710,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
     if (kt + 1 < nt) body(IC<1>{}, kt + 1);
     if (kt + 2 < nt) body(IC<2>{}, kt + 2);
   }
-  __syncthreads();                                   // ring -> store scratch
-  if (!active) return;
-  store_rows_t<HD>(dqacc, scale, smem + wave * 32 * (HDP * 2 + 16), dQ + hb + (size_t)q0 * ld, ld, lane);
+  if constexpr (QKN) {
+    QkPref<HD> pf;
+    if (active) { qk_prefetch<HD>(pf, qn, 0, b, hh, H, N, q0, lane); qk_prefetch_cs<HD>(pf, qn, q0, lane); }
+    __syncthreads();                                 // ring -> store scratch
+    float cs2[2][8];
+    if (active) qknorm_rows_bwd<HD>(dqacc, scale, smem + wave * 32 * (HDP * 2 + 16), lane, qn, 0, b, hh, H, N, q0, pf, cs2[0], cs2[1]);
+    const int qb = lid % qblocks;
+    const size_t blk = (size_t)b * qblocks + qb;
+    float* const dst[2] = {qn.Pw + (blk * H + hh) * (2 * HD), qn.Pb + blk * (3 * H * HD) + (size_t)hh * HD};
+    wg_colsums<HD, 2>(cs2, (float*)(smem + 4 * 32 * (HDP * 2 + 16)), wave, lane, active, min(4, (N - qb * 128) / 32), dst);
+  } else {
+    __syncthreads();                                   // ring -> store scratch
+    if (!active) return;
+    store_rows_t<HD>(dqacc, scale, smem + wave * 32 * (HDP * 2 + 16), dQ + hb + (size_t)q0 * ld, ld, lane);
+  }
 }
 
 // ================================================================================================ f32 path (parity)
@@ -837,8 +1019,8 @@ static int attention_bwd_core(int dtype, const void* q, const void* k, const voi
 #define L(HD) { \
     hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
     hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, rcs, (bf16*)dq, H, N, scale, Lq, Lv); \
-    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, delta, rcs, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv); }
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, rcs, (bf16*)dq, H, N, scale, Lq, Lv, QkNormBwd{}); \
+    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, delta, rcs, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv, QkNormBwd{}); }
     ATTN_HD_DISPATCH(hd, L);
 #undef L
   } else {
@@ -900,4 +1082,48 @@ extern "C" int ldmae_attention_bwd_pv(int dtype, const void* q, const void* k, c
   const QkvLayout hm{(long)H * N * hd, (long)N * hd, (long)hd}, pk{(long)N * 3 * hw, (long)hd, 3 * hw};
   return attention_bwd_core(dtype, q, k, (const bf16*)qkv + 2 * hw, o, do_, lse, dq, dk, (bf16*)dqkv + 2 * hw, delta, B, H, N, hd, scale, hm, pk,
                             as_stream(stream));
+}
+
+// ---- attention backward + QK-RMSNorm / RoPE backward in one (LightningDiT block, bf16): dq / dk never exist head-major; the packed dqkv
+// comes out complete (q | k through the norm / rope backward in the epilogues, v as attention_bwd_pv), with the norm-weight gradients
+// and the qkv bias gradient.  Replaces ldmae_attention_bwd_pv + ldmae_qknorm_rope_bwd for head dims 64 / 128.
+extern "C" long ldmae_colsum_workspace_bytes(int M, int N);
+extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, float beta, float* workspace, void* stream);
+extern "C" long ldmae_attention_bwd_pv_qknorm_workspace_bytes(int B, int H, int N, int hd) {
+  const long blk = (long)B * ((N + 127) / 128);
+  const long cw = ldmae_colsum_workspace_bytes((int)(blk * H), 2 * hd), cb = ldmae_colsum_workspace_bytes((int)blk, 3 * H * hd);
+  return (2L * B * H * N + blk * H * 2 * hd + blk * 3 * H * hd + 2L * hd) * 4 + (cw > cb ? cw : cb);
+}
+extern "C" int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const void* k, const void* qkv, const void* o, const void* do_,
+                                             const float* lse, const float* wq, const float* wk, const float* cos, const float* sin, float eps,
+                                             void* dqkv, float* dwq, float* dwk, float* dbias, float* workspace, int B, int H, int N, int hd,
+                                             float scale, void* stream) {
+  LDMAE_REQUIRE(q && k && qkv && o && do_ && lse && wq && wk && cos && sin && dqkv && dwq && dwk && dbias && workspace, "attention_bwd_pv_qknorm: null pointer");
+  LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_bwd_pv_qknorm: bf16 only");
+  LDMAE_REQUIRE(hd == 64 || hd == 128, "attention_bwd_pv_qknorm: head_dim %d (64 or 128; others: attention_bwd_pv + qknorm_rope_bwd)", hd);
+  if (int e = attn_check("attention_bwd_pv_qknorm", dtype, B, H, N, hd)) return e;
+  hipStream_t st = as_stream(stream);
+  const long hw = (long)H * hd, items = (long)B * H * N, blk = (long)B * ((N + 127) / 128);
+  const QkvLayout hm{(long)H * N * hd, (long)N * hd, (long)hd}, pk{(long)N * 3 * hw, (long)hd, 3 * hw};
+  float* rowc = workspace;
+  float* Pw = rowc + 2 * items;
+  float* Pb = Pw + blk * H * 2 * hd;
+  float* dw2 = Pb + blk * 3 * H * hd;              // [2*hd] = dwq | dwk
+  float* cws = dw2 + 2 * hd;
+  const QkNormBwd qn{(const bf16*)qkv, wq, wk, cos, sin, (bf16*)dqkv, Pw, Pb, eps};
+  const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
+  const bf16* v = (const bf16*)qkv + 2 * hw;
+  bf16* dv = (bf16*)dqkv + 2 * hw;
+#define L(HD) { \
+    hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
+    hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<HD, true>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, v, (const bf16*)o, (const bf16*)do_, lse, rowc, items, (bf16*)nullptr, H, N, scale, hm, pk, qn); \
+    hipLaunchKernelGGL((attn_bwd_dkdv_bf16_kernel<HD, true>), dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, v, (const bf16*)do_, rowc, items, (bf16*)nullptr, dv, H, N, scale, hm, pk, qn); }
+  if (hd == 64) L(64) else L(128)
+#undef L
+  LDMAE_CHECK_LAUNCH("attention_bwd_pv_qknorm");
+  if (int e = ldmae_colsum(LDMAE_F32, Pw, 2 * hd, (int)(blk * H), 2 * hd, dw2, 0.f, cws, stream)) return e;
+  hipMemcpyAsync(dwq, dw2, hd * sizeof(float), hipMemcpyDeviceToDevice, st);
+  hipMemcpyAsync(dwk, dw2 + hd, hd * sizeof(float), hipMemcpyDeviceToDevice, st);
+  return ldmae_colsum(LDMAE_F32, Pb, 3 * (int)hw, (int)blk, 3 * (int)hw, dbias, 0.f, cws, stream);
 }

@@ -645,14 +645,24 @@ static int colsum_rows(int M, int N) {
   int r = 8; while (r < rows && r < 256) r <<= 1;
   return r;
 }
+// a column block narrower than 1024 columns leaves threads without a column: they take interleaved rows of the same columns instead
+// (N = 128: 8 row streams per workgroup instead of 32 busy threads) and the streams are summed in fixed order through LDS
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ldx, int M, int N, int rows, float* __restrict__ P) {
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c >= N) return;
+  __shared__ float4 red[256];
+  const int ncol4 = min(N / 4 - (int)blockIdx.x * 256, 256), nsub = 256 / ncol4;
+  const int ci = threadIdx.x % ncol4, rsub = threadIdx.x / ncol4, c = (blockIdx.x * 256 + ci) * 4;
   const int m0 = blockIdx.y * rows, m1 = min(M, m0 + rows);
   float4 s = f4(0.f);
-  for (int m = m0; m < m1; ++m) s = s + load4<T>(X + (size_t)m * ldx + c);
-  *(float4*)(P + (size_t)blockIdx.y * N + c) = s;
+  if (rsub < nsub)
+    for (int m = m0 + rsub; m < m1; m += nsub) s = s + load4<T>(X + (size_t)m * ldx + c);
+  if (nsub > 1) {
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rsub == 0)
+      for (int k = 1; k < nsub; ++k) s = s + red[k * ncol4 + ci];
+  }
+  if (rsub == 0) *(float4*)(P + (size_t)blockIdx.y * N + c) = s;
 }
 extern "C" long ldmae_colsum_workspace_bytes(int M, int N) { return (long)cdiv(M, colsum_rows(M, N)) * N * 4; }
 extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, float beta, float* workspace, void* stream) {

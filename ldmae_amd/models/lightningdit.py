@@ -19,6 +19,8 @@ from __future__ import annotations
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
@@ -138,6 +140,9 @@ def _dmod_times_w(dmod, adaw):
     return ops.gemm_nt(dmod, ops.cast_weight(adaw, torch.float32, True, False)[1])
 
 
+_FUSED_QKN_BWD = os.environ.get("LDMAE_FUSED_QKN_BWD", "1") != "0"      # A/B switch (tools/): 0 = attention_bwd_pv + qknorm_rope_bwd
+
+
 class _GradChain:
     """Hand-off between the backward passes of consecutive members of LightningDiT.forward's block chain (one object per forward).
     Backward of member j+1 ends with norm1's backward, which finishes the residual-stream gradient dx that member j's backward starts
@@ -235,7 +240,9 @@ class _DiTBlockFn(torch.autograd.Function):
         # ---- attention branch
         dWp = sg.tn(dy1, o.view(M, D))
         do = ops.gemm_nt(dy1, WpT)
-        if v is None:
+        if v is None and hd in (64, 128) and _FUSED_QKN_BWD:      # QK-norm / RoPE backward inside the attention backward's epilogues: no head-major dq / dk
+            dqkv, dqn, dkn, dbqkv = ops.attention_bwd_pv_qknorm(q, k, qkv, o, do, lse, hd ** -0.5, qnw, knw, cos, sin, eps)
+        elif v is None:
             dq, dk, dqkv = ops.attention_bwd_pv(q, k, qkv, o, do, lse, hd ** -0.5)          # dv lands in the v slot of dqkv
             dqkv, dqn, dkn, dbqkv = ops.qknorm_rope_bwd(dq, dk, None, qkv, qnw, knw, cos, sin, B, N, H, hd, eps, with_bias=True, dqkv=dqkv)
         else:

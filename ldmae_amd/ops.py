@@ -289,6 +289,20 @@ def attention_bwd_pv(q, k, qkv, o, do, lse, scale):
     return dq, dk, dqkv
 
 
+def attention_bwd_pv_qknorm(q, k, qkv, o, do, lse, scale, wq, wk, cos, sin, eps=1e-6):
+    """attention_bwd_pv + qknorm_rope_bwd(with_bias=True) in one (bf16, head_dim 64 / 128): -> (dqkv [B,N,3,H,hd] complete, dwq, dwk,
+    dbias [3*H*hd])."""
+    B, H, N, hd = q.shape
+    dqkv = torch.empty_like(qkv)
+    dwq = torch.empty(hd, dtype=torch.float32, device=q.device)
+    dwk = torch.empty_like(dwq)
+    db = torch.empty(3 * H * hd, dtype=torch.float32, device=q.device)
+    ws = workspace(L.load().ldmae_attention_bwd_pv_qknorm_workspace_bytes(B, H, N, hd), q.device)
+    call("ldmae_attention_bwd_pv_qknorm", dt(q.dtype), ptr(q), ptr(k), ptr(qkv), ptr(o), ptr(_c(do)), ptr(lse), ptr(wq), ptr(wk), ptr(cos),
+         ptr(sin), float(eps), ptr(dqkv), ptr(dwq), ptr(dwk), ptr(db), ptr(ws), B, H, N, hd, float(scale), stream())
+    return dqkv, dwq, dwk, db
+
+
 def attention_fwd_qkv(qkv, B, N, H, hd, scale):
     """Attention straight on the packed token-major qkv [B*N, 3*H*hd] (bf16): no head-major relayout.  -> (o [B,N,H*hd], lse)."""
     o = torch.empty(B, N, H * hd, dtype=qkv.dtype, device=qkv.device)

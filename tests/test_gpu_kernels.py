@@ -222,6 +222,30 @@ def test_qknorm_rope(ops, dtype, hd, H):
     assert rel_err(db.cpu(), dqkv.float().cpu().reshape(B * N, 3 * H * hd).sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("hd,H,N", [(64, 3, 128), (64, 12, 1024), (128, 2, 192)])
+def test_attention_bwd_pv_qknorm_fused(ops, hd, H, N):
+    """Attention backward with the QK-RMSNorm / RoPE backward folded into its epilogues against the two entry points it replaces
+    (attention_bwd_pv + qknorm_rope_bwd): same per-element formulas on the same bf16-rounded dq / dk, so dqkv agrees to bf16 rounding of
+    isolated elements (the row sums are formed over 8 instead of 16 lanes) and the weight / bias gradient sums to f32 summation order."""
+    B, grid = 2, int(N ** 0.5) if int(N ** 0.5) ** 2 == N else None
+    g = torch.Generator().manual_seed(11)
+    qkv = (torch.randn(B, N, 3, H, hd, generator=g)).to(BF16).cuda()
+    wq, wk = (1 + 0.1 * torch.randn(hd, generator=g)).cuda(), (1 + 0.1 * torch.randn(hd, generator=g)).cuda()
+    cos, sin = torch.rand(N, hd, generator=g).cuda(), torch.rand(N, hd, generator=g).cuda()      # any table: the kernels only index it
+    do = torch.randn(B, N, H * hd, generator=g).to(BF16).cuda()
+    q, k, _ = ops.qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, copy_v=False)
+    o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5)
+    dq, dk, dqkv_a = ops.attention_bwd_pv(q, k, qkv, o, do, lse, hd ** -0.5)
+    dqkv_a, dwq_a, dwk_a, db_a = ops.qknorm_rope_bwd(dq, dk, None, qkv, wq, wk, cos, sin, B, N, H, hd, with_bias=True, dqkv=dqkv_a)
+    dqkv_b, dwq_b, dwk_b, db_b = ops.attention_bwd_pv_qknorm(q, k, qkv, o, do, lse, hd ** -0.5, wq, wk, cos, sin)
+    assert torch.equal(dqkv_a[:, :, 2], dqkv_b[:, :, 2])                      # dv: identical path
+    assert rel_err(dqkv_b.float().cpu(), dqkv_a.float().cpu()) < 2e-3
+    assert (dqkv_a != dqkv_b).float().mean().item() < 0.02
+    assert rel_err(dwq_b.cpu(), dwq_a.cpu()) < 1e-4 and rel_err(dwk_b.cpu(), dwk_a.cpu()) < 1e-4
+    assert rel_err(db_b.cpu(), db_a.cpu()) < 1e-3
+    assert rel_err(db_b.cpu(), dqkv_b.float().cpu().reshape(B * N, 3 * H * hd).sum(0)) < 1e-5      # = column sums of dqkv as stored
+
+
 def _attn_ref(qq, kk, vv, scale):
     s = (qq @ kk.transpose(-2, -1)) * scale
     o = s.softmax(-1) @ vv

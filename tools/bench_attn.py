@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=256)
     ap.add_argument("--ref", action="store_true")
+    ap.add_argument("--fused", action="store_true")
     args = ap.parse_args()
     B, H, N, hd = args.b, 12, 1024, 64
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -41,6 +42,21 @@ def main():
         t = timed(lambda: ops.attention_fwd(q, k, v, scale))
         tb = timed(lambda: ops.attention_bwd(q, k, v, o, do, lse, scale))
         print(f"round {r}: fwd {t:.3f} ms {fl / t / 1e9:7.1f} TF/s | bwd {tb:.3f} ms {2.5 * fl / tb / 1e9:7.1f} TF/s (algorithmic 2.5x fwd)")
+    if args.fused:
+        # LightningDiT block form: v in the packed qkv, QK-norm / RoPE backward either as its own pass or inside the attention epilogues
+        qkv = torch.randn(B, N, 3, H, hd, device="cuda", generator=g).to(torch.bfloat16)
+        wq, wk = torch.ones(hd, device="cuda"), torch.ones(hd, device="cuda")
+        cos, sin = torch.rand(N, hd, device="cuda", generator=g), torch.rand(N, hd, device="cuda", generator=g)
+        q2, k2, _ = ops.qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, copy_v=False)
+        o2, lse2 = ops.attention_fwd_pv(q2, k2, qkv, scale)
+
+        def two_pass():
+            dq, dk, dqkv = ops.attention_bwd_pv(q2, k2, qkv, o2, do, lse2, scale)
+            return ops.qknorm_rope_bwd(dq, dk, None, qkv, wq, wk, cos, sin, B, N, H, hd, with_bias=True, dqkv=dqkv)
+        for r in range(3):
+            ta = timed(two_pass)
+            tb = timed(lambda: ops.attention_bwd_pv_qknorm(q2, k2, qkv, o2, do, lse2, scale, wq, wk, cos, sin))
+            print(f"round {r}: attention_bwd_pv + qknorm_rope_bwd {ta:.3f} ms | attention_bwd_pv_qknorm {tb:.3f} ms")
     if args.ref:
         qq, kk, vv = (x.clone().requires_grad_(True) for x in (q, k, v))
         t = timed(lambda: torch.nn.functional.scaled_dot_product_attention(qq, kk, vv))
