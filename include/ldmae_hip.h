@@ -77,18 +77,18 @@ int ldmae_cast(int src_dtype, int dst_dtype, const void* src, void* dst, long n,
  * shift/scale are [batch, mod_ld] f32 views (column slices of the adaLN output). */
 int ldmae_rmsnorm_modulate_fwd(int out_dtype, const float* x, const float* w, const float* shift, const float* scale,
                                int mod_ld, void* out, float* rstd, int M, int D, int rows_per_batch, float eps, void* stream);
-/* dx_accum += d(x); dshift/dscale [batch, dmod_ld] = per-sample sums; dw[D] += sum (beta_w).  workspace from
+/* dx_accum = beta_x * dx_accum + d(x) (beta_x 0 or 1; 0 writes dx without reading it); dshift/dscale [batch, dmod_ld] = per-sample sums; dw[D] += sum (beta_w).  workspace from
  * ldmae_rmsnorm_modulate_bwd_workspace_bytes. */
 long ldmae_rmsnorm_modulate_bwd_workspace_bytes(int M, int D, int rows_per_batch);
 int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
-                               const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                               const float* rstd, float* dx_accum, float beta_x, float* dshift, float* dscale, int dmod_ld, float* dw,
                                float beta_w, int M, int D, int rows_per_batch, float* workspace, void* stream);
 /* The same followed by the gated-residual backward (ldmae_gate_bwd) of the updated dx_accum, in one pass over the rows (the block's
  * norm2 backward feeds the attention branch's gate: lightningdit.py:247-248 read backwards): dy = dx_accum * gate[b] (in `dtype`),
  * dgate [B, dgate_ld] = sum_n dx_accum * y, dbias [D] = column sums of dy. */
 long ldmae_rmsnorm_modulate_bwd_gate_workspace_bytes(int M, int D, int rows_per_batch);
 int ldmae_rmsnorm_modulate_bwd_gate(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
-                                    const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                                    const float* rstd, float* dx_accum, float beta_x, float* dshift, float* dscale, int dmod_ld, float* dw,
                                     float beta_w, const void* y, const float* gate, int gate_ld, void* dy, float* dgate, int dgate_ld,
                                     float* dbias, int M, int D, int rows_per_batch, float* workspace, void* stream);
 

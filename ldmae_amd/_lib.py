@@ -34,9 +34,9 @@ SIGNATURES = {
     "ldmae_cast": (_i, [_i, _i, _vp, _vp, _l, _vp]),
     "ldmae_rmsnorm_modulate_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
     "ldmae_rmsnorm_modulate_bwd_workspace_bytes": (_l, [_i, _i, _i]),
-    "ldmae_rmsnorm_modulate_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _i, _i, _i, _vp, _vp]),
+    "ldmae_rmsnorm_modulate_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _f, _i, _i, _i, _vp, _vp]),
     "ldmae_rmsnorm_modulate_bwd_gate_workspace_bytes": (_l, [_i, _i, _i]),
-    "ldmae_rmsnorm_modulate_bwd_gate": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _i, _vp, _vp, _i, _vp,
+    "ldmae_rmsnorm_modulate_bwd_gate": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _f, _vp, _vp, _i, _vp, _vp, _i, _vp,
                                              _i, _i, _i, _vp, _vp]),
     "ldmae_qknorm_rope_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_qknorm_rope_bwd_workspace_bytes": (_l, [_i, _i, _i, _i]),

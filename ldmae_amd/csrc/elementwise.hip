@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __res
 // gradient is consumed while it is in registers -- dy = dx_new * gate[b] (rounded to T), dgate partials sum dx_new * y, bias-gradient
 // partials sum dy -- instead of being re-read by a separate gate_bwd pass (805 MB per block).  Same arithmetic, same partial layout
 // and same summation order as gate_bwd_kernel.
-struct GateBwdArgs { const void* y; const float* gate; int gate_ld; void* dy; float* Pg; float* Pb; };
+struct GateBwdArgs { const void* y; const float* gate; int gate_ld; void* dy; float* Pg; float* Pb; int dx_overwrite; };
 template <int NCH, typename T, bool GATE>
 __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x,
                                                               const float* __restrict__ w, const float* __restrict__ scale, int mod_ld,
@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
       const int c = lane + 64 * i;
       if (c < nch) {
         float* p = dx + (size_t)m * D + 4 * c;
-        const float4 g = *(const float4*)p + (dn[i] - nv[i] * dot) * rs;
+        const float4 d0 = (dn[i] - nv[i] * dot) * rs;
+        const float4 g = ga.dx_overwrite ? d0 : *(const float4*)p + d0;        // beta_x = 0: dx is written, not read (no memset by the caller)
         *(float4*)p = g;
         if constexpr (GATE) {
           a_g[i] = a_g[i] + g * load4<T>(gy + (size_t)m * D + 4 * c);
@@ -267,7 +268,7 @@ extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, flo
 extern "C" long ldmae_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch);
 
 static int rmsnorm_modulate_bwd_core(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
-                                     const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                                     const float* rstd, float* dx_accum, float beta_x, float* dshift, float* dscale, int dmod_ld, float* dw,
                                      float beta_w, int M, int D, int rows_per_batch, float* workspace, const GateBwdArgs* gate,
                                      float* dgate, int dgate_ld, float* dbias, void* stream) {
   LDMAE_REQUIRE(dout && x && w && rstd && dx_accum && dw && workspace, "rmsnorm_modulate_bwd: null pointer");
@@ -280,8 +281,10 @@ static int rmsnorm_modulate_bwd_core(int dtype, const void* dout, const float* x
   float* dwb = workspace + (size_t)G * 3 * D;
   float* gws = dwb + (size_t)B * D;                     // gate partials (fused form): [G][D] dgate, [G][D] bias, colsum scratch
   const size_t lds = (size_t)4 * 3 * D * sizeof(float);
-  GateBwdArgs ga{nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+  LDMAE_REQUIRE(beta_x == 0.f || beta_x == 1.f, "rmsnorm_modulate_bwd: beta_x must be 0 (write dx) or 1 (accumulate into dx)");
+  GateBwdArgs ga{nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
   if (gate) { ga = *gate; ga.Pg = gws; ga.Pb = gws + (size_t)G * D; }
+  ga.dx_overwrite = beta_x == 0.f;
 #define LAUNCH(T, GATE) DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NCH, T, GATE>), dim3(G), dim3(256), lds, st, (const T*)dout, x, w, scale, mod_ld, rstd, dx_accum, P, M, D, rows_per_batch, rw, ga))
   if (dtype == LDMAE_BF16) { if (gate) { LAUNCH(bf16, true); } else { LAUNCH(bf16, false); } }
   else { if (gate) { LAUNCH(float, true); } else { LAUNCH(float, false); } }
@@ -299,9 +302,9 @@ static int rmsnorm_modulate_bwd_core(int dtype, const void* dout, const float* x
 }
 
 extern "C" int ldmae_rmsnorm_modulate_bwd(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
-                                          const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                                          const float* rstd, float* dx_accum, float beta_x, float* dshift, float* dscale, int dmod_ld, float* dw,
                                           float beta_w, int M, int D, int rows_per_batch, float* workspace, void* stream) {
-  return rmsnorm_modulate_bwd_core(dtype, dout, x, w, scale, mod_ld, rstd, dx_accum, dshift, dscale, dmod_ld, dw, beta_w, M, D, rows_per_batch,
+  return rmsnorm_modulate_bwd_core(dtype, dout, x, w, scale, mod_ld, rstd, dx_accum, beta_x, dshift, dscale, dmod_ld, dw, beta_w, M, D, rows_per_batch,
                                    workspace, nullptr, nullptr, 0, nullptr, stream);
 }
 
@@ -312,13 +315,13 @@ extern "C" long ldmae_rmsnorm_modulate_bwd_gate_workspace_bytes(int M, int D, in
 // rmsnorm_modulate_bwd followed by gate_bwd of the updated dx_accum (dy = dx_accum * gate[b] in `dtype`; dgate [B, dgate_ld] = sum_n
 // dx_accum * y; dbias [D] = column sums of dy) in one pass over the rows.
 extern "C" int ldmae_rmsnorm_modulate_bwd_gate(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
-                                               const float* rstd, float* dx_accum, float* dshift, float* dscale, int dmod_ld, float* dw,
+                                               const float* rstd, float* dx_accum, float beta_x, float* dshift, float* dscale, int dmod_ld, float* dw,
                                                float beta_w, const void* y, const float* gate, int gate_ld, void* dy, float* dgate,
                                                int dgate_ld, float* dbias, int M, int D, int rows_per_batch, float* workspace, void* stream) {
   LDMAE_REQUIRE(y && gate && dy && dgate && dbias, "rmsnorm_modulate_bwd_gate: null pointer");
   LDMAE_REQUIRE(gate_ld % 4 == 0, "rmsnorm_modulate_bwd_gate: gate_ld=%d must be a multiple of 4", gate_ld);
-  const GateBwdArgs ga{y, gate, gate_ld, dy, nullptr, nullptr};
-  return rmsnorm_modulate_bwd_core(dtype, dout, x, w, scale, mod_ld, rstd, dx_accum, dshift, dscale, dmod_ld, dw, beta_w, M, D, rows_per_batch,
+  const GateBwdArgs ga{y, gate, gate_ld, dy, nullptr, nullptr, 0};
+  return rmsnorm_modulate_bwd_core(dtype, dout, x, w, scale, mod_ld, rstd, dx_accum, beta_x, dshift, dscale, dmod_ld, dw, beta_w, M, D, rows_per_batch,
                                    workspace, &ga, dgate, dgate_ld, dbias, stream);
 }
 

@@ -154,16 +154,16 @@ class _GradChain:
     def __init__(self):
         self.up, self.pre = {}, {}
 
-    def norm_bwd(self, j, dout, x, w, scale, rstd, dx, dshift, dscale, N, dtype):
+    def norm_bwd(self, j, dout, x, w, scale, rstd, dx, dshift, dscale, N, dtype, accumulate=True):
         """norm backward of member j (accumulating into dx); fused with member j-1's gate backward when that member is registered."""
         D = x.shape[1]
         prev = self.up.get(j - 1)
         if prev is None:
-            return ops.rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx, dshift, dscale, N)
+            return ops.rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx, dshift, dscale, N, accumulate)
         y2p, modp = prev
         dmodp = torch.empty_like(modp)
         dw, dy2p, db3p = ops.rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx, dshift, dscale, y2p, modp[:, 5 * D:6 * D],
-                                                       dmodp[:, 5 * D:6 * D], N, dtype)
+                                                       dmodp[:, 5 * D:6 * D], N, dtype, accumulate)
         self.pre[j - 1] = (dx.data_ptr(), dy2p, db3p, dmodp)
         return dw
 
@@ -289,12 +289,12 @@ class _FinalLayerFn(torch.autograd.Function):
         ga = ops.cast(g, dtype)
         dlw, dlb = ops.gemm_tn(ga, xf), ops.colsum(g)
         dxf = ops.gemm_nt(g, ops.cast_weight(lw, torch.float32, True, False)[1], out_dtype=dtype)     # K = p*p*C (16): f32 MFMA
-        dx = torch.zeros(M, D, dtype=torch.float32, device=g.device)
+        dx = torch.empty(M, D, dtype=torch.float32, device=g.device)     # written, not accumulated into: no 805 MB memset + read
         dmod = torch.empty_like(mod)
         if ctx.chain is not None:
-            dnw = ctx.chain.norm_bwd(ctx.idx, dxf, x2, nw, mod[:, D:], rstd, dx, dmod[:, :D], dmod[:, D:], N, dtype)
+            dnw = ctx.chain.norm_bwd(ctx.idx, dxf, x2, nw, mod[:, D:], rstd, dx, dmod[:, :D], dmod[:, D:], N, dtype, accumulate=False)
         else:
-            dnw = ops.rmsnorm_modulate_bwd(dxf, x2, nw, mod[:, D:], rstd, dx, dmod[:, :D], dmod[:, D:], N)
+            dnw = ops.rmsnorm_modulate_bwd(dxf, x2, nw, mod[:, D:], rstd, dx, dmod[:, :D], dmod[:, D:], N, accumulate=False)
         dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
         dsc = _dmod_times_w(dmod, adaw)
         return dx.view(B, N, D), dsc, None, None, None, None, dnw, dlw, dlb, dadaw, dadab

@@ -17,8 +17,8 @@ class _RMSNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x2, w, rstd = ctx.saved_tensors
-        dx = torch.zeros_like(x2)
-        dw = ops.rmsnorm_modulate_bwd(g.float().contiguous().view_as(x2), x2, w, None, rstd, dx, None, None, x2.shape[0])
+        dx = torch.empty_like(x2)
+        dw = ops.rmsnorm_modulate_bwd(g.float().contiguous().view_as(x2), x2, w, None, rstd, dx, None, None, x2.shape[0], accumulate=False)
         return dx.view(g.shape), dw, None
 
 

@@ -199,18 +199,19 @@ def rmsnorm_modulate_fwd(x, w, shift, scale, rows_per_batch, out_dtype, eps=1e-6
     return out, rstd
 
 
-def rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx_accum, dshift, dscale, rows_per_batch):
-    """dx_accum += dx (in place); writes dshift/dscale views ([B,D], any row stride); returns dw [D]."""
+def rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx_accum, dshift, dscale, rows_per_batch, accumulate=True):
+    """dx_accum += dx (in place; accumulate=False: dx_accum = dx, the buffer may be uninitialised); writes dshift/dscale views ([B,D], any
+    row stride); returns dw [D]."""
     M, D = x.shape
     dw = torch.empty(D, dtype=torch.float32, device=x.device)
     ws = workspace(L.load().ldmae_rmsnorm_modulate_bwd_workspace_bytes(M, D, rows_per_batch), x.device)
     call("ldmae_rmsnorm_modulate_bwd", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(scale), scale.stride(0) if scale is not None else 0,
-         ptr(rstd), ptr(dx_accum), ptr(dshift), ptr(dscale), dshift.stride(0) if dshift is not None else 0, ptr(dw), 0.0, M, D,
-         rows_per_batch, ptr(ws), stream())
+         ptr(rstd), ptr(dx_accum), 1.0 if accumulate else 0.0, ptr(dshift), ptr(dscale), dshift.stride(0) if dshift is not None else 0,
+         ptr(dw), 0.0, M, D, rows_per_batch, ptr(ws), stream())
     return dw
 
 
-def rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx_accum, dshift, dscale, y, gate, dgate, rows_per_batch, act_dtype):
+def rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx_accum, dshift, dscale, y, gate, dgate, rows_per_batch, act_dtype, accumulate=True):
     """rmsnorm_modulate_bwd followed by gate_bwd(dx_accum, y, gate, dgate, with_bias=True) in one pass over the rows.
     Returns (dw [D], dy [M,D] act dtype, dbias [D])."""
     M, D = x.shape
@@ -219,7 +220,7 @@ def rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx_accum, dshift, dscale,
     dbias = torch.empty(D, dtype=torch.float32, device=x.device)
     ws = workspace(L.load().ldmae_rmsnorm_modulate_bwd_gate_workspace_bytes(M, D, rows_per_batch), x.device)
     call("ldmae_rmsnorm_modulate_bwd_gate", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(scale), scale.stride(0) if scale is not None else 0,
-         ptr(rstd), ptr(dx_accum), ptr(dshift), ptr(dscale), dshift.stride(0) if dshift is not None else 0, ptr(dw), 0.0,
+         ptr(rstd), ptr(dx_accum), 1.0 if accumulate else 0.0, ptr(dshift), ptr(dscale), dshift.stride(0) if dshift is not None else 0, ptr(dw), 0.0,
          ptr(y), ptr(gate), gate.stride(0), ptr(dy), ptr(dgate), dgate.stride(0), ptr(dbias), M, D, rows_per_batch, ptr(ws), stream())
     return dw, dy, dbias
 
