@@ -39,7 +39,7 @@ extern "C" {
 #define LDMAE_EPI_GATE_RES 1   /* y = acc + bias ; xout = xin + gate[b]*y  (gate NULL -> 1)    */
 #define LDMAE_EPI_BIAS_POS 2   /* C = acc + bias + pos[m % rows_per_batch]  (patch-embed)      */
 #define LDMAE_EPI_BIAS_GELU 3  /* C = gelu_erf(acc + bias)  (VMAE Mlp fc1), pre-activation to C2 */
-#define LDMAE_EPI_SWIGLU 4     /* bf16 only: B = w12 [2Hs,K]; C = h12 [M,2Hs] = acc+bias, xout(as bf16*) = hid [M,Hs] = silu(x1)*x2 */
+#define LDMAE_EPI_SWIGLU 4     /* bf16 only: B = w12 [2Hs,K]; C = h12 [M,2Hs] = acc+bias (NULL: not stored -- forward-only), xout(as bf16*) = hid [M,Hs] = silu(x1)*x2 */
 #define LDMAE_EPI_SWIGLU_BWD 5 /* bf16 only: acc = dhid [M,Hs]; xin(as bf16*) = h12 [M,2Hs]; C = dh12 [M,2Hs]; xout (optional) =
                                   [ceil(M/128)][2Hs] f32 partial column sums of dh12 as stored (bias gradient; caller sums the rows) */
 

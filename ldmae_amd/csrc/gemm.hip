@@ -710,7 +710,7 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
     e.C2 = xout;   /* pre-activation copy, same dtype/ld as C */
   } else if (epi == LDMAE_EPI_SWIGLU) {
     LDMAE_REQUIRE(dtype == LDMAE_BF16 && out_dtype == LDMAE_BF16, "gemm_nt: swiglu epilogue is bf16 only");
-    LDMAE_REQUIRE(C && xout && N % 256 == 0 && K % 32 == 0 && ldc == N, "gemm_nt: swiglu epilogue needs h12 (C, ldc = N), hid (xout), N %% 256 == 0 (N=%d)", N);
+    LDMAE_REQUIRE(xout && N % 256 == 0 && K % 32 == 0 && (!C || ldc == N), "gemm_nt: swiglu epilogue needs hid (xout), N %% 256 == 0 (N=%d); h12 (C, ldc = N) may be NULL in forward-only calls", N);
     e.xout = xout;
   } else if (epi == LDMAE_EPI_SWIGLU_BWD) {
     LDMAE_REQUIRE(dtype == LDMAE_BF16 && out_dtype == LDMAE_BF16, "gemm_nt: swiglu-bwd epilogue is bf16 only");

@@ -165,8 +165,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
           x2[0] = (bf16)(v.x + b2.x); x2[1] = (bf16)(v.y + b2.y); x2[2] = (bf16)(v.z + b2.z); x2[3] = (bf16)(v.w + b2.w);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { const float a = (float)x1[j]; ho[j] = (bf16)(a * fast_sigmoid(a) * (float)x2[j]); }
-          *(bf16x4*)(h12 + (size_t)m * N + hc) = x1;
-          *(bf16x4*)(h12 + (size_t)m * N + Hs + hc) = x2;
+          if (h12) {                                   // wave-uniform; NULL = forward-only call: h12 is only read by the backward pass
+            *(bf16x4*)(h12 + (size_t)m * N + hc) = x1;
+            *(bf16x4*)(h12 + (size_t)m * N + Hs + hc) = x2;
+          }
           *(bf16x4*)(hid + (size_t)m * Hs + hc) = ho;
         }
       }

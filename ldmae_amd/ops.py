@@ -114,13 +114,14 @@ def gemm_nt_gelu(a, b, bias, save_pre=True):
     return out, pre
 
 
-def gemm_nt_swiglu(a, w12, b12):
+def gemm_nt_swiglu(a, w12, b12, save_h12=True):
     """(h12, hid): h12 = a @ w12^T + b12 ([x1 | x2]), hid = silu(x1) * x2.  bf16: one GEMM with the SwiGLU epilogue;
-    otherwise the GEMM followed by ldmae_swiglu_fwd (same numbers: the epilogue rounds to bf16 before the activation)."""
+    otherwise the GEMM followed by ldmae_swiglu_fwd (same numbers: the epilogue rounds to bf16 before the activation).
+    save_h12=False (forward-only; bf16 path): h12, which only the backward pass reads, is not stored and None is returned for it."""
     M, K = a.shape
     N = w12.shape[0]
     if a.dtype == torch.bfloat16 and N % 256 == 0 and K % 64 == 0:
-        h12 = torch.empty(M, N, dtype=a.dtype, device=a.device)
+        h12 = torch.empty(M, N, dtype=a.dtype, device=a.device) if save_h12 else None
         hid = torch.empty(M, N // 2, dtype=a.dtype, device=a.device)
         call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU, ptr(a), a.stride(0), ptr(w12), w12.stride(0), ptr(h12), N, M, N, K, ptr(b12), 0.0,
              None, ptr(hid), None, 0, 0, stream())

@@ -59,10 +59,11 @@ class _ViTBlockFn(torch.autograd.Function):
         B, N, D = x.shape
         M, hd = B * N, D // H
         x2 = x.contiguous().view(M, D)
-        Wqkv, WqkvT = _wcopies(qkvw, dtype)
-        Wp, WpT = _wcopies(pw, dtype)
-        W1, W1T = _wcopies(f1w, dtype)
-        W2, W2T = _wcopies(f2w, dtype)
+        bwd = any(ctx.needs_input_grad)       # forward-only calls (encode / decode under no_grad) skip what only the backward pass reads
+        Wqkv, WqkvT = _wcopies(qkvw, dtype, bwd)
+        Wp, WpT = _wcopies(pw, dtype, bwd)
+        W1, W1T = _wcopies(f1w, dtype, bwd)
+        W2, W2T = _wcopies(f2w, dtype, bwd)
         h1, mu1, rs1 = ops.layernorm_fwd(x2, n1w, n1b, dtype, eps)
         qkv = ops.gemm_nt(h1, Wqkv, qkvb)                                     # activation dtype: bf16 under autocast
         if dtype == torch.bfloat16:      # flash kernel on the packed qkv as the Linear wrote it (head_dim 16 padded to 32 in LDS)
@@ -75,8 +76,10 @@ class _ViTBlockFn(torch.autograd.Function):
         oa = o.view(M, D)
         xmid, _ = ops.gemm_nt_gate_res(oa, Wp, pb, x2, None, N, save_y=False)
         h2, mu2, rs2 = ops.layernorm_fwd(xmid, n2w, n2b, dtype, eps)
-        act, pre = ops.gemm_nt_gelu(h2, W1, f1b)
+        act, pre = ops.gemm_nt_gelu(h2, W1, f1b, save_pre=bwd)
         xout, _ = ops.gemm_nt_gate_res(act, W2, f2b, xmid, None, N, save_y=False)
+        if not bwd:
+            return xout.view(B, N, D)
         ctx.save_for_backward(x2, h1, mu1, rs1, qkv, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T)
         ctx.dims = (B, N, D, H, hd, dtype)
         ctx.inplace = bool(inplace)
