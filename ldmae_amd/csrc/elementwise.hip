@@ -369,6 +369,48 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const T* __restric
   }
 }
 
+// Head dims whose 4-element chunk count is not a power of two (LightningDiT-XL: 72 -> 18 chunks): the lane-group form above rounds the
+// group up to 32 lanes and leaves 14 of them idle (2.0 TB/s at hd = 72).  Here the workgroup's threads are packed densely -- thread t
+// serves chunk t % cpi of item t / cpi, 14 items x 18 chunks = 252 of 256 threads at hd = 72, consecutive threads on consecutive
+// bytes -- and the two row sums go through LDS (every thread adds its item's cpi partials in the same order).  Same arithmetic per element.
+template <typename T>
+__global__ __launch_bounds__(256) void qknorm_rope_fwd_dense_kernel(const T* __restrict__ qkv, const float* __restrict__ wq,
+                                                                    const float* __restrict__ wk, const float* __restrict__ cosT,
+                                                                    const float* __restrict__ sinT, T* __restrict__ q, T* __restrict__ k,
+                                                                    T* __restrict__ v, int B, int N, int H, int hd, float eps) {
+  __shared__ float2 red[256];
+  const int cpi = hd >> 2, ipw = 256 / cpi, t = threadIdx.x, li = t / cpi, c4 = (t % cpi) * 4;
+  const bool lane_ok = li < ipw;
+  const long items = (long)B * N * H;
+  const float4 wqv = *(const float4*)(wq + c4), wkv = *(const float4*)(wk + c4);
+  for (long base = (long)blockIdx.x * ipw; base < items; base += (long)gridDim.x * ipw) {
+    const long it = base + li;
+    const bool act = lane_ok && it < items;
+    const int h = it % H, n = (it / H) % N, b = it / ((long)H * N);
+    const T* src = qkv + ((size_t)(b * N + n) * 3 * H + h) * hd + c4;
+    const size_t dst = ((size_t)(b * H + h) * N + n) * hd + c4;
+    float4 qv = f4(0.f), kv = f4(0.f), vv = f4(0.f), cs = f4(0.f), sn = f4(0.f);
+    if (act) {
+      qv = load4<T>(src); kv = load4<T>(src + (size_t)H * hd);
+      if (v) vv = load4<T>(src + (size_t)2 * H * hd);
+      cs = *(const float4*)(cosT + (size_t)n * hd + c4); sn = *(const float4*)(sinT + (size_t)n * hd + c4);
+    }
+    red[t] = make_float2(hsum(qv * qv), hsum(kv * kv));
+    __syncthreads();
+    float sq = 0.f, sk = 0.f;
+    if (lane_ok) {
+      for (int j = 0; j < cpi; ++j) { const float2 p = red[li * cpi + j]; sq += p.x; sk += p.y; }
+    }
+    __syncthreads();
+    if (act) {
+      const float rq = rsqrtf(sq / (float)hd + eps), rk = rsqrtf(sk / (float)hd + eps);
+      store4<T>(q + dst, rope_apply((qv * rq) * wqv, cs, sn));
+      store4<T>(k + dst, rope_apply((kv * rk) * wkv, cs, sn));
+      if (v) store4<T>(v + dst, vv);
+    }
+  }
+}
+
 template <int LPR, typename T>
 __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restrict__ dq, const T* __restrict__ dk, const T* __restrict__ dv,
                                                               const T* __restrict__ qkv, const float* __restrict__ wq,
@@ -453,7 +495,14 @@ extern "C" int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq
   hipStream_t st = as_stream(stream);
   const long items = (long)B * N * H;
 #define QK_FWD(LPR, T) hipLaunchKernelGGL((qknorm_rope_fwd_kernel<LPR, T>), dim3(qk_grid(items, LPR)), dim3(256), 0, st, (const T*)qkv, wq, wk, cos, sin, (T*)q, (T*)k, (T*)v, B, N, H, hd, eps)
-  if (hd <= 64) { if (dtype == LDMAE_BF16) QK_FWD(16, bf16); else QK_FWD(16, float); }
+  const int cpi = hd / 4;
+  if (wq && hd > 64 && (cpi & (cpi - 1)) != 0) {      // e.g. hd = 72: densely packed threads instead of 32-lane groups with 18 busy lanes
+    const long wgs = (items + 256 / cpi - 1) / (256 / cpi);
+    const unsigned grid = (unsigned)(wgs < 4096 ? wgs : 4096);
+    if (dtype == LDMAE_BF16) hipLaunchKernelGGL(qknorm_rope_fwd_dense_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)qkv, wq, wk, cos, sin, (bf16*)q, (bf16*)k, (bf16*)v, B, N, H, hd, eps);
+    else hipLaunchKernelGGL(qknorm_rope_fwd_dense_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)qkv, wq, wk, cos, sin, (float*)q, (float*)k, (float*)v, B, N, H, hd, eps);
+  }
+  else if (hd <= 64) { if (dtype == LDMAE_BF16) QK_FWD(16, bf16); else QK_FWD(16, float); }
   else { if (dtype == LDMAE_BF16) QK_FWD(32, bf16); else QK_FWD(32, float); }
 #undef QK_FWD
   LDMAE_CHECK_LAUNCH("qknorm_rope_fwd");
