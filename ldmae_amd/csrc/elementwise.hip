@@ -386,7 +386,12 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_dense_kernel(const T* __r
   for (long base = (long)blockIdx.x * ipw; base < items; base += (long)gridDim.x * ipw) {
     const long it = base + li;
     const bool act = lane_ok && it < items;
-    const int h = it % H, n = (it / H) % N, b = it / ((long)H * N);
+    // item order: tiles of 8 tokens x H heads, token fastest inside a head -- consecutive items then write consecutive rows of ONE head
+    // (8 rows of 144 B = 9 whole lines at hd = 72; with the head fastest every 144-B row is a partial-line write of its own)
+    const long tile = it / (8 * H);
+    const int rr = (int)(it % (8 * H)), h = rr >> 3;
+    const long tok = tile * 8 + (rr & 7);
+    const int n = (int)(tok % N), b = (int)(tok / N);
     const T* src = qkv + ((size_t)(b * N + n) * 3 * H + h) * hd + c4;
     const size_t dst = ((size_t)(b * H + h) * N + n) * hd + c4;
     float4 qv = f4(0.f), kv = f4(0.f), vv = f4(0.f), cs = f4(0.f), sn = f4(0.f);
@@ -496,7 +501,7 @@ extern "C" int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq
   const long items = (long)B * N * H;
 #define QK_FWD(LPR, T) hipLaunchKernelGGL((qknorm_rope_fwd_kernel<LPR, T>), dim3(qk_grid(items, LPR)), dim3(256), 0, st, (const T*)qkv, wq, wk, cos, sin, (T*)q, (T*)k, (T*)v, B, N, H, hd, eps)
   const int cpi = hd / 4;
-  if (wq && hd > 64 && (cpi & (cpi - 1)) != 0) {      // e.g. hd = 72: densely packed threads instead of 32-lane groups with 18 busy lanes
+  if (wq && hd > 64 && (cpi & (cpi - 1)) != 0 && N % 8 == 0) {      // e.g. hd = 72: densely packed threads instead of 32-lane groups with 18 busy lanes
     const long wgs = (items + 256 / cpi - 1) / (256 / cpi);
     const unsigned grid = (unsigned)(wgs < 4096 ? wgs : 4096);
     if (dtype == LDMAE_BF16) hipLaunchKernelGGL(qknorm_rope_fwd_dense_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)qkv, wq, wk, cos, sin, (bf16*)q, (bf16*)k, (bf16*)v, B, N, H, hd, eps);
