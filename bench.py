@@ -44,6 +44,7 @@ def build(device, per_gpu_batch):
     model = model.to(device).train()
     opt = AdamWEMA(model, lr=2e-4, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9999)
     reducer = GradBucketReducer(opt.flat)
+    model.direct_param_grads = os.environ.get("LDMAE_DIRECT_GRADS", "1") != "0"       # every .grad is a slab view and backward is a plain loss.backward(): dW goes straight into the slab
     reducer.broadcast_params(0)
     opt.ema.copy_(opt.flat.params)
     transport = create_transport("Linear", "velocity", None, None, None, use_cosine_loss=False, use_lognorm=True)

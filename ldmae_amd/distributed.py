@@ -52,7 +52,9 @@ class GradBucketReducer:
         self.sync = True
         if self.world > 1:
             for n, p in flat.trainable:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(n)))
+                h = self._make_hook(n)
+                self._hooks.append(p.register_post_accumulate_grad_hook(h))
+                p._ldmae_grad_ready = h          # for gradients written into .grad without AccumulateGrad (models.lightningdit._dw_into_grad)
             if self.is_cuda and os.environ.get("LDMAE_TUNE") is None:
                 # RCCL's collective kernels hold some CUs while the all-reduce of a bucket overlaps backward.  A persistent GEMM
                 # (exactly one workgroup per CU for the whole launch) would then run its displaced workgroups as a second round;

@@ -141,6 +141,19 @@ def _dmod_times_w(dmod, adaw):
     return ops.gemm_nt(dmod, ops.cast_weight(adaw, torch.float32, True, False)[1])
 
 
+def _dw_into_grad(sg, dy, x, param, direct):
+    """Weight gradient dy^T x.  `direct` (the training driver opted in: LightningDiT.direct_param_grads) and the parameter already has a
+    contiguous f32 `.grad` (a view of the optimizer's gradient slab): the TN GEMM's deterministic slab reduce ADDS into it (beta = 1, what
+    AccumulateGrad would do with a separate pass over the 2.4-14 MB tensor) and autograd is handed None; the data-parallel reducer, whose
+    post-accumulate hook then does not fire, is told through the callback it left on the parameter.  Otherwise: a new tensor for autograd."""
+    g = param.grad if direct else None
+    if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == (dy.shape[1], x.shape[1]):
+        sg.tn(dy, x, out=g, beta=1.0)
+        ready = getattr(param, "_ldmae_grad_ready", None)
+        return None, ready
+    return sg.tn(dy, x), None
+
+
 _FUSED_QKN_BWD = os.environ.get("LDMAE_FUSED_QKN_BWD", "1") != "0"      # A/B switch (tools/): 0 = attention_bwd_pv + qknorm_rope_bwd
 
 
@@ -173,7 +186,7 @@ class _DiTBlockFn(torch.autograd.Function):
     """LightningDiTBlock.forward (:239-250) with RMSNorm, QK-norm, RoPE, SwiGLU, shift."""
 
     @staticmethod
-    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace, chain, idx,
+    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace, chain, idx, direct,
                 n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12, b12, w3, b3, adaw, adab):
         B, N, D = x.shape
         M, hd = B * N, D // H
@@ -209,6 +222,7 @@ class _DiTBlockFn(torch.autograd.Function):
         ctx.dims = (B, N, D, H, hd, eps, dtype)
         ctx.inplace = bool(inplace)
         ctx.chain, ctx.idx = chain, idx
+        ctx.direct, ctx.wparams = bool(direct), (qkvw, pw, w12, w3)
         if chain is not None:
             chain.up[idx] = (y2, mod)
         return xout.view(B, N, D)
@@ -236,15 +250,17 @@ class _DiTBlockFn(torch.autograd.Function):
         else:
             dmod = torch.empty_like(mod)
             dy2, db3 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype, with_bias=True)   # bias grads where dy is produced
-        dW3 = sg.tn(dy2, hid)
+        qkvw_p, pw_p, w12_p, w3_p = ctx.wparams
+        notify = []
+        dW3, r = _dw_into_grad(sg, dy2, hid, w3_p, ctx.direct); notify.append((r, w3_p))
         dh12, db12 = ops.gemm_nt_swiglu_bwd(dy2, W3T, h12, with_bias=True)
-        dW12 = sg.tn(dh12, xm2)
+        dW12, r = _dw_into_grad(sg, dh12, xm2, w12_p, ctx.direct); notify.append((r, w12_p))
         dxm2 = ops.gemm_nt(dh12, W12T)
         # norm2 backward and the attention branch's gate backward in one pass (the updated dx is consumed from registers)
         dn2, dy1, dbp = ops.rmsnorm_modulate_bwd_gate(dxm2, xmid, n2w, s2, rstd2, dx, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D],
                                                       y1, g1, dmod[:, 2 * D:3 * D], N, dtype)
         # ---- attention branch
-        dWp = sg.tn(dy1, o.view(M, D))
+        dWp, r = _dw_into_grad(sg, dy1, o.view(M, D), pw_p, ctx.direct); notify.append((r, pw_p))
         do = ops.gemm_nt(dy1, WpT)
         if v is None and hd in (64, 128) and _FUSED_QKN_BWD:      # QK-norm / RoPE backward inside the attention backward's epilogues: no head-major dq / dk
             dqkv, dqn, dkn, dbqkv = ops.attention_bwd_pv_qknorm(q, k, qkv, o, do, lse, hd ** -0.5, qnw, knw, cos, sin, eps)
@@ -255,7 +271,7 @@ class _DiTBlockFn(torch.autograd.Function):
             dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
             dqkv, dqn, dkn, dbqkv = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, B, N, H, hd, eps, with_bias=True)
         dqkv = dqkv.view(M, 3 * D)
-        dWqkv = sg.tn(dqkv, xm1)
+        dWqkv, r = _dw_into_grad(sg, dqkv, xm1, qkvw_p, ctx.direct); notify.append((r, qkvw_p))
         dxm1 = ops.gemm_nt(dqkv, WqkvT)
         if chain is not None:
             dn1 = chain.norm_bwd(idx, dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N, dtype)
@@ -265,7 +281,10 @@ class _DiTBlockFn(torch.autograd.Function):
         dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
         dsc = _dmod_times_w(dmod, adaw)
         sg.join()
-        return (dx.view(B, N, D), dsc, None, None, None, None, None, None, None, None,
+        for r, p_ in notify:          # gradients written straight into .grad: tell the reducer (no-op without one)
+            if r is not None:
+                r(p_)
+        return (dx.view(B, N, D), dsc, None, None, None, None, None, None, None, None, None,
                 dn1, dWqkv, dbqkv, dqn, dkn, dWp, dbp, dn2, dW12, db12, dW3, db3, dadaw, dadab)
 
 
@@ -414,14 +433,14 @@ class LightningDiTBlock(nn.Module):
         self.wo_shift = wo_shift
         self.precision = None
 
-    def forward(self, x, c, feat_rope=None, _silu_c=None, _dtype=None, _inplace_grad=False, _chain=None, _idx=0):
+    def forward(self, x, c, feat_rope=None, _silu_c=None, _dtype=None, _inplace_grad=False, _chain=None, _idx=0, _direct=False):
         if feat_rope is None:
             raise NotImplementedError("ldmae_amd LightningDiTBlock needs feat_rope (use_rope=True)")
         sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
         a, m = self.attn, self.mlp
         return _DiTBlockFn.apply(
             x.float(), sc, feat_rope.freqs_cos, feat_rope.freqs_sin, a.num_heads, self.norm1.eps, _dtype or _act_dtype(self.precision),
-            _inplace_grad, _chain, _idx,
+            _inplace_grad, _chain, _idx, _direct,
             self.norm1.weight, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.k_norm.weight, a.proj.weight, a.proj.bias,
             self.norm2.weight, m.w12.weight, m.w12.bias, m.w3.weight, m.w3.bias,
             self.adaLN_modulation[1].weight, self.adaLN_modulation[1].bias)
@@ -456,6 +475,9 @@ class LightningDiT(nn.Module):
         super().__init__()
         if not use_rope:
             raise NotImplementedError("ldmae_amd LightningDiT: use_rope=True only (the shipped configuration)")
+        # opt-in of the training driver (which owns a gradient slab and calls plain loss.backward()): the four Linear weight gradients
+        # of every block are accumulated straight into param.grad by the GEMM's reduce instead of through autograd's AccumulateGrad
+        self.direct_param_grads = False
         self.learn_sigma = learn_sigma
         self.in_channels = in_channels
         self.out_channels = in_channels if not learn_sigma else in_channels * 2
@@ -544,7 +566,7 @@ class LightningDiT(nn.Module):
                 if self.use_checkpoint:
                     x = checkpoint(block, x, c, self.feat_rope, sc, dtype, not hooked[i], use_reentrant=True)
                 else:
-                    x = block(x, c, self.feat_rope, sc, dtype, not hooked[i], chain, i)
+                    x = block(x, c, self.feat_rope, sc, dtype, not hooked[i], chain, i, self.direct_param_grads and chain is not None)
             x = self.final_layer(x, c, sc, dtype, chain, len(self.blocks))
             x = self.unpatchify(x)
             if self.learn_sigma:

@@ -56,12 +56,12 @@ class SideGemms:
         self.main = torch.cuda.current_stream(device)
         self.side = side_stream(device) if self.enabled else None
 
-    def tn(self, a, b):
+    def tn(self, a, b, out=None, beta=0.0):
         if not self.enabled:
-            return gemm_tn(a, b)
+            return gemm_tn(a, b, out=out, beta=beta)
         self.side.wait_stream(self.main)
         with torch.cuda.stream(self.side):
-            return gemm_tn(a, b, ws_slot="tn_side")
+            return gemm_tn(a, b, out=out, beta=beta, ws_slot="tn_side")
 
     def join(self):
         if self.enabled:

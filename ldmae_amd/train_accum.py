@@ -129,6 +129,7 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
     o = cfg['optimizer']
     opt = AdamWEMA(model, lr=o['lr'], betas=(0.9, o['beta2']), weight_decay=0.0, ema_decay=0.9999)
     reducer = GradBucketReducer(opt.flat)
+    model.direct_param_grads = True       # every .grad is a slab view and backward is a plain loss.backward(): dW goes straight into the slab
     reducer.broadcast_params(0)
     opt.ema.copy_(opt.flat.params)                               # update_ema(ema, model, decay=0), train_accum.py:166
     t = cfg['transport']

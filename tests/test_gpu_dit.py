@@ -286,6 +286,29 @@ def test_forward_hook_tapping_a_block_output_keeps_gradients_exact():
             assert torch.equal(p.grad, main[k]), k
 
 
+def test_direct_param_grads_equal_autograd_accumulation():
+    """LightningDiT.direct_param_grads (the training driver's opt-in): the block weight gradients are added into the existing .grad by the
+    TN GEMM's reduce instead of by autograd -- bitwise the same gradients, also on a second backward that accumulates on top."""
+    sd = tiny_sd()
+    m = build(TINY, sd).train()
+    x, t, y = det_randn("dx", (4, 16, 8, 8), 5).cuda(), torch.tensor([0.2, 0.4, 0.6, 0.8]).cuda(), torch.tensor([1, 2, 3, 4]).cuda()
+
+    def two_backwards(direct):
+        m.direct_param_grads = direct
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+        torch.manual_seed(0)                      # label dropout draws
+        m(x, t, y).square().mean().backward()
+        torch.manual_seed(0)
+        (2.0 * m(x, t, y).square().mean()).backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    a, b = two_backwards(False), two_backwards(True)
+    m.direct_param_grads = False
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert any(v.abs().sum() > 0 for k, v in b.items() if k.endswith("attn.qkv.weight"))
+
+
 def test_xl1_real_width_forward_vs_oracle():
     """LightningDiT-XL/1 geometry at the real width (1152, 16 heads, head_dim 72, SwiGLU hidden 3072, 1024 tokens), depth 2, batch 1:
     fp32 forward within 1e-4 of the oracle; bf16 autocast (native head_dim-72 flash kernel, LDS padded to 96) within 2e-2."""
