@@ -48,7 +48,9 @@ def _wcopies(w, dtype, transposed=True):
     only the backward pass reads."""
     if dtype == torch.float32:
         return w, (ops.cast_weight(w, dtype, transposed=True, straight=False)[1] if transposed else None)
-    return ops.cast_weight(w, dtype, transposed=transposed, straight=True)
+    if not transposed:
+        return ops.cached_weight_copy(w, dtype), None
+    return ops.cast_weight(w, dtype, transposed=True, straight=True)
 
 
 # ----------------------------------------------------------------------------- autograd Functions

@@ -7,6 +7,7 @@ PyTorch: if the library is missing, or a tensor is on the CPU, they raise.
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -379,12 +380,38 @@ def label_embed_bwd(dout, y, drop, num_classes, rows):
     return dtable
 
 
+# Bumped by every op that rewrites parameter storage through the C ABI (torch's own version counters do not see those writes): part of the
+# key of the forward-only weight-copy cache below.
+WEIGHT_EPOCH = 0
+_WCACHE: dict = {}
+
+
+def cached_weight_copy(w, dtype):
+    """`dtype` copy of the f32 master weight `w` for FORWARD-ONLY use (sampling / encoding under no_grad runs the same weights hundreds of
+    times: 112 cast launches per XL/1 forward).  Valid while the storage pointer, torch's version counter of `w` and WEIGHT_EPOCH are
+    unchanged; training never comes here (its weights change every step)."""
+    key = (id(w), dtype)
+    stamp = (w.data_ptr(), w._version, WEIGHT_EPOCH)
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == stamp:      # the weak reference guards against a recycled id()
+        return hit[2]
+    if len(_WCACHE) > 4096:
+        _WCACHE.clear()
+    c = cast_weight(w, dtype, transposed=False, straight=True)[0]
+    _WCACHE[key] = (weakref.ref(w), stamp, c)
+    return c
+
+
 def adamw_ema(p, g, m, v, ema, step, lr, beta1, beta2, eps, weight_decay, ema_decay, grad_scale=1.0):
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
     call("ldmae_adamw_ema", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), int(step), float(lr), float(beta1), float(beta2),
          float(eps), float(weight_decay), float(ema_decay), float(grad_scale), stream())
 
 
 def ema_only(ema, p, ema_decay):
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
     call("ldmae_ema_only", ptr(ema), ptr(p), p.numel(), float(ema_decay), stream())
 
 

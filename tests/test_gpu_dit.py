@@ -387,3 +387,35 @@ def test_loss_curve_100_steps_matches_reference_golden(golden):
     sdm = dict(m.named_parameters())
     for i, k in enumerate(str(s) for s in g["curve_probe"]):
         assert abs(float(sdm[k].double().norm()) - g["curve_param_norm"][i]) < 1e-3 * g["curve_param_norm"][i] + 1e-6, k
+
+
+def test_forward_only_weight_copy_cache_tracks_weight_changes():
+    """no_grad forwards re-use the bf16 weight copies (ops.cached_weight_copy); a torch in-place update (version counter), an optimizer
+    step through the C ABI (ops.WEIGHT_EPOCH) and a new model at recycled addresses must all be seen."""
+    from ldmae_amd import ops as _ops
+    from ldmae_amd.optim import AdamWEMA
+    sd = tiny_sd()
+    m = build(TINY, sd).eval()
+    x, t, y = det_randn("wc", (2, 16, 8, 8), 9).cuda(), torch.tensor([0.3, 0.7]).cuda(), torch.tensor([1, 2]).cuda()
+
+    def fwd(model):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return model(x, t, y).clone()
+    a = fwd(m)
+    assert torch.equal(a, fwd(m))                                  # cached copies: same result
+    with torch.no_grad():
+        m.blocks[0].attn.qkv.weight.mul_(1.5)                      # torch-side in-place update
+    b = fwd(m)
+    assert not torch.equal(a, b)
+    m.train()
+    opt = AdamWEMA(m, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.99)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        m(x, t, y).square().mean().backward()
+    e0 = _ops.WEIGHT_EPOCH
+    opt.step()                                                     # raw write through the C ABI
+    assert _ops.WEIGHT_EPOCH > e0
+    m.eval()
+    c = fwd(m)
+    assert not torch.equal(b, c)
+    ref = build(TINY, {k: v.detach().clone() for k, v in m.state_dict().items()}).eval()     # fresh model, same weights, no cache entries
+    assert torch.equal(c, fwd(ref))
