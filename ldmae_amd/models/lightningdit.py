@@ -188,7 +188,7 @@ class _DiTBlockFn(torch.autograd.Function):
     """LightningDiTBlock.forward (:239-250) with RMSNorm, QK-norm, RoPE, SwiGLU, shift."""
 
     @staticmethod
-    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace, chain, idx, direct,
+    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace, chain, idx, direct, fwd_only,
                 n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12, b12, w3, b3, adaw, adab):
         B, N, D = x.shape
         M, hd = B * N, D // H
@@ -197,8 +197,9 @@ class _DiTBlockFn(torch.autograd.Function):
         mod = ops.gemm_nt(sc, adaw, adab, out_dtype=torch.float32)                       # [B, 6D] f32
         sh1, s1, g1, sh2, s2, g2 = (mod[:, i * D:(i + 1) * D] for i in range(6))          # :246 chunk order
         # forward-only calls (torch.no_grad sampling: forward_with_cfg) skip everything only the backward pass reads: the transposed
-        # weight copies, the pre-gate branch outputs y1 / y2 and h12 = [x1 | x2] of the SwiGLU (1.6 GB per XL/1 block at batch 128)
-        bwd = any(ctx.needs_input_grad)
+        # weight copies, the pre-gate branch outputs y1 / y2 and h12 = [x1 | x2] of the SwiGLU (1.6 GB per XL/1 block at batch 128).
+        # The flag comes from the module (grad mode is always off in here and needs_input_grad ignores torch.no_grad()).
+        bwd = not fwd_only and any(ctx.needs_input_grad)
         Wqkv, WqkvT = _wcopies(qkvw, dtype, bwd)
         Wp, WpT = _wcopies(pw, dtype, bwd)
         W12, W12T = _wcopies(w12, dtype, bwd)
@@ -286,7 +287,7 @@ class _DiTBlockFn(torch.autograd.Function):
         for r, p_ in notify:          # gradients written straight into .grad: tell the reducer (no-op without one)
             if r is not None:
                 r(p_)
-        return (dx.view(B, N, D), dsc, None, None, None, None, None, None, None, None, None,
+        return (dx.view(B, N, D), dsc, None, None, None, None, None, None, None, None, None, None,
                 dn1, dWqkv, dbqkv, dqn, dkn, dWp, dbp, dn2, dW12, db12, dW3, db3, dadaw, dadab)
 
 
@@ -442,7 +443,7 @@ class LightningDiTBlock(nn.Module):
         a, m = self.attn, self.mlp
         return _DiTBlockFn.apply(
             x.float(), sc, feat_rope.freqs_cos, feat_rope.freqs_sin, a.num_heads, self.norm1.eps, _dtype or _act_dtype(self.precision),
-            _inplace_grad, _chain, _idx, _direct,
+            _inplace_grad, _chain, _idx, _direct, not torch.is_grad_enabled(),
             self.norm1.weight, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.k_norm.weight, a.proj.weight, a.proj.bias,
             self.norm2.weight, m.w12.weight, m.w12.bias, m.w3.weight, m.w3.bias,
             self.adaLN_modulation[1].weight, self.adaLN_modulation[1].bias)

@@ -55,11 +55,13 @@ class _ViTBlockFn(torch.autograd.Function):
     """Block.forward (:176-187): x += proj(attn(LN1(x))); x += fc2(gelu(fc1(LN2(x))))."""
 
     @staticmethod
-    def forward(ctx, x, H, eps, dtype, inplace, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
+    def forward(ctx, x, H, eps, dtype, inplace, fwd_only, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
         B, N, D = x.shape
         M, hd = B * N, D // H
         x2 = x.contiguous().view(M, D)
-        bwd = any(ctx.needs_input_grad)       # forward-only calls (encode / decode under no_grad) skip what only the backward pass reads
+        # forward-only calls (encode / decode under no_grad; the flag comes from the module: grad mode is always off in here) skip what only
+        # the backward pass reads
+        bwd = not fwd_only and any(ctx.needs_input_grad)
         Wqkv, WqkvT = _wcopies(qkvw, dtype, bwd)
         Wp, WpT = _wcopies(pw, dtype, bwd)
         W1, W1T = _wcopies(f1w, dtype, bwd)
@@ -110,7 +112,7 @@ class _ViTBlockFn(torch.autograd.Function):
             dqkv = ops.heads_merge(dq, dk, dv, B, N, H, hd)
         dWqkv, dbqkv = ops.gemm_tn(dqkv, h1, with_bias=True)
         dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT), x2, n1w, mu1, rs1, dx)
-        return (dx.view(B, N, D), None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
+        return (dx.view(B, N, D), None, None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -219,7 +221,7 @@ class Block(nn.Module):
     def forward(self, x, _inplace_grad=False):
         a, m = self.attn, self.mlp
         return _ViTBlockFn.apply(x.float(), a.num_heads, self.norm1.eps, _act_dtype(self.precision), _inplace_grad,
-                                 self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                                 not torch.is_grad_enabled(), self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                  self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
 
 
