@@ -43,6 +43,7 @@ class GradBucketReducer:
             for n in ns:
                 self.param_bucket[n] = bi
         self._pending = [len(ns) for _, _, ns in self.buckets]
+        self._seen = [set() for _ in self.buckets]
         self._works = []
         self._hooks = []
         self._exposed = []
@@ -67,6 +68,9 @@ class GradBucketReducer:
             if not self.sync:
                 return
             bi = self.param_bucket[name]
+            if name in self._seen[bi]:        # idempotent: a parameter may be announced by its post-accumulate hook AND by the callback
+                return                        # of a gradient written straight into .grad (autograd may still visit its AccumulateGrad)
+            self._seen[bi].add(name)
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._launch(bi)
@@ -104,6 +108,7 @@ class GradBucketReducer:
                 self._exposed.append((ev0, ev1))
         self._works = []
         self._pending = [len(ns) for _, _, ns in self.buckets]
+        self._seen = [set() for _ in self.buckets]
         return 1.0 / self.world
 
     def exposed_comm_ms(self) -> float:

@@ -64,6 +64,7 @@ def _worker(rank, world, port, q):
     opt = AdamWEMA(m, lr=1e-3)
     red = GradBucketReducer(opt.flat, bucket_bytes=256 << 10)            # several buckets, launched from the hooks on the side stream
     red.broadcast_params(0)
+    m.direct_param_grads = True      # as the train drivers do: block weight gradients go straight into the slab and notify the reducer by callback
     assert len(red.buckets) >= 3 and red.overlap
     assert _lib.load().ldmae_tune_query(8) == 2                          # multi-rank launches: one tile per workgroup
     sl = slice(rank * 4, rank * 4 + 4)
