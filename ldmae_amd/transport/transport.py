@@ -82,7 +82,13 @@ class Transport:
             t = self.sample_logit_normal(shifted_mu, 1, size=B) * (t1 - t0) + t0
         if sp_timesteps is not None:
             t = th.rand((B,)) * (sp_timesteps[1] - sp_timesteps[0]) + sp_timesteps[0]
-        return t.to(x1), x0, x1
+        # host-drawn t -> device through pinned memory, asynchronously: a pageable .to(device) makes torch synchronise the stream, i.e. the
+        # host waits for the whole previous step and the GPU then idles (~1 ms per step) while the next step's first kernels are launched
+        if x1.is_cuda and not t.is_cuda:
+            t = t.to(x1.dtype).pin_memory().to(x1.device, non_blocking=True)
+        else:
+            t = t.to(x1)
+        return t, x0, x1
 
     def training_losses(self, model, x1, model_kwargs=None, sp_timesteps=None, shifted_mu=0):
         """transport.py:169-215."""
