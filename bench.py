@@ -149,6 +149,50 @@ def cpu_baseline(max_seconds=30.0):
                       f"{torch.get_num_threads()} threads = the cores this process may use ({os.cpu_count()} CPUs visible on the host)"}
 
 
+class PowerSampler:
+    """Package power and shader clock from rocm-smi, polled at ~2 Hz on a host thread while the timed loop runs (a subprocess per sample:
+    no GPU work, no synchronisation).  Reported beside the roofline because the MFMA kernels of this step run at the 1400 W package
+    limit (profiles/r02_pmc_mfma.md): the clock they hold is part of the measurement.  None when rocm-smi is unavailable."""
+
+    def __init__(self, enabled=True, card=0):
+        import threading
+        self.enabled, self.card = enabled, f"card{card}"
+        self.samples, self._stop, self._th = [], False, threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re, subprocess
+        while not self._stop:
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5).stdout
+                row = [l for l in out.splitlines() if l.startswith(self.card + ",")]
+                if row:
+                    f = row[0].split(",")
+                    sclk = [int(re.sub(r"\D", "", x)) for x in f[5:6] if re.sub(r"\D", "", x)]
+                    self.samples.append((float(f[-1]), sclk[0] if sclk else None))
+            except Exception:
+                return
+            time.sleep(0.5)
+
+    def __enter__(self):
+        if self.enabled:
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self.enabled:
+            self._th.join(timeout=6)
+
+    def summary(self):
+        s = self.samples[1:] if len(self.samples) > 2 else self.samples      # the first sample may predate the loop
+        if not s:
+            return None
+        w = [x[0] for x in s]
+        c = [x[1] for x in s if x[1]]
+        return {"package_w_mean": round(sum(w) / len(w), 1), "package_w_max": max(w), "sclk_mhz_mean": round(sum(c) / len(c)) if c else None,
+                "samples": len(s), "source": f"rocm-smi --showpower --showclocks polled at 2 Hz during the timed loop ({self.card}, rank 0)"}
+
+
 def timed_loop(fn, steps, warmup, world):
     for _ in range(warmup):
         fn()
@@ -200,7 +244,8 @@ def bench_dit(args, world, rank, device, lib, backend):
     for _ in range(min(2, args.warmup)):
         step()
     reducer.exposed_comm_ms()                                  # drop warm-up samples
-    elapsed, loss = timed_loop(step, args.steps, max(0, args.warmup - 2), world)
+    with PowerSampler(enabled=rank == 0, card=device.index or 0) as ps:
+        elapsed, loss = timed_loop(step, args.steps, max(0, args.warmup - 2), world)
     exposed = reducer.exposed_comm_ms() / max(1, args.steps + max(0, args.warmup - 2))
     if world > 1:
         tt = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -222,6 +267,7 @@ def bench_dit(args, world, rank, device, lib, backend):
                    "parallelism": f"dp{world}", "loss": round(final_loss, 5)},
         "step_mfma_frac": round(FLOPS_PER_IMAGE * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4),
         "roofline": roof,
+        "power": ps.summary(),
     }
     if world > 1:
         out["comm"] = {"backend": "rccl" if backend == "nccl" else backend, "rccl_ranks": world if backend == "nccl" else 0,
