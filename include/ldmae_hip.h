@@ -11,10 +11,9 @@
  *  - plain device pointers + explicit sizes, no torch types; `stream` is a hipStream_t (NULL = default).
  *  - every call only ENQUEUES on `stream`: no allocation, no synchronisation; compute entry points keep no state
  *    between calls and are callable from the Python main thread and the autograd thread concurrently.
- *    Workspaces are caller-owned.  The only process-wide mutable state is diagnostic and opt-in: the A/B knobs of
- *    ldmae_tune() (plain ints read at launch time; 0 = shipped behaviour), the event list of the ldmae_prof_*
- *    timing hook (mutex-protected, off by default) and the stamp buffer of ldmae_debug_nt_stamps(); per-device
- *    launch attributes (CU count, dynamic-LDS opt-in) are looked up per call.
+ *    Workspaces are caller-owned.  The only process-wide mutable state is the event list of the opt-in ldmae_prof_*
+ *    timing hook (mutex-protected, off by default); per-device launch attributes (CU count, dynamic-LDS opt-in) are looked
+ *    up per call.  A/B knobs and timeline stamps live in the separate diagnostic build only (csrc/probe/ldmae_diag.h).
  *  - return 0 on success, negative on error; ldmae_last_error() gives the thread-local message.
  *  - dtype codes select the activation type: LDMAE_F32 (parity path, exact-f32 MFMA) or LDMAE_BF16
  *    (throughput path, bf16 MFMA with f32 accumulation).  Residual stream, norms' statistics,
@@ -42,6 +41,10 @@ extern "C" {
 #define LDMAE_EPI_SWIGLU 4     /* bf16 only: B = w12 [2Hs,K]; C = h12 [M,2Hs] = acc+bias (NULL: not stored -- forward-only), xout(as bf16*) = hid [M,Hs] = silu(x1)*x2 */
 #define LDMAE_EPI_SWIGLU_BWD 5 /* bf16 only: acc = dhid [M,Hs]; xin(as bf16*) = h12 [M,2Hs]; C = dh12 [M,2Hs]; xout (optional) =
                                   [ceil(M/128)][2Hs] f32 partial column sums of dh12 as stored (bias gradient; caller sums the rows) */
+/* launch mode, or'ed into `epi` per call (bf16 GEMMs): one 256x256 tile per workgroup instead of one persistent workgroup per CU.  A
+   data-parallel caller sets it while RCCL's collective kernels share the chip with backward (ldmae_amd/distributed.py); results are
+   bitwise equal to the persistent launch */
+#define LDMAE_EPI_TILE_LAUNCH 0x100
 
 const char* ldmae_last_error(void);
 const char* ldmae_version(void);
@@ -104,6 +107,12 @@ long ldmae_qknorm_rope_bwd_workspace_bytes(int B, int N, int H, int hd);
 int ldmae_qknorm_rope_bwd(int dtype, const void* dq, const void* dk, const void* dv, const void* qkv, const float* wq,
                           const float* wk, const float* cos, const float* sin, void* dqkv, float* dwq, float* dwk, float beta_w,
                           float* dbias_hqd, int B, int N, int H, int hd, float eps, float* workspace, void* stream);
+
+/* Standalone 2-D RoPE, the callable form of VisionRotaryEmbeddingFast.forward (pos_embed.py:135; rotate_half :38-42):
+ * out[r,:] = t[r,:]*cos[r % N,:] + rotate_half(t[r,:])*sin[r % N,:] on [rows, hd] (rows = anything x N).  transposed = 1: the adjoint
+ * (backward).  The LightningDiT block does not use it: there the rotation is fused into ldmae_qknorm_rope_fwd / _bwd. */
+int ldmae_rope(int dtype, const void* t, const float* cos, const float* sin, void* out, long rows, int N, int hd, int transposed,
+               void* stream);
 
 /* ---- attention core (F.scaled_dot_product_attention, lightningdit.py:76-80; manual softmax attention
  *      models_mae.py:135-141).  q,k,v [B,H,N,hd]; o [B,N,H*hd]; lse [B,H,N] f32 (natural log). */
@@ -192,13 +201,6 @@ int ldmae_conv3x3_bwd(const float* dout, const float* x, const float* w, float* 
 /* When enabled, ldmae_gemm_nt brackets each launch with HIP events on the launch stream. */
 int ldmae_prof_enable(int on);
 int ldmae_prof_collect(double* total_ms, double* total_flops, long* launches);   /* syncs the events; resets */
-
-/* kernel-variant selection for tuning / A-B measurements (key 0: bf16 NT GEMM variant, key 1: bf16 TN GEMM variant) */
-int ldmae_tune(int key, int value);
-int ldmae_tune_query(int key);   /* current value of a knob (0 = shipped default) */
-/* diagnostic: device buffer (>= 64 B x 256 workgroups x tiles-per-workgroup) that receives s_memrealtime stamps of the
-   persistent NT GEMM (tile start / main loop end / epilogue issued / stores drained); NULL (default) = off */
-void ldmae_debug_nt_stamps(void* buf);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ldmae_qknorm_rope_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_qknorm_rope_bwd_workspace_bytes": (_l, [_i, _i, _i, _i]),
     "ldmae_qknorm_rope_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "ldmae_rope": (_i, [_i, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "ldmae_attention_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_attention_fwd_qkv": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
@@ -72,12 +73,16 @@ SIGNATURES = {
     "ldmae_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_conv3x3_bwd_workspace_bytes": (_l, [_i]),
     "ldmae_conv3x3_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "ldmae_tune": (_i, [_i, _i]),
-    "ldmae_tune_query": (_i, [_i]),
-    "ldmae_debug_nt_stamps": (None, [_vp]),
     "ldmae_prof_enable": (_i, [_i]),
     "ldmae_prof_collect": (_i, [C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
 }
+# csrc/probe/ldmae_diag.h: present only in the diagnostic build (LDMAE_HIP_LIB=.../libldmae_hip_diag.so, used by tools/)
+DIAG_SIGNATURES = {
+    "ldmae_tune": (_i, [_i, _i]),
+    "ldmae_tune_query": (_i, [_i]),
+    "ldmae_debug_nt_stamps": (None, [_vp]),
+}
+EPI_TILE_LAUNCH = 0x100
 
 _lib = None
 
@@ -96,10 +101,14 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    # LDMAE_TUNE="key=value,..." presets the library's A/B knobs (ldmae_tune) for profiling runs; unset = shipped defaults
-    for kv in filter(None, os.environ.get("LDMAE_TUNE", "").split(",")):
-        k, v = kv.split("=")
-        lib.ldmae_tune(int(k), int(v))
+    if hasattr(lib, "ldmae_tune"):          # diagnostic build: LDMAE_TUNE="key=value,..." presets its A/B knobs for profiling runs
+        for name, (res, args) in DIAG_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        for kv in filter(None, os.environ.get("LDMAE_TUNE", "").split(",")):
+            k, v = kv.split("=")
+            lib.ldmae_tune(int(k), int(v))
     _lib = lib
     return lib
 

@@ -107,7 +107,13 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// A/B knobs and the tile-timeline stamps exist only in the DIAGNOSTIC build (`make diag` -> libldmae_hip_diag.so, -DLDMAE_DIAG,
+// declared in probe/ldmae_diag.h).  In the product library every knob reads 0 (the shipped behaviour) at compile time.
+#ifdef LDMAE_DIAG
 int ldmae_tune_get(int key);
+#else
+static inline constexpr int ldmae_tune_get(int) { return 0; }
+#endif
 // timing hook (core.hip)
 bool ldmae_prof_is_on();
 long ldmae_prof_begin(hipStream_t st, double flops);

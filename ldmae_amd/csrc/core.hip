@@ -15,7 +15,7 @@ void ldmae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ldmae_last_error(void) { return g_err; }
-extern "C" const char* ldmae_version(void) { return "ldmae_hip 0.2 (round 2)"; }
+extern "C" const char* ldmae_version(void) { return "ldmae_hip 0.3 (round 3)"; }
 extern "C" const char* ldmae_arch(void) { return "gfx950"; }
 
 // ---------------------------------------------------------------- timing hook (bench.py roofline line)
@@ -67,6 +67,7 @@ extern "C" int ldmae_prof_collect(double* total_ms, double* total_flops, long* l
   return LDMAE_OK;
 }
 
+#ifdef LDMAE_DIAG
 // ---------------------------------------------------------------- tuning knobs (kernel variant selection; not part of the reference seam)
 static int g_tune[16] = {0};
 int ldmae_tune_get(int key) { return (key >= 0 && key < 16) ? g_tune[key] : 0; }
@@ -76,3 +77,4 @@ extern "C" int ldmae_tune(int key, int value) {
   g_tune[key] = value;
   return LDMAE_OK;
 }
+#endif

@@ -561,6 +561,35 @@ extern "C" int ldmae_qknorm_rope_bwd(int dtype, const void* dq, const void* dk, 
   return LDMAE_OK;
 }
 
+// ------------------------------------------------------------------ standalone RoPE (VisionRotaryEmbeddingFast.forward, pos_embed.py:135)
+// out[r, :] = t[r, :] * cos[r % N, :] + rotate_half(t[r, :]) * sin[r % N, :]  (rotate_half: (x0, x1) -> (-x1, x0) per pair);
+// transposed = 1: the adjoint (its backward).  The block path never comes here (RoPE is fused into ldmae_qknorm_rope_*).
+template <typename T>
+__global__ void rope_kernel(const T* __restrict__ t, const float* __restrict__ cosT, const float* __restrict__ sinT, T* __restrict__ out,
+                            long rows, int N, int hd, int transposed) {
+  const long n4 = rows * (hd / 4), per = hd / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / per;
+    const int c4 = (int)(i % per) * 4, n = (int)(r % N);
+    const float4 v = load4<T>(t + r * hd + c4);
+    const float4 cs = *(const float4*)(cosT + (size_t)n * hd + c4), sn = *(const float4*)(sinT + (size_t)n * hd + c4);
+    store4<T>(out + r * hd + c4, transposed ? rope_apply_bwd(v, cs, sn) : rope_apply(v, cs, sn));
+  }
+}
+
+extern "C" int ldmae_rope(int dtype, const void* t, const float* cos, const float* sin, void* out, long rows, int N, int hd, int transposed,
+                          void* stream) {
+  LDMAE_REQUIRE(t && cos && sin && out && rows > 0 && N > 0, "rope: null pointer or empty input");
+  LDMAE_REQUIRE(hd % 4 == 0 && rows % N == 0, "rope: head_dim=%d must be a multiple of 4 and rows=%ld a multiple of N=%d", hd, rows, N);
+  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "rope: bad dtype %d", dtype);
+  const long n4 = rows * (hd / 4);
+  const unsigned grid = (unsigned)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(rope_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16*)t, cos, sin, (bf16*)out, rows, N, hd, transposed);
+  else hipLaunchKernelGGL(rope_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)t, cos, sin, (float*)out, rows, N, hd, transposed);
+  LDMAE_CHECK_LAUNCH("rope");
+  return LDMAE_OK;
+}
+
 // ------------------------------------------------------------------ SwiGLU
 template <typename T>
 __global__ void swiglu_fwd_kernel(const T* __restrict__ h12, T* __restrict__ hid, long M, int Hs) {

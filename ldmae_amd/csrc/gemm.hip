@@ -619,11 +619,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, float* __restr
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+#ifdef LDMAE_DIAG
 static void* g_nt_stamps = nullptr;
-// diagnostic: device buffer that receives s_memrealtime stamps of the persistent NT kernel (NULL = off, the default)
+// diagnostic build only: device buffer that receives s_memrealtime stamps of the persistent NT kernel (NULL = off)
 extern "C" void ldmae_debug_nt_stamps(void* buf) { g_nt_stamps = buf; }
+#else
+static constexpr void* g_nt_stamps = nullptr;
+#endif
 template <typename OutT>
-static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
+static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
                      hipStream_t st) {
   const long pi = (ldmae_prof_is_on() && dtype == LDMAE_BF16) ? ldmae_prof_begin(st, 2.0 * M * N * K) : -1;
   // per call and per device (a process may drive several GPUs; the query is a cached driver attribute, ~100 ns)
@@ -635,10 +639,12 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
     ncu = n >= 8 ? n / 8 * 8 : 8;
   }
   const int ntiles = cdiv(M, 256) * cdiv(N, 256);
-  // tune key 8: 2 = one tile per workgroup; otherwise persistent (one workgroup per CU), the default
-  const bool pers = ldmae_tune_get(8) != 2;
+  // launch mode, a per-call argument (LDMAE_EPI_TILE_LAUNCH or'ed into `epi` by the caller): one 256x256 tile per workgroup instead of
+  // one persistent workgroup per CU -- what a data-parallel caller asks for while RCCL's collective kernels hold some CUs
+  const bool pers = !tile_launch && ldmae_tune_get(8) != 2;
   const int pgrid = (pers && ntiles != ncu) ? ncu : ntiles;
-  // tune key 0: 1 = the one-wave-per-SIMD kernel of gemm_w4.hip (bf16; bias / gated residual / SwiGLU / SwiGLU-bwd epilogues)
+#ifdef LDMAE_DIAG
+  // tune key 0: 1 / 2 = the experimental kernels of probe/gemm_w4.hip (diagnostic build only)
   if (dtype == LDMAE_BF16 && ldmae_tune_get(0) != 0 &&
       (ldmae_tune_get(0) == 1 ? ldmae_launch_nt_w4(epi, sizeof(OutT) == 2, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st)
                                 : ldmae_launch_nt_p8(epi, sizeof(OutT) == 2, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st))) {
@@ -646,6 +652,7 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
     LDMAE_CHECK_LAUNCH("gemm_nt_w4");
     return LDMAE_OK;
   }
+#endif
   // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup (A/B knob),
   // key 7 = diagnostic per-K-step stamp build.
 #define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048 + 16384)
@@ -685,6 +692,8 @@ static int launch_nt(int dtype, int epi, const void* A, const void* B, int M, in
 extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                              int M, int N, int K, const float* bias, float beta, const float* xin, float* xout,
                              const float* gate, int gate_ld, int rows_per_batch, void* stream) {
+  const bool tile_launch = (epi & LDMAE_EPI_TILE_LAUNCH) != 0;
+  epi &= ~LDMAE_EPI_TILE_LAUNCH;
   LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "gemm_nt: bad dtype %d", dtype);
   LDMAE_REQUIRE(out_dtype == LDMAE_F32 || out_dtype == LDMAE_BF16, "gemm_nt: bad out_dtype %d", out_dtype);
   LDMAE_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
@@ -720,8 +729,8 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
   } else {
     LDMAE_FAIL(LDMAE_ERR_INVALID, "gemm_nt: unknown epilogue %d", epi);
   }
-  return out_dtype == LDMAE_BF16 ? launch_nt<bf16>(dtype, epi, A, B, M, N, K, lda, ldb, e, as_stream(stream))
-                                 : launch_nt<float>(dtype, epi, A, B, M, N, K, lda, ldb, e, as_stream(stream));
+  return out_dtype == LDMAE_BF16 ? launch_nt<bf16>(dtype, epi, tile_launch, A, B, M, N, K, lda, ldb, e, as_stream(stream))
+                                 : launch_nt<float>(dtype, epi, tile_launch, A, B, M, N, K, lda, ldb, e, as_stream(stream));
 }
 
 static int tn_plan(int dtype, int M, int N, int K, int* rows_out) {

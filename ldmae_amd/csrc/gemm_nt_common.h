@@ -21,11 +21,13 @@ struct EpiArgs {
   float beta;           // EPI_BIAS with f32 out: C = acc + bias + beta*C   (beta 0 or 1: gradient accumulation)
 };
 
-// gemm_w4.hip: the one-wave-per-SIMD kernel (returns 0 if it has no instantiation for `epi`)
+#ifdef LDMAE_DIAG
+// probe/gemm_w4.hip (diagnostic build): experimental NT kernels; return 0 if they have no instantiation for `epi`
 int ldmae_launch_nt_w4(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
                        int ntiles, hipStream_t st);
 int ldmae_launch_nt_p8(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
                        int ntiles, hipStream_t st);
+#endif
 
 template <int EPI, typename OutT>
 __device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M, int N, float acc) {

@@ -14,9 +14,9 @@
 // DMA addressing: wave-uniform 64-bit base in SGPRs (advanced by scalar adds) + one 32-bit VGPR offset per piece that is
 // constant for the whole tile: no vector address arithmetic in the loop.
 // LDS stage image and swizzle: identical to gemm.hip (64-B rows, chunk c of row r at c ^ F[(r >> 2) & 3]).
-#include "common.h"
+#include "../common.h"
 
-#include "gemm_nt_common.h"
+#include "../gemm_nt_common.h"
 
 #include <type_traits>
 #include <utility>

@@ -11,7 +11,7 @@ import torch
 from safetensors import safe_open
 from torch.utils.data import Dataset
 
-from tokenizer.util.misc import DiagonalGaussianDistribution
+from ldmae_amd.tokenizer.util.misc import DiagonalGaussianDistribution
 
 
 class ImgLatentDataset(Dataset):

@@ -8,6 +8,11 @@ on a side HIP stream as soon as the last gradient in it has been accumulated, ov
 backward; the 1/world scaling is folded into the fused AdamW kernel (``AdamWEMA.step(grad_scale)``).
 xGMI is point-to-point (7 links x ~153 GB/s), so buckets are large (default 64 MiB: ~8 collectives per
 step) rather than DDP's 25 MiB.  Works unchanged on CPU tensors with the gloo backend (tests).
+
+RCCL's collective kernels hold some CUs while a bucket overlaps backward; a persistent GEMM (exactly one workgroup per CU for
+the whole launch) would run its displaced workgroups as a second round.  The DRIVER that builds a reducer with world > 1 therefore
+asks for one-tile-per-workgroup GEMM launches, ``ops.set_gemm_launch_mode(reducer.recommended_gemm_launch_mode())`` -- a per-call
+flag of the C ABI (LDMAE_EPI_TILE_LAUNCH), not library state; this class does not touch it.
 """
 from __future__ import annotations
 
@@ -47,6 +52,7 @@ class GradBucketReducer:
         self._works = []
         self._hooks = []
         self._exposed = []
+        self.measure_exposed = False      # bench.py sets it: two timing events per step, drained by exposed_comm_ms(); off in training
         # DDP.no_sync() equivalent: with gradient accumulation the slab holds the LOCAL sum of the micro-step gradients and is
         # all-reduced once, on the last micro-step (`sync = True` before that backward).  All-reducing the accumulating slab on
         # every micro-step would re-sum earlier micro-steps across ranks (world * g1 + g2).
@@ -56,12 +62,9 @@ class GradBucketReducer:
                 h = self._make_hook(n)
                 self._hooks.append(p.register_post_accumulate_grad_hook(h))
                 p._ldmae_grad_ready = h          # for gradients written into .grad without AccumulateGrad (models.lightningdit._dw_into_grad)
-            if self.is_cuda and os.environ.get("LDMAE_TUNE") is None:
-                # RCCL's collective kernels hold some CUs while the all-reduce of a bucket overlaps backward.  A persistent GEMM
-                # (exactly one workgroup per CU for the whole launch) would then run its displaced workgroups as a second round;
-                # one-tile-per-workgroup launches (1 % slower alone) refill whatever CUs are free at tile granularity.
-                from . import _lib
-                _lib.load().ldmae_tune(8, 2)
+
+    def recommended_gemm_launch_mode(self) -> str:
+        return "tile" if (self.world > 1 and self.is_cuda) else "persistent"
 
     def _make_hook(self, name):
         def hook(_p):
@@ -96,7 +99,7 @@ class GradBucketReducer:
                 if pend > 0:
                     self._launch(bi)
             ev0 = ev1 = None
-            if self.is_cuda:
+            if self.is_cuda and self.measure_exposed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record(torch.cuda.current_stream())
             for w in self._works:
@@ -125,3 +128,6 @@ class GradBucketReducer:
         """DDP-constructor equivalent: replicate rank `src` parameters (and nothing else) to every rank."""
         if self.world > 1:
             dist.broadcast(self.flat.params, src=src, group=self.pg)
+            if self.is_cuda:
+                from . import ops
+                ops.invalidate_weight_cache()        # the slab was rewritten behind the parameter views' version counters

@@ -25,8 +25,8 @@ import torch
 import torch.nn as nn
 from torch.utils.checkpoint import checkpoint
 
-from .. import ops
-from ..tables import sincos_2d
+from ldmae_amd import ops
+from ldmae_amd.tables import sincos_2d
 from .pos_embed import VisionRotaryEmbeddingFast
 from .rmsnorm import RMSNorm
 from .swiglu_ffn import SwiGLUFFN
@@ -173,7 +173,9 @@ class _GradChain:
     def norm_bwd(self, j, dout, x, w, scale, rstd, dx, dshift, dscale, N, dtype, accumulate=True):
         """norm backward of member j (accumulating into dx); fused with member j-1's gate backward when that member is registered."""
         D = x.shape[1]
-        prev = self.up.get(j - 1)
+        # consumed once: the chain must not keep y2 / mod of every block alive until the whole graph dies (0.4 GB per block at bs 256).
+        # On a second pass over a retained graph the entry is gone and both members take their unfused paths.
+        prev = self.up.pop(j - 1, None)
         if prev is None:
             return ops.rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx, dshift, dscale, N, accumulate)
         y2p, modp = prev
@@ -291,6 +293,49 @@ class _DiTBlockFn(torch.autograd.Function):
                 dn1, dWqkv, dbqkv, dqn, dkn, dWp, dbp, dn2, dW12, db12, dW3, db3, dadaw, dadab)
 
 
+class _AttentionFn(torch.autograd.Function):
+    """Attention.forward (:66-91) on its own: qkv Linear -> QK-RMSNorm -> RoPE -> softmax attention -> proj, the same kernels the block
+    uses.  Activations in `dtype` (bf16 under autocast, like the reference's autocast Linear / SDPA; else f32)."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin, H, eps, dtype, qkvw, qkvb, qnw, knw, pw, pb):
+        B, N, D = x.shape
+        M, hd = B * N, D // H
+        xa = ops.cast(x.contiguous().view(M, D), dtype)
+        Wqkv, WqkvT = _wcopies(qkvw, dtype, True)
+        Wp, WpT = _wcopies(pw, dtype, True)
+        qkv = ops.gemm_nt(xa, Wqkv, qkvb)
+        if dtype == torch.bfloat16:
+            q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps, copy_v=False)
+            o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5)
+        else:
+            q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
+            o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)
+        out = ops.gemm_nt(o.view(M, D), Wp, pb)
+        ctx.save_for_backward(xa, cos, sin, qkv, q, k, v, o, lse, qnw, knw, WqkvT, WpT)
+        ctx.dims = (B, N, D, H, hd, eps, x.dtype)
+        return out.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        xa, cos, sin, qkv, q, k, v, o, lse, qnw, knw, WqkvT, WpT = ctx.saved_tensors
+        B, N, D, H, hd, eps, xdt = ctx.dims
+        M = B * N
+        dy = ops.cast(g.contiguous().view(M, D), xa.dtype)
+        dWp, dbp = ops.gemm_tn(dy, o.view(M, D), with_bias=True)
+        do = ops.gemm_nt(dy, WpT)
+        if v is None:
+            dq, dk, dqkv = ops.attention_bwd_pv(q, k, qkv, o, do, lse, hd ** -0.5)
+            dqkv, dqn, dkn, dbqkv = ops.qknorm_rope_bwd(dq, dk, None, qkv, qnw, knw, cos, sin, B, N, H, hd, eps, with_bias=True, dqkv=dqkv)
+        else:
+            dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
+            dqkv, dqn, dkn, dbqkv = ops.qknorm_rope_bwd(dq, dk, dv, qkv, qnw, knw, cos, sin, B, N, H, hd, eps, with_bias=True)
+        dqkv = dqkv.view(M, 3 * D)
+        dWqkv = ops.gemm_tn(dqkv, xa)
+        dx = ops.gemm_nt(dqkv, WqkvT).view(B, N, D).to(xdt) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, None, dWqkv, dbqkv, dqn, dkn, dWp, dbp
+
+
 class _FinalLayerFn(torch.autograd.Function):
     """FinalLayer.forward (:267-272): adaLN(2) -> RMSNorm -> modulate -> Linear."""
 
@@ -403,7 +448,8 @@ class LabelEmbedder(nn.Module):
 
 
 class Attention(nn.Module):
-    """Parameter container of :32-64 (qkv, q_norm, k_norm, proj); computed inside _DiTBlockFn."""
+    """:32-91 (qkv, q_norm, k_norm, proj).  Inside LightningDiTBlock the branch runs as part of _DiTBlockFn; called on its own
+    (`block.attn(x, rope)`, the reference's signature) it runs the same kernels through _AttentionFn."""
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_norm=False, use_rmsnorm=False, **_):
         super().__init__()
@@ -415,6 +461,21 @@ class Attention(nn.Module):
         self.q_norm = RMSNorm(self.head_dim) if qk_norm else nn.Identity()
         self.k_norm = RMSNorm(self.head_dim) if qk_norm else nn.Identity()
         self.proj = nn.Linear(dim, dim)
+        self.precision = None
+
+    def forward(self, x, rope=None):
+        if not isinstance(self.q_norm, RMSNorm):
+            raise NotImplementedError("ldmae_amd Attention: qk_norm=True with RMSNorm only (the shipped configuration)")
+        B, N, C = x.shape
+        if rope is not None:
+            cos, sin = rope.freqs_cos, rope.freqs_sin
+        else:                                            # :71 -- no rotation: identity tables
+            cos = torch.ones(N, self.head_dim, device=x.device)
+            sin = torch.zeros(N, self.head_dim, device=x.device)
+        dtype = _act_dtype(self.precision)
+        with torch.autocast(device_type="cuda", enabled=False):
+            return _AttentionFn.apply(x, cos, sin, self.num_heads, self.q_norm.eps, dtype, self.qkv.weight, self.qkv.bias,
+                                      self.q_norm.weight, self.k_norm.weight, self.proj.weight, self.proj.bias)
 
 
 class LightningDiTBlock(nn.Module):
@@ -508,6 +569,7 @@ class LightningDiT(nn.Module):
         self.precision = dtype
         for b in self.blocks:
             b.precision = dtype
+            b.attn.precision = dtype
         self.final_layer.precision = dtype
         return self
 

@@ -2,13 +2,29 @@
 import torch
 from torch import nn
 
-from ..tables import rope_2d
+from ldmae_amd import ops
+from ldmae_amd.tables import rope_2d
+
+
+class _RopeFn(torch.autograd.Function):
+    """t * cos + rotate_half(t) * sin (:135, rotate_half :38-42); the backward is the adjoint rotation."""
+
+    @staticmethod
+    def forward(ctx, t, cos, sin):
+        ctx.save_for_backward(cos, sin)
+        return ops.rope(t, cos, sin)
+
+    @staticmethod
+    def backward(ctx, g):
+        cos, sin = ctx.saved_tensors
+        return ops.rope(g.contiguous(), cos, sin, transposed=True), None, None
 
 
 class VisionRotaryEmbeddingFast(nn.Module):
     """Holds the `freqs_cos` / `freqs_sin` [N, head_dim] buffers (same names / shapes as the reference,
-    so checkpoints load).  The rotation itself is fused into ldmae_qknorm_rope_{fwd,bwd}: this module
-    is only a table holder and is not callable on its own."""
+    so checkpoints load).  Inside LightningDiTBlock the rotation is fused into ldmae_qknorm_rope_{fwd,bwd}
+    (the block hands the tables to the kernel); called on its own -- `rope(q)` as the reference's Attention.forward does (:72-73) --
+    it runs the standalone ldmae_rope kernel on t [..., N, head_dim] (f32 or bf16)."""
 
     def __init__(self, dim, pt_seq_len=16, ft_seq_len=None, custom_freqs=None, freqs_for='lang', theta=10000,
                  max_freq=10, num_freqs=1):
@@ -21,5 +37,6 @@ class VisionRotaryEmbeddingFast(nn.Module):
         self.register_buffer("freqs_sin", sin)
 
     def forward(self, t):
-        raise NotImplementedError("RoPE is fused into the attention front-end kernel (ldmae_qknorm_rope_fwd); "
-                                  "VisionRotaryEmbeddingFast only holds the tables")
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            t = t.float()
+        return _RopeFn.apply(t, self.freqs_cos, self.freqs_sin)

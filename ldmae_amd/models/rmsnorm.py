@@ -2,7 +2,7 @@
 import torch
 from torch import nn
 
-from .. import ops
+from ldmae_amd import ops
 
 
 class _RMSNormFn(torch.autograd.Function):

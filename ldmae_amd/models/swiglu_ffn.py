@@ -4,7 +4,7 @@ from typing import Callable, Optional
 import torch
 from torch import Tensor, nn
 
-from .. import ops
+from ldmae_amd import ops
 
 
 class _SwiGLUFn(torch.autograd.Function):

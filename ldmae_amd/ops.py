@@ -12,8 +12,8 @@ import weakref
 import torch
 
 from . import _lib as L
-from ._lib import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_GATE_RES, EPI_SWIGLU, EPI_SWIGLU_BWD, F32, call, dt, ptr,
-                   stream)
+from ._lib import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_GATE_RES, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_TILE_LAUNCH, F32, call, dt,
+                   ptr, stream)
 
 _ws = {}
 
@@ -70,6 +70,23 @@ class SideGemms:
 
 
 # ----------------------------------------------------------------------------- GEMMs
+# Launch mode of the bf16 GEMMs, owned by the CALLER (a train driver that knows it shares the chip with RCCL's collective kernels sets
+# "tile"; everything else keeps "persistent") and handed to the library PER CALL as a flag in `epi` -- the C ABI keeps no mode.
+_GEMM_LAUNCH = 0
+
+
+def set_gemm_launch_mode(mode: str) -> None:
+    """"persistent" (default: one workgroup per CU walks the tiles) or "tile" (one 256x256 tile per workgroup; bitwise-equal results)."""
+    global _GEMM_LAUNCH
+    if mode not in ("persistent", "tile"):
+        raise ValueError(f"gemm launch mode {mode!r}: 'persistent' or 'tile'")
+    _GEMM_LAUNCH = EPI_TILE_LAUNCH if mode == "tile" else 0
+
+
+def gemm_launch_mode() -> str:
+    return "tile" if _GEMM_LAUNCH else "persistent"
+
+
 def gemm_nt(a, b, bias=None, out_dtype=None, out=None, beta=0.0):
     """out[M,N] = a[M,K] @ b[N,K]^T + bias (+ beta*out)."""
     M, K = a.shape
@@ -77,7 +94,7 @@ def gemm_nt(a, b, bias=None, out_dtype=None, out=None, beta=0.0):
     out_dtype = out_dtype or a.dtype
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
-    call("ldmae_gemm_nt", dt(a.dtype), dt(out.dtype), EPI_BIAS, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
+    call("ldmae_gemm_nt", dt(a.dtype), dt(out.dtype), EPI_BIAS | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
          M, N, K, ptr(bias), float(beta), None, None, None, 0, 0, stream())
     return out
 
@@ -89,7 +106,7 @@ def gemm_nt_gate_res(a, b, bias, xin, gate, rows_per_batch, save_y=True, xout=No
     y = torch.empty(M, N, dtype=a.dtype, device=a.device) if save_y else None
     if xout is None:
         xout = torch.empty_like(xin)
-    call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_GATE_RES, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(y), N,
+    call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_GATE_RES | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(y), N,
          M, N, K, ptr(bias), 0.0, ptr(xin), ptr(xout), ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch, stream())
     return xout, y
 
@@ -99,7 +116,7 @@ def gemm_nt_pos(a, b, bias, pos, rows_per_batch):
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    call("ldmae_gemm_nt", dt(a.dtype), F32, EPI_BIAS_POS, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
+    call("ldmae_gemm_nt", dt(a.dtype), F32, EPI_BIAS_POS | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
          M, N, K, ptr(bias), 0.0, ptr(pos), None, None, 0, rows_per_batch, stream())
     return out
 
@@ -110,7 +127,7 @@ def gemm_nt_gelu(a, b, bias, save_pre=True):
     N = b.shape[0]
     out = torch.empty(M, N, dtype=a.dtype, device=a.device)
     pre = torch.empty_like(out) if save_pre else None
-    call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_BIAS_GELU, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
+    call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_BIAS_GELU | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
          M, N, K, ptr(bias), 0.0, None, ptr(pre), None, 0, 0, stream())
     return out, pre
 
@@ -124,7 +141,7 @@ def gemm_nt_swiglu(a, w12, b12, save_h12=True):
     if a.dtype == torch.bfloat16 and N % 256 == 0 and K % 64 == 0:
         h12 = torch.empty(M, N, dtype=a.dtype, device=a.device) if save_h12 else None
         hid = torch.empty(M, N // 2, dtype=a.dtype, device=a.device)
-        call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU, ptr(a), a.stride(0), ptr(w12), w12.stride(0), ptr(h12), N, M, N, K, ptr(b12), 0.0,
+        call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(w12), w12.stride(0), ptr(h12), N, M, N, K, ptr(b12), 0.0,
              None, ptr(hid), None, 0, 0, stream())
         return h12, hid
     h12 = gemm_nt(a, w12, b12)
@@ -139,7 +156,7 @@ def gemm_nt_swiglu_bwd(dy, w3t, h12, with_bias=False):
     if dy.dtype == torch.bfloat16 and Hs % 4 == 0 and K % 64 == 0:
         dh12 = torch.empty_like(h12)
         part = torch.zeros((M + 127) // 128, 2 * Hs, dtype=torch.float32, device=dy.device) if with_bias else None
-        call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU_BWD, ptr(dy), dy.stride(0), ptr(w3t), w3t.stride(0), ptr(dh12), 2 * Hs, M, Hs, K, None, 0.0,
+        call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU_BWD | _GEMM_LAUNCH, ptr(dy), dy.stride(0), ptr(w3t), w3t.stride(0), ptr(dh12), 2 * Hs, M, Hs, K, None, 0.0,
              ptr(h12), ptr(part), None, 0, 0, stream())
         return (dh12, colsum(part)) if with_bias else dh12
     dh12 = swiglu_bwd(gemm_nt(dy, w3t), h12)
@@ -250,6 +267,18 @@ def qknorm_rope_bwd(dq, dk, dv, qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6, wi
     if with_bias:
         return dqkv, dwq, dwk, db.permute(1, 0, 2).reshape(-1)          # (head, q|k|v, d) -> the Linear's (q|k|v, head, d) order
     return dqkv, dwq, dwk
+
+
+def rope(t, cos, sin, transposed=False):
+    """t [..., N, hd] (f32 or bf16, contiguous) -> t*cos + rotate_half(t)*sin with cos/sin [N, hd] f32 (VisionRotaryEmbeddingFast.forward);
+    transposed: the adjoint (backward)."""
+    N, hd = cos.shape
+    if t.shape[-2:] != (N, hd):
+        raise RuntimeError(f"rope: the last two dims of t {tuple(t.shape)} must be (N, head_dim) = {(N, hd)}")
+    t = _c(t)
+    out = torch.empty_like(t)
+    call("ldmae_rope", dt(t.dtype), ptr(t), ptr(cos), ptr(sin), ptr(out), t.numel() // hd, N, hd, 1 if transposed else 0, stream())
+    return out
 
 
 def attention_fwd(q, k, v, scale):
@@ -384,6 +413,14 @@ def label_embed_bwd(dout, y, drop, num_classes, rows):
 # key of the forward-only weight-copy cache below.
 WEIGHT_EPOCH = 0
 _WCACHE: dict = {}
+
+
+def invalidate_weight_cache() -> None:
+    """Call after writing parameter STORAGE behind torch's back -- through the flat slab the parameters are views of (dist.broadcast(
+    flat.params), flat.params.copy_(ema), a checkpoint restored into the slab): those writes bump neither the parameters' version
+    counters nor WEIGHT_EPOCH, and a cached bf16 copy would silently go stale."""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
 
 
 def cached_weight_copy(w, dtype):

@@ -115,3 +115,13 @@ class AdamWEMA:
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.ema.copy_(sd["ema"])
+
+    @torch.no_grad()
+    def swap_in_ema(self):
+        """Exchange the live parameters with their EMA (sampling from the EMA weights inside a training process; call again to swap
+        back).  Writes the slab directly, so the forward-only weight-copy cache is invalidated."""
+        f = self.flat
+        tmp = f.params.clone()
+        f.params.copy_(self.ema)
+        self.ema.copy_(tmp)
+        ops.invalidate_weight_cache()

@@ -20,8 +20,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
-from ..models.lightningdit import PatchEmbed, _act_dtype, _wcopies
+from ldmae_amd import ops
+from ldmae_amd.models.lightningdit import PatchEmbed, _act_dtype, _wcopies
 from .util.misc import DiagonalGaussianDistribution
 from .util.pos_embed import get_2d_sincos_pos_embed
 

@@ -26,6 +26,7 @@ if _HERE not in sys.path:
 if os.path.dirname(_HERE) not in sys.path:
     sys.path.insert(0, os.path.dirname(_HERE))
 
+from ldmae_amd import ops                                 # noqa: E402
 from ldmae_amd.distributed import GradBucketReducer      # noqa: E402
 from ldmae_amd.models.lightningdit import LightningDiT_models  # noqa: E402
 from ldmae_amd.optim import AdamWEMA                      # noqa: E402
@@ -84,11 +85,11 @@ def make_loader(cfg, per_gpu, rank, world, synthetic):
     from torch.utils.data.distributed import DistributedSampler
     d = cfg['data']
     if synthetic:
-        from datasets.img_latent_dataset import SyntheticLatentDataset
+        from ldmae_amd.datasets.img_latent_dataset import SyntheticLatentDataset
         ds_ = SyntheticLatentDataset(channels=cfg['model'].get('in_chans', 4), size=d['image_size'] // cfg['vae'].get('downsample_ratio', 16),
                                      num_classes=d['num_classes'], seed=cfg['train'].get('global_seed', 0))
     else:
-        from datasets.img_latent_dataset import ImgLatentDataset
+        from ldmae_amd.datasets.img_latent_dataset import ImgLatentDataset
         path = d['data_path'] + ('_sample' if 'sample' in d else '')                 # key presence, train_accum.py:124-125
         ds_ = ImgLatentDataset(data_dir=path, latent_norm=d.get('latent_norm', False), latent_multiplier=d.get('latent_multiplier', 0.18215),
                                sample=d.get('sample', False))
@@ -129,6 +130,7 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
     o = cfg['optimizer']
     opt = AdamWEMA(model, lr=o['lr'], betas=(0.9, o['beta2']), weight_decay=0.0, ema_decay=0.9999)
     reducer = GradBucketReducer(opt.flat)
+    ops.set_gemm_launch_mode(reducer.recommended_gemm_launch_mode())     # world > 1: one tile per workgroup (RCCL kernels share the chip)
     model.direct_param_grads = True       # every .grad is a slab view and backward is a plain loss.backward(): dW goes straight into the slab
     reducer.broadcast_params(0)
     opt.ema.copy_(opt.flat.params)                               # update_ema(ema, model, decay=0), train_accum.py:166

@@ -66,7 +66,10 @@ def _worker(rank, world, port, q):
     red.broadcast_params(0)
     m.direct_param_grads = True      # as the train drivers do: block weight gradients go straight into the slab and notify the reducer by callback
     assert len(red.buckets) >= 3 and red.overlap
-    assert _lib.load().ldmae_tune_query(8) == 2                          # multi-rank launches: one tile per workgroup
+    from ldmae_amd import ops
+    assert ops.gemm_launch_mode() == "persistent" and red.recommended_gemm_launch_mode() == "tile"   # the reducer only recommends
+    ops.set_gemm_launch_mode(red.recommended_gemm_launch_mode())         # ... the driver sets it: one tile per workgroup, per call
+    red.measure_exposed = True
     sl = slice(rank * 4, rank * 4 + 4)
     for it in range(2):                                                  # twice: the counters re-arm
         _grad_slab(m, opt.flat, x[sl], t[sl], y[sl], tgt[sl])
@@ -119,3 +122,18 @@ def test_train_driver_comes_up_under_two_process_launch(tmp_path):
     assert all(torch.isfinite(v).all() for v in ck["model"].values())
     loss = float(log.split("(step=0000002) Train Loss: ")[1].split(",")[0])
     assert np.isfinite(loss) and 0.1 < loss < 10.0
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset) must itself bring up 2 ranks (reference launcher:
+    run_train.sh:13-22) and label the line n_gpus = 2 with a `comm` block; here the two ranks share cuda:0 over gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LDMAE_BENCH_BACKEND="gloo", LDMAE_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-power"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
+    assert line["comm"]["backend"] == "gloo" and line["comm"]["buckets"] >= 1 and line["comm"]["gemm_launch_mode"] == "one tile per workgroup"
+    assert line["value"] > 0 and line["roofline"]["achieved"] > 0 and "cpu_baseline" not in line

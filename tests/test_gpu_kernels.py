@@ -93,7 +93,7 @@ def test_gemm_nt_persistent_multi_tile_ragged(ops):
     ref = a.float() @ w.float().T + bias
     outs = {}
     for mode in (0, 2):
-        _lib.load().ldmae_tune(8, mode)
+        ops.set_gemm_launch_mode("tile" if mode == 2 else "persistent")      # per-call flag of the C ABI (LDMAE_EPI_TILE_LAUNCH)
         out = ops.gemm_nt(a, w, bias)
         outs[mode] = out
         assert rel_err(out.float().cpu(), ref.cpu()) < TOL[BF16]
@@ -103,7 +103,8 @@ def test_gemm_nt_persistent_multi_tile_ragged(ops):
         xo, y = ops.gemm_nt_gate_res(a, w, bias, xin, gate, T)
         assert torch.equal(y, out)
         assert rel_err(xo.cpu(), (xin + gate.repeat_interleave(T, 0) * ref).cpu()) < 1e-5      # residual uses the unrounded f32 product
-    _lib.load().ldmae_tune(8, 0)
+    ops.set_gemm_launch_mode("persistent")
+    assert not hasattr(_lib.load(), "ldmae_tune")    # the product library has no process-wide knobs (csrc/probe/ldmae_diag.h is a separate build)
     assert torch.equal(outs[0], outs[2])             # persistent and one-tile-per-workgroup launches (the multi-rank mode): bitwise equal
     Hs = 1280                                        # N = 2560 = 10 tile columns, 420 tiles
     w12 = (torch.randn(2 * Hs, K, device="cuda", generator=g) * K ** -0.5).to(BF16)

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for l in "$@"; do
   rm -rf gpurun_out/ab_$l
-  LDMAE_HIP_LIB=$GRAFT_REPO_ROOT/ldmae_amd/libldmae_hip$l.so rocprofv3 --kernel-trace --stats -d gpurun_out/ab_$l -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/ab_$l.log 2>&1
+  LDMAE_HIP_LIB=$GRAFT_REPO_ROOT/ldmae_amd/libldmae_hip$l.so rocprofv3 --kernel-trace --stats -d gpurun_out/ab_$l -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-power --no-extra > gpurun_out/ab_$l.log 2>&1
 done
 python3 - "$@" <<'PY'
 import csv,glob,sys

@@ -5,7 +5,7 @@ i=0
 for e in "$@"; do
   i=$((i+1)); rm -rf gpurun_out/abe_$i
   export $e
-  rocprofv3 --kernel-trace --stats -d gpurun_out/abe_$i -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/abe_$i.log 2>&1
+  rocprofv3 --kernel-trace --stats -d gpurun_out/abe_$i -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-power --no-extra > gpurun_out/abe_$i.log 2>&1
 done
 python3 - $i <<'PY'
 import csv,glob,sys

@@ -2,9 +2,10 @@
 """The eight bf16 NT GEMMs of one LightningDiT-B/1 block (bs=256: M = 262144 token rows) with their real epilogues, timed
 for each value of a tune key (default key 8: 1 = persistent workgroups, 2 = one tile per workgroup).
     python tools/bench_nt.py [--key 8] [--values 1,2] [--rounds 3]"""
-import argparse, os, sys
+import os, argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LDMAE_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldmae_amd", "libldmae_hip_diag.so"))   # A/B knobs live in the diagnostic build only (make -C ldmae_amd/csrc diag)
 from ldmae_amd import _lib, ops
 
 

@@ -5,6 +5,7 @@ import os, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LDMAE_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldmae_amd", "libldmae_hip_diag.so"))   # A/B knobs live in the diagnostic build only (make -C ldmae_amd/csrc diag)
 from ldmae_amd import _lib, ops
 N, K = int(sys.argv[1]), int(sys.argv[2])
 delay = int(sys.argv[3]) if len(sys.argv) > 3 else 0

@@ -3,6 +3,7 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LDMAE_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldmae_amd", "libldmae_hip_diag.so"))   # A/B knobs live in the diagnostic build only (make -C ldmae_amd/csrc diag)
 from ldmae_amd import _lib, ops
 kind, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 v = int(sys.argv[4]) if len(sys.argv) > 4 else 0

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-power --no-extra > /tmp/pmc_$c.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, os
@@ -21,6 +21,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         out.setdefault(k, {})[c + "_KB_avg"] = sum(v) / len(v); out[k]["launches"] = len(v)
 for k in out:
     out[k]["hbm_bytes_per_launch"] = (2 * out[k].get("FETCH_SIZE_KB_avg", 0) + out[k].get("WRITE_SIZE_KB_avg", 0)) * 1024
+import hashlib
+h = hashlib.sha256()
+for f in ("gemm.hip", "gemm_nt_common.h", "common.h"):
+    h.update(open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "ldmae_amd", "csrc", f), "rb").read())
+out["kernel_source_sha"] = h.hexdigest()[:16]      # bench.py quotes this file only while the kernel sources still hash to this
 out["note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1; FETCH_SIZE x2 (gfx950 correction)"
 json.dump(out, open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "pmc_bench.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

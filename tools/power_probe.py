@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Package power and shader clock (rocm-smi) while one kernel family runs back to back for a few seconds.
+"""Package power and shader clock (sysfs hwmon) while one kernel family runs back to back for a few seconds.
     python tools/power_probe.py [nt|tn|attn|row]"""
-import os, subprocess, sys, threading, time
+import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ldmae_amd import ops
@@ -20,23 +20,14 @@ elif kind == "attn":
 else:
     x = torch.randn(M, 768, device="cuda"); y = torch.empty_like(x)
     fn = lambda: torch.add(x, 1.0, out=y)
-samples, stop = [], False
-def poll():
-    while not stop:
-        try:
-            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5).stdout
-            samples.append(out.strip().splitlines()[-1] if out.strip() else "(empty)")
-        except Exception as e:
-            samples.append(f"err {e}")
-        time.sleep(0.3)
-th = threading.Thread(target=poll); th.start()
-t0 = time.time(); n = 0
-while time.time() - t0 < 4.0:
-    for _ in range(20): fn()
-    torch.cuda.synchronize(); n += 20
-dt = time.time() - t0
-stop = True; th.join()
+# power / clock are read in process from the card's sysfs hwmon files (bench.PowerSampler): no rocm-smi child, so the probe is
+# safe under rocprofv3 (a child would inherit the profiler's preloaded library and exec through `env` with the GPU initialised)
+from bench import PowerSampler
+with PowerSampler(enabled=True, device_index=0) as ps:
+    t0 = time.time(); n = 0
+    while time.time() - t0 < 4.0:
+        for _ in range(20): fn()
+        torch.cuda.synchronize(); n += 20
+    dt = time.time() - t0
 print(kind, f"{dt / n * 1e3:.3f} ms per launch")
-hdr = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True).stdout.strip().splitlines()
-print(hdr[0] if hdr else "(no header)")
-for s in samples[2:8]: print(s)
+print(ps.summary())

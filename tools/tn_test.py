@@ -2,6 +2,7 @@
 """bf16 TN (weight-gradient) GEMM variants on the LightningDiT-B/1 bs=256 shapes, with and without the fused bias gradient."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("LDMAE_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldmae_amd", "libldmae_hip_diag.so"))   # A/B knobs live in the diagnostic build only (make -C ldmae_amd/csrc diag)
 from ldmae_amd import _lib, ops
 lib = _lib.load()
 M = 262144
