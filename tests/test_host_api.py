@@ -119,4 +119,5 @@ def test_out_of_scope_transport_configurations_raise_by_design():
         with pytest.raises(NotImplementedError, match="hot path"):
             create_transport(**kw)
     t = create_transport("Linear", "velocity", None, None, None)
-    assert not hasattr(Sampler(t), "sample_sde")
+    with pytest.raises(NotImplementedError):
+        Sampler(t).sample_sde()
