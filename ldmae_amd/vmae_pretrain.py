@@ -6,9 +6,14 @@ schedule set-up of VMAE/main_pretrain.py:236-300 (minimal slic
 
 What is kept: forward_vanilla loss (masked / visible MSE + KL), per-iteration half-cycle cosine LR with linear warm-up
 (util/lr_sched.py:9-25), AdamW(betas 0.9 / 0.95) with timm's ``param_groups_weight_decay`` split (no decay on biases and other
-1-D parameters, main_pretrain.py:258-259), gradient accumulation.  What differs on purpose: bf16 autocast instead of fp16 +
-GradScaler (bf16 has f32's exponent range, so no loss scaling and no overflow skipping), the fused AdamW kernel on a grouped
-contiguous slab instead of torch.optim.AdamW.
+1-D parameters, main_pretrain.py:258-259), gradient accumulation, and the GradScaler PROTOCOL of the reference's
+``NativeScalerWithGradNormCount`` (VMAE/util/misc.py:406-435: scale the loss, unscale, SKIP the optimizer step when a gradient is
+inf / nan and halve the scale, double it after 2000 clean steps) -- ``LossScaler`` below, with 1/scale folded into the fused AdamW
+kernel's grad_scale.  What differs on purpose: the activation type is bf16 where the reference's ``torch.amp.autocast('cuda')`` gives
+fp16 (engine_pretrain.py:51-57).  bf16 keeps f32's exponent range, so the scaler never has an overflow to back off from in practice
+(it is kept for the skip-on-non-finite semantics and so that checkpoints carry the same ``amp_scaler`` state); it has 8 significant
+bits against fp16's 11, which is what the bf16-vs-f32 tolerance in tests/test_gpu_mae.py (loss within 2e-2 relative) prices.  The
+kernels have no fp16 path.  Also: the fused AdamW kernel on a grouped contiguous slab instead of torch.optim.AdamW.
 """
 import argparse
 import math
@@ -46,8 +51,45 @@ def build_optimizer(model, lr, weight_decay):
                     group_weight_decay={0: weight_decay, 1: 0.0})
 
 
-def train_one_epoch(model, loader, opt, epoch, args, log=print):
-    """engine_pretrain.py:21-110 without the metric logger."""
+class LossScaler:
+    """torch.amp.GradScaler's protocol (defaults init_scale 65536, growth 2, backoff 0.5, growth_interval 2000) as the reference drives it
+    through NativeScalerWithGradNormCount.__call__ (VMAE/util/misc.py:413-430), on the flat gradient slab: ``scale`` multiplies the loss
+    before backward; ``step`` looks for a non-finite gradient (one reduction over the slab), SKIPS the optimizer step if there is one,
+    otherwise steps with 1/scale folded into the fused kernel; then updates the scale.  Returns the unscaled gradient norm, like the
+    reference's get_grad_norm_ (None when the step was skipped)."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self.scale = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval, self.enabled = growth_factor, backoff_factor, growth_interval, enabled
+        self._good, self.skipped = 0, 0
+
+    def step(self, opt):
+        g = opt.flat.grads
+        norm = torch.linalg.vector_norm(g)                       # inf / nan anywhere in the slab makes the norm non-finite
+        if self.enabled and not bool(torch.isfinite(norm)):
+            self.skipped += 1
+            self._good = 0
+            self.scale *= self.backoff_factor
+            return None
+        opt.step(grad_scale=1.0 / self.scale)
+        if self.enabled:
+            self._good += 1
+            if self._good >= self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good = 0
+        return float(norm) / self.scale
+
+    def state_dict(self):
+        return {"scale": self.scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": self._good}
+
+    def load_state_dict(self, sd):
+        self.scale, self._good = float(sd["scale"]), int(sd.get("_growth_tracker", 0))
+
+
+def train_one_epoch(model, loader, opt, epoch, args, log=print, scaler=None):
+    """engine_pretrain.py:21-110 without the metric logger.  `scaler`: a LossScaler (the reference's loss_scaler argument); None = plain
+    steps."""
     model.train(True)
     opt.zero_grad()
     n = len(loader)
@@ -60,9 +102,12 @@ def train_one_epoch(model, loader, opt, epoch, args, log=print):
             loss, _, _, vis_loss, mask_loss, kl_loss = model(samples, mask_ratio=args.mask_ratio, visible_loss_ratio=args.visible_loss_ratio)
         if not math.isfinite(float(loss)):
             raise RuntimeError(f"Loss is {float(loss)}, stopping training")
-        (loss / args.accum_iter).backward()
+        (loss * (scaler.scale if scaler is not None else 1.0) / args.accum_iter).backward()
         if (it + 1) % args.accum_iter == 0:
-            opt.step()
+            if scaler is not None:
+                scaler.step(opt)
+            else:
+                opt.step()
             opt.zero_grad()
         stats = dict(loss=float(loss), vis_loss=float(vis_loss), mask_loss=float(mask_loss), kl_loss=float(kl_loss) if kl_loss is not None else 0.0,
                      lr=opt.lr)
@@ -113,8 +158,9 @@ def main():
     opt = build_optimizer(model, args.lr, args.weight_decay)
     loader = torch.utils.data.DataLoader(_SyntheticImages(args.batch_size * args.steps_per_epoch, args.input_size), batch_size=args.batch_size,
                                          drop_last=True)
+    scaler = LossScaler(enabled=args.precision == "bf16")          # main_pretrain.py:268: loss_scaler = NativeScaler()
     for epoch in range(args.epochs):
-        print("Averaged stats:", train_one_epoch(model, loader, opt, epoch, args))
+        print("Averaged stats:", train_one_epoch(model, loader, opt, epoch, args, scaler=scaler), "skipped steps:", scaler.skipped)
 
 
 if __name__ == "__main__":

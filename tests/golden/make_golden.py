@@ -279,6 +279,54 @@ def gen_mae(out):
     out["mae_img8_head"] = img8[:, :4, :4].copy()
 
 
+def gen_mae_train(out):
+    """SURVEY 8(f)4 pin: the reference's own pre-training forward ``MaskedAutoencoderViT.forward(imgs, mask_ratio, visible_loss_ratio)``
+    (tokenizer/models_mae.py:811-815 -> forward_vanilla :756-790 -> forward_loss :733-754) and its backward, at 128 px with encoder /
+    decoder depth 2 (same block classes and widths as mae_for_ldmae_f8d16_prev), f32, eager.  The two random draws of the step are
+    recorded as inputs: the masking noise (torch.rand in random_masking, :480) is reproduced by re-seeding, the posterior noise
+    (randn_tensor in DiagonalGaussianDistribution.sample, util/misc.py:87-96) is captured from the call itself."""
+    from functools import partial
+    sys.path.insert(0, os.path.join(REF, "tokenizer"))
+    from tokenizer import models_mae
+    misc = sys.modules[models_mae.DiagonalGaussianDistribution.__module__]      # `util.misc`, the module object models_mae itself imported
+    m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192,
+                                        decoder_depth=2, decoder_num_heads=12, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                        latent_dim=16, no_cls=True, kl_loss_weight=1e-3, smooth_output=True)
+    load_det(m, seed=6, skip=("pos_embed", "decoder_pos_embed"))
+    m.train()
+    out["mt_keys"] = np.array(sorted(k for k, p in m.named_parameters() if p.requires_grad))
+    imgs = det_randn("img128p", (2, 3, 128, 128), 4).clamp(-1, 1)
+    captured = []
+    orig = misc.randn_tensor
+
+    def spy(*a, **k):
+        t = orig(*a, **k)
+        captured.append(t.detach().clone())
+        return t
+    misc.randn_tensor = spy
+    try:
+        for tag, ratio, vlr in (("a", 0.75, 0.5), ("b", 0.5, 0.25)):
+            captured.clear()
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(77)
+            noise = torch.rand(2, 256)
+            assert (np.diff(np.sort(noise.numpy(), axis=1), axis=1) > 0).all(), "noise has ties; pick another seed"
+            torch.manual_seed(77)
+            loss, pred, mask, vis, mask_loss, kl = m(imgs, ratio, vlr)
+            assert len(captured) == 1, "expected exactly one posterior draw"
+            loss.backward()
+            out.update({f"mt{tag}_ratio": np.array([ratio, vlr]), f"mt{tag}_noise": noise.numpy(), f"mt{tag}_eps": captured[0].numpy(),
+                        f"mt{tag}_loss": np.array([float(loss), float(vis), float(mask_loss), float(kl)], dtype=np.float64),
+                        f"mt{tag}_mask": mask.detach().numpy(), f"mt{tag}_pred_head": pred.detach()[:, :6, :24].numpy().copy(),
+                        f"mt{tag}_pred_norm": np.array(float(pred.detach().double().norm())),
+                        f"mt{tag}_grad_norms": np.array([float(p.grad.double().norm()) for k, p in sorted(m.named_parameters())
+                                                         if p.requires_grad], dtype=np.float64),
+                        f"mt{tag}_grad_smoother": m.decoder_pred.conv_smoother.weight.grad.numpy().copy(),
+                        f"mt{tag}_grad_to_latent_head": m.to_latent.weight.grad[:4, :8].numpy().copy()})
+    finally:
+        misc.randn_tensor = orig
+
+
 # --------------------------------------------------------------------------- 100-step loss curve, B/1 bs=4
 def gen_dataset(out):
     """the reference's own ``ImgLatentDataset`` (datasets/img_latent_dataset.py:16-93) on a tiny generated shard
@@ -385,13 +433,14 @@ def main():
     ap.add_argument("--curve", action="store_true", help="also run the 100-step B/1 bs=4 loss curve (~15 min)")
     ap.add_argument("--only-curve", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,dataset}")
+    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,dataset}")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     install_shims()
     sys.path.insert(0, REF)
     if not args.only_curve:
-        gens = (("dit_tiny", gen_dit_tiny), ("kernels", gen_tables_and_kernels), ("mae", gen_mae), ("dataset", gen_dataset))
+        gens = (("dit_tiny", gen_dit_tiny), ("kernels", gen_tables_and_kernels), ("mae", gen_mae), ("mae_train", gen_mae_train),
+                ("dataset", gen_dataset))
         for name, fn in gens:
             if args.only and name not in args.only.split(","):
                 continue

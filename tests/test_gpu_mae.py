@@ -157,3 +157,60 @@ def test_vmae_pretrain_driver_steps():
     last = vp.train_one_epoch(m, loader, opt, 1, args, log=lambda s: None)
     assert opt.step_count == 13 and np.isfinite(last["loss"]) and last["loss"] < first["loss"]
     assert 0 < last["lr"] < 1e-3 and torch.isfinite(m.norm.weight).all() and not torch.equal(m.norm.weight, ln_w)
+
+
+def test_pretraining_forward_and_grads_vs_reference_golden(golden):
+    """The product's pre-training forward + backward against the REFERENCE's own MaskedAutoencoderViT.forward outputs and gradient
+    norms (tests/golden/mae_train.npz, generated by importing tokenizer/models_mae.py:733-790, 811-815), on the recorded draws."""
+    g = golden("mae_train")
+    cfg = omae.MAEConfig(img_size=128, depth=2, decoder_depth=2)
+    sd = full_sd(cfg, seed=6)
+    from ldmae_amd.tokenizer import models_mae
+    m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192,
+                                        decoder_depth=2, decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16,
+                                        no_cls=True, kl_loss_weight=1e-3, smooth_output=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    imgs = det_randn("img128p", (2, 3, 128, 128), 4).clamp(-1, 1).cuda()
+    names = sorted(k for k, p in m.named_parameters() if p.requires_grad)
+    assert names == [str(k) for k in g["mt_keys"]]
+    for tag in ("a", "b"):
+        ratio, vlr = (float(v) for v in g[f"mt{tag}_ratio"])
+        m.zero_grad(set_to_none=True)
+        loss, pred, mask, vis, msk, kl = m(imgs, ratio, vlr, _noise=torch.from_numpy(g[f"mt{tag}_noise"]).cuda(),
+                                           _eps=torch.from_numpy(g[f"mt{tag}_eps"]).cuda())
+        np.testing.assert_array_equal(mask.cpu().numpy(), g[f"mt{tag}_mask"])                       # bit-exact
+        np.testing.assert_allclose([float(loss), float(vis), float(msk), float(kl)], g[f"mt{tag}_loss"], rtol=1e-4)
+        assert rel_err(pred.detach()[:, :6, :24].cpu(), g[f"mt{tag}_pred_head"]) < 1e-4
+        loss.backward()
+        params = dict(m.named_parameters())
+        norms = np.array([float(params[k].grad.double().norm()) for k in names])
+        np.testing.assert_allclose(norms, g[f"mt{tag}_grad_norms"], rtol=3e-4, atol=1e-8)
+        assert rel_err(params["decoder_pred.conv_smoother.weight"].grad.cpu(), g[f"mt{tag}_grad_smoother"]) < 2e-4
+
+
+def test_loss_scaler_protocol_skips_non_finite_steps():
+    """The reference's GradScaler protocol (VMAE/util/misc.py:406-435, engine_pretrain.py:72-76) on the flat slab: a non-finite gradient
+    skips the step and halves the scale; clean steps apply 1/scale inside the fused AdamW kernel and grow the scale on schedule."""
+    from ldmae_amd import vmae_pretrain as vp
+    lin = torch.nn.Linear(64, 64).cuda()
+    opt = vp.build_optimizer(lin, 1e-2, 0.0)
+    sc = vp.LossScaler(init_scale=1024.0, growth_interval=2)
+    w0 = lin.weight.detach().clone()
+    x = torch.randn(8, 64, device="cuda")
+    (lin(x).pow(2).mean() * sc.scale).backward()
+    ref = lin.weight.grad.detach().clone() / sc.scale
+    opt.flat.grads[3] = float("inf")
+    assert sc.step(opt) is None and sc.scale == 512.0 and sc.skipped == 1 and torch.equal(lin.weight, w0) and opt.step_count == 0
+    opt.zero_grad()
+    (lin(x).pow(2).mean() * sc.scale).backward()
+    gn = sc.step(opt)
+    assert opt.step_count == 1 and not torch.equal(lin.weight, w0) and abs(gn - float(torch.cat([ref.flatten(), lin.bias.grad.flatten() / sc.scale]).norm())) < 1e-3 * gn
+    # first AdamW step moves every weight by lr * sign(g) (m / sqrt(v) = +-1): the 1/scale factor reached the kernel
+    moved = (lin.weight.detach() - w0)
+    nz = ref.abs() > 1e-6
+    assert torch.allclose(moved[nz], -1e-2 * torch.sign(ref[nz]), atol=2e-4)
+    opt.zero_grad()
+    (lin(x).pow(2).mean() * sc.scale).backward()
+    sc.step(opt)
+    assert sc.scale == 1024.0                      # two clean steps: growth

@@ -171,3 +171,31 @@ def test_adamw_restatement_matches_torch_optim():
 def test_curve_fixture_present(golden):
     g = golden("curve")
     assert len(g["curve_losses"]) == 100
+
+
+def test_mae_pretraining_forward_and_grads_vs_reference_golden(golden):
+    """SURVEY 8(f)4 pin: oracle.mae.forward_vanilla (and torch autograd through it) against the reference's own
+    MaskedAutoencoderViT.forward + backward (tokenizer/models_mae.py:733-790, 811-815) on the recorded masking / posterior noise."""
+    g = golden("mae_train")
+    cfg = mae.MAEConfig(img_size=128, depth=2, decoder_depth=2)
+    sd = det_weights(mae.param_shapes(cfg), 6)
+    sd.update(mae.fixed_tables(cfg))
+    keys = sorted(mae.param_shapes(cfg))
+    assert keys == [str(k) for k in g["mt_keys"]]                 # the reference's trainable-parameter names
+    imgs = det_randn("img128p", (2, 3, 128, 128), 4).clamp(-1, 1)
+    for tag in ("a", "b"):
+        ratio, vlr = (float(v) for v in g[f"mt{tag}_ratio"])
+        leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+        osd = dict(sd)
+        osd.update(leaves)
+        loss, pred, mask, vis, mloss, kl = mae.forward_vanilla(osd, imgs, torch.from_numpy(g[f"mt{tag}_noise"]), torch.from_numpy(g[f"mt{tag}_eps"]),
+                                                               ratio, vlr, 1e-3, cfg)
+        np.testing.assert_array_equal(mask.numpy(), g[f"mt{tag}_mask"])                       # bit-exact
+        np.testing.assert_allclose([float(loss), float(vis), float(mloss), float(kl)], g[f"mt{tag}_loss"], rtol=2e-5)
+        assert rel_err(pred.detach()[:, :6, :24], g[f"mt{tag}_pred_head"]) < 1e-5
+        assert abs(float(pred.detach().double().norm()) - float(g[f"mt{tag}_pred_norm"])) < 1e-5 * float(g[f"mt{tag}_pred_norm"])
+        loss.backward()
+        norms = np.array([float(leaves[k].grad.double().norm()) for k in keys])
+        np.testing.assert_allclose(norms, g[f"mt{tag}_grad_norms"], rtol=2e-4, atol=1e-9)
+        assert rel_err(leaves["decoder_pred.conv_smoother.weight"].grad, g[f"mt{tag}_grad_smoother"]) < 1e-4
+        assert rel_err(leaves["to_latent.weight"].grad[:4, :8], g[f"mt{tag}_grad_to_latent_head"]) < 1e-4
