@@ -118,8 +118,9 @@ int ldmae_rope(int dtype, const void* t, const float* cos, const float* sin, voi
  *      models_mae.py:135-141).  q,k,v [B,H,N,hd]; o [B,N,H*hd]; lse [B,H,N] f32 (natural log). */
 int ldmae_attention_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N, int hd,
                         float scale, void* stream);
-/* delta: [2][B,H,N] f32 workspace (bf16: -rowsum(dO*O) | -lse*log2(e), the initial accumulators of the dK/dV pass; f32: slot 0 =
- * rowsum(dO*O)); dq,dk,dv [B,H,N,hd]; do_ [B,N,H*hd] */
+/* N is arbitrary (the last 64-row tile of a sweep may be ragged: its missing rows are masked to -inf before the exponential).
+ * delta: [2][B,H,NP] f32 workspace, NP = N rounded up to a multiple of 64 (bf16: -rowsum(dO*O) | -lse*log2(e), the initial accumulators
+ * of the dK/dV pass; f32: slot 0 = rowsum(dO*O), first B*H*N floats); dq,dk,dv [B,H,N,hd]; do_ [B,N,H*hd] */
 int ldmae_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
                         void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, void* stream);
 

@@ -129,6 +129,16 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
 }
 __device__ __forceinline__ int acc_row(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
+// Sequence lengths that are not a multiple of 64 (VMAE: int(L * (1 - mask_ratio)) kept tokens for any ratio, models_mae.py:472-497): the
+// LAST tile of a sweep is ragged.  Its missing rows are staged as copies of row N-1 (finite data, in bounds) and the score-chain
+// accumulator rows that belong to them are set to -inf before the exponential: p = exp2(-inf) = 0, so they add nothing to the row sums,
+// to O, or to any gradient.  `base` = first row of the 32-row block the accumulator covers; element t of half h is row acc_row(t, h).
+__device__ __forceinline__ void mask_rows_past(f32x16& x, int base, int h, int N) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (base + (t & 3) + 8 * (t >> 2) + 4 * h >= N) x[t] = -__builtin_inff();
+}
+
 // K/V (Q/dO) tiles travel through a STAGES-deep LDS ring: global_load_lds stays in flight across the per-tile
 // barrier (raw s_barrier + counted vmcnt), `ahead` = number of later stages allowed to be still in flight.
 template <int PPW, int STAGES> __device__ __forceinline__ void ring_wait(int ahead) {
@@ -149,7 +159,8 @@ constexpr float RESCALE_THR = 6.0f;
 // workgroup then costs ~9k cycles, MI355X_MICROARCH 'attention epilogue store tail'); instead the tile goes through a wave-private
 // LDS image (144-B row pitch) and leaves as whole 128-B rows, 16 B per lane, 8 rows per instruction.  `mul` is per lane (= per row).
 template <int HD>
-__device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[hd_pad(HD) / 32], float mul, char* lds_wave, bf16* gbase, long gstride, int lane) {
+__device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[hd_pad(HD) / 32], float mul, char* lds_wave, bf16* gbase, long gstride, int lane,
+                                             int nrows = 32) {      // nrows: rows of the wave's 32 that exist (ragged last block when N % 32 != 0)
   constexpr int PITCH = hd_pad(HD) * 2 + 16, CPR = HD / 8;    // bytes per LDS row; 16-B chunks per (true) row
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -164,7 +175,7 @@ __device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[hd_pad(HD) / 32
 #pragma unroll
   for (int it = 0; it < (32 * CPR + 63) / 64; ++it) {
     const int idx = it * 64 + lane, row = idx / CPR, ch = idx % CPR;
-    if ((32 * CPR) % 64 == 0 || idx < 32 * CPR) {
+    if (((32 * CPR) % 64 == 0 || idx < 32 * CPR) && row < nrows) {
       const bf16x8 v = *(const bf16x8*)(lds_wave + row * PITCH + ch * 16);
       *(bf16x8*)(gbase + (long)row * gstride + ch * 8) = v;
     }
@@ -332,7 +343,7 @@ struct QkvLayout { long sb, sh, ld; };
 // (i) q carries scale*log2(e) (rounded once more to bf16 in registers) and every score chain starts from the accumulator block
 // nm = -(running max): the MFMA result is already the exponent, p = exp2(s) is ONE instruction per score; (ii) the running max only
 // moves in the (rare, wave-uniform) rescale branch, which shifts the tile's scores and refreshes nm; (iii) K / V tile addresses are scalar.
-template <int HD>
+template <int HD, bool RAGGED = false>      // RAGGED: N % 64 != 0 (its own instantiation: the masking costs the hot shapes no registers)
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                             bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L, QkvLayout Lv) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
@@ -356,7 +367,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   for (int d = 0; d < DB; ++d) oacc[d] = splat16(0.f);
   f32x16 nm = splat16(0.f);                // -ms in every element: the C operand of the first MFMA of a score chain
   float ms = 0.f, l = 0.f;                 // ms is set from the first tile (rescale branch), so 0 is never used as a maximum
-  const int nt = N / 64;
+  const int nt = (N + 63) / 64;
+  constexpr bool ragged = RAGGED;          // the last key tile has N % 64 real rows (see mask_rows_past)
   constexpr int PPW = 2 * (TB / 1024) / 4;
   TileMap<HD, 64> mk, mv;
   mk.init(ld, wave, lane);
@@ -364,6 +376,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int kt) {
     const int so = (kt % ATT_STAGES) * 2 * TB;
+    if (ragged && kt == nt - 1) {          // same number of LDS-DMA instructions per wave as the hoisted form: the vmcnt counts hold
+      stage_tile<HD, 64>(kp + (size_t)kt * 64 * ld, ld, N - 1 - kt * 64, smem + so, wave, lane);
+      stage_tile<HD, 64>(vp + (size_t)kt * 64 * ldv, ldv, N - 1 - kt * 64, smem + so + TB, wave, lane);
+      return;
+    }
     mk.issue(kp + (size_t)kt * 64 * ld, ld, smem + so, lds0 + so, wave, lane);
     mv.issue(vp + (size_t)kt * 64 * ldv, ldv, smem + so + TB, lds0 + so + TB, wave, lane);
   };
@@ -408,6 +425,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
           for (int d = 0; d < DB; ++d) vfr[kb][s2][d] = frag_tr<HDP>(Vt, kb * 32 + 16 * s2, d * 32, lane);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (ragged && kt == nt - 1) { mask_rows_past(s[0], kt * 64, h, N); mask_rows_past(s[1], kt * 64 + 32, h, N); }
     // s = score * scale * log2(e) - ms
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
@@ -455,8 +473,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   if (!active) return;
   const float inv = 1.f / l;
   const int b = bh / H, hh = bh % H;
-  store_rows_t<HD>(oacc, inv, smem + wave * 32 * (HDP * 2 + 16), O + ((size_t)(b * N + q0) * H + hh) * HD, (long)H * HD, lane);
-  if (h == 0) LSE[(size_t)bh * N + q0 + r] = (ms + log2f(l)) * 0.6931471805599453f;
+  store_rows_t<HD>(oacc, inv, smem + wave * 32 * (HDP * 2 + 16), O + ((size_t)(b * N + q0) * H + hh) * HD, (long)H * HD, lane, N - q0);
+  if (h == 0 && q0 + r < N) LSE[(size_t)bh * N + q0 + r] = (ms + log2f(l)) * 0.6931471805599453f;
 }
 
 // delta[b,h,n] = sum_d o[b,n,h,d] * do[b,n,h,d]
@@ -486,7 +504,7 @@ __global__ void attn_delta_kernel(const T* __restrict__ O, const T* __restrict__
 // ROWC = [2][B*H*N] f32 written by the dQ kernel (which runs first): slot 0 = -delta, slot 1 = -lse * log2(e).  They are the INITIAL
 // ACCUMULATORS of the dP and S chains (a query row = an accumulator element here, so they come from the LDS copy of the tile's 64 values
 // by ds_read_b128), k carries scale*log2(e): p = exp2(S) and dS = p * dP are one instruction per element each.
-template <int HD, bool QKN = false>
+template <int HD, bool QKN = false, bool RAGGED = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                  const bf16* __restrict__ dO, const float* __restrict__ ROWC, long rc_stride,
                                                                  bf16* __restrict__ dK, bf16* __restrict__ dV,
@@ -515,17 +533,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   f32x16 dkacc[DB], dvacc[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d) { dkacc[d] = splat16(0.f); dvacc[d] = splat16(0.f); }
-  const int nt = N / 64;
+  const int nt = (N + 63) / 64, NP = nt * 64;      // ROWC rows are padded to whole tiles: the dQ kernel fills the pad with (-inf, 0)
+  constexpr bool ragged = RAGGED;
   constexpr int PPW = 2 * (TB / 1024) / 4 + 1;
-  const float* rowc = ROWC + (size_t)bh * N + ((wave & 1) ? 0 : rc_stride);     // wave 0/2: -lse2, wave 1/3: -delta
+  const float* rowc = ROWC + (size_t)bh * NP + ((wave & 1) ? 0 : rc_stride);     // wave 0/2: -lse2, wave 1/3: -delta
   TileMap<HD, 64> mq, mo;
   mq.init(ld, wave, lane);
   mo.init(dold, wave, lane);
   const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int qt) {
     const int so = (qt % ATT_STAGES) * BUF;
+    if (ragged && qt == nt - 1) {          // missing query rows: copies of row N-1; their -lse2 = -inf in ROWC zeroes p (and with it dS)
+      stage_tile<HD, 64>(qp + (size_t)qt * 64 * ld, ld, N - 1 - qt * 64, smem + so, wave, lane);
+      stage_tile<HD, 64>(dop + (size_t)qt * 64 * dold, dold, N - 1 - qt * 64, smem + so + TB, wave, lane);
+    } else {
     mq.issue(qp + (size_t)qt * 64 * ld, ld, smem + so, lds0 + so, wave, lane);
     mo.issue(dop + (size_t)qt * 64 * dold, dold, smem + so + TB, lds0 + so + TB, wave, lane);
+    }
     // 64 floats of -lse2 (slot 0) / -delta (slot 1); waves 2,3 fill scratch slots so every wave issues PPW loads
     glds4_s(rowc + qt * 64, lane * 4, lds0 + so + 2 * TB + wave * 256);
   };
@@ -603,13 +627,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
     __syncthreads();                                   // ring -> store scratch
     if (!active) return;
     char* sw = smem + wave * 32 * (HDP * 2 + 16);
-    store_rows_t<HD>(dkacc, scale, sw, dK + hb + (size_t)k0 * ld, ld, lane);
-    store_rows_t<HD>(dvacc, 1.f, sw, dV + hbv + (size_t)k0 * Lv.ld, Lv.ld, lane);       // same wave, same scratch: LDS ops stay in order
+    store_rows_t<HD>(dkacc, scale, sw, dK + hb + (size_t)k0 * ld, ld, lane, N - k0);
+    store_rows_t<HD>(dvacc, 1.f, sw, dV + hbv + (size_t)k0 * Lv.ld, Lv.ld, lane, N - k0);       // same wave, same scratch: LDS ops stay in order
   }
 }
 
 // ================================================================================================ backward dQ, bf16
-template <int HD, bool QKN = false>
+template <int HD, bool QKN = false, bool RAGGED = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                const bf16* __restrict__ O, const bf16* __restrict__ dO,
                                                                const float* __restrict__ LSE, float* __restrict__ ROWC, long rc_stride,
@@ -646,15 +670,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   }
   const float dl = dpart + __shfl_xor(dpart, 32);
   const float lse2 = LSE[(size_t)bh * N + qrow] * 1.4426950408889634f;
-  if (h == 0 && q0 + r < N) {
-    ROWC[(size_t)bh * N + qrow] = -dl;
-    ROWC[rc_stride + (size_t)bh * N + qrow] = -lse2;
+  const int NP = (N + 63) / 64 * 64;        // ROWC rows padded to whole tiles; pad rows (-delta, -lse2) = (0, -inf): p = dS = 0 in the dK/dV kernel
+  if (h == 0 && q0 + r < NP) {
+    const bool real = q0 + r < N;
+    ROWC[(size_t)bh * NP + q0 + r] = real ? -dl : 0.f;
+    ROWC[rc_stride + (size_t)bh * NP + q0 + r] = real ? -lse2 : -__builtin_inff();
   }
   const f32x16 nl = splat16(-lse2), nd = splat16(-dl);
   f32x16 dqacc[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d) dqacc[d] = splat16(0.f);
-  const int nt = N / 64;
+  const int nt = (N + 63) / 64;
+  constexpr bool ragged = RAGGED;
   constexpr int PPW = 2 * (TB / 1024) / 4;
   TileMap<HD, 64> mk, mv;
   mk.init(ld, wave, lane);
@@ -662,6 +689,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int kt) {
     const int so = (kt % ATT_STAGES) * 2 * TB;
+    if (ragged && kt == nt - 1) {
+      stage_tile<HD, 64>(kp + (size_t)kt * 64 * ld, ld, N - 1 - kt * 64, smem + so, wave, lane);
+      stage_tile<HD, 64>(vp + (size_t)kt * 64 * ldv, ldv, N - 1 - kt * 64, smem + so + TB, wave, lane);
+      return;
+    }
     mk.issue(kp + (size_t)kt * 64 * ld, ld, smem + so, lds0 + so, wave, lane);
     mv.issue(vp + (size_t)kt * 64 * ldv, ldv, smem + so + TB, lds0 + so + TB, wave, lane);
   };
@@ -687,6 +719,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
         s = MFMA_BF16(frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], ks == 0 ? nl : s);
         dp = MFMA_BF16(frag_row<HDP>(Vt, kb * 32, ks, lane), dof[ks], ks == 0 ? nd : dp);
       }
+      if (ragged && kt == nt - 1) mask_rows_past(s, kt * 64 + kb * 32, h, N);       // keys past N: p = 0, dS = 0
       bf16x8 ktr[2][DB];
       if constexpr (BTR) {
 #pragma unroll
@@ -723,7 +756,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   } else {
     __syncthreads();                                   // ring -> store scratch
     if (!active) return;
-    store_rows_t<HD>(dqacc, scale, smem + wave * 32 * (HDP * 2 + 16), dQ + hb + (size_t)q0 * ld, ld, lane);
+    store_rows_t<HD>(dqacc, scale, smem + wave * 32 * (HDP * 2 + 16), dQ + hb + (size_t)q0 * ld, ld, lane, N - q0);
   }
 }
 
@@ -758,10 +791,10 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 #pragma unroll
     for (int t = 0; t < 16; ++t) oacc[d][t] = 0.f;
   float ms = -1e30f, l = 0.f;
-  for (int kt = 0; kt < N / 64; ++kt) {
+  for (int kt = 0; kt < (N + 63) / 64; ++kt) {
     __syncthreads();
-    stage_tile_f32<HD, 64>(K + ((size_t)bh * N + kt * 64) * HD, HD, 64, Ks);
-    stage_tile_f32<HD, 64>(V + ((size_t)bh * N + kt * 64) * HD, HD, 64, Vs);
+    stage_tile_f32<HD, 64>(K + ((size_t)bh * N + kt * 64) * HD, HD, N - kt * 64, Ks);      // rows past N: zeros, masked below
+    stage_tile_f32<HD, 64>(V + ((size_t)bh * N + kt * 64) * HD, HD, N - kt * 64, Vs);
     __syncthreads();
     f32x16 s[2];
 #pragma unroll
@@ -770,6 +803,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
       for (int t = 0; t < 16; ++t) s[kb][t] = 0.f;
 #pragma unroll 8
       for (int kk = 0; kk < HD; kk += 2) s[kb] = MFMA_F32(Ks[(kb * 32 + r) * LD + kk + h], Qs[(wave * 32 + r) * LD + kk + h], s[kb]);
+      if (kt * 64 + 64 > N) mask_rows_past(s[kb], kt * 64 + kb * 32, h, N);
     }
     float mx = s[0][0];
 #pragma unroll
@@ -807,9 +841,9 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int dd = d * 32 + acc_row(t, h);
-      if (dd < HD) op[dd] = oacc[d][t] * inv;
+      if (dd < HD && q0 + r < N) op[dd] = oacc[d][t] * inv;
     }
-  if (h == 0) LSE[(size_t)bh * N + q0 + r] = (ms + log2f(l)) * 0.6931471805599453f;
+  if (h == 0 && q0 + r < N) LSE[(size_t)bh * N + q0 + r] = (ms + log2f(l)) * 0.6931471805599453f;
 }
 
 template <int HD>
@@ -838,12 +872,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_f32_kernel(const float* __r
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int t = 0; t < 16; ++t) { dkacc[d][t] = 0.f; dvacc[d][t] = 0.f; }
-  for (int qt = 0; qt < N / 64; ++qt) {
+  for (int qt = 0; qt < (N + 63) / 64; ++qt) {
     __syncthreads();
-    stage_tile_f32<HD, 64>(Q + ((size_t)bh * N + qt * 64) * HD, HD, 64, Qs);
-    stage_tile_f32<HD, 64>(dO + (((size_t)b * N + qt * 64) * H + hh) * HD, (long)H * HD, 64, dOs);
-    if (threadIdx.x < 64) lse2[threadIdx.x] = LSE[(size_t)bh * N + qt * 64 + threadIdx.x] * 1.4426950408889634f;
-    else if (threadIdx.x < 128) dl[threadIdx.x - 64] = DELTA[(size_t)bh * N + qt * 64 + threadIdx.x - 64];
+    stage_tile_f32<HD, 64>(Q + ((size_t)bh * N + qt * 64) * HD, HD, N - qt * 64, Qs);
+    stage_tile_f32<HD, 64>(dO + (((size_t)b * N + qt * 64) * H + hh) * HD, (long)H * HD, N - qt * 64, dOs);
+    // query rows past N: lse = +inf -> p = exp2(0 - inf) = 0, so they add nothing to dV or dK
+    if (threadIdx.x < 64) lse2[threadIdx.x] = qt * 64 + (int)threadIdx.x < N ? LSE[(size_t)bh * N + qt * 64 + threadIdx.x] * 1.4426950408889634f : __builtin_inff();
+    else if (threadIdx.x < 128) dl[threadIdx.x - 64] = qt * 64 + (int)threadIdx.x - 64 < N ? DELTA[(size_t)bh * N + qt * 64 + threadIdx.x - 64] : 0.f;
     __syncthreads();
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -874,7 +909,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_f32_kernel(const float* __r
       }
     }
   }
-  if (!active) return;
+  if (!active || k0 + r >= N) return;
   float* dkp = dK + ((size_t)bh * N + k0 + r) * HD;
   float* dvp = dV + ((size_t)bh * N + k0 + r) * HD;
 #pragma unroll
@@ -911,10 +946,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __res
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int t = 0; t < 16; ++t) dqacc[d][t] = 0.f;
-  for (int kt = 0; kt < N / 64; ++kt) {
+  for (int kt = 0; kt < (N + 63) / 64; ++kt) {
     __syncthreads();
-    stage_tile_f32<HD, 64>(K + ((size_t)bh * N + kt * 64) * HD, HD, 64, Ks);
-    stage_tile_f32<HD, 64>(V + ((size_t)bh * N + kt * 64) * HD, HD, 64, Vs);
+    stage_tile_f32<HD, 64>(K + ((size_t)bh * N + kt * 64) * HD, HD, N - kt * 64, Ks);
+    stage_tile_f32<HD, 64>(V + ((size_t)bh * N + kt * 64) * HD, HD, N - kt * 64, Vs);
     __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -926,6 +961,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __res
         s = MFMA_F32(Ks[(kb * 32 + r) * LD + kk + h], Qs[(wave * 32 + r) * LD + kk + h], s);
         dp = MFMA_F32(Vs[(kb * 32 + r) * LD + kk + h], dOs[(wave * 32 + r) * LD + kk + h], dp);
       }
+      if (kt * 64 + 64 > N) mask_rows_past(s, kt * 64 + kb * 32, h, N);       // keys past N: p = 0
 #pragma unroll
       for (int t = 0; t < 16; ++t) dp[t] = exp2f(s[t] * c - lse2) * (dp[t] - dl);
 #pragma unroll
@@ -937,7 +973,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __res
       }
     }
   }
-  if (!active) return;
+  if (!active || q0 + r >= N) return;
   float* dqp = dQ + ((size_t)bh * N + q0 + r) * HD;
 #pragma unroll
   for (int d = 0; d < DB; ++d)
@@ -965,8 +1001,7 @@ static int attn_lds(int hd, int extra) {
 static int attn_check(const char* who, int dtype, int B, int H, int N, int hd) {
   LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "%s: bad dtype %d", who, dtype);
   LDMAE_REQUIRE(B > 0 && H > 0 && N > 0 && hd > 0, "%s: empty problem", who);
-  LDMAE_REQUIRE(N % 64 == 0, "%s: sequence length N=%d must be a multiple of 64", who, N);
-  return LDMAE_OK;
+  return LDMAE_OK;      // any N: the last 64-row tile of a sweep may be ragged (mask_rows_past)
 }
 
 static int attention_fwd_core(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N, int hd,
@@ -974,10 +1009,12 @@ static int attention_fwd_core(int dtype, const void* q, const void* k, const voi
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const float c = scale * 1.4426950408889634f;
   if (dtype == LDMAE_BF16) {
-#define L(HD) hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq, Lv)
+#define LR(HD, R) { hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<HD, R>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, R>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq, Lv); }
+#define L(HD) if (N % 64 == 0) LR(HD, false) else LR(HD, true)
     ATTN_HD_DISPATCH(hd, L);
 #undef L
+#undef LR
   } else {
     LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd && Lv.ld == hd && Lv.sh == (long)N * hd, "attention_fwd(f32): head-major q/k/v only");
 #define L(HD) { const size_t lds = (size_t)(128 + 64 + 64) * (HD + 1) * 4; \
@@ -1012,17 +1049,20 @@ extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, floa
 static int attention_bwd_core(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
                               void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, QkvLayout Lq, QkvLayout Lv, hipStream_t st) {
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
-  const long items = (long)B * N * H, rcs = items;      // delta = [2][B*H*N] f32 workspace (bf16: -delta | -lse*log2e; f32: slot 0 = delta)
+  // delta = [2][B*H*NP] f32 workspace, NP = N rounded up to 64 (bf16: -delta | -lse*log2e, rows padded to whole tiles; f32: slot 0 = delta, unpadded)
+  const long items = (long)B * N * H, rcs = (long)B * H * ((N + 63) / 64 * 64);
   const unsigned dgrid = (unsigned)((items * 8 + 255) / 256 < 8192 ? (items * 8 + 255) / 256 : 8192);
   if (dtype == LDMAE_BF16) {
     // dQ first: it forms delta = rowsum(dO * O) from its own fragments and publishes it for the dK/dV kernel
-#define L(HD) { \
-    hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
-    hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, rcs, (bf16*)dq, H, N, scale, Lq, Lv, QkNormBwd{}); \
-    hipLaunchKernelGGL(attn_bwd_dkdv_bf16_kernel<HD>, dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, delta, rcs, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv, QkNormBwd{}); }
+#define LR(HD, R) { \
+    hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD, false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
+    hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD, false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<HD, false, R>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, rcs, (bf16*)dq, H, N, scale, Lq, Lv, QkNormBwd{}); \
+    hipLaunchKernelGGL((attn_bwd_dkdv_bf16_kernel<HD, false, R>), dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, delta, rcs, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv, QkNormBwd{}); }
+#define L(HD) if (N % 64 == 0) LR(HD, false) else LR(HD, true)
     ATTN_HD_DISPATCH(hd, L);
 #undef L
+#undef LR
   } else {
     LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd && Lv.ld == hd && Lv.sh == (long)N * hd, "attention_bwd(f32): head-major q/k/v only");
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(dgrid), dim3(256), 0, st, (const float*)o, (const float*)do_, delta, B, H, N, hd);
@@ -1102,6 +1142,7 @@ extern "C" int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const voi
   LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_bwd_pv_qknorm: bf16 only");
   LDMAE_REQUIRE(hd == 64 || hd == 128, "attention_bwd_pv_qknorm: head_dim %d (64 or 128; others: attention_bwd_pv + qknorm_rope_bwd)", hd);
   if (int e = attn_check("attention_bwd_pv_qknorm", dtype, B, H, N, hd)) return e;
+  LDMAE_REQUIRE(N % 64 == 0, "attention_bwd_pv_qknorm: N=%d must be a multiple of 64 (ragged N: attention_bwd_pv + qknorm_rope_bwd)", N);
   hipStream_t st = as_stream(stream);
   const long hw = (long)H * hd, items = (long)B * H * N, blk = (long)B * ((N + 127) / 128);
   const QkvLayout hm{(long)H * N * hd, (long)N * hd, (long)hd}, pk{(long)N * 3 * hw, (long)hd, 3 * hw};

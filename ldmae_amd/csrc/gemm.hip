@@ -265,6 +265,9 @@ constexpr int TN_BN = 128, TN_BK = 128, TN_BM = 64;
 constexpr int TN_TILE_BYTES = TN_BM * 128 * 2;   // 16 KiB
 
 __device__ __forceinline__ int tn_sw(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+// token rows past the end of a split (M % 64 != 0: VMAE keeps int(L * (1 - mask_ratio)) tokens for any ratio) are fetched from these
+// 16 zero bytes -- the LDS-DMA source address is per lane -- so they add nothing to the products
+__device__ __attribute__((aligned(16))) unsigned g_tn_zero16[4] = {0u, 0u, 0u, 0u};
 
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                            float* __restrict__ P, int M, int N, int K, int lda, int ldb,
@@ -291,9 +294,10 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restric
     char* base = smem + buf * 2 * TN_TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const size_t m = (size_t)min(mt + arow[i], M - 1);
-      glds16(A + m * lda + acol[i], base + (wave * 4 + i) * 1024);
-      glds16(B + m * ldb + bcol[i], base + TN_TILE_BYTES + (wave * 4 + i) * 1024);
+      const size_t m = (size_t)(mt + arow[i]);
+      const bool real = mt + arow[i] < mend;
+      glds16(real ? (const void*)(A + m * lda + acol[i]) : (const void*)g_tn_zero16, base + (wave * 4 + i) * 1024);
+      glds16(real ? (const void*)(B + m * ldb + bcol[i]) : (const void*)g_tn_zero16, base + TN_TILE_BYTES + (wave * 4 + i) * 1024);
     }
   };
   f32x4 acc[4][4];
@@ -315,8 +319,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restric
   };
 
   const int nsteps = (mend - mbeg + TN_BM - 1) / TN_BM;
-  // rows past mend inside the last step must contribute zero: handled by requiring rows_per_split % 64 == 0
-  // and M % 64 == 0 on the host side (checked there).
+  // rows past mend inside the last step contribute zero (zero DMA source above); rows_per_split % 64 == 0 (host)
   if (nsteps > 0) {
     stage(0, mbeg);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -765,7 +768,6 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   const int al = dtype == LDMAE_BF16 ? 8 : 4;
   LDMAE_REQUIRE(N % al == 0 && K % al == 0 && lda % al == 0 && ldb % al == 0, "gemm_tn: N=%d K=%d lda=%d ldb=%d must be multiples of %d", N, K, lda, ldb, al);
   LDMAE_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0, "gemm_tn: pointers must be 16-B aligned");
-  if (dtype == LDMAE_BF16) LDMAE_REQUIRE(M % TN_BM == 0, "gemm_tn(bf16): M=%d must be a multiple of %d", M, TN_BM);
   int rows = 0;
   const int splits = tn_plan(dtype, M, N, K, &rows);
   const bool ring = dtype == LDMAE_BF16 && ldmae_tune_get(1) == 0 && M % 32 == 0;

@@ -46,8 +46,44 @@ def sample_latents(model, sample_fn, n, cfg_scale, cfg_interval_start, device, n
     return out, y[:n]
 
 
+class PngWriter:
+    """PNG encoding on a host thread: the reference writes each image synchronously inside the sampling loop (inference.py:293-297),
+    so the GPU sits idle while 256 PNGs are compressed; here the loop hands the uint8 batch over and goes on enqueueing the next
+    batch's Euler steps.  Bounded queue (2 batches) so host memory stays flat; `close()` drains it and re-raises a writer error."""
+
+    def __init__(self, depth=2):
+        import queue
+        import threading
+        self.q, self.err = queue.Queue(maxsize=depth), None
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        from PIL import Image
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            try:
+                imgs, paths = item
+                for im, path in zip(imgs, paths):
+                    Image.fromarray(im).save(path)
+            except Exception as e:          # surfaced by close()
+                self.err = e
+
+    def put(self, imgs, paths):
+        if self.err is not None:
+            raise self.err
+        self.q.put((imgs, paths))
+
+    def close(self):
+        self.q.put(None)
+        self.th.join()
+        if self.err is not None:
+            raise self.err
+
+
 def do_sample(cfg, ckpt_path, out_dir, num_samples=None, precision="bf16"):
-    from PIL import Image
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -70,13 +106,16 @@ def do_sample(cfg, ckpt_path, out_dir, num_samples=None, precision="bf16"):
     total = int(math.ceil((num_samples or s['fid_num']) / (n * world)) * n * world)
     os.makedirs(out_dir, exist_ok=True)
     done = 0
-    for it in range(total // (n * world)):
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16"):
-            lat, _ = sample_latents(model, sample_fn, n, s['cfg_scale'], s.get('cfg_interval_start', 0), device, cfg['data']['num_classes'])
-        imgs = vae.decode_to_images(lat * std / mult + mean)
-        for i, im in enumerate(imgs):
-            Image.fromarray(im).save(f"{out_dir}/{i * world + rank + done:06d}.png")
-        done += n * world
+    writer = PngWriter()
+    try:
+        for it in range(total // (n * world)):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16"):
+                lat, _ = sample_latents(model, sample_fn, n, s['cfg_scale'], s.get('cfg_interval_start', 0), device, cfg['data']['num_classes'])
+            imgs = vae.decode_to_images(lat * std / mult + mean)                     # uint8 NHWC on the host (inference.py:290-292)
+            writer.put(imgs, [f"{out_dir}/{i * world + rank + done:06d}.png" for i in range(len(imgs))])   # index rule: inference.py:294
+            done += n * world
+    finally:
+        writer.close()
     return out_dir
 
 

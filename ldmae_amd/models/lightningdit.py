@@ -267,7 +267,7 @@ class _DiTBlockFn(torch.autograd.Function):
         # ---- attention branch
         dWp, r = _dw_into_grad(sg, dy1, o.view(M, D), pw_p, ctx.direct); notify.append((r, pw_p))
         do = ops.gemm_nt(dy1, WpT)
-        if v is None and hd in (64, 128) and _FUSED_QKN_BWD:      # QK-norm / RoPE backward inside the attention backward's epilogues: no head-major dq / dk
+        if v is None and hd in (64, 128) and N % 64 == 0 and _FUSED_QKN_BWD:      # QK-norm / RoPE backward inside the attention backward's epilogues: no head-major dq / dk
             dqkv, dqn, dkn, dbqkv = ops.attention_bwd_pv_qknorm(q, k, qkv, o, do, lse, hd ** -0.5, qnw, knw, cos, sin, eps)
         elif v is None:
             dq, dk, dqkv = ops.attention_bwd_pv(q, k, qkv, o, do, lse, hd ** -0.5)          # dv lands in the v slot of dqkv

@@ -295,7 +295,7 @@ def attention_fwd(q, k, v, scale):
 def attention_bwd(q, k, v, o, do, lse, scale):
     B, H, N, hd = q.shape
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-    delta = torch.empty(2, B, H, N, dtype=torch.float32, device=q.device)
+    delta = torch.empty(2, B, H, (N + 63) // 64 * 64, dtype=torch.float32, device=q.device)      # rows padded to whole 64-row tiles
     call("ldmae_attention_bwd", dt(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(_c(do)), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta),
          B, H, N, hd, float(scale), stream())
     return dq, dk, dv
@@ -315,7 +315,7 @@ def attention_bwd_pv(q, k, qkv, o, do, lse, scale):
     B, H, N, hd = q.shape
     dq, dk = torch.empty_like(q), torch.empty_like(q)
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(2, B, H, N, dtype=torch.float32, device=q.device)
+    delta = torch.empty(2, B, H, (N + 63) // 64 * 64, dtype=torch.float32, device=q.device)
     call("ldmae_attention_bwd_pv", dt(q.dtype), ptr(q), ptr(k), ptr(qkv), ptr(o), ptr(_c(do)), ptr(lse), ptr(dq), ptr(dk), ptr(dqkv), ptr(delta),
          B, H, N, hd, float(scale), stream())
     return dq, dk, dqkv
@@ -346,7 +346,7 @@ def attention_fwd_qkv(qkv, B, N, H, hd, scale):
 def attention_bwd_qkv(qkv, o, do, lse, B, N, H, hd, scale):
     """-> dqkv [B*N, 3*H*hd] (dq / dk / dv written in the packed layout)."""
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(2, B, H, N, dtype=torch.float32, device=qkv.device)
+    delta = torch.empty(2, B, H, (N + 63) // 64 * 64, dtype=torch.float32, device=qkv.device)
     call("ldmae_attention_bwd_qkv", dt(qkv.dtype), ptr(qkv), ptr(o), ptr(_c(do)), ptr(lse), ptr(dqkv), ptr(delta), B, H, N, hd, float(scale), stream())
     return dqkv
 

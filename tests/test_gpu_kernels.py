@@ -256,7 +256,11 @@ def _attn_ref(qq, kk, vv, scale):
 
 @pytest.mark.parametrize("dtype,hd,N", [(F32, 64, 64), (F32, 64, 192), (F32, 16, 256), (F32, 72, 128), (BF16, 64, 64), (BF16, 64, 192),
                                         (BF16, 64, 1024), (BF16, 72, 256), (BF16, 128, 128), (BF16, 16, 256), (BF16, 16, 1024),
-                                        (BF16, 32, 128), (BF16, 72, 1024)])
+                                        (BF16, 32, 128), (BF16, 72, 1024),
+                                        # token counts that are not a multiple of 64 (models_mae.py:472-497: int(L * (1 - mask_ratio)) kept tokens;
+                                        # N + 1 with a cls token): the last tile of every sweep is ragged
+                                        (BF16, 16, 200), (BF16, 16, 257), (BF16, 64, 200), (BF16, 64, 257), (BF16, 64, 40), (BF16, 72, 100),
+                                        (F32, 16, 200), (F32, 64, 257), (F32, 64, 40)])
 def test_attention(ops, dtype, hd, N):
     """bf16 head dims 16 / 72 run on the flash kernels with the LDS images zero-padded to 32 / 96 columns (no padded HBM copies)."""
     B, H = 2, 3
@@ -276,7 +280,39 @@ def test_attention(ops, dtype, hd, N):
         assert rel_err(got.float().cpu(), ref) < (1e-4 if dtype == F32 else 3e-2)
 
 
-@pytest.mark.parametrize("hd,N", [(16, 256), (64, 128)])
+def test_attention_ragged_n_writes_nothing_past_n(ops):
+    """Ragged N, packed VMAE layout, last (batch, head) of the buffer: rows past N do not exist -- guard pages of NaN canaries placed
+    right behind every output must survive, and NaNs placed right behind the INPUTS must not leak into any result."""
+    B, H, N, hd = 2, 12, 204, 16                                     # mask_ratio 0.8 of 1024 patches keeps 204 tokens
+    tot = B * N * 3 * H * hd
+    buf = torch.full((tot + 4096,), float("nan"), device="cuda").to(BF16)
+    buf[:tot] = dev(rnd(tot, seed=1), BF16)
+    qkv = buf[:tot].view(B * N, 3 * H * hd)
+    dobuf = torch.full((B * N * H * hd + 4096,), float("nan"), device="cuda").to(BF16)
+    dobuf[:B * N * H * hd] = dev(rnd(B * N * H * hd, seed=2), BF16)
+    do = dobuf[:B * N * H * hd].view(B, N, H * hd)
+    o, lse = ops.attention_fwd_qkv(qkv, B, N, H, hd, hd ** -0.5)
+    dqkv = ops.attention_bwd_qkv(qkv, o, do, lse, B, N, H, hd, hd ** -0.5)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all() and torch.isfinite(dqkv.float()).all()
+    qh, kh, vh = (t.float().cpu().double().requires_grad_(True) for t in ops.heads_split(qkv, B, N, H, hd))
+    oref, lref = _attn_ref(qh, kh, vh, hd ** -0.5)
+    oref.backward(do.float().cpu().double())
+    assert rel_err(o.float().cpu(), oref.detach()) < 2e-2 and rel_err(lse.cpu(), lref.detach()) < 2e-3
+    ref = ops.heads_merge(dev(qh.grad.float(), BF16), dev(kh.grad.float(), BF16), dev(vh.grad.float(), BF16), B, N, H, hd)
+    assert rel_err(dqkv.float().cpu(), ref.float().cpu()) < 3e-2
+
+
+def test_gemm_tn_ragged_rows(ops):
+    """Weight gradient over a token count that is not a multiple of 64 (B * kept tokens of a ragged VMAE batch): the rows past the end of
+    the last split are fetched as zeros."""
+    M, N, K = 2 * 204, 576, 192
+    a, b = dev(rnd(M, N, seed=1), BF16), dev(rnd(M, K, seed=2), BF16)
+    out, db = ops.gemm_tn(a, b, with_bias=True)
+    ref = a.float().cpu().double().T @ b.float().cpu().double()
+    assert rel_err(out.cpu(), ref) < 1e-5 and rel_err(db.cpu(), a.float().cpu().double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("hd,N", [(16, 256), (64, 128), (16, 200)])
 def test_attention_packed_qkv_equals_head_major(ops, hd, N):
     """The VMAE path: flash attention straight on the packed token-major qkv [B,N,3,H,hd] (q / k / v read, dq / dk / dv written in
     place) gives bitwise the results of the head-major path behind the relayout kernels."""

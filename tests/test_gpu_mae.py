@@ -62,8 +62,10 @@ def test_encode_decode_docking_matches_reference_golden(golden):
     assert (np.abs(img8[:, :4, :4].astype(int) - g["mae_img8_head"].astype(int)) <= 1).all()
 
 
-def test_masked_encoder_gradients_vs_oracle():
-    """img 128 -> 256 patches, mask 0.75 -> 64 kept tokens; every encoder parameter gradient vs torch autograd on the oracle."""
+@pytest.mark.parametrize("ratio", [0.75, 0.8, 0.3])
+def test_masked_encoder_gradients_vs_oracle(ratio):
+    """img 128 -> 256 patches, mask 0.75 -> 64 kept tokens; every encoder parameter gradient vs torch autograd on the oracle.
+    Ratios 0.8 / 0.3 keep int(256 * 0.2) = 51 / 179 tokens (models_mae.py:480): ragged attention tiles and GEMM row counts."""
     cfg = omae.MAEConfig(img_size=128, depth=2)
     shapes = omae.param_shapes(cfg)
     sd = full_sd(cfg, seed=3)
@@ -81,16 +83,25 @@ def test_masked_encoder_gradients_vs_oracle():
     leaves = {k: own[k].clone().requires_grad_(True) for k in enc_keys}
     osd = dict(own)
     osd.update(leaves)
-    olat, omask, oids = omae.forward_encoder(osd, imgs, noise, 0.75, cfg)
+    olat, omask, oids = omae.forward_encoder(osd, imgs, noise, ratio, cfg)
     w = det_randn("w", tuple(olat.shape), 5)
     (olat * w).sum().backward()
-    lat, mask, ids = m.forward_encoder(imgs.cuda(), 0.75, noise=noise.cuda())
+    lat, mask, ids = m.forward_encoder(imgs.cuda(), ratio, noise=noise.cuda())
+    assert lat.shape[1] == int(256 * (1 - ratio))
     assert torch.equal(mask.cpu(), omask) and torch.equal(ids.cpu(), oids)
     assert rel_err(lat.detach().cpu(), olat.detach()) < 1e-4
     (lat * w.cuda()).sum().backward()
     params = dict(m.named_parameters())
     for k in enc_keys:
         assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 2e-4, k
+    if ratio != 0.75:                  # the same ragged shapes through the bf16 kernels (flash attention on the packed qkv, bf16 TN GEMM)
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lat16, mask16, _ = m.forward_encoder(imgs.cuda(), ratio, noise=noise.cuda())
+        assert torch.equal(mask16.cpu(), omask) and rel_err(lat16.detach().float().cpu(), olat.detach()) < 3e-2
+        (lat16.float() * w.cuda()).sum().backward()
+        for k in ("blocks.0.attn.qkv.weight", "blocks.1.mlp.fc2.weight", "patch_embed.proj.weight"):
+            assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 6e-2, k
 
 
 def test_pretraining_step_loss_and_all_grads_vs_oracle():
