@@ -37,7 +37,11 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
   const int wm = wave / WN, wn = wave % WN;
   const unsigned tiles_n = (N + BN - 1) / BN;
   float* ew = (float*)(smem + STAGES * STAGE_BYTES) + wave * (16 * 68);
-  float* ex = (float*)(smem + STAGES * STAGE_BYTES + 8 * 16 * 68 * 4 + 2048) + wave * 512;    // per-wave column-sum scratch (SwiGLU-bwd)
+  // per-wave column-sum scratch of the SwiGLU-bwd epilogue (1024 floats): ring stage STAGES-1.  The prologue of the next tile fills stages
+  // 0 .. STAGES-2 only, and stage STAGES-1 is first written by the K-step-0 load phase, behind the tile-start barrier every wave reaches
+  // after its epilogue -- so during an epilogue that stage is free
+  float* ex = (float*)(smem + (STAGES - 1) * STAGE_BYTES) + wave * 1024;
+  static_assert(STAGE_BYTES >= 8 * 1024 * 4, "epilogue scratch does not fit a ring stage");
   // workgroup b sits on XCD b % 8 (256 workgroups, one per CU): give each XCD a contiguous run of 32 tiles per round so the
   // workgroups that share an A row-block (and the whole of B) share an L2
   // (gridDim.x == ntiles: one tile per workgroup, the classic launch -- the hardware then overlaps a finished workgroup's store
@@ -658,9 +662,9 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
 #endif
   // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup (A/B knob),
   // key 7 = diagnostic per-K-step stamp build.
-#define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048 + 16384)
+#define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048)
 #define PERS_GO(...)                                                                                                             \
-  hipLaunchKernelGGL((gemm_nt_persist_kernel<__VA_ARGS__>), dim3(pgrid), dim3(512), lds + 2048 + 16384, st, (const bf16*)A, (const bf16*)B, \
+  hipLaunchKernelGGL((gemm_nt_persist_kernel<__VA_ARGS__>), dim3(pgrid), dim3(512), lds + 2048, st, (const bf16*)A, (const bf16*)B, \
                      M, N, K, lda, ldb, e, ntiles, ldmae_tune_get(5), (unsigned long long*)g_nt_stamps)
 #define PERS(E)                                                                                                                  \
   {                                                                                                                               \
@@ -726,7 +730,7 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
     e.xout = xout;
   } else if (epi == LDMAE_EPI_SWIGLU_BWD) {
     LDMAE_REQUIRE(dtype == LDMAE_BF16 && out_dtype == LDMAE_BF16, "gemm_nt: swiglu-bwd epilogue is bf16 only");
-    LDMAE_REQUIRE(C && xin && N % 4 == 0 && K % 32 == 0, "gemm_nt: swiglu-bwd epilogue needs dh12 (C) and h12 (xin)");
+    LDMAE_REQUIRE(C && xin && N % 8 == 0 && K % 32 == 0, "gemm_nt: swiglu-bwd epilogue needs dh12 (C), h12 (xin) and Hs = N %% 8 == 0 (N=%d)", N);
     e.xin = xin;
     e.xout = xout;   /* optional: [ceil(M/128)][2*Hs] f32 partial column sums of dh12 (bias gradient of w12) */
   } else {

@@ -130,7 +130,7 @@ struct NoHook { __device__ __forceinline__ void operator()(int, int) const {} };
 // on): the one-wave-per-SIMD kernel re-zeroes them there on the idle matrix pipe instead of in a pass of its own.
 template <int EPI, typename OutT, int TM, int TNn, int MI, int NI, typename Hook = NoHook>
 __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, float* ex, const EpiArgs& e, int m0, int n0, int wm, int wn,
-                                            int lane, int M, int N, Hook consumed = Hook()) {   // ew: strip [16][68]; ex: 512 more private floats
+                                            int lane, int M, int N, Hook consumed = Hook()) {   // ew: strip [16][68]; ex: 1024 more private floats
   constexpr int ELD = 68;
   auto fill = [&](int i, int cblk) {
 #pragma unroll
@@ -186,13 +186,16 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
     return;
   }
   if constexpr (EPI == LDMAE_EPI_SWIGLU_BWD) {
-    // acc = dhid (N = Hs columns); a,b = h12[:, n], h12[:, Hs+n]; dh12 = (g*b*s*(1+a(1-s)), g*a*s) with g rounded to bf16 first
+    // acc = dhid (N = Hs columns); a,b = h12[:, n], h12[:, Hs+n]; dh12 = (g*b*s*(1+a(1-s)), g*a*s) with g rounded to bf16 first.
+    // Every global access is 16 B per lane: a lane owns 8 columns of one row, 8 lanes a 128-B line, one wave instruction 8 whole rows
+    // (the 8-B form, 4 rows x 128 B per instruction, issued twice the loads and stores for the same lines: the epilogue is bound by
+    // the number of VMEM instructions it has to issue and retire in order, not by bytes).  Hs % 8 == 0 (host check).
     const int Hs = N;
     const bf16* h12 = (const bf16*)e.xin;
     bf16* dh12 = (bf16*)e.C;
 #pragma unroll
     for (int cblk = 0; cblk < TNn / 64; ++cblk) {
-      const int n = n0 + wn * TNn + cblk * 64 + (lane & 15) * 4;
+      const int n = n0 + wn * TNn + cblk * 64 + (lane & 7) * 8;
       const int mw = m0 + wm * TM;
       const bool inr = n < Hs;
       // h12 rows of strip i+1 are requested before the stores of strip i (see the note on vmcnt order below)
@@ -200,47 +203,52 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
 #define NT_HPF 1
 #endif
       constexpr int HPF = NT_HPF;                   // h12 rows are requested HPF strips ahead of their use
-      bf16x4 hv[MI + HPF][4][2];
+      bf16x8 hv[MI + HPF][2][2];
       auto ldh = [&](int i) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int m = min(mw + i * 16 + it * 4 + (lane >> 4), M - 1);
+        for (int it = 0; it < 2; ++it) {
+          const int m = min(mw + i * 16 + it * 8 + (lane >> 3), M - 1);
           const bf16* hp = h12 + (size_t)m * 2 * Hs + (inr ? n : 0);
-          hv[i][it][0] = *(const bf16x4*)hp; hv[i][it][1] = *(const bf16x4*)(hp + Hs);
+          hv[i][it][0] = *(const bf16x8*)hp; hv[i][it][1] = *(const bf16x8*)(hp + Hs);
         }
       };
       const bool whole = mw + TM <= M && n0 + wn * TNn + cblk * 64 + 64 <= Hs;     // wave-uniform: straight-line stores (see SwiGLU fwd)
       // bias gradient of w12 = column sums of dh12 AS STORED (bf16), formed here while the values are in registers: per wave the
-      // sums over its 128 rows go to e.xout[(m0 / 128 + wm)][2 * Hs] (one partial row per 128 output rows; summed by the caller)
-      // (kept in the wave's LDS scratch ex[row group q = lane >> 4][da 64 | db 64]: eight more live registers spilled the kernel)
-      float* exq = ex + (lane >> 4) * 128 + (lane & 15) * 4;
+      // sums over its 128 rows go to e.xout[(m0 / 128 + wm)][2 * Hs] (one partial row per 128 output rows; summed by the caller).
+      // Kept in the wave's LDS scratch ex[row group q = lane >> 3][da 64 | db 64] (sixteen more live registers spilled the kernel).
+      float* exq = ex + (lane >> 3) * 128 + (lane & 7) * 8;
       const bool sums = e.xout != nullptr;
-      if (sums) { *(float4*)exq = make_float4(0.f, 0.f, 0.f, 0.f); *(float4*)(exq + 64) = make_float4(0.f, 0.f, 0.f, 0.f); }
+      if (sums) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)exq = z; *(float4*)(exq + 4) = z; *(float4*)(exq + 64) = z; *(float4*)(exq + 68) = z;
+      }
       auto strip = [&](int i, bool guard) {
         fill(i, cblk);
         if (i + HPF < MI) ldh(i + HPF);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int row = it * 4 + (lane >> 4), m = mw + i * 16 + row;
-          const float4 gv = *(const float4*)(ew + row * ELD + (lane & 15) * 4);
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 8 + (lane >> 3), m = mw + i * 16 + row;
+          const float4 g0 = *(const float4*)(ew + row * ELD + (lane & 7) * 8), g1 = *(const float4*)(ew + row * ELD + (lane & 7) * 8 + 4);
           if (!guard || (m < M && inr)) {
-            const bf16x4 av = hv[i][it][0], bv = hv[i][it][1];
-            const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
-            bf16x4 da, db;
+            const bf16x8 av = hv[i][it][0], bv = hv[i][it][1];
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            bf16x8 da, db;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
               const float g = (float)(bf16)gg[j], a = (float)av[j], b = (float)bv[j], sg = fast_sigmoid(a);
               da[j] = (bf16)(g * b * sg * (1.f + a * (1.f - sg)));
               db[j] = (bf16)(g * a * sg);
             }
             if (sums) {
-              float4 ua = *(float4*)exq, ub = *(float4*)(exq + 64);
+              float4 ua = *(float4*)exq, ua2 = *(float4*)(exq + 4), ub = *(float4*)(exq + 64), ub2 = *(float4*)(exq + 68);
               ua.x += (float)da[0]; ua.y += (float)da[1]; ua.z += (float)da[2]; ua.w += (float)da[3];
+              ua2.x += (float)da[4]; ua2.y += (float)da[5]; ua2.z += (float)da[6]; ua2.w += (float)da[7];
               ub.x += (float)db[0]; ub.y += (float)db[1]; ub.z += (float)db[2]; ub.w += (float)db[3];
-              *(float4*)exq = ua; *(float4*)(exq + 64) = ub;
+              ub2.x += (float)db[4]; ub2.y += (float)db[5]; ub2.z += (float)db[6]; ub2.w += (float)db[7];
+              *(float4*)exq = ua; *(float4*)(exq + 4) = ua2; *(float4*)(exq + 64) = ub; *(float4*)(exq + 68) = ub2;
             }
-            __builtin_nontemporal_store(da, (bf16x4*)(dh12 + (size_t)m * 2 * Hs + n));
-            __builtin_nontemporal_store(db, (bf16x4*)(dh12 + (size_t)m * 2 * Hs + Hs + n));
+            __builtin_nontemporal_store(da, (bf16x8*)(dh12 + (size_t)m * 2 * Hs + n));
+            __builtin_nontemporal_store(db, (bf16x8*)(dh12 + (size_t)m * 2 * Hs + Hs + n));
           }
         }
       };
@@ -253,12 +261,16 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
 #pragma unroll
         for (int i = 0; i < MI; ++i) strip(i, true);
       }
-      if (sums && lane < 32 && inr && mw < M) {          // lanes 0-15 sum the da halves of the 4 row groups, lanes 16-31 the db halves
-        const float* src = ex + (lane >> 4) * 64 + (lane & 15) * 4;
-        float4 t = *(const float4*)src;
+      if (sums && lane < 16 && inr && mw < M) {          // lanes 0-7 sum the da halves of the 8 row groups, lanes 8-15 the db halves
+        const float* src = ex + (lane >> 3) * 64 + (lane & 7) * 8;
+        float4 t = *(const float4*)src, t2 = *(const float4*)(src + 4);
 #pragma unroll
-        for (int qg = 1; qg < 4; ++qg) { const float4 u = *(const float4*)(src + qg * 128); t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-        *(float4*)(e.xout + (size_t)(mw / TM) * 2 * Hs + (lane >> 4) * Hs + n) = t;
+        for (int qg = 1; qg < 8; ++qg) {
+          const float4 u = *(const float4*)(src + qg * 128), u2 = *(const float4*)(src + qg * 128 + 4);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; t2.x += u2.x; t2.y += u2.y; t2.z += u2.z; t2.w += u2.w;
+        }
+        float* dst = e.xout + (size_t)(mw / TM) * 2 * Hs + (lane >> 3) * Hs + n;
+        *(float4*)dst = t; *(float4*)(dst + 4) = t2;
       }
     }
     return;

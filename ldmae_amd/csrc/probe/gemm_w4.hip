@@ -324,7 +324,7 @@ int ldmae_launch_nt_p8(int epi, int out_bf16, const void* A, const void* B, int 
     case LDMAE_EPI_BIAS: P8(LDMAE_EPI_BIAS); break;
     case LDMAE_EPI_GATE_RES: P8(LDMAE_EPI_GATE_RES); break;
     case LDMAE_EPI_SWIGLU: go_p8<LDMAE_EPI_SWIGLU, bf16>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st); break;
-    case LDMAE_EPI_SWIGLU_BWD: go_p8<LDMAE_EPI_SWIGLU_BWD, bf16>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st); break;
+    // (SwiGLU-bwd: the shared epilogue now needs 1024 floats of per-wave scratch, which these experimental kernels do not reserve: shipped kernel)
     default: return 0;
   }
 #undef P8
@@ -340,7 +340,6 @@ int ldmae_launch_nt_w4(int epi, int out_bf16, const void* A, const void* B, int 
     case LDMAE_EPI_BIAS: W4(LDMAE_EPI_BIAS); break;
     case LDMAE_EPI_GATE_RES: W4(LDMAE_EPI_GATE_RES); break;
     case LDMAE_EPI_SWIGLU: go_w4<LDMAE_EPI_SWIGLU, bf16>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st); break;
-    case LDMAE_EPI_SWIGLU_BWD: go_w4<LDMAE_EPI_SWIGLU_BWD, bf16>(A, B, M, N, K, lda, ldb, e, grid, ntiles, st); break;
     default: return 0;
   }
 #undef W4

@@ -153,7 +153,7 @@ def gemm_nt_swiglu_bwd(dy, w3t, h12, with_bias=False):
     bias gradient of w12), formed in the GEMM epilogue as per-128-row partials and summed here."""
     M, K = dy.shape
     Hs = w3t.shape[0]
-    if dy.dtype == torch.bfloat16 and Hs % 4 == 0 and K % 64 == 0:
+    if dy.dtype == torch.bfloat16 and Hs % 8 == 0 and K % 64 == 0:
         dh12 = torch.empty_like(h12)
         part = torch.zeros((M + 127) // 128, 2 * Hs, dtype=torch.float32, device=dy.device) if with_bias else None
         call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU_BWD | _GEMM_LAUNCH, ptr(dy), dy.stride(0), ptr(w3t), w3t.stride(0), ptr(dh12), 2 * Hs, M, Hs, K, None, 0.0,

@@ -5,7 +5,8 @@ for each value of a tune key (default key 8: 1 = persistent workgroups, 2 = one 
 import os, argparse, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("LDMAE_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldmae_amd", "libldmae_hip_diag.so"))   # A/B knobs live in the diagnostic build only (make -C ldmae_amd/csrc diag)
+if "--key=-1" not in sys.argv:          # A/B knobs live in the diagnostic build only (make -C ldmae_amd/csrc diag); --key=-1: no knob, time
+    os.environ.setdefault("LDMAE_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ldmae_amd", "libldmae_hip_diag.so"))   # whatever library LDMAE_HIP_LIB names (A/B of two BUILDS: run twice in one gpurun call)
 from ldmae_amd import _lib, ops
 
 
@@ -25,7 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     args = ap.parse_args()
     lib = _lib.load()
-    vals = [int(v) for v in args.values.split(",")]
+    vals = [int(v) for v in args.values.split(",")] if args.key >= 0 else [0]
     M, D, H = 262144, 768, 2048
     g = torch.Generator(device="cuda").manual_seed(0)
     rb = lambda *s: torch.randn(*s, device="cuda", generator=g).to(torch.bfloat16)
@@ -49,9 +50,11 @@ def main():
     for _ in range(args.rounds):
         for name, fl, fn in cases:
             for v in vals:
-                lib.ldmae_tune(args.key, v)
+                if args.key >= 0:
+                    lib.ldmae_tune(args.key, v)
                 res[(name, v)].append(timed(fn))
-    lib.ldmae_tune(args.key, 0)
+    if args.key >= 0:
+        lib.ldmae_tune(args.key, 0)
     tot = {v: 0.0 for v in vals}
     for name, fl, fn in cases:
         line = f"{name}:"
