@@ -182,6 +182,14 @@ int ldmae_random_masking(const float* noise, long long* ids_restore, float* mask
 /* out[n,j,:] = x[n, ids[n,j], :]  (torch.gather on dim 1, :486); bwd scatters (ids unique per n) */
 int ldmae_gather_rows(const float* x, const long long* ids, float* out, int N, int L, int keep, int D, void* stream);
 int ldmae_scatter_rows(const float* dout, const long long* ids, float* dx, int N, int L, int keep, int D, void* stream);
+/* The whole encoder stack after the gather -- nblocks x Block (models_mae.py:149-187) + the closing LayerNorm (:369, 521) -- as ONE kernel
+ * for the shipped geometry at mask_ratio 0.75 (tokens = 256 kept tokens per image, dim 192, 12 heads, hidden 768; anything else returns
+ * LDMAE_ERR_INVALID: use the per-layer entry points).  Inference only, bf16 MFMA, f32 residual stream held in registers: one workgroup
+ * per image, activations never leave the CU.  x, out [B, tokens, dim] f32.  blob: ldmae_vmae_encoder_blob_bytes(nblocks) bytes of
+ * weights as pre-arranged MFMA operand fragments in order of use (layout: csrc/vmae_fused.hip; packer: tokenizer/fused_encoder.py). */
+long ldmae_vmae_encoder_blob_bytes(int nblocks);
+int ldmae_vmae_encoder_fwd(const float* x, float* out, const void* blob, int B, int tokens, int dim, int heads, int hidden, int nblocks,
+                           float eps, void* stream);
 /* LayerNorm with affine (models_mae.py:163,171,369; eps 1e-6).  mean/rstd [M] saved. */
 int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w, const float* b, void* out, float* mean, float* rstd,
                         int M, int D, float eps, void* stream);

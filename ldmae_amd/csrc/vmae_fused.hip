@@ -1,0 +1,300 @@
+// The VMAE masked-token ENCODER as one kernel (inference, bf16 MFMA, f32 residual stream): tokenizer/models_mae.py:499-523 after the
+// gather -- depth x Block (:149-187: LN -> qkv -> softmax attention -> proj -> +x ; LN -> fc1 -> exact GELU -> fc2 -> +x) -> LayerNorm
+// (:369) -- for the shipped tokenizer geometry at mask_ratio 0.75: 256 kept tokens per image, width 192, 12 heads of 16, hidden 768.
+//
+// Why one kernel: as separate launches the block is 7 kernels whose activations (x f32, LN output, qkv, attention output, hidden) make
+// 800 MB of HBM traffic per block at batch 256, ~1.9 ms per encoder pass before a single FLOP -- and every GEMM is a K = 192 tile that is
+// all prologue and epilogue (profiles/r03_vmae_kernel_stats.csv: 3.4 ms per pass).  256 kept tokens are exactly what one workgroup can own:
+//
+//   * one 512-thread workgroup per IMAGE; wave w owns tokens 32w .. 32w+31 for the whole encoder.  The residual stream lives in registers
+//     as x^T accumulator blocks (lane = token, 96 f32 per lane): it is read from HBM once and the result written once -- nothing else
+//     of the activations ever leaves the CU.
+//   * every Linear is computed TRANSPOSED, Y^T[f, tok] = W[f, :] . X^T[:, tok] (v32x32x16 bf16 MFMA, A = weight rows, B = activations), so
+//       - LayerNorm is a per-lane reduction over the lane's 96 values + one cross-half shuffle,
+//       - an accumulator block converts in registers into the B operand of the NEXT product (LN output -> qkv / fc1, GELU(fc1) -> fc2,
+//         attention output -> proj): no activation goes through LDS except K and V, which every wave needs from every other wave.
+//       The k-order a C/D block has when re-used as an operand is absorbed by permuting the weight columns once on the host.
+//   * weights stream through a 3-slot LDS ring by LDS-DMA (global_load_lds, 1 KiB per wave instruction) in the exact order of use, stored by
+//     the host as ready-made MFMA A-operand fragments (lane-linear 1-KiB images: conflict-free ds_read_b128, no address arithmetic);
+//     the small f32 vectors (LayerNorm weights, biases) ride in the same slots.  One s_barrier per step of 24 MFMAs per wave, counted vmcnt.
+//   * attention per pair of heads: q^T, k^T from the transposed product (a lane's 8 values ARE its QK^T operand fragment), v from the
+//     un-transposed product (MFMA(A = x, B = Wv): lane = head-dim column, accumulator rows = tokens = the PV operand k-order); K and V^T go
+//     to LDS as fragment images, S^T = K . Q^T keeps a query on a lane (row max / sum without shuffles), online softmax over 64-key steps,
+//     P^T re-used from the accumulator as the B operand of O^T += V^T . P^T.
+#include "common.h"
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+namespace {
+constexpr int VD = 192, VHID = 768, VH = 12, VTOK = 256;
+constexpr int FRAG = 1024, PANEL = 12 * FRAG, VECB = 2048;         // a panel = 12 operand fragments; 2 KiB of f32 vectors per slot
+constexpr int SLOTB = 2 * PANEL + VECB, NSLOT = 3, PIECES = SLOTB / 1024;   // 26 KiB per step, 26 DMA pieces
+constexpr int STEPS = 36;                                          // per block: 6 head pairs x 2 + 24 MLP chunks
+constexpr int KVB = 32768;                                         // K [2 heads][8 key blocks][1 KiB] | V^T [8 key blocks][2 k-steps][1 KiB]
+constexpr int LDS_BYTES = NSLOT * SLOTB + KVB;                     // 112,640 B
+
+__device__ __forceinline__ bf16x8 cvt8(const f32x16& x, int s, float mul = 1.f) {
+  bf16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (bf16)(x[8 * s + j] * mul);
+  return f;
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 o;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) o[t] = 0.f;
+  return o;
+}
+// exact-erf GELU (timm Mlp act, models_mae.py:172) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, three orders below the bf16
+// rounding of the result): 2 transcendental + ~12 plain instructions, no branches.  libm's erff is ~40 instructions with three
+// branches, and 16 of them per lane per MLP step made the step VALU-bound (1.50 -> see profiles/r03 notes).
+__device__ __forceinline__ float gelu_erf(float y) {
+  const float x = y * 0.70710678118654752f, ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float er = fmaf(-poly, __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f), 1.f);      // erf(|x|)
+  return 0.5f * y * (1.f + copysignf(er, x));
+}
+}  // namespace
+
+// x, out: [B, 256, 192] f32.  blob: nblk * 36 slots of SLOTB bytes (ldmae_amd/tokenizer/fused_encoder.py packs it; layout in the header).
+__global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, const char* __restrict__ blob,
+                                                               int nblk, float eps, float qscale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* kv = smem + NSLOT * SLOTB;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+  const int total = nblk * STEPS;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(void, smem));
+  const bool extra = wave < PIECES - 24;                            // waves 0, 1 carry the two vector pieces
+  auto issue = [&](int g) {
+    const char* src = blob + (size_t)g * SLOTB;
+    const unsigned dst = lds0 + (g % NSLOT) * SLOTB;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) glds16_s(src, (unsigned)((wave + 8 * i) * 1024 + lane * 16), dst + (wave + 8 * i) * 1024);
+    if (extra) glds16_s(src, (unsigned)((24 + wave) * 1024 + lane * 16), dst + (24 + wave) * 1024);
+  };
+  issue(0);
+  if (total > 1) issue(1);
+
+  // residual stream: xacc[d][4g + j] = x[token][32 d + 8 g + 4 h + j]   (C/D block d: rows = features 32d .. 32d+31, column = token)
+  f32x16 xacc[6];
+  {
+    const float* xr = x + ((size_t)blockIdx.x * VTOK + wave * 32 + r) * VD;
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = *(const float4*)(xr + 32 * d + 8 * g + 4 * h);
+        xacc[d][4 * g] = v.x; xacc[d][4 * g + 1] = v.y; xacc[d][4 * g + 2] = v.z; xacc[d][4 * g + 3] = v.w;
+      }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);          // the x loads have landed (and with them the two prologue slots): no compiler-counted wait inside the loop
+
+  bf16x8 xf[12];                               // LayerNorm output as operand fragments: k-step ks = features 16 ks .. 16 ks + 15
+  auto layernorm = [&](const float* w, const float* b, auto&& emit) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) s += xacc[d][t];
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.f / VD);
+    float v = 0.f;
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { const float c = xacc[d][t] - mean; v += c * c; }
+    v += __shfl_xor(v, 32, 64);
+    const float rstd = rsqrtf(v * (1.f / VD) + eps);
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 w4 = *(const float4*)(w + 32 * d + 8 * g + 4 * h), b4 = *(const float4*)(b + 32 * d + 8 * g + 4 * h);
+        emit(d, g, make_float4((xacc[d][4 * g] - mean) * rstd * w4.x + b4.x, (xacc[d][4 * g + 1] - mean) * rstd * w4.y + b4.y,
+                               (xacc[d][4 * g + 2] - mean) * rstd * w4.z + b4.z, (xacc[d][4 * g + 3] - mean) * rstd * w4.w + b4.w));
+      }
+      __builtin_amdgcn_sched_barrier(0);       // keep the 48 weight / bias reads from being hoisted in one batch (192 registers)
+    }
+  };
+  auto to_frags = [&](int d, int g, float4 y) {      // element 4g + j of block d -> fragment 2d + (g >> 1), slot 4 (g & 1) + j
+    const int f = 2 * d + (g >> 1), o = 4 * (g & 1);
+    xf[f][o] = (bf16)y.x; xf[f][o + 1] = (bf16)y.y; xf[f][o + 2] = (bf16)y.z; xf[f][o + 3] = (bf16)y.w;
+  };
+  auto add_rowvec = [&](const float* v) {             // xacc += v[feature] (proj / fc2 bias)
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *(const float4*)(v + 32 * d + 8 * g + 4 * h);
+        xacc[d][4 * g] += b4.x; xacc[d][4 * g + 1] += b4.y; xacc[d][4 * g + 2] += b4.z; xacc[d][4 * g + 3] += b4.w;
+      }
+  };
+  auto add_rows32 = [&](f32x16& a, const float* v) {   // a[4g + j] += v[8 g + 4 h + j]: per-row bias of one 32-row block
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b4 = *(const float4*)(v + 8 * g + 4 * h);
+      a[4 * g] += b4.x; a[4 * g + 1] += b4.y; a[4 * g + 2] += b4.z; a[4 * g + 3] += b4.w;
+    }
+  };
+
+  // one ring step: own pieces of slot g have landed (slot g + 1's may stay in flight); the barrier then makes everyone's visible and
+  // tells that every wave is done with slot g - 1, which the DMA of slot g + 2 overwrites.  Returns this lane's fragment base in slot g.
+  int g = 0;
+  auto next_slot = [&]() -> const char* {
+    if (g + 1 < total) {
+      if (extra) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g + 2 < total) issue(g + 2);
+    const char* slot = smem + (g % NSLOT) * SLOTB;
+    ++g;
+    return slot;
+  };
+  for (int blk = 0; blk < nblk; ++blk) {
+    // ================= attention branch: six pairs of heads, two ring steps each
+    for (int hp = 0; hp < 6; ++hp) {
+      bf16x8 qf[2];                            // this wave's queries of the head pair (operand fragments, scale * log2(e) folded in)
+      {
+        // ---- step A: q^T and k^T of heads 2hp, 2hp+1 (panel rows = Wqkv rows 32hp.. and 192 + 32hp..)
+        const char* slot = next_slot();
+        const char* p0 = slot + lane * 16;             // fragment i of panel 0: p0 + i * 1024
+        const char* p1 = p0 + PANEL;
+        const float* vec = (const float*)(slot + 2 * PANEL);   // [0..191] row vector #1, [192..383] #2, [384..511] misc
+        if (hp == 0) layernorm(vec, vec + VD, to_frags);
+        f32x16 qT = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+          qT = MFMA(*(const bf16x8*)(p0 + ks * FRAG), xf[ks], qT);
+          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // at most 4 weight fragments in flight
+        }
+        add_rows32(qT, vec + 384);
+        // a lane's elements 8e .. 8e+7 are head e's 8 head-dim values of its half: exactly the 16-B operand fragment of S^T = K . Q^T
+        // (both operands in the same implicit order of the head dim, which a dot product does not care about)
+        qf[0] = cvt8(qT, 0, qscale); qf[1] = cvt8(qT, 1, qscale);
+        f32x16 kT = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+          kT = MFMA(*(const bf16x8*)(p1 + ks * FRAG), xf[ks], kT);
+          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        add_rows32(kT, vec + 416);
+        *(bf16x8*)(kv + (0 * 8 + wave) * FRAG + lane * 16) = cvt8(kT, 0);
+        *(bf16x8*)(kv + (1 * 8 + wave) * FRAG + lane * 16) = cvt8(kT, 1);
+      }
+      {
+        // ---- step B: v (un-transposed: rows = tokens, columns = 2 heads x 16), attention of both heads, proj into the residual stream
+        const char* slot = next_slot();
+        const char* p0 = slot + lane * 16;
+        const char* p1 = p0 + PANEL;
+        const float* vec = (const float*)(slot + 2 * PANEL);
+        f32x16 v = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) {
+          v = MFMA(xf[ks], *(const bf16x8*)(p0 + ks * FRAG), v);
+          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        const float bv = vec[384 + r];
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) v[tt] += bv;
+        // V^T image: [key block = wave][k-step s][lane = (h, column d)]: elements 8s .. 8s+7 are tokens in the accumulator k-order
+        *(bf16x8*)(kv + 16384 + (wave * 2 + 0) * FRAG + lane * 16) = cvt8(v, 0);
+        *(bf16x8*)(kv + 16384 + (wave * 2 + 1) * FRAG + lane * 16) = cvt8(v, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // K (written in step A) and V^T of all 256 tokens are in LDS
+        bf16x8 of[2];                                        // o^T of the two heads as proj operand fragments
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          // two passes over the 8 key blocks (a score product is ONE MFMA at head dim 16, cheaper than an online rescale of O):
+          // pass 1 finds the row maximum; pass 2 starts every score chain from -max, so p = exp2(score) is one instruction
+          f32x16 mv = MFMA(*(const bf16x8*)(kv + (e * 8) * FRAG + lane * 16), qf[e], zero16());
+#pragma unroll
+          for (int kb = 1; kb < 8; ++kb) {
+            const f32x16 sc = MFMA(*(const bf16x8*)(kv + (e * 8 + kb) * FRAG + lane * 16), qf[e], zero16());
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) mv[tt] = fmaxf(mv[tt], sc[tt]);
+          }
+          float mx = mv[0];
+#pragma unroll
+          for (int tt = 1; tt < 16; ++tt) mx = fmaxf(mx, mv[tt]);
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          f32x16 nm;
+#pragma unroll
+          for (int tt = 0; tt < 16; ++tt) nm[tt] = -mx;
+          f32x16 o = zero16();
+          float l = 0.f;
+#pragma unroll
+          for (int kb = 0; kb < 8; ++kb) {
+            f32x16 sc = MFMA(*(const bf16x8*)(kv + (e * 8 + kb) * FRAG + lane * 16), qf[e], nm);
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) { sc[tt] = __builtin_amdgcn_exp2f(sc[tt]); l += sc[tt]; }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+              o = MFMA(*(const bf16x8*)(kv + 16384 + (kb * 2 + s2) * FRAG + lane * 16), cvt8(sc, s2), o);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          l += __shfl_xor(l, 32, 64);
+          // rows 16e .. 16e+15 of o^T (elements 8e .. 8e+7) belong to head e; the other half multiplied the other head's V: dropped
+          of[e] = cvt8(o, e, 1.f / l);
+        }
+        // proj: x^T += Wp[:, 32hp .. 32hp+31] . o_pair^T   (panel 1: 6 feature blocks x 2 k-steps; k-step e = head e of the pair)
+#pragma unroll
+        for (int fb = 0; fb < 6; ++fb) {
+          xacc[fb] = MFMA(*(const bf16x8*)(p1 + (2 * fb) * FRAG), of[0], xacc[fb]);
+          xacc[fb] = MFMA(*(const bf16x8*)(p1 + (2 * fb + 1) * FRAG), of[1], xacc[fb]);
+          if (fb & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (hp == 5) add_rowvec(vec);                        // + proj bias, once per block
+      }
+    }
+    // ================= MLP: 24 chunks of 32 hidden units (panel 0 = fc1 rows, panel 1 = fc2 columns of the same units)
+    for (int c = 0; c < 24; ++c) {
+      const char* slot = next_slot();
+      const char* p0 = slot + lane * 16;
+      const char* p1 = p0 + PANEL;
+      const float* vec = (const float*)(slot + 2 * PANEL);
+      if (c == 0) layernorm(vec, vec + VD, to_frags);
+      f32x16 hT = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 12; ++ks) {
+        hT = MFMA(*(const bf16x8*)(p0 + ks * FRAG), xf[ks], hT);
+        if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      add_rows32(hT, vec + 384);
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt) {
+        hT[tt] = gelu_erf(hT[tt]);
+        if ((tt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      const bf16x8 hf0 = cvt8(hT, 0), hf1 = cvt8(hT, 1);
+#pragma unroll
+      for (int fb = 0; fb < 6; ++fb) {
+        xacc[fb] = MFMA(*(const bf16x8*)(p1 + (2 * fb) * FRAG), hf0, xacc[fb]);
+        xacc[fb] = MFMA(*(const bf16x8*)(p1 + (2 * fb + 1) * FRAG), hf1, xacc[fb]);
+        if (fb & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (c == 23) add_rowvec(vec);                          // + fc2 bias
+    }
+  }
+  // closing LayerNorm (models_mae.py:369, 521): its weight / bias ride in the second-to-last slot, which nothing has overwritten
+  const float* nv = (const float*)(smem + ((total - 2) % NSLOT) * SLOTB + 2 * PANEL);
+  float* orow = out + ((size_t)blockIdx.x * VTOK + wave * 32 + r) * VD;
+  layernorm(nv, nv + VD, [&](int d, int g, float4 y) { *(float4*)(orow + 32 * d + 8 * g + 4 * h) = y; });
+}
+
+extern "C" long ldmae_vmae_encoder_blob_bytes(int nblocks) { return (long)nblocks * STEPS * SLOTB; }
+
+extern "C" int ldmae_vmae_encoder_fwd(const float* x, float* out, const void* blob, int B, int tokens, int dim, int heads, int hidden, int nblocks,
+                                      float eps, void* stream) {
+  LDMAE_REQUIRE(x && out && blob && B > 0, "vmae_encoder_fwd: null pointer or empty batch");
+  LDMAE_REQUIRE(tokens == VTOK && dim == VD && heads == VH && hidden == VHID,
+                "vmae_encoder_fwd: fused kernel is built for %d tokens x width %d, %d heads, hidden %d (got %d, %d, %d, %d): use the per-layer entry points",
+                VTOK, VD, VH, VHID, tokens, dim, heads, hidden);
+  LDMAE_REQUIRE(nblocks >= 1, "vmae_encoder_fwd: nblocks=%d", nblocks);
+  LDMAE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)blob & 15) == 0, "vmae_encoder_fwd: pointers must be 16-B aligned");
+  hipFuncSetAttribute((const void*)vmae_encoder_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  const float qscale = 0.25f * 1.4426950408889634f;          // head_dim^-0.5 (models_mae.py:123) * log2(e)
+  hipLaunchKernelGGL(vmae_encoder_fwd_kernel, dim3(B), dim3(512), LDS_BYTES, as_stream(stream), x, out, (const char*)blob, nblocks, eps, qscale);
+  LDMAE_CHECK_LAUNCH("vmae_encoder_fwd");
+  return LDMAE_OK;
+}

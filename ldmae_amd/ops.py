@@ -477,6 +477,19 @@ def scatter_rows(dout, ids, Lq):
     return dx
 
 
+def vmae_encoder_fwd(x, blob, nblocks, dim, heads, hidden, eps=1e-6):
+    """The whole VMAE encoder stack (blocks + closing LayerNorm) in one launch: x [B, tokens, dim] f32 -> same shape (inference, bf16 MFMA,
+    f32 residual stream in registers).  `blob`: weights packed by tokenizer/fused_encoder.py."""
+    B, T, D = x.shape
+    x = _c(x.float())
+    need = L.load().ldmae_vmae_encoder_blob_bytes(nblocks)
+    if blob.numel() * blob.element_size() != need:
+        raise RuntimeError(f"vmae_encoder_fwd: weight blob has {blob.numel() * blob.element_size()} bytes, the kernel expects {need}")
+    out = torch.empty_like(x)
+    call("ldmae_vmae_encoder_fwd", ptr(x), ptr(out), ptr(blob), B, T, D, heads, hidden, nblocks, float(eps), stream())
+    return out
+
+
 def heads_split(qkv, B, N, H, hd):
     """[B,N,3,H,hd] -> q,k,v [B,H,N,hd] (no norm / rope)."""
     q = torch.empty(B, H, N, hd, dtype=qkv.dtype, device=qkv.device)

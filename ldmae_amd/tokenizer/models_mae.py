@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from ldmae_amd import ops
 from ldmae_amd.models.lightningdit import PatchEmbed, _act_dtype, _wcopies
+from . import fused_encoder
 from .util.misc import DiagonalGaussianDistribution
 from .util.pos_embed import get_2d_sincos_pos_embed
 
@@ -285,6 +286,7 @@ class MaskedAutoencoderViT(nn.Module):
             self.decoder_pred = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
         self.norm_pix_loss = norm_pix_loss
         self.precision = None
+        self.fused_encoder = True          # False: always the per-layer kernels (A/B and parity tests)
         self.initialize_weights()
 
     def initialize_weights(self):
@@ -356,6 +358,11 @@ class MaskedAutoencoderViT(nn.Module):
         with torch.autocast(device_type="cuda", enabled=False):
             x = self._embed(x, dtype)
             x, mask, ids_restore = self.random_masking(x, mask_ratio, noise)
+            # inference in bf16 on the shipped geometry with 256 kept tokens (mask_ratio 0.75): the whole stack + the closing LayerNorm
+            # is ONE kernel, one workgroup per image, the residual stream in registers (csrc/vmae_fused.hip)
+            if (self.fused_encoder and dtype == torch.bfloat16 and not torch.is_grad_enabled() and fused_encoder.supported(self, x)
+                    and not any(not self._chain_ok(blk) for blk in self.blocks)):
+                return fused_encoder.encoder_forward(self, x), mask, ids_restore
             for blk in self.blocks:
                 blk.precision = dtype
                 x = blk(x, self._chain_ok(blk))

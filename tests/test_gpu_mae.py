@@ -225,3 +225,46 @@ def test_loss_scaler_protocol_skips_non_finite_steps():
     (lin(x).pow(2).mean() * sc.scale).backward()
     sc.step(opt)
     assert sc.scale == 1024.0                      # two clean steps: growth
+
+
+def test_fused_encoder_kernel_matches_per_layer_path(golden):
+    """csrc/vmae_fused.hip (the whole encoder stack in one launch, one workgroup per image) against the per-layer bf16 kernels and the f32
+    path, on the reference-pinned weights / images / masking noise of mae.npz at mask_ratio 0.75 (256 kept tokens)."""
+    from ldmae_amd.tokenizer import fused_encoder
+    g = golden("mae")
+    cfg = omae.MAEConfig()
+    m = build({}, full_sd(cfg), 256)
+    imgs = det_randn("mae_img", (5, 3, 256, 256), 2).clamp(-1, 1).cuda()
+    noise = torch.rand(5, 1024, generator=torch.Generator().manual_seed(3)).cuda()
+    calls = []
+    orig = fused_encoder.encoder_forward
+    fused_encoder.encoder_forward = lambda model, x: (calls.append(tuple(x.shape)), orig(model, x))[1]
+    try:
+        with torch.no_grad():
+            lat32, mask, _ = m.forward_encoder(imgs, 0.75, noise=noise)                       # f32: never the fused kernel
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                fused, mask_f, _ = m.forward_encoder(imgs, 0.75, noise=noise)
+                m.fused_encoder = False
+                layered, _, _ = m.forward_encoder(imgs, 0.75, noise=noise)
+                m.fused_encoder = True
+                other, _, _ = m.forward_encoder(imgs, 0.5, noise=noise)                       # 512 kept tokens: per-layer path
+        assert calls == [(5, 256, 192)] and other.shape[1] == 512
+        assert fused.dtype == torch.float32 and torch.equal(mask_f, mask)
+        assert rel_err(fused.cpu(), lat32.cpu()) < 3e-2 and rel_err(layered.cpu(), lat32.cpu()) < 3e-2
+        assert rel_err(fused.cpu(), layered.cpu()) < 2e-2
+        # every image is independent (one workgroup each): a batch of one gives the same bits
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            one, _, _ = m.forward_encoder(imgs[3:4], 0.75, noise=noise[3:4])
+        assert torch.equal(one[0], fused[3])
+        # the packed weights follow the parameters
+        with torch.no_grad():
+            m.blocks[7].mlp.fc2.weight.mul_(1.5)          # (a uniform bias shift would be removed again by the next LayerNorm)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                moved, _, _ = m.forward_encoder(imgs, 0.75, noise=noise)
+        assert rel_err(moved.cpu(), fused.cpu()) > 1e-3
+        # under autograd the encoder stays on the differentiable per-layer path
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lat_g, _, _ = m.forward_encoder(imgs[:1], 0.75, noise=noise[:1])
+        assert lat_g.requires_grad and len(calls) == 3
+    finally:
+        fused_encoder.encoder_forward = orig
