@@ -25,6 +25,9 @@
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
+#ifndef VF_DBG
+#define VF_DBG 0      // ablation builds for tools/ only: 1 = no GELU arithmetic, 2 = no softmax / PV, 3 = no LDS-DMA waits (stale weights), 4 = no MLP
+#endif
 namespace {
 constexpr int VD = 192, VHID = 768, VH = 12, VTOK = 256;
 constexpr int FRAG = 1024, PANEL = 12 * FRAG, VECB = 2048;         // a panel = 12 operand fragments; 2 KiB of f32 vectors per slot
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
         bf16x8 of[2];                                        // o^T of the two heads as proj operand fragments
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
+          if (VF_DBG == 2) { of[e] = qf[e]; continue; }
           // two passes over the 8 key blocks (a score product is ONE MFMA at head dim 16, cheaper than an online rescale of O):
           // pass 1 finds the row maximum; pass 2 starts every score chain from -max, so p = exp2(score) is one instruction
           f32x16 mv = MFMA(*(const bf16x8*)(kv + (e * 8) * FRAG + lane * 16), qf[e], zero16());
@@ -250,6 +254,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
     // ================= MLP: 24 chunks of 32 hidden units (panel 0 = fc1 rows, panel 1 = fc2 columns of the same units)
     for (int c = 0; c < 24; ++c) {
       const char* slot = next_slot();
+      if (VF_DBG == 4) continue;
       const char* p0 = slot + lane * 16;
       const char* p1 = p0 + PANEL;
       const float* vec = (const float*)(slot + 2 * PANEL);
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
       add_rows32(hT, vec + 384);
 #pragma unroll
       for (int tt = 0; tt < 16; ++tt) {
-        hT[tt] = gelu_erf(hT[tt]);
+        if (VF_DBG != 1) hT[tt] = gelu_erf(hT[tt]);
         if ((tt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       const bf16x8 hf0 = cvt8(hT, 0), hf1 = cvt8(hT, 1);
