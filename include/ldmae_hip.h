@@ -179,6 +179,12 @@ int ldmae_ema_only(float* ema, const float* p, long n, double ema_decay, void* s
  * index first).  ids_restore i64 [N,L], mask f32 [N,L], ids_keep i64 [N,keep]. L <= 4096. */
 int ldmae_random_masking(const float* noise, long long* ids_restore, float* mask, long long* ids_keep, int N, int L, int keep,
                          void* stream);
+/* Patch-embed operand of the kept tokens only (inference; the mask depends on the noise alone, :472-497, so it can be applied BEFORE the
+ * embedding conv of :502): tok [N*keep, C*p*p] (dtype tok_dtype) = the pixels of patch ids[n,j] of img [N,C,S,S] in the conv weight's
+ * (c, i, j) order; posg [N*keep, D] f32 = pos[ids[n,j], :].  ldmae_gemm_nt(EPI_GATE_RES, xin = posg, gate = NULL) then gives the same bits
+ * as embedding every patch and gathering. */
+int ldmae_patch_gather(int tok_dtype, const float* img, const long long* ids, const float* pos, void* tok, float* posg, int N, int keep,
+                       int C, int S, int p, int D, void* stream);
 /* out[n,j,:] = x[n, ids[n,j], :]  (torch.gather on dim 1, :486); bwd scatters (ids unique per n) */
 int ldmae_gather_rows(const float* x, const long long* ids, float* out, int N, int L, int keep, int D, void* stream);
 int ldmae_scatter_rows(const float* dout, const long long* ids, float* dx, int N, int L, int keep, int D, void* stream);

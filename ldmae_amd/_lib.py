@@ -63,6 +63,7 @@ SIGNATURES = {
     "ldmae_adamw_ema": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _d, _d, _d, _d, _d, _d, _d, _vp]),
     "ldmae_ema_only": (_i, [_vp, _vp, _l, _d, _vp]),
     "ldmae_random_masking": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ldmae_patch_gather": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ldmae_gather_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_scatter_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_vmae_encoder_blob_bytes": (_l, [_i]),

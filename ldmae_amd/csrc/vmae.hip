@@ -66,6 +66,31 @@ __global__ void scatter_rows_kernel(const float* __restrict__ dout, const long l
   float4* d = (float4*)(dx + ((size_t)n * L + dst) * D);
   for (int i = threadIdx.x; i < D / 4; i += blockDim.x) d[i] = s[i];
 }
+// Patch-embed input of the KEPT tokens only (inference: the mask depends on the noise alone, so masking can run before the embedding and the
+// conv GEMM sees a quarter of the patches at mask_ratio 0.75): tok[n*keep + j, (c, i, jj)] = img[n, c, ph*p + i, pw*p + jj] for patch
+// ids[n, j] = ph * grid + pw, in the conv weight's (c, i, jj) order (models_mae.py:342 PatchEmbed), and posg[n*keep + j, :] = pos[ids[n, j], :].
+template <typename T>
+__global__ void patch_gather_kernel(const float* __restrict__ img, const long long* __restrict__ ids, const float* __restrict__ pos,
+                                    T* __restrict__ tok, float* __restrict__ posg, int keep, int C, int S, int p, int D) {
+  const int n = blockIdx.y, j = blockIdx.x, grid = S / p, K = C * p * p;
+  const int idx = (int)ids[(size_t)n * keep + j], ph = idx / grid, pw = idx % grid;
+  const size_t row = (size_t)n * keep + j;
+  for (int e = threadIdx.x; e < K; e += blockDim.x) {
+    const int c = e / (p * p), i = (e / p) % p, jj = e % p;
+    tok[row * K + e] = from_f<T>(img[(((size_t)n * C + c) * S + ph * p + i) * S + pw * p + jj]);
+  }
+  for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) *(float4*)(posg + row * D + d) = *(const float4*)(pos + (size_t)idx * D + d);
+}
+extern "C" int ldmae_patch_gather(int tok_dtype, const float* img, const long long* ids, const float* pos, void* tok, float* posg, int N, int keep,
+                                  int C, int S, int p, int D, void* stream) {
+  LDMAE_REQUIRE(img && ids && pos && tok && posg && N > 0 && keep > 0, "patch_gather: null pointer or empty input");
+  LDMAE_REQUIRE(p > 0 && S % p == 0 && D % 4 == 0, "patch_gather: image size %d must be a multiple of the patch size %d, D=%d of 4", S, p, D);
+  if (tok_dtype == LDMAE_BF16) hipLaunchKernelGGL(patch_gather_kernel<bf16>, dim3(keep, N), dim3(64), 0, as_stream(stream), img, ids, pos, (bf16*)tok, posg, keep, C, S, p, D);
+  else hipLaunchKernelGGL(patch_gather_kernel<float>, dim3(keep, N), dim3(64), 0, as_stream(stream), img, ids, pos, (float*)tok, posg, keep, C, S, p, D);
+  LDMAE_CHECK_LAUNCH("patch_gather");
+  return LDMAE_OK;
+}
+
 extern "C" int ldmae_gather_rows(const float* x, const long long* ids, float* out, int N, int L, int keep, int D, void* stream) {
   LDMAE_REQUIRE(x && ids && out && N > 0 && L > 0 && keep > 0 && D % 4 == 0, "gather_rows: bad arguments (D=%d multiple of 4)", D);
   hipLaunchKernelGGL(gather_rows_kernel, dim3(keep, N), dim3(64), 0, as_stream(stream), x, ids, out, L, keep, D);

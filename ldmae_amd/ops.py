@@ -462,6 +462,19 @@ def random_masking(noise, keep):
     return ids_keep, mask, ids_restore
 
 
+def patch_embed_kept(img, ids_keep, pos, w2d, bias, patch, dtype):
+    """Patch embedding of the kept tokens only: img [N,C,S,S] f32, ids_keep [N,keep] i64, pos [L,D] f32, w2d [D, C*p*p] f32 master weight
+    -> [N, keep, D] f32 = conv(img)[kept] + bias + pos[kept].  Same bits as embedding all patches (gemm_nt_pos) and gathering."""
+    N, C, S, _ = img.shape
+    keep, D = ids_keep.shape[1], w2d.shape[0]
+    tok = torch.empty(N * keep, C * patch * patch, dtype=dtype, device=img.device)
+    posg = torch.empty(N * keep, D, dtype=torch.float32, device=img.device)
+    call("ldmae_patch_gather", dt(dtype), ptr(_c(img.float())), ptr(ids_keep), ptr(pos), ptr(tok), ptr(posg), N, keep, C, S, patch, D, stream())
+    wb = w2d if dtype == torch.float32 else cached_weight_copy(w2d, dtype)
+    out, _ = gemm_nt_gate_res(tok, wb, bias, posg, None, keep, save_y=False, xout=posg)
+    return out.view(N, keep, D)
+
+
 def gather_rows(x, ids):
     N, Lq, D = x.shape
     keep = ids.shape[1]

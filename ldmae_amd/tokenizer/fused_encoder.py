@@ -11,6 +11,8 @@ vectors (512 floats): [0:192] row vector #1, [192:384] #2, [384:512] misc -- see
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from ldmae_amd import ops
@@ -76,11 +78,11 @@ def pack_encoder(blocks, final_norm) -> torch.Tensor:
     return blob
 
 
-def supported(model, x) -> bool:
+def supported(model, tokens: int, dim: int) -> bool:
     """The fused kernel covers exactly the shipped encoder geometry on a 256-token sequence (mask_ratio 0.75 of 1024 patches)."""
     b0 = model.blocks[0]
-    return (x.dim() == 3 and x.shape[1] == TOKENS and x.shape[2] == DIM and b0.attn.num_heads == HEADS and
-            b0.mlp.fc1.weight.shape[0] == HIDDEN and isinstance(model.norm, torch.nn.LayerNorm) and
+    return (tokens == TOKENS and dim == DIM and b0.attn.num_heads == HEADS and b0.mlp.fc1.weight.shape[0] == HIDDEN and
+            isinstance(model.norm, torch.nn.LayerNorm) and
             all(abs(blk.norm1.eps - model.norm.eps) < 1e-12 and abs(blk.norm2.eps - model.norm.eps) < 1e-12 for blk in model.blocks))
 
 
@@ -93,10 +95,12 @@ def encoder_blob(model) -> torch.Tensor:
     ps = [p for blk in model.blocks for p in blk.parameters()] + list(model.norm.parameters())
     stamp = (ops.WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for p in ps)
     hit = _CACHE.get(id(model))
-    if hit is not None and hit[0] == stamp:
-        return hit[1]
+    if hit is not None and hit[0]() is model and hit[1] == stamp:      # the weak reference guards against a recycled id()
+        return hit[2]
+    for k in [k for k, v in _CACHE.items() if v[0]() is None]:         # models that are gone: drop their 11 MB blobs
+        del _CACHE[k]
     blob = pack_encoder(model.blocks, model.norm)
-    _CACHE[id(model)] = (stamp, blob)
+    _CACHE[id(model)] = (weakref.ref(model), stamp, blob)
     return blob
 
 

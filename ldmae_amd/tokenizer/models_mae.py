@@ -356,13 +356,22 @@ class MaskedAutoencoderViT(nn.Module):
         """:499-523."""
         dtype = _act_dtype(self.precision)
         with torch.autocast(device_type="cuda", enabled=False):
+            # inference in bf16 on the shipped geometry with 256 kept tokens (mask_ratio 0.75): mask FIRST (it depends on the noise alone),
+            # embed only the kept quarter of the patches, then the whole stack + the closing LayerNorm as ONE kernel, one workgroup per
+            # image, the residual stream in registers (csrc/vmae_fused.hip)
+            pe = self.patch_embed
+            L = pe.num_patches
+            keep = int(L * (1 - mask_ratio))
+            if (self.fused_encoder and dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.dim() == 4 and
+                    fused_encoder.supported(self, keep, self.pos_embed.shape[-1]) and all(self._chain_ok(blk) for blk in self.blocks)):
+                if noise is None:
+                    noise = torch.rand(x.shape[0], L, device=x.device)             # the draw random_masking makes (:480)
+                ids_keep, mask, ids_restore = ops.random_masking(noise.float().contiguous(), keep)
+                w2d = pe.proj.weight.view(pe.proj.weight.shape[0], -1)
+                xk = ops.patch_embed_kept(x, ids_keep, self.pos_embed[0], w2d, pe.proj.bias, pe.patch_size[0], dtype)
+                return fused_encoder.encoder_forward(self, xk), mask, ids_restore
             x = self._embed(x, dtype)
             x, mask, ids_restore = self.random_masking(x, mask_ratio, noise)
-            # inference in bf16 on the shipped geometry with 256 kept tokens (mask_ratio 0.75): the whole stack + the closing LayerNorm
-            # is ONE kernel, one workgroup per image, the residual stream in registers (csrc/vmae_fused.hip)
-            if (self.fused_encoder and dtype == torch.bfloat16 and not torch.is_grad_enabled() and fused_encoder.supported(self, x)
-                    and not any(not self._chain_ok(blk) for blk in self.blocks)):
-                return fused_encoder.encoder_forward(self, x), mask, ids_restore
             for blk in self.blocks:
                 blk.precision = dtype
                 x = blk(x, self._chain_ok(blk))

@@ -268,3 +268,22 @@ def test_fused_encoder_kernel_matches_per_layer_path(golden):
         assert lat_g.requires_grad and len(calls) == 3
     finally:
         fused_encoder.encoder_forward = orig
+
+
+def test_patch_embed_of_kept_tokens_equals_embed_then_gather():
+    """Inference masks first and embeds the kept quarter of the patches (ldmae_patch_gather + the gated-residual GEMM epilogue with the
+    gathered pos rows as residual): same bits as the reference order, embed every patch then gather (models_mae.py:502-510)."""
+    from ldmae_amd import ops
+    cfg = omae.MAEConfig()
+    m = build({}, full_sd(cfg), 256)
+    imgs = det_randn("mae_img", (3, 3, 256, 256), 5).clamp(-1, 1).cuda()
+    noise = torch.rand(3, 1024, generator=torch.Generator().manual_seed(4)).cuda()
+    pe = m.patch_embed
+    w2d = pe.proj.weight.view(192, -1)
+    for dtype in (torch.bfloat16, torch.float32):
+        with torch.no_grad():
+            full = m._embed(imgs, dtype)
+            ids_keep, mask, ids_restore = ops.random_masking(noise, 256)
+            ref = ops.gather_rows(full.contiguous(), ids_keep)
+            got = ops.patch_embed_kept(imgs, ids_keep, m.pos_embed[0], w2d, pe.proj.bias, 8, dtype)
+        assert got.shape == ref.shape == (3, 256, 192) and torch.equal(got, ref), dtype
