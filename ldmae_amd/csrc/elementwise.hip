@@ -69,6 +69,8 @@ __device__ __forceinline__ float4 mul_rn(float4 a, float4 b) {
 }
 
 // ------------------------------------------------------------------ RMSNorm + modulate
+// (Round 3: a variant with all four rows of a wave requested up front -- 12 loads in flight per lane, 100 VGPRs -- measured 3 % SLOWER
+// than this form at 54 VGPRs: here the waves in flight carry the bandwidth, 5.2 TB/s.)
 template <int NCH, typename OutT>
 __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ shift, const float* __restrict__ scale,
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __res
 // partials sum dy -- instead of being re-read by a separate gate_bwd pass (805 MB per block).  Same arithmetic, same partial layout
 // and same summation order as gate_bwd_kernel.
 struct GateBwdArgs { const void* y; const float* gate; int gate_ld; void* dy; float* Pg; float* Pb; int dx_overwrite; };
-template <int NCH, typename T, bool GATE>
+template <int NCH, typename T, bool GATE, bool FULL = false>
 __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x,
                                                               const float* __restrict__ w, const float* __restrict__ scale, int mod_ld,
                                                               const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ P,
@@ -147,6 +149,53 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
     a_sh[i] = a_sc[i] = a_w[i] = f4(0.f);
     if constexpr (GATE) a_g[i] = a_b[i] = f4(0.f);
   }
+  if constexpr (FULL) {
+    // D == NCH * 256 (host): no per-chunk guards, and everything a row needs from HBM -- dout, x, the old dx and (GATE) y -- is requested
+    // before the first use: 4 * NCH loads in flight per lane.  (The guarded form below compiles to one branch + `s_waitcnt vmcnt(0)` per
+    // chunk: 2 loads in flight.)  Per-element arithmetic and summation order are those of the guarded form.
+    for (int r = wave; r < rows_per_wg; r += 4) {
+      const int m = m_base + r;
+      if (m >= M) break;
+      const size_t ro = (size_t)m * D + 4 * lane;
+      float4 g[NCH], nv[NCH], dold[NCH], yv[GATE ? NCH : 1];
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) { g[i] = load4<T>(dout + ro + 256 * i); nv[i] = *(const float4*)(x + ro + 256 * i); }
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        dold[i] = ga.dx_overwrite ? f4(0.f) : *(const float4*)(dx + ro + 256 * i);
+        if constexpr (GATE) yv[i] = load4<T>(gy + ro + 256 * i);
+      }
+      const float rs = rstd[m];
+      float4 dn[NCH];
+      float dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        const float4 wc = GATE ? *(const float4*)(cw + 4 * c) : wv[i], sc = GATE ? *(const float4*)(cs + 4 * c) : sc1[i];
+        nv[i] = nv[i] * rs;
+        const float4 dy = g[i] * sc;
+        a_sh[i] = a_sh[i] + g[i];
+        a_sc[i] = a_sc[i] + g[i] * (nv[i] * wc);
+        a_w[i] = a_w[i] + dy * nv[i];
+        dn[i] = dy * wc;
+        dot += hsum(dn[i] * nv[i]);
+      }
+      dot = wave_sum(dot) / (float)D;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        const float4 d0 = (dn[i] - nv[i] * dot) * rs;
+        const float4 gn = ga.dx_overwrite ? d0 : dold[i] + d0;
+        *(float4*)(dx + ro + 256 * i) = gn;
+        if constexpr (GATE) {
+          a_g[i] = a_g[i] + gn * yv[i];
+          const float4 d = mul_rn(gn, *(const float4*)(cg + 4 * c));
+          store4<T>(gdy + ro + 256 * i, d);
+          a_b[i] = a_b[i] + make_float4(to_f<T>(from_f<T>(d.x)), to_f<T>(from_f<T>(d.y)), to_f<T>(from_f<T>(d.z)), to_f<T>(from_f<T>(d.w)));
+        }
+      }
+    }
+  } else
   for (int r = wave; r < rows_per_wg; r += 4) {
     const int m = m_base + r;
     if (m >= M) break;
@@ -286,9 +335,12 @@ static int rmsnorm_modulate_bwd_core(int dtype, const void* dout, const float* x
   if (gate) { ga = *gate; ga.Pg = gws; ga.Pb = gws + (size_t)G * D; }
   ga.dx_overwrite = beta_x == 0.f;
 #define LAUNCH(T, GATE) DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NCH, T, GATE>), dim3(G), dim3(256), lds, st, (const T*)dout, x, w, scale, mod_ld, rstd, dx_accum, P, M, D, rows_per_batch, rw, ga))
-  if (dtype == LDMAE_BF16) { if (gate) { LAUNCH(bf16, true); } else { LAUNCH(bf16, false); } }
+#define LAUNCH_FULL(T, GATE) DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NCH, T, GATE, true>), dim3(G), dim3(256), lds, st, (const T*)dout, x, w, scale, mod_ld, rstd, dx_accum, P, M, D, rows_per_batch, rw, ga))
+  if (dtype == LDMAE_BF16 && D % 256 == 0) { if (gate) { LAUNCH_FULL(bf16, true); } else { LAUNCH_FULL(bf16, false); } }
+  else if (dtype == LDMAE_BF16) { if (gate) { LAUNCH(bf16, true); } else { LAUNCH(bf16, false); } }
   else { if (gate) { LAUNCH(float, true); } else { LAUNCH(float, false); } }
 #undef LAUNCH
+#undef LAUNCH_FULL
   LDMAE_CHECK_LAUNCH("rmsnorm_modulate_bwd");
   hipLaunchKernelGGL(mod_partials_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, P, D, gps, dshift, dscale, dmod_ld, dwb);
   group_reduce(dwb, D, 1, D, B, dw, D, beta_w, st);
@@ -366,6 +418,57 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const T* __restric
       store4<T>(k + dst, rope_apply((kv * rk) * wkv, cs, sn));
       if (v) store4<T>(v + dst, vv);            // v == NULL: attention reads v from the packed qkv itself (ldmae_attention_fwd_pv)
     }
+  }
+}
+
+// bf16, head dims 64 / 128: 8 elements = 16 B per lane and access (the 4-element form above moves 8 B per lane for bf16: half-width
+// requests at 0.54-0.70x the 16-B rate, MI355X_MICROARCH), 8 / 16 lanes per item, two items in flight per lane group.
+template <int LPR>
+__global__ __launch_bounds__(256) void qknorm_rope_fwd8_kernel(const bf16* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
+                                                               const float* __restrict__ cosT, const float* __restrict__ sinT, bf16* __restrict__ q,
+                                                               bf16* __restrict__ k, int B, int N, int H, float eps) {
+  constexpr int hd = LPR * 8;
+  const int sub = threadIdx.x % LPR, c8 = sub * 8;
+  const long items = (long)B * N * H;
+  const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / LPR, gstride = (long)gridDim.x * 256 / LPR;
+  float wqv[8], wkv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { wqv[j] = wq[c8 + j]; wkv[j] = wk[c8 + j]; }
+  auto one = [&](long it, bf16x8 qi, bf16x8 ki) {
+    const int h = it % H, n = (it / H) % N, b = it / ((long)H * N);
+    const float4 c0 = *(const float4*)(cosT + (size_t)n * hd + c8), c1 = *(const float4*)(cosT + (size_t)n * hd + c8 + 4);
+    const float4 s0 = *(const float4*)(sinT + (size_t)n * hd + c8), s1 = *(const float4*)(sinT + (size_t)n * hd + c8 + 4);
+    float qv[8], kv[8], sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { qv[j] = (float)qi[j]; kv[j] = (float)ki[j]; }
+    // same association as the 4-element form: (x0^2 + x1^2) + (x2^2 + x3^2) per 4-chunk, chunks summed by the lane-group butterfly
+    sq = ((qv[0] * qv[0] + qv[1] * qv[1]) + (qv[2] * qv[2] + qv[3] * qv[3])) + ((qv[4] * qv[4] + qv[5] * qv[5]) + (qv[6] * qv[6] + qv[7] * qv[7]));
+    sk = ((kv[0] * kv[0] + kv[1] * kv[1]) + (kv[2] * kv[2] + kv[3] * kv[3])) + ((kv[4] * kv[4] + kv[5] * kv[5]) + (kv[6] * kv[6] + kv[7] * kv[7]));
+    const float rq = rsqrtf(group_sum<LPR>(sq) / (float)hd + eps), rk = rsqrtf(group_sum<LPR>(sk) / (float)hd + eps);
+    const float4 a0 = rope_apply(make_float4(qv[0] * rq * wqv[0], qv[1] * rq * wqv[1], qv[2] * rq * wqv[2], qv[3] * rq * wqv[3]), c0, s0);
+    const float4 a1 = rope_apply(make_float4(qv[4] * rq * wqv[4], qv[5] * rq * wqv[5], qv[6] * rq * wqv[6], qv[7] * rq * wqv[7]), c1, s1);
+    const float4 b0 = rope_apply(make_float4(kv[0] * rk * wkv[0], kv[1] * rk * wkv[1], kv[2] * rk * wkv[2], kv[3] * rk * wkv[3]), c0, s0);
+    const float4 b1 = rope_apply(make_float4(kv[4] * rk * wkv[4], kv[5] * rk * wkv[5], kv[6] * rk * wkv[6], kv[7] * rk * wkv[7]), c1, s1);
+    bf16x8 qo, ko;
+    qo[0] = (bf16)a0.x; qo[1] = (bf16)a0.y; qo[2] = (bf16)a0.z; qo[3] = (bf16)a0.w; qo[4] = (bf16)a1.x; qo[5] = (bf16)a1.y; qo[6] = (bf16)a1.z; qo[7] = (bf16)a1.w;
+    ko[0] = (bf16)b0.x; ko[1] = (bf16)b0.y; ko[2] = (bf16)b0.z; ko[3] = (bf16)b0.w; ko[4] = (bf16)b1.x; ko[5] = (bf16)b1.y; ko[6] = (bf16)b1.z; ko[7] = (bf16)b1.w;
+    const size_t dst = ((size_t)(b * H + h) * N + n) * hd + c8;
+    __builtin_nontemporal_store(qo, (bf16x8*)(q + dst));
+    __builtin_nontemporal_store(ko, (bf16x8*)(k + dst));
+  };
+  auto src_of = [&](long it) { const int h = it % H; const long bn = it / H; return qkv + ((size_t)bn * 3 * H + h) * hd + c8; };
+  long it = gid;
+  for (; it + gstride < items; it += 2 * gstride) {          // two items in flight
+    const bf16* p0 = src_of(it);
+    const bf16* p1 = src_of(it + gstride);
+    const bf16x8 q0 = __builtin_nontemporal_load((const bf16x8*)p0), k0 = __builtin_nontemporal_load((const bf16x8*)(p0 + (size_t)H * hd));
+    const bf16x8 q1 = __builtin_nontemporal_load((const bf16x8*)p1), k1 = __builtin_nontemporal_load((const bf16x8*)(p1 + (size_t)H * hd));
+    one(it, q0, k0);
+    one(it + gstride, q1, k1);
+  }
+  if (it < items) {
+    const bf16* p0 = src_of(it);
+    one(it, *(const bf16x8*)p0, *(const bf16x8*)(p0 + (size_t)H * hd));
   }
 }
 
@@ -506,6 +609,12 @@ extern "C" int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq
     const unsigned grid = (unsigned)(wgs < 4096 ? wgs : 4096);
     if (dtype == LDMAE_BF16) hipLaunchKernelGGL(qknorm_rope_fwd_dense_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)qkv, wq, wk, cos, sin, (bf16*)q, (bf16*)k, (bf16*)v, B, N, H, hd, eps);
     else hipLaunchKernelGGL(qknorm_rope_fwd_dense_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)qkv, wq, wk, cos, sin, (float*)q, (float*)k, (float*)v, B, N, H, hd, eps);
+  }
+  else if (dtype == LDMAE_BF16 && wq && !v && (hd == 64 || hd == 128) && items % (256 / (hd / 8)) == 0) {
+    // the LightningDiT block's form (v stays in the packed qkv): 16-B accesses, whole lane groups
+    const unsigned grid = qk_grid(items, hd / 8);
+    if (hd == 64) hipLaunchKernelGGL(qknorm_rope_fwd8_kernel<8>, dim3(grid), dim3(256), 0, st, (const bf16*)qkv, wq, wk, cos, sin, (bf16*)q, (bf16*)k, B, N, H, eps);
+    else hipLaunchKernelGGL(qknorm_rope_fwd8_kernel<16>, dim3(grid), dim3(256), 0, st, (const bf16*)qkv, wq, wk, cos, sin, (bf16*)q, (bf16*)k, B, N, H, eps);
   }
   else if (hd <= 64) { if (dtype == LDMAE_BF16) QK_FWD(16, bf16); else QK_FWD(16, float); }
   else { if (dtype == LDMAE_BF16) QK_FWD(32, bf16); else QK_FWD(32, float); }
