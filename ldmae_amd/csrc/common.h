@@ -88,6 +88,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// The same sum without LDS round trips: four DPP adds leave every 16-lane row holding its row sum, four v_readlane + three adds join the
+// rows (wave-uniform result).  __shfl_xor is a ds_bpermute: six DEPENDENT LDS round trips per reduction (~700 cycles) that sit in the
+// middle of every row of the row-wise kernels; this form is ~50 cycles.  Different association than wave_sum (not bitwise interchangeable).
+template <int CTRL> __device__ __forceinline__ float dpp_add_f(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add_f<0xB1>(v);            // quad_perm [1,0,3,2]
+  v = dpp_add_f<0x4E>(v);            // quad_perm [2,3,0,1]
+  v = dpp_add_f<0x141>(v);           // row_half_mirror
+  v = dpp_add_f<0x140>(v);           // row_mirror
+  const int i = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+  return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
         dn[i] = dy * wc;
         dot += hsum(dn[i] * nv[i]);
       }
-      dot = wave_sum(dot) / (float)D;
+      dot = wave_sum_dpp(dot) / (float)D;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
