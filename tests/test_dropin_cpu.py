@@ -82,3 +82,19 @@ def test_plain_run_of_the_fake_reference_is_the_reference(tmp_path):
     ref = fake_reference(tmp_path)
     code = "from models.lightningdit import LightningDiT_models; print(LightningDiT_models)"
     assert "reference" in run(["-c", code], str(ref), {})
+
+
+def test_under_accelerate_launch_the_reference_launcher(tmp_path):
+    """run_train.sh:13-22 starts the driver with `accelerate launch ... train_accum.py`: the start-up hook must reach the rank process
+    (PYTHONPATH is inherited), and `accelerate launch -m ldmae_amd.launch driver.py` must work too."""
+    import shutil
+    import pytest
+    if shutil.which("accelerate") is None:
+        pytest.skip("accelerate CLI not installed")
+    ref = fake_reference(tmp_path)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    for extra, args in (({"PYTHONPATH": os.path.join(PKG, "dropin")}, ["driver.py", "--config", "a.yaml"]),
+                        ({"PYTHONPATH": ROOT}, ["-m", "ldmae_amd.launch", "driver.py", "--config", "a.yaml"])):
+        r = subprocess.run(["accelerate", "launch", "--num_processes", "1", "--cpu"] + args, cwd=str(ref), env=dict(env, **extra),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DROPIN-OK" in r.stdout and "ARGV ['--config', 'a.yaml']" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
