@@ -470,7 +470,7 @@ def patch_embed_kept(img, ids_keep, pos, w2d, bias, patch, dtype):
     tok = torch.empty(N * keep, C * patch * patch, dtype=dtype, device=img.device)
     posg = torch.empty(N * keep, D, dtype=torch.float32, device=img.device)
     call("ldmae_patch_gather", dt(dtype), ptr(_c(img.float())), ptr(ids_keep), ptr(pos), ptr(tok), ptr(posg), N, keep, C, S, patch, D, stream())
-    wb = w2d if dtype == torch.float32 else cached_weight_copy(w2d, dtype)
+    wb = cast(_c(w2d), dtype)          # 192 x 192: one tiny launch (w2d is a fresh view per call, so the id-keyed weight cache does not apply)
     out, _ = gemm_nt_gate_res(tok, wb, bias, posg, None, keep, save_y=False, xout=posg)
     return out.view(N, keep, D)
 
