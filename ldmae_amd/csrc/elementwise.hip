@@ -69,9 +69,12 @@ __device__ __forceinline__ float4 mul_rn(float4 a, float4 b) {
 }
 
 // ------------------------------------------------------------------ RMSNorm + modulate
-// (Round 3: a variant with all four rows of a wave requested up front -- 12 loads in flight per lane, 100 VGPRs -- measured 3 % SLOWER
-// than this form at 54 VGPRs: here the waves in flight carry the bandwidth, 5.2 TB/s.)
-template <int NCH, typename OutT>
+// FULL (D % 256 == 0, M % 16 == 0, rows_per_batch % 16 == 0: the workgroup's 16 rows belong to one sample): no per-chunk guards, and the
+// per-sample (1 + scale) / shift vectors are loaded ONCE per wave before the row loop.  The guarded form re-loads them per row and chunk
+// behind a branch and a full `s_waitcnt vmcnt(0)` each: six serialized L2 round trips in the middle of every row.
+// (A variant with all four rows of a wave requested up front -- 12 loads in flight per lane, 100 VGPRs -- measured 3 % SLOWER than one row
+// at a time: here the waves in flight carry the bandwidth.)
+template <int NCH, typename OutT, bool FULL = false>
 __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ shift, const float* __restrict__ scale,
                                                               int mod_ld, OutT* __restrict__ out, float* __restrict__ rstd, int M, int D,
@@ -80,6 +83,35 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __res
   float4 wv[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) { const int c = lane + 64 * i; wv[i] = c < nch ? *(const float4*)(w + 4 * c) : f4(0.f); }
+  if constexpr (FULL) {
+    const int m0 = (blockIdx.x * 4 + wave) * 4, b = m0 / rpb;
+    float4 sc1[NCH], sh[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      sc1[i] = scale ? f4(1.f) + *(const float4*)(scale + (size_t)b * mod_ld + 4 * lane + 256 * i) : f4(1.f);
+      sh[i] = shift ? *(const float4*)(shift + (size_t)b * mod_ld + 4 * lane + 256 * i) : f4(0.f);
+    }
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + r;
+      float4 xv[NCH];
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) xv[i] = *(const float4*)(x + (size_t)m * D + 4 * lane + 256 * i);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) ss += hsum(xv[i] * xv[i]);
+      ss = wave_sum(ss);
+      const float rs = rsqrtf(ss / (float)D + eps);
+      if (lane == 0 && rstd) rstd[m] = rs;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        float4 y = (xv[i] * rs) * wv[i];
+        if (scale) y = y * sc1[i];
+        if (shift) y = y + sh[i];
+        store4<OutT>(out + (size_t)m * D + 4 * lane + 256 * i, y);
+      }
+    }
+    return;
+  }
   for (int r = 0; r < 4; ++r) {
     const int m = (blockIdx.x * 4 + wave) * 4 + r;
     if (m >= M) return;
@@ -297,7 +329,9 @@ extern "C" int ldmae_rmsnorm_modulate_fwd(int out_dtype, const float* x, const f
   LDMAE_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0, "rmsnorm_modulate_fwd: M=%d %% rows_per_batch=%d != 0", M, rows_per_batch);
   hipStream_t st = as_stream(stream);
   const unsigned grid = cdiv(M, 16);
-  if (out_dtype == LDMAE_BF16) {
+  if (out_dtype == LDMAE_BF16 && D % 256 == 0 && M % 16 == 0 && rows_per_batch % 16 == 0) {
+    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, bf16, true>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (bf16*)out, rstd, M, D, rows_per_batch, eps));
+  } else if (out_dtype == LDMAE_BF16) {
     DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, bf16>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (bf16*)out, rstd, M, D, rows_per_batch, eps));
   } else {
     DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, float>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (float*)out, rstd, M, D, rows_per_batch, eps));
