@@ -11,3 +11,12 @@ if __name__.partition(".")[0] != "ldmae_amd":      # imported under the referenc
         _sp.loader.exec_module(_m)
     from ldmae_amd import _dropin
     _sys.modules[__name__] = _dropin.alias(__name__)     # `datasets.x` IS `ldmae_amd.datasets.x` from here on (ldmae_amd/_dropin.py)
+else:
+    # This package takes the top-level name `datasets` exactly as the reference's LDMAE/datasets/ does -- and so hides the Hugging Face
+    # package of that name when it is installed.  accelerate.prepare() (LDMAE/train_accum.py:188) then does
+    # `from datasets import IterableDataset` for an isinstance test: give it something to test against instead of an ImportError.
+    class IterableDataset:      # never instantiated here
+        pass
+
+    class Dataset:
+        pass
