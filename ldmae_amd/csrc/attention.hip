@@ -1163,8 +1163,12 @@ extern "C" int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const voi
   if (hd == 64) L(64) else L(128)
 #undef L
   LDMAE_CHECK_LAUNCH("attention_bwd_pv_qknorm");
-  if (int e = ldmae_colsum(LDMAE_F32, Pw, 2 * hd, (int)(blk * H), 2 * hd, dw2, 0.f, cws, stream)) return e;
-  hipMemcpyAsync(dwq, dw2, hd * sizeof(float), hipMemcpyDeviceToDevice, st);
-  hipMemcpyAsync(dwk, dw2 + hd, hd * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (dwk == dwq + hd) {        // the caller keeps dwq | dwk adjacent: reduce straight into them
+    if (int e = ldmae_colsum(LDMAE_F32, Pw, 2 * hd, (int)(blk * H), 2 * hd, dwq, 0.f, cws, stream)) return e;
+  } else {
+    if (int e = ldmae_colsum(LDMAE_F32, Pw, 2 * hd, (int)(blk * H), 2 * hd, dw2, 0.f, cws, stream)) return e;
+    hipMemcpyAsync(dwq, dw2, hd * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(dwk, dw2 + hd, hd * sizeof(float), hipMemcpyDeviceToDevice, st);
+  }
   return ldmae_colsum(LDMAE_F32, Pb, 3 * (int)hw, (int)blk, 3 * (int)hw, dbias, 0.f, cws, stream);
 }

@@ -155,7 +155,9 @@ def gemm_nt_swiglu_bwd(dy, w3t, h12, with_bias=False):
     Hs = w3t.shape[0]
     if dy.dtype == torch.bfloat16 and Hs % 8 == 0 and K % 64 == 0:
         dh12 = torch.empty_like(h12)
-        part = torch.zeros((M + 127) // 128, 2 * Hs, dtype=torch.float32, device=dy.device) if with_bias else None
+        # every (128-row group, column) of the partial-sum matrix is written by exactly one wave when the tile grid is whole: no 33 MB fill
+        whole = M % 128 == 0 and Hs % 64 == 0
+        part = (torch.empty if whole else torch.zeros)((M + 127) // 128, 2 * Hs, dtype=torch.float32, device=dy.device) if with_bias else None
         call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU_BWD | _GEMM_LAUNCH, ptr(dy), dy.stride(0), ptr(w3t), w3t.stride(0), ptr(dh12), 2 * Hs, M, Hs, K, None, 0.0,
              ptr(h12), ptr(part), None, 0, 0, stream())
         return (dh12, colsum(part)) if with_bias else dh12
@@ -326,8 +328,8 @@ def attention_bwd_pv_qknorm(q, k, qkv, o, do, lse, scale, wq, wk, cos, sin, eps=
     dbias [3*H*hd])."""
     B, H, N, hd = q.shape
     dqkv = torch.empty_like(qkv)
-    dwq = torch.empty(hd, dtype=torch.float32, device=q.device)
-    dwk = torch.empty_like(dwq)
+    dw2 = torch.empty(2 * hd, dtype=torch.float32, device=q.device)      # dwq | dwk adjacent: the library reduces straight into them
+    dwq, dwk = dw2[:hd], dw2[hd:]
     db = torch.empty(3 * H * hd, dtype=torch.float32, device=q.device)
     ws = workspace(L.load().ldmae_attention_bwd_pv_qknorm_workspace_bytes(B, H, N, hd), q.device)
     call("ldmae_attention_bwd_pv_qknorm", dt(q.dtype), ptr(q), ptr(k), ptr(qkv), ptr(o), ptr(_c(do)), ptr(lse), ptr(wq), ptr(wk), ptr(cos),
