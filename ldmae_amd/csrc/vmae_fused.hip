@@ -23,6 +23,8 @@
 //     P^T re-used from the accumulator as the B operand of O^T += V^T . P^T.
 #include "common.h"
 
+#include <type_traits>
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 #ifndef VF_DBG
@@ -141,6 +143,45 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
     }
   };
 
+  // 12 weight fragments of a panel against the LayerNorm output, software-pipelined in groups of four: the next group's ds_read_b128 are in
+  // flight under the current group's MFMAs (a plain loop exposed one LDS round trip per group: 40 % of the wave cycles were parked).
+  // SWAP: un-transposed product (A = activations, B = weights).
+  auto mm12 = [&](f32x16 acc, const char* p, auto SWAP) -> f32x16 {
+    constexpr bool swap = decltype(SWAP)::value;
+    bf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fa[j] = *(const bf16x8*)(p + j * FRAG);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(p + (4 + j) * FRAG);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = swap ? MFMA(xf[j], fa[j], acc) : MFMA(fa[j], xf[j], acc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fa[j] = *(const bf16x8*)(p + (8 + j) * FRAG);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = swap ? MFMA(xf[4 + j], fb[j], acc) : MFMA(fb[j], xf[4 + j], acc);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = swap ? MFMA(xf[8 + j], fa[j], acc) : MFMA(fa[j], xf[8 + j], acc);
+    return acc;
+  };
+  // 6 feature blocks x 2 k-steps of a [192 x 32] panel into the residual stream, same pipelining
+  auto mm_out = [&](const char* p, bf16x8 b0, bf16x8 b1) {
+    bf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fa[j] = *(const bf16x8*)(p + j * FRAG);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(p + (4 + j) * FRAG);
+    __builtin_amdgcn_sched_barrier(0);
+    xacc[0] = MFMA(fa[0], b0, xacc[0]); xacc[0] = MFMA(fa[1], b1, xacc[0]); xacc[1] = MFMA(fa[2], b0, xacc[1]); xacc[1] = MFMA(fa[3], b1, xacc[1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fa[j] = *(const bf16x8*)(p + (8 + j) * FRAG);
+    __builtin_amdgcn_sched_barrier(0);
+    xacc[2] = MFMA(fb[0], b0, xacc[2]); xacc[2] = MFMA(fb[1], b1, xacc[2]); xacc[3] = MFMA(fb[2], b0, xacc[3]); xacc[3] = MFMA(fb[3], b1, xacc[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    xacc[4] = MFMA(fa[0], b0, xacc[4]); xacc[4] = MFMA(fa[1], b1, xacc[4]); xacc[5] = MFMA(fa[2], b0, xacc[5]); xacc[5] = MFMA(fa[3], b1, xacc[5]);
+  };
   // one ring step: own pieces of slot g have landed (slot g + 1's may stay in flight); the barrier then makes everyone's visible and
   // tells that every wave is done with slot g - 1, which the DMA of slot g + 2 overwrites.  Returns this lane's fragment base in slot g.
   int g = 0;
@@ -165,22 +206,12 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
         const char* p1 = p0 + PANEL;
         const float* vec = (const float*)(slot + 2 * PANEL);   // [0..191] row vector #1, [192..383] #2, [384..511] misc
         if (hp == 0) layernorm(vec, vec + VD, to_frags);
-        f32x16 qT = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 12; ++ks) {
-          qT = MFMA(*(const bf16x8*)(p0 + ks * FRAG), xf[ks], qT);
-          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // at most 4 weight fragments in flight
-        }
+        f32x16 qT = mm12(zero16(), p0, std::false_type{});
         add_rows32(qT, vec + 384);
         // a lane's elements 8e .. 8e+7 are head e's 8 head-dim values of its half: exactly the 16-B operand fragment of S^T = K . Q^T
         // (both operands in the same implicit order of the head dim, which a dot product does not care about)
         qf[0] = cvt8(qT, 0, qscale); qf[1] = cvt8(qT, 1, qscale);
-        f32x16 kT = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 12; ++ks) {
-          kT = MFMA(*(const bf16x8*)(p1 + ks * FRAG), xf[ks], kT);
-          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
+        f32x16 kT = mm12(zero16(), p1, std::false_type{});
         add_rows32(kT, vec + 416);
         *(bf16x8*)(kv + (0 * 8 + wave) * FRAG + lane * 16) = cvt8(kT, 0);
         *(bf16x8*)(kv + (1 * 8 + wave) * FRAG + lane * 16) = cvt8(kT, 1);
@@ -191,12 +222,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
         const char* p0 = slot + lane * 16;
         const char* p1 = p0 + PANEL;
         const float* vec = (const float*)(slot + 2 * PANEL);
-        f32x16 v = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 12; ++ks) {
-          v = MFMA(xf[ks], *(const bf16x8*)(p0 + ks * FRAG), v);
-          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
+        f32x16 v = mm12(zero16(), p0, std::true_type{});
         const float bv = vec[384 + r];
 #pragma unroll
         for (int tt = 0; tt < 16; ++tt) v[tt] += bv;
@@ -242,12 +268,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
           of[e] = cvt8(o, e, 1.f / l);
         }
         // proj: x^T += Wp[:, 32hp .. 32hp+31] . o_pair^T   (panel 1: 6 feature blocks x 2 k-steps; k-step e = head e of the pair)
-#pragma unroll
-        for (int fb = 0; fb < 6; ++fb) {
-          xacc[fb] = MFMA(*(const bf16x8*)(p1 + (2 * fb) * FRAG), of[0], xacc[fb]);
-          xacc[fb] = MFMA(*(const bf16x8*)(p1 + (2 * fb + 1) * FRAG), of[1], xacc[fb]);
-          if (fb & 1) __builtin_amdgcn_sched_barrier(0);
-        }
+        mm_out(p1, of[0], of[1]);
         if (hp == 5) add_rowvec(vec);                        // + proj bias, once per block
       }
     }
@@ -259,12 +280,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
       const char* p1 = p0 + PANEL;
       const float* vec = (const float*)(slot + 2 * PANEL);
       if (c == 0) layernorm(vec, vec + VD, to_frags);
-      f32x16 hT = zero16();
-#pragma unroll
-      for (int ks = 0; ks < 12; ++ks) {
-        hT = MFMA(*(const bf16x8*)(p0 + ks * FRAG), xf[ks], hT);
-        if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
+      f32x16 hT = mm12(zero16(), p0, std::false_type{});
       add_rows32(hT, vec + 384);
 #pragma unroll
       for (int tt = 0; tt < 16; ++tt) {
@@ -272,12 +288,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
         if ((tt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       const bf16x8 hf0 = cvt8(hT, 0), hf1 = cvt8(hT, 1);
-#pragma unroll
-      for (int fb = 0; fb < 6; ++fb) {
-        xacc[fb] = MFMA(*(const bf16x8*)(p1 + (2 * fb) * FRAG), hf0, xacc[fb]);
-        xacc[fb] = MFMA(*(const bf16x8*)(p1 + (2 * fb + 1) * FRAG), hf1, xacc[fb]);
-        if (fb & 1) __builtin_amdgcn_sched_barrier(0);
-      }
+      mm_out(p1, hf0, hf1);
       if (c == 23) add_rowvec(vec);                          // + fc2 bias
     }
   }

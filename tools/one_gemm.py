@@ -8,7 +8,8 @@ from ldmae_amd import _lib, ops
 kind, N, K = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 v = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 M = 262144
-_lib.load().ldmae_tune(8 if kind == "nt" else 4, v)      # nt: 2 = one tile per workgroup; tn: 3 / 4 = 16-wave variants
+if kind in ("nt", "tn"):
+    _lib.load().ldmae_tune(8 if kind == "nt" else 4, v)      # nt: 2 = one tile per workgroup; tn: 3 / 4 = 16-wave variants
 g = torch.Generator(device="cuda").manual_seed(0)
 if kind == "nt":
     a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
@@ -20,6 +21,13 @@ elif kind == "tn":
     b = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     for _ in range(3):
         ops.gemm_tn(a, b)
+elif kind == "vmae":          # the one-kernel VMAE encoder, 256 images (one workgroup per CU)
+    from ldmae_amd.tokenizer import fused_encoder, models_mae
+    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).cuda().eval()
+    x = torch.randn(256, 256, 192, device="cuda", generator=g)
+    blob = fused_encoder.encoder_blob(m)
+    for _ in range(3):
+        ops.vmae_encoder_fwd(x, blob, 12, 192, 12, 768, 1e-6)
 else:
     B, H, NN, hd = 256, 12, 1024, 64
     q, k, vv = (torch.randn(B, H, NN, hd, device="cuda", generator=g).to(torch.bfloat16) for _ in range(3))
