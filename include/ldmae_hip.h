@@ -185,6 +185,12 @@ int ldmae_random_masking(const float* noise, long long* ids_restore, float* mask
  * as embedding every patch and gathering. */
 int ldmae_patch_gather(int tok_dtype, const float* img, const long long* ids, const float* pos, void* tok, float* posg, int N, int keep,
                        int C, int S, int p, int D, void* stream);
+/* Latent-dataset prologue on the device, per batch (reference: datasets/img_latent_dataset.py:79-93 does it per item on the host; the shards
+ * are written by extract_features.py:163-212).  sample = 1: moments [B, 2C, HW] f32 (mean | logvar) and noise [B, C, HW] ->
+ * out[b,c,:] = ((mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) - lat_mean[c]) / lat_std[c] * multiplier; sample = 0: moments is the
+ * plain latent [B, C, HW] and noise is ignored.  lat_mean / lat_std [C] (latents_stats.pt) or both NULL (latent_norm off).  HW % 4 == 0. */
+int ldmae_latent_prologue(const float* moments, const float* noise, const float* lat_mean, const float* lat_std, float multiplier,
+                          float* out, int B, int C, int HW, int sample, void* stream);
 /* out[n,j,:] = x[n, ids[n,j], :]  (torch.gather on dim 1, :486); bwd scatters (ids unique per n) */
 int ldmae_gather_rows(const float* x, const long long* ids, float* out, int N, int L, int keep, int D, void* stream);
 int ldmae_scatter_rows(const float* dout, const long long* ids, float* dx, int N, int L, int keep, int D, void* stream);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ldmae_ema_only": (_i, [_vp, _vp, _l, _d, _vp]),
     "ldmae_random_masking": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "ldmae_patch_gather": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ldmae_latent_prologue": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_gather_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_scatter_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_vmae_encoder_blob_bytes": (_l, [_i]),

@@ -91,6 +91,43 @@ extern "C" int ldmae_patch_gather(int tok_dtype, const float* img, const long lo
   return LDMAE_OK;
 }
 
+// Latent-dataset prologue (datasets/img_latent_dataset.py:79-93 of the reference, per batch on the device instead of per item on the host):
+// moments [B, 2C, HW] (mean | logvar halves, what extract_features.py stores under data.sample) or plain latents [B, C, HW] ->
+// x[b, c, :] = ((mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) - lat_mean[c]) / lat_std[c] * multiplier, the model input.
+// One pass: 12 B read + 4 B written per element (HBM-bound, 16 B per lane).
+__global__ void latent_prologue_kernel(const float* __restrict__ mom, const float* __restrict__ noise, const float* __restrict__ lmean,
+                                       const float* __restrict__ lstd, float mult, float* __restrict__ out, int C, int HW, int sample) {
+  const int b = blockIdx.y, c = blockIdx.z;
+  const float mu = lmean ? lmean[c] : 0.f;
+  const size_t ob = ((size_t)b * C + c) * HW;
+  const float* m = mom + ((size_t)b * (sample ? 2 * C : C) + c) * HW;
+  const float* lv = m + (size_t)C * HW;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HW; i += gridDim.x * blockDim.x * 4) {
+    float4 v = *(const float4*)(m + i);
+    if (sample) {
+      const float4 l = *(const float4*)(lv + i), e = *(const float4*)(noise + ob + i);
+      v.x += expf(0.5f * fminf(fmaxf(l.x, -30.f), 20.f)) * e.x; v.y += expf(0.5f * fminf(fmaxf(l.y, -30.f), 20.f)) * e.y;
+      v.z += expf(0.5f * fminf(fmaxf(l.z, -30.f), 20.f)) * e.z; v.w += expf(0.5f * fminf(fmaxf(l.w, -30.f), 20.f)) * e.w;
+    }
+    // (x - mean) / std, then * multiplier: the reference's two roundings (a true division, not a multiply by the reciprocal)
+    if (lstd) { const float sd = lstd[c]; v.x = (v.x - mu) / sd; v.y = (v.y - mu) / sd; v.z = (v.z - mu) / sd; v.w = (v.w - mu) / sd; }
+    else { v.x -= mu; v.y -= mu; v.z -= mu; v.w -= mu; }
+    *(float4*)(out + ob + i) = make_float4(v.x * mult, v.y * mult, v.z * mult, v.w * mult);
+  }
+}
+extern "C" int ldmae_latent_prologue(const float* moments, const float* noise, const float* lat_mean, const float* lat_std, float multiplier,
+                                     float* out, int B, int C, int HW, int sample, void* stream) {
+  LDMAE_REQUIRE(moments && out && B > 0 && C > 0 && HW > 0, "latent_prologue: null pointer or empty input");
+  LDMAE_REQUIRE(HW % 4 == 0, "latent_prologue: H*W=%d must be a multiple of 4", HW);
+  LDMAE_REQUIRE(!sample || noise, "latent_prologue: sample=1 needs the noise tensor");
+  LDMAE_REQUIRE((lat_mean == nullptr) == (lat_std == nullptr), "latent_prologue: give both latent mean and std, or neither");
+  LDMAE_REQUIRE(B <= 65535 && C <= 65535, "latent_prologue: B=%d C=%d exceed the grid limits", B, C);
+  hipLaunchKernelGGL(latent_prologue_kernel, dim3(cdiv(HW, 1024), B, C), dim3(256), 0, as_stream(stream), moments, noise, lat_mean, lat_std, multiplier,
+                     out, C, HW, sample);
+  LDMAE_CHECK_LAUNCH("latent_prologue");
+  return LDMAE_OK;
+}
+
 extern "C" int ldmae_gather_rows(const float* x, const long long* ids, float* out, int N, int L, int keep, int D, void* stream) {
   LDMAE_REQUIRE(x && ids && out && N > 0 && L > 0 && keep > 0 && D % 4 == 0, "gather_rows: bad arguments (D=%d multiple of 4)", D);
   hipLaunchKernelGGL(gather_rows_kernel, dim3(keep, N), dim3(64), 0, as_stream(stream), x, ids, out, L, keep, D);

@@ -15,8 +15,10 @@ from ldmae_amd.tokenizer.util.misc import DiagonalGaussianDistribution
 
 
 class ImgLatentDataset(Dataset):
-    def __init__(self, data_dir, latent_norm=True, latent_multiplier=1.0, sample=False):
-        self.data_dir, self.latent_norm, self.latent_multiplier, self.sample = data_dir, latent_norm, latent_multiplier, sample
+    def __init__(self, data_dir, latent_norm=True, latent_multiplier=1.0, sample=False, raw=False):
+        """raw=True (not in the reference): __getitem__ stops after the shard read and the flip pick and returns the stored tensor
+        (moments when `sample`); posterior sampling, normalisation and the multiplier then run per BATCH on the GPU -- LatentPrologue."""
+        self.data_dir, self.latent_norm, self.latent_multiplier, self.sample, self.raw = data_dir, latent_norm, latent_multiplier, sample, raw
         self.files = sorted(glob(os.path.join(data_dir, "*.safetensors")))
         self.index = []                                    # global idx -> (file, idx in file)
         for f in self.files:
@@ -56,11 +58,35 @@ class ImgLatentDataset(Dataset):
         f, i = self.index[idx]
         key = "latents" if np.random.uniform(0, 1) > 0.5 else "latents_flip"      # per-item flip pick (:79)
         x, y = self._read(f, i, key), self._read(f, i, "labels")
+        if self.raw:
+            return x.squeeze(0), y.squeeze(0)
         if self.sample:
             x = DiagonalGaussianDistribution(x).sample()
         if self.latent_norm:
             x = (x - self._latent_mean) / self._latent_std
         return (x * self.latent_multiplier).squeeze(0), y.squeeze(0)
+
+
+class LatentPrologue(torch.nn.Module):
+    """The part of ImgLatentDataset.__getitem__ after the shard read (:82-93), as one HIP kernel per batch (ops.latent_prologue,
+    SURVEY 8f rank 3 "fused GPU prologue"): x = ((mean + std * noise) - latent_mean) / latent_std * multiplier.  Built from a dataset
+    opened with raw=True; the noise comes from the DEVICE generator (the reference draws it on the host inside the DataLoader workers:
+    same distribution, a different stream of numbers) unless the caller passes it."""
+
+    def __init__(self, dataset):
+        super().__init__()
+        self.sample, self.multiplier, self.norm = bool(dataset.sample), float(dataset.latent_multiplier), bool(dataset.latent_norm)
+        if self.norm:
+            self.register_buffer("latent_mean", dataset._latent_mean.float().reshape(-1).clone())
+            self.register_buffer("latent_std", dataset._latent_std.float().reshape(-1).clone())
+
+    def forward(self, stored, noise=None, generator=None):
+        from ldmae_amd import ops
+        if self.sample and noise is None:
+            B, C2, H, W = stored.shape
+            noise = torch.randn(B, C2 // 2, H, W, device=stored.device, dtype=torch.float32, generator=generator)
+        return ops.latent_prologue(stored, noise, self.latent_mean if self.norm else None, self.latent_std if self.norm else None,
+                                   self.multiplier, self.sample)
 
 
 class SyntheticLatentDataset(Dataset):

@@ -477,6 +477,20 @@ def patch_embed_kept(img, ids_keep, pos, w2d, bias, patch, dtype):
     return out.view(N, keep, D)
 
 
+def latent_prologue(moments, noise=None, lat_mean=None, lat_std=None, multiplier=1.0, sample=True):
+    """Device-side counterpart of ImgLatentDataset.__getitem__ after the shard read: moments [B, 2C, H, W] f32 (sample) or latents
+    [B, C, H, W] -> normalised model input [B, C, H, W] f32.  noise [B, C, H, W] (drawn by the caller); lat_mean / lat_std [C]-sized."""
+    B, C2, H, W = moments.shape
+    C = C2 // 2 if sample else C2
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=moments.device)
+    mom = _c(moments.float())
+    nz = _c(noise.float()) if noise is not None else None
+    mu, sd = (_c(t.float().reshape(-1)) if t is not None else None for t in (lat_mean, lat_std))
+    call("ldmae_latent_prologue", ptr(mom), ptr(nz) if nz is not None else None, ptr(mu) if mu is not None else None,
+         ptr(sd) if sd is not None else None, float(multiplier), ptr(out), B, C, H * W, 1 if sample else 0, stream())
+    return out
+
+
 def gather_rows(x, ids):
     N, Lq, D = x.shape
     keep = ids.shape[1]

@@ -51,6 +51,35 @@ class MAEOutput:
     latent_dist: object
 
 
+# ----------------------------------------------------------------------------- host-side image preprocessing (:85-103, :935-950)
+def center_crop_arr(pil_image, image_size):
+    """ADM's centre crop as the reference applies it (:85-103): halve with a BOX filter while the short side is >= 2x the target, one
+    BICUBIC resize that brings the short side to the target, then the central image_size x image_size window."""
+    from PIL import Image
+    while min(pil_image.size) >= 2 * image_size:
+        pil_image = pil_image.resize((pil_image.size[0] // 2, pil_image.size[1] // 2), resample=Image.BOX)
+    scale = image_size / min(pil_image.size)
+    pil_image = pil_image.resize((round(pil_image.size[0] * scale), round(pil_image.size[1] * scale)), resample=Image.BICUBIC)
+    arr = np.asarray(pil_image)
+    top, left = (arr.shape[0] - image_size) // 2, (arr.shape[1] - image_size) // 2
+    return Image.fromarray(arr[top:top + image_size, left:left + image_size])
+
+
+class ImageTransform:
+    """What ``img_transform`` returns (:935-950) without torchvision: centre crop -> horizontal flip with probability p_hflip (one
+    ``torch.rand(1)`` draw per image, like RandomHorizontalFlip) -> CHW float in [0, 1] -> (x - 0.5) / 0.5."""
+
+    def __init__(self, p_hflip, img_size):
+        self.p_hflip, self.img_size = float(p_hflip), int(img_size)
+
+    def __call__(self, pil_image):
+        arr = np.asarray(center_crop_arr(pil_image.convert("RGB"), self.img_size))
+        if torch.rand(1) < self.p_hflip:
+            arr = arr[:, ::-1]
+        x = torch.from_numpy(np.array(arr)).permute(2, 0, 1).to(torch.float32).div_(255.0)
+        return x.sub_(0.5).div_(0.5)
+
+
 # ----------------------------------------------------------------------------- autograd Functions
 class _ViTBlockFn(torch.autograd.Function):
     """Block.forward (:176-187): x += proj(attn(LN1(x))); x += fc2(gelu(fc1(LN2(x))))."""
@@ -466,6 +495,10 @@ class MaskedAutoencoderViT(nn.Module):
     @property
     def dtype(self):
         return next(self.parameters()).dtype
+
+    def img_transform(self, p_hflip=0, img_size=None):
+        """:935-950 -- PIL image -> normalised CHW tensor (extract_features.py:105-108 builds its two ImageFolders with it)."""
+        return ImageTransform(p_hflip, img_size if img_size is not None else self.img_size)
 
     def encode_images(self, images):
         with torch.no_grad():

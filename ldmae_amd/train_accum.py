@@ -91,8 +91,9 @@ def make_loader(cfg, per_gpu, rank, world, synthetic):
     else:
         from ldmae_amd.datasets.img_latent_dataset import ImgLatentDataset
         path = d['data_path'] + ('_sample' if 'sample' in d else '')                 # key presence, train_accum.py:124-125
+        # data.gpu_prologue (not a reference key): posterior sampling + normalisation per batch on the GPU instead of per item in the workers
         ds_ = ImgLatentDataset(data_dir=path, latent_norm=d.get('latent_norm', False), latent_multiplier=d.get('latent_multiplier', 0.18215),
-                               sample=d.get('sample', False))
+                               sample=d.get('sample', False), raw=bool(d.get('gpu_prologue', False)))
     sampler = DistributedSampler(ds_, num_replicas=world, rank=rank, shuffle=True, seed=cfg['train'].get('global_seed', 0)) if world > 1 else None
     return ds_, DataLoader(ds_, batch_size=per_gpu, shuffle=sampler is None, sampler=sampler, num_workers=d.get('num_workers', 0),
                            pin_memory=True, drop_last=True)
@@ -152,6 +153,10 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
     per_gpu = int(np.round(tr_cfg['global_batch_size'] / world))
     accum = int(tr_cfg['gradient_accumulation_steps'])
     dataset, loader = make_loader(cfg, per_gpu, rank, world, synthetic)
+    prologue = None
+    if getattr(dataset, "raw", False):
+        from ldmae_amd.datasets.img_latent_dataset import LatentPrologue
+        prologue = LatentPrologue(dataset).to(device)
     logger.info(f"LightningDiT Parameters: {sum(p.numel() for p in model.parameters()) / 1e6:.2f}M; {len(dataset):,} samples; "
                 f"batch {per_gpu}/gpu x {world} gpus x {accum} accumulation; precision {precision}")
     max_steps = max_steps or tr_cfg['max_steps']
@@ -165,6 +170,8 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
         epoch += 1
         for x, y in loader:
             x, y = x.to(device, non_blocking=True), y.to(device, non_blocking=True)
+            if prologue is not None:
+                x = prologue(x)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16"):
                 terms = transport.training_losses(model, x, dict(y=y))
             loss = terms["loss"].mean()

@@ -360,6 +360,28 @@ def gen_dataset(out):
         shutil.rmtree(d)
 
 
+IMG_CASES = ((300, 200, 64), (130, 97, 64), (64, 64, 64), (517, 389, 64), (97, 260, 32))      # (width, height, target)
+
+
+def synth_image(w, h, seed):
+    """Seeded test image: smooth colour ramps + noise (so that BOX / BICUBIC resampling has structure to act on)."""
+    r = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([xx * 255.0 / max(w - 1, 1), yy * 255.0 / max(h - 1, 1), (xx + yy) % 256], axis=-1)
+    return np.clip(base + r.randint(-40, 41, size=(h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def gen_images(out):
+    """The reference's own ``center_crop_arr`` (tokenizer/models_mae.py:85-103; what ``img_transform`` :935-950 starts with) on seeded
+    images: pins the host-side preprocessing of extract_features.py (BOX halvings, the BICUBIC resize, the crop window)."""
+    from PIL import Image
+    sys.path.insert(0, os.path.join(REF, "tokenizer"))
+    from tokenizer import models_mae
+    for i, (w, h, size) in enumerate(IMG_CASES):
+        res = models_mae.center_crop_arr(Image.fromarray(synth_image(w, h, 100 + i)), size)
+        out[f"crop{i}"] = np.asarray(res)
+
+
 def ref_style_init(model, seed):
     """Reference init *scheme* (zero adaLN / final, Xavier Linears) with name-keyed
     values so the oracle / HIP side can rebuild the identical start point."""
@@ -433,14 +455,14 @@ def main():
     ap.add_argument("--curve", action="store_true", help="also run the 100-step B/1 bs=4 loss curve (~15 min)")
     ap.add_argument("--only-curve", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,dataset}")
+    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,dataset,images}")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     install_shims()
     sys.path.insert(0, REF)
     if not args.only_curve:
         gens = (("dit_tiny", gen_dit_tiny), ("kernels", gen_tables_and_kernels), ("mae", gen_mae), ("mae_train", gen_mae_train),
-                ("dataset", gen_dataset))
+                ("dataset", gen_dataset), ("images", gen_images))
         for name, fn in gens:
             if args.only and name not in args.only.split(","):
                 continue

@@ -96,3 +96,47 @@ def test_vmae_pretrain_schedule_and_param_groups():
     for n, p in net.named_parameters():
         lo, hi = flat.groups[no_decay(n, p)]
         assert lo <= flat.offsets[n][0] < hi and torch.equal(p.data, before[n])           # values unchanged, each name inside its group
+
+
+def _synth_image(w, h, seed):          # same generator as tests/golden/make_golden.py:synth_image
+    r = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([xx * 255.0 / max(w - 1, 1), yy * 255.0 / max(h - 1, 1), (xx + yy) % 256], axis=-1)
+    return np.clip(base + r.randint(-40, 41, size=(h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def test_center_crop_matches_reference_golden():
+    """Host preprocessing of extract_features.py: our center_crop_arr against the reference's own function on the same seeded images
+    (tests/golden/make_golden.py:gen_images imports it; BOX halvings + BICUBIC resize + crop window), then the full img_transform."""
+    from PIL import Image
+    from ldmae_amd.tokenizer.models_mae import ImageTransform, center_crop_arr
+    g = np.load(os.path.join(ROOT, "tests", "golden", "images.npz"))
+    cases = ((300, 200, 64), (130, 97, 64), (64, 64, 64), (517, 389, 64), (97, 260, 32))
+    for i, (w, h, size) in enumerate(cases):
+        img = Image.fromarray(_synth_image(w, h, 100 + i))
+        got = np.asarray(center_crop_arr(img, size))
+        assert got.shape == (size, size, 3) and np.array_equal(got, g[f"crop{i}"]), i
+        plain, flipped = ImageTransform(0.0, size)(img), ImageTransform(1.0, size)(img)
+        want = torch.from_numpy(g[f"crop{i}"].copy()).permute(2, 0, 1).float() / 255.0
+        assert torch.equal(plain, (want - 0.5) / 0.5) and torch.equal(flipped, plain.flip(-1))
+        assert plain.dtype == torch.float32 and float(plain.min()) >= -1.0 and float(plain.max()) <= 1.0
+
+
+def test_image_folder_order_and_labels(tmp_path):
+    """torchvision ImageFolder semantics without torchvision: classes = sorted dir names, samples sorted inside a class, non-images skipped."""
+    from PIL import Image
+    from ldmae_amd.datasets.image_folder import ImageFolder
+    for c, names in (("n02", ("b.png", "a.JPEG", "notes.txt")), ("n01", ("z.png",)), ("n10", ("sub/k.bmp", "c.png"))):
+        for n in names:
+            p = tmp_path / c / n
+            p.parent.mkdir(parents=True, exist_ok=True)
+            if n.endswith(".txt"):
+                p.write_text("x")
+            else:
+                Image.fromarray(_synth_image(20, 12, len(str(p)))).save(str(p), format="PNG" if n.lower().endswith("jpeg") else None)
+    ds = ImageFolder(str(tmp_path))
+    assert ds.classes == ["n01", "n02", "n10"] and ds.class_to_idx == {"n01": 0, "n02": 1, "n10": 2}
+    rel = [(os.path.relpath(p, tmp_path), t) for p, t in ds.samples]
+    assert rel == [("n01/z.png", 0), ("n02/a.JPEG", 1), ("n02/b.png", 1), ("n10/c.png", 2), ("n10/sub/k.bmp", 2)]
+    img, t = ds[3]
+    assert img.size == (20, 12) and img.mode == "RGB" and t == 2

@@ -93,3 +93,109 @@ def test_png_writer_surfaces_errors(tmp_path):
     w.put([np.zeros((4, 4, 3), np.uint8)], [str(tmp_path / "nodir" / "x.png")])
     with pytest.raises(Exception):
         w.close()
+
+
+def test_extract_features_writes_reference_shards(tmp_path):
+    """SURVEY 8(f)3, the WRITER (reference extract_features.py:103-218): an image folder -> VMAE moments of every image and of its mirror
+    image -> shards named / keyed / tagged as the reference writes them -> latents_stats.pt; read back through ImgLatentDataset."""
+    from PIL import Image
+    from safetensors import safe_open
+    import ldmae_amd.extract_features as ef
+    from ldmae_amd.datasets.img_latent_dataset import ImgLatentDataset
+    from ldmae_amd.tokenizer import models_mae
+    rs = np.random.RandomState(0)
+    root = tmp_path / "1K_dataset"
+    n_img = 0
+    for c in ("n03", "n01", "n02"):
+        (root / "train" / c).mkdir(parents=True)
+        for i in range(4 if c != "n02" else 3):
+            w, h = int(rs.randint(70, 140)), int(rs.randint(70, 140))
+            Image.fromarray(rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)).save(str(root / "train" / c / f"img{i}.png"))
+            n_img += 1
+    vae = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=True, no_cls=True, kl_loss_weight=True, smooth_output=True, img_size=64)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        for p in vae.parameters():
+            if p.requires_grad and p.ndim > 1:
+                p.copy_(torch.randn_like(p) * 0.05)
+    torch.save({"model": vae.state_dict()}, tmp_path / "vmae.pth")
+    cfg = dict(vae=dict(model_name="vmae_f8d16", weight_path=str(tmp_path / "vmae.pth")),
+               data=dict(origin_path=str(root), name="imagenet", sample=True))
+    import argparse
+    args = argparse.Namespace(data_split="train", output_dir=None, image_size=64, batch_size=4, seed=42, num_workers=0, precision="fp32",
+                              synthetic=0)
+    out_dir, files = ef.main(args, cfg)
+    assert out_dir == str(tmp_path / "vmae_feature_imagenet_train_64_sample")            # extract_features.py:49-52
+    # 11 images, batch 4 -> 3 batches; a shard closes after 10000 // 4 batches, so everything lands in the remainder shard
+    assert [os.path.basename(f) for f in files] == ["latents_rank00_shard000.safetensors"]
+    with safe_open(files[0], framework="pt") as h:
+        assert sorted(h.keys()) == ["labels", "latents", "latents_flip"]
+        assert h.metadata() == {"total_size": str(n_img), "dtype": "torch.float32", "device": "cpu"}
+        lat, flip, labels = h.get_tensor("latents"), h.get_tensor("latents_flip"), h.get_tensor("labels")
+    assert lat.shape == (n_img, 32, 8, 8) and flip.shape == lat.shape and lat.dtype == torch.float32 and labels.dtype == torch.int64
+    assert labels.tolist() == [0] * 4 + [1] * 3 + [2] * 4                                # classes sorted: n01, n02, n03
+    # contents: the tokenizer's own _encode of the transformed images, in ImageFolder order; the flipped loader sees mirror images
+    from ldmae_amd.datasets.image_folder import ImageFolder
+    vae = vae.cuda().eval()
+    ds = ImageFolder(str(root / "train"), transform=vae.img_transform(p_hflip=0.0, img_size=64))
+    x = torch.stack([ds[i][0] for i in range(n_img)]).cuda()
+    with torch.no_grad():
+        want, want_flip = vae._encode(x).float().cpu(), vae._encode(x.flip(-1)).float().cpu()
+    assert torch.allclose(lat, want, atol=1e-5, rtol=1e-5) and torch.allclose(flip, want_flip, atol=1e-5, rtol=1e-5)
+    assert not torch.allclose(lat, flip, atol=1e-3)
+    # the reader + cached stats
+    assert os.path.exists(os.path.join(out_dir, "latents_stats.pt"))
+    rd = ImgLatentDataset(out_dir, latent_norm=True, latent_multiplier=1.0, sample=True)
+    assert len(rd) == n_img
+    f, y = rd[5]
+    assert f.shape == (16, 8, 8) and int(y) == 1 and torch.isfinite(f).all()
+    # shard-closing rule with a small shard size: 3 batches of 4 at shard_images = 8 -> shards of 8 and 3 images
+    loaders = [torch.utils.data.DataLoader(ImageFolder(str(root / "train"), transform=vae.img_transform(p_hflip=p, img_size=64)), batch_size=4)
+               for p in (0.0, 1.0)]
+    files2 = ef.extract(vae, loaders, str(tmp_path / "two"), batch_size=4, sample=False, shard_images=8, log=lambda *_: None)
+    assert [os.path.basename(f) for f in files2] == ["latents_rank00_shard000.safetensors", "latents_rank00_shard001.safetensors"]
+    with safe_open(files2[0], framework="pt") as h0, safe_open(files2[1], framework="pt") as h1:
+        a, b = h0.get_tensor("latents"), h1.get_tensor("latents")
+        assert a.shape == (8, 16, 8, 8) and b.shape == (3, 16, 8, 8)                      # posterior mode: the mean half of the moments
+        assert torch.allclose(torch.cat([a, b]), want[:, :16], atol=1e-5, rtol=1e-5)
+
+
+def test_latent_prologue_matches_reference_dataset_golden(tmp_path):
+    """SURVEY 8(f)3 'fused GPU prologue': ImgLatentDataset(raw=True) + LatentPrologue (one HIP kernel per batch) must give what the
+    REFERENCE's ImgLatentDataset returned per item for the same shards, flip picks and noise (tests/golden/dataset.npz, generated by
+    importing the reference class): posterior sample from the moments, (x - mean) / std, multiplier."""
+    from safetensors.torch import save_file
+    from ldmae_amd.datasets.img_latent_dataset import ImgLatentDataset, LatentPrologue
+    g = np.load(os.path.join(ROOT, "tests", "golden", "dataset.npz"))
+    for tag, kw in (("a", dict(latent_norm=True, latent_multiplier=1.0, sample=True)), ("b", dict(latent_norm=False, latent_multiplier=0.18215, sample=False)),
+                    ("c", dict(latent_norm=True, latent_multiplier=0.5, sample=False))):
+        d = tmp_path / tag
+        d.mkdir()
+        for s in range(2):
+            save_file({k: torch.from_numpy(g[f"ds_shard{s}_{k}"]) for k in ("latents", "latents_flip", "labels")},
+                      str(d / f"latents_rank00_shard{s:03d}.safetensors"))
+        np.random.seed(7)
+        torch.manual_seed(7)
+        ds = ImgLatentDataset(str(d), raw=True, **kw)                  # stats: same RNG consumption as the reference's constructor
+        if kw["latent_norm"]:
+            assert np.allclose(ds._latent_mean.numpy(), g[f"ds_{tag}_mean"], atol=1e-6) and np.allclose(ds._latent_std.numpy(), g[f"ds_{tag}_std"], atol=1e-6)
+        stored, labels, noise = [], [], []
+        for i in g[f"ds_{tag}_order"]:
+            x, y = ds[int(i)]                                          # np.random.uniform: the flip pick
+            stored.append(x); labels.append(y)
+            if kw["sample"]:
+                noise.append(torch.randn(1, x.shape[0] // 2, *x.shape[1:]))      # the draw DiagonalGaussianDistribution.sample makes per item
+        pro = LatentPrologue(ds).cuda()
+        out = pro(torch.stack(stored).cuda(), noise=torch.cat(noise).cuda() if noise else None)
+        want = torch.from_numpy(g[f"ds_{tag}_feat"])
+        assert out.shape == want.shape and out.dtype == torch.float32
+        assert torch.allclose(out.cpu(), want, atol=2e-6, rtol=2e-6), (tag, float((out.cpu() - want).abs().max()))
+        assert torch.equal(torch.stack(labels), torch.from_numpy(g[f"ds_{tag}_label"]))
+    # device-generator noise: right statistics, reproducible under a seeded generator
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    mom = torch.cat([torch.zeros(64, 4, 8, 8), torch.full((64, 4, 8, 8), 2 * float(np.log(3.0)))], dim=1).cuda()      # mean 0, std 3
+    ds.sample, ds.latent_norm, ds.latent_multiplier = True, False, 1.0
+    pro = LatentPrologue(ds).cuda()
+    a = pro(mom, generator=gen)
+    b = pro(mom, generator=torch.Generator(device="cuda").manual_seed(5))
+    assert torch.equal(a, b) and abs(float(a.std()) - 3.0) < 0.1 and abs(float(a.mean())) < 0.1
