@@ -203,16 +203,25 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
 #define NT_HPF 1
 #endif
       constexpr int HPF = NT_HPF;                   // h12 rows are requested HPF strips ahead of their use
-      bf16x8 hv[MI + HPF][2][2];
+      bf16x8 hv[MI][2][2];
+      const bool whole = mw + TM <= M && n0 + wn * TNn + cblk * 64 + 64 <= Hs;     // wave-uniform: straight-line stores (see SwiGLU fwd)
+      // whole tiles: wave-uniform row base (SGPR pair) + one 32-bit lane offset shared by every access of the epilogue -- the loads and
+      // stores take the saddr form and no 64-bit address lives in VGPRs (the per-access v_lshl_add_u64 / v_mad_i64 chains and their
+      // registers were what kept the h12 look-ahead at one strip)
+      const unsigned loff = (unsigned)(lane >> 3) * (unsigned)(4 * Hs) + (unsigned)(n0 + wn * TNn + cblk * 64 + (lane & 7) * 8) * 2u;
       auto ldh = [&](int i) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          const int m = min(mw + i * 16 + it * 8 + (lane >> 3), M - 1);
-          const bf16* hp = h12 + (size_t)m * 2 * Hs + (inr ? n : 0);
-          hv[i][it][0] = *(const bf16x8*)hp; hv[i][it][1] = *(const bf16x8*)(hp + Hs);
+          if (whole) {
+            const char* rb = (const char*)h12 + (size_t)(mw + i * 16 + it * 8) * (size_t)(4 * Hs);
+            hv[i][it][0] = *(const bf16x8*)(rb + loff); hv[i][it][1] = *(const bf16x8*)(rb + 2 * Hs + loff);
+          } else {
+            const int m = min(mw + i * 16 + it * 8 + (lane >> 3), M - 1);
+            const bf16* hp = h12 + (size_t)m * 2 * Hs + (inr ? n : 0);
+            hv[i][it][0] = *(const bf16x8*)hp; hv[i][it][1] = *(const bf16x8*)(hp + Hs);
+          }
         }
       };
-      const bool whole = mw + TM <= M && n0 + wn * TNn + cblk * 64 + 64 <= Hs;     // wave-uniform: straight-line stores (see SwiGLU fwd)
       // bias gradient of w12 = column sums of dh12 AS STORED (bf16), formed here while the values are in registers: per wave the
       // sums over its 128 rows go to e.xout[(m0 / 128 + wm)][2 * Hs] (one partial row per 128 output rows; summed by the caller).
       // Kept in the wave's LDS scratch ex[row group q = lane >> 3][da 64 | db 64] (sixteen more live registers spilled the kernel).
@@ -224,7 +233,11 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
       }
       auto strip = [&](int i, bool guard) {
         fill(i, cblk);
-        if (i + HPF < MI) ldh(i + HPF);
+        // look-ahead grows as accumulator registers die: one strip ahead while strips 0 / 1 still hold 112 / 96 of them, two from then on
+        if (HPF == 1) { if (i + 1 < MI) ldh(i + 1); }
+        else if (i == 0) ldh(1);
+        else if (i == 1) { ldh(2); ldh(3); }
+        else if (i + 2 < MI) ldh(i + 2);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int row = it * 8 + (lane >> 3), m = mw + i * 16 + row;
@@ -247,13 +260,18 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
               ub2.x += (float)db[4]; ub2.y += (float)db[5]; ub2.z += (float)db[6]; ub2.w += (float)db[7];
               *(float4*)exq = ua; *(float4*)(exq + 4) = ua2; *(float4*)(exq + 64) = ub; *(float4*)(exq + 68) = ub2;
             }
-            __builtin_nontemporal_store(da, (bf16x8*)(dh12 + (size_t)m * 2 * Hs + n));
-            __builtin_nontemporal_store(db, (bf16x8*)(dh12 + (size_t)m * 2 * Hs + Hs + n));
+            if (!guard) {
+              char* wb = (char*)dh12 + (size_t)(mw + i * 16 + it * 8) * (size_t)(4 * Hs);
+              __builtin_nontemporal_store(da, (bf16x8*)(wb + loff));
+              __builtin_nontemporal_store(db, (bf16x8*)(wb + 2 * Hs + loff));
+            } else {
+              __builtin_nontemporal_store(da, (bf16x8*)(dh12 + (size_t)m * 2 * Hs + n));
+              __builtin_nontemporal_store(db, (bf16x8*)(dh12 + (size_t)m * 2 * Hs + Hs + n));
+            }
           }
         }
       };
-#pragma unroll
-      for (int i = 0; i < HPF; ++i) ldh(i);
+      ldh(0);
       if (whole) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) strip(i, false);
@@ -305,19 +323,18 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
 #ifndef NT_XPF
 #define NT_XPF 1
 #endif
-      constexpr int XPF = NT_XPF;                    // residual rows are requested XPF strips ahead of their use
-      float4 xi[MI + XPF][2][2];                     // fully unrolled: only XPF + 1 strips' worth are live at a time
+      constexpr int XPF = NT_XPF;                    // residual rows are requested XPF strips ahead of their use (2: one ahead for strips 0 / 1)
+      float4 xi[MI][2][2];                           // fully unrolled: only the look-ahead's worth is live at a time
+      // wave-uniform row base + one 32-bit lane offset for every residual access (saddr form: no 64-bit addresses in VGPRs)
+      const unsigned xoff = ((unsigned)(lane >> 3) * (unsigned)N + (unsigned)(nb + c8)) * 4u;
       auto ldx = [&](int i) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          const size_t o = (size_t)(mw + i * 16 + it * 8 + (lane >> 3)) * N + nb + c8;
-          xi[i][it][0] = *(const float4*)(e.xin + o); xi[i][it][1] = *(const float4*)(e.xin + o + 4);
+          const char* rb = (const char*)e.xin + (size_t)(mw + i * 16 + it * 8) * (size_t)N * 4;
+          xi[i][it][0] = *(const float4*)(rb + xoff); xi[i][it][1] = *(const float4*)(rb + xoff + 16);
         }
       };
-      if constexpr (EPI == LDMAE_EPI_GATE_RES) {
-#pragma unroll
-        for (int i = 0; i < XPF; ++i) ldx(i);
-      }
+      if constexpr (EPI == LDMAE_EPI_GATE_RES) ldx(0);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         fill(i, cblk);
@@ -329,17 +346,22 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
           a[it][0] = make_float4(u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w);
           a[it][1] = make_float4(v.x + b1.x, v.y + b1.y, v.z + b1.z, v.w + b1.w);
         }
-        if constexpr (EPI == LDMAE_EPI_GATE_RES) { if (i + XPF < MI) ldx(i + XPF); }
+        if constexpr (EPI == LDMAE_EPI_GATE_RES) {
+          if (XPF == 1) { if (i + 1 < MI) ldx(i + 1); }
+          else if (i == 0) ldx(1);
+          else if (i == 1) { ldx(2); ldx(3); }
+          else if (i + 2 < MI) ldx(i + 2);
+        }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int m = mw + i * 16 + it * 8 + (lane >> 3);
           const size_t oc = (size_t)m * e.ldc + nb + c8;
           const float4 p = a[it][0], q = a[it][1];
           if constexpr (EPI == LDMAE_EPI_GATE_RES) {
-            const size_t o = (size_t)m * N + nb + c8;
+            char* wb = (char*)e.xout + (size_t)(mw + i * 16 + it * 8) * (size_t)N * 4;
             const float4 x0 = xi[i][it][0], x1 = xi[i][it][1];
-            *(float4*)(e.xout + o) = make_float4(x0.x + g0.x * p.x, x0.y + g0.y * p.y, x0.z + g0.z * p.z, x0.w + g0.w * p.w);
-            *(float4*)(e.xout + o + 4) = make_float4(x1.x + g1.x * q.x, x1.y + g1.y * q.y, x1.z + g1.z * q.z, x1.w + g1.w * q.w);
+            *(float4*)(wb + xoff) = make_float4(x0.x + g0.x * p.x, x0.y + g0.y * p.y, x0.z + g0.z * p.z, x0.w + g0.w * p.w);
+            *(float4*)(wb + xoff + 16) = make_float4(x1.x + g1.x * q.x, x1.y + g1.y * q.y, x1.z + g1.z * q.z, x1.w + g1.w * q.w);
             if (e.C) put8(e.C, oc, p, q);
           } else if constexpr (EPI == LDMAE_EPI_BIAS_GELU) {
             auto g = [](float y) { return 0.5f * y * (1.f + erff(y * 0.70710678118654752f)); };
