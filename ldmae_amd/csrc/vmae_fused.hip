@@ -14,7 +14,7 @@
 //       - an accumulator block converts in registers into the B operand of the NEXT product (LN output -> qkv / fc1, GELU(fc1) -> fc2,
 //         attention output -> proj): no activation goes through LDS except K and V, which every wave needs from every other wave.
 //       The k-order a C/D block has when re-used as an operand is absorbed by permuting the weight columns once on the host.
-//   * weights stream through a 3-slot LDS ring by LDS-DMA (global_load_lds, 1 KiB per wave instruction) in the exact order of use, stored by
+//   * weights stream through a 4-slot LDS ring by LDS-DMA (global_load_lds, 1 KiB per wave instruction) in the exact order of use, stored by
 //     the host as ready-made MFMA A-operand fragments (lane-linear 1-KiB images: conflict-free ds_read_b128, no address arithmetic);
 //     the small f32 vectors (LayerNorm weights, biases) ride in the same slots.  One s_barrier per step of 24 MFMAs per wave, counted vmcnt.
 //   * attention per pair of heads: q^T, k^T from the transposed product (a lane's 8 values ARE its QK^T operand fragment), v from the
@@ -27,16 +27,19 @@
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
+#ifndef VF_TL
+#define VF_TL 0
+#endif
 #ifndef VF_DBG
 #define VF_DBG 0      // ablation builds for tools/ only: 1 = no GELU arithmetic, 2 = no softmax / PV, 3 = no LDS-DMA waits (stale weights), 4 = no MLP
 #endif
 namespace {
 constexpr int VD = 192, VHID = 768, VH = 12, VTOK = 256;
 constexpr int FRAG = 1024, PANEL = 12 * FRAG, VECB = 2048;         // a panel = 12 operand fragments; 2 KiB of f32 vectors per slot
-constexpr int SLOTB = 2 * PANEL + VECB, NSLOT = 3, PIECES = SLOTB / 1024;   // 26 KiB per step, 26 DMA pieces
+constexpr int SLOTB = 2 * PANEL + VECB, NSLOT = 4, PIECES = SLOTB / 1024;   // 26 KiB per step, 26 DMA pieces; 4 slots: slot g - 1 stays readable during step g
 constexpr int STEPS = 36;                                          // per block: 6 head pairs x 2 + 24 MLP chunks
 constexpr int KVB = 32768;                                         // K [2 heads][8 key blocks][1 KiB] | V^T [8 key blocks][2 k-steps][1 KiB]
-constexpr int LDS_BYTES = NSLOT * SLOTB + KVB;                     // 112,640 B
+constexpr int LDS_BYTES = NSLOT * SLOTB + KVB;                     // 139,264 B
 
 __device__ __forceinline__ bf16x8 cvt8(const f32x16& x, int s, float mul = 1.f) {
   bf16x8 f;
@@ -82,6 +85,9 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
   if (total > 1) issue(1);
 
   // residual stream: xacc[d][4g + j] = x[token][32 d + 8 g + 4 h + j]   (C/D block d: rows = features 32d .. 32d+31, column = token)
+#if VF_TL
+  unsigned long long tl[20] = {};
+#endif
   f32x16 xacc[6];
   {
     const float* xr = x + ((size_t)blockIdx.x * VTOK + wave * 32 + r) * VD;
@@ -272,30 +278,79 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
         if (hp == 5) add_rowvec(vec);                        // + proj bias, once per block
       }
     }
-    // ================= MLP: 24 chunks of 32 hidden units (panel 0 = fc1 rows, panel 1 = fc2 columns of the same units)
-    for (int c = 0; c < 24; ++c) {
-      const char* slot = next_slot();
-      if (VF_DBG == 4) continue;
-      const char* p0 = slot + lane * 16;
-      const char* p1 = p0 + PANEL;
-      const float* vec = (const float*)(slot + 2 * PANEL);
-      if (c == 0) layernorm(vec, vec + VD, to_frags);
-      f32x16 hT = mm12(zero16(), p0, std::false_type{});
-      add_rows32(hT, vec + 384);
+    // ================= MLP: 24 chunks of 32 hidden units (panel 0 = fc1 rows, panel 1 = fc2 columns of the same units), skewed by one
+    // chunk inside the wave: step c runs fc1 of chunk c with the GELU of chunk c - 1 spread between its MFMAs (the GELU is ~20 vector
+    // instructions per element and was the longest phase of the step, with the matrix pipe idle), then fc2 of chunk c - 1 out of the
+    // PREVIOUS slot's panel 1 -- which the 4-slot ring keeps readable for one more step.
+    {
+#if VF_TL
+#define TLS(k) if (blk == 1 && c >= 4 && c < 8) tl[(c - 4) * 5 + (k)] = __builtin_amdgcn_s_memtime()
+#else
+#define TLS(k)
+#endif
+      f32x16 hprev = zero16();
+      const char* p1prev = nullptr;
+      const float* vec = nullptr;
+      auto gelu4 = [&](f32x16& hh, int q) {
 #pragma unroll
-      for (int tt = 0; tt < 16; ++tt) {
-        if (VF_DBG != 1) hT[tt] = gelu_erf(hT[tt]);
-        if ((tt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        for (int tt = 4 * q; tt < 4 * q + 4; ++tt)
+          if (VF_DBG != 1) hh[tt] = gelu_erf(hh[tt]);
+      };
+      for (int c = 0; c < 24; ++c) {
+        TLS(0);
+        const char* slot = next_slot();
+        TLS(1);
+        if (VF_DBG == 4) continue;
+        const char* p0 = slot + lane * 16;
+        vec = (const float*)(slot + 2 * PANEL);
+        if (c == 0) layernorm(vec, vec + VD, to_frags);
+        f32x16 hT = zero16();
+        bf16x8 fa[3], fb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fa[j] = *(const bf16x8*)(p0 + j * FRAG);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {            // 3 fc1 MFMAs + 4 GELUs of the previous chunk per group; next group's fragments in flight
+          if (q < 3) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) (q & 1 ? fa : fb)[j] = *(const bf16x8*)(p0 + (3 * (q + 1) + j) * FRAG);
+          }
+          // the fc1 MFMAs form ONE dependency chain (same accumulator): an in-order wave that meets the next MFMA before the previous one
+          // has finished just waits, so a GELU sits BETWEEN every two of them (scheduling fences keep the compiler from regrouping)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            hT = MFMA((q & 1 ? fb : fa)[j], xf[3 * q + j], hT);
+            if (c > 0 && VF_DBG != 1) hprev[4 * q + j] = gelu_erf(hprev[4 * q + j]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (c > 0 && VF_DBG != 1) hprev[4 * q + 3] = gelu_erf(hprev[4 * q + 3]);
+        }
+        TLS(2);
+        add_rows32(hT, vec + 384);
+        const bf16x8 h0 = cvt8(hprev, 0), h1 = cvt8(hprev, 1);
+        TLS(3);
+        if (c > 0) mm_out(p1prev, h0, h1);
+        TLS(4);
+        hprev = hT;
+        p1prev = p0 + PANEL;
       }
-      const bf16x8 hf0 = cvt8(hT, 0), hf1 = cvt8(hT, 1);
-      mm_out(p1, hf0, hf1);
-      if (c == 23) add_rowvec(vec);                          // + fc2 bias
+      if (VF_DBG != 4) {                         // drain: GELU and fc2 of the last chunk, + fc2 bias
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { gelu4(hprev, q); __builtin_amdgcn_sched_barrier(0); }
+        mm_out(p1prev, cvt8(hprev, 0), cvt8(hprev, 1));
+        add_rowvec(vec);
+      }
     }
   }
   // closing LayerNorm (models_mae.py:369, 521): its weight / bias ride in the second-to-last slot, which nothing has overwritten
   const float* nv = (const float*)(smem + ((total - 2) % NSLOT) * SLOTB + 2 * PANEL);
   float* orow = out + ((size_t)blockIdx.x * VTOK + wave * 32 + r) * VD;
   layernorm(nv, nv + VD, [&](int d, int g, float4 y) { *(float4*)(orow + 32 * d + 8 * g + 4 * h) = y; });
+#if VF_TL
+  if (lane == 0 && (wave == 0 || wave == 4)) {          // timing build only: the stamps overwrite the head of this wave's output rows
+    unsigned long long* o = (unsigned long long*)orow;
+    for (int i = 0; i < 20; ++i) o[i] = tl[i];
+  }
+#endif
 }
 
 extern "C" long ldmae_vmae_encoder_blob_bytes(int nblocks) { return (long)nblocks * STEPS * SLOTB; }
