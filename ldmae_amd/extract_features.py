@@ -133,7 +133,7 @@ def main(args, cfg):
         print("Not launched under torch.distributed: running in local mode.")
         rank, world = 0, 1
     device = int(os.environ.get("LDMAE_DEVICE", rank % torch.cuda.device_count()))
-    torch.manual_seed(args.seed + rank)
+    torch.manual_seed(args.seed)                 # the same initial weights on every rank when no checkpoint is loaded (--synthetic)
     torch.cuda.set_device(device)
     model_name = cfg["vae"]["model_name"].split("_")[0]
     if model_name != "vmae":
@@ -152,6 +152,7 @@ def main(args, cfg):
     elif not args.synthetic:
         raise FileNotFoundError(f"vae.weight_path {chkpt!r} not found")
     tokenizer = tokenizer.cuda().eval()
+    torch.manual_seed(args.seed + rank)          # extract_features.py:33,41: per-rank seed for everything after the model
     if args.precision == "bf16":
         tokenizer.set_precision(torch.bfloat16)
     if args.synthetic:

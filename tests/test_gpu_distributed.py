@@ -137,3 +137,32 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
     assert line["comm"]["backend"] == "gloo" and line["comm"]["buckets"] >= 1 and line["comm"]["gemm_launch_mode"] == "one tile per workgroup"
     assert line["value"] > 0 and line["roofline"]["achieved"] > 0 and "cpu_baseline" not in line
+
+
+def test_extract_features_two_ranks_share_the_dataset(tmp_path):
+    """The shard writer under a launcher (reference extract_features.py:27-41, 109-118): 2 ranks (gloo, both on cuda:0) over 10 synthetic
+    images -> rank r encodes samples r, r + 2, ... (DistributedSampler, shuffle=False), each writes latents_rank{r:02d}_shard000, rank 0
+    alone builds latents_stats.pt after the barrier; the reader sees all 10."""
+    import yaml
+    from safetensors import safe_open
+    cfg = dict(vae=dict(model_name="vmae_f8d16", weight_path=""), data=dict(origin_path=str(tmp_path / "ds" / "root"), name="imagenet", sample=True))
+    (tmp_path / "cfg.yaml").write_text(yaml.safe_dump(cfg))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LDMAE_DIST_BACKEND="gloo", LDMAE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", "-m", "ldmae_amd.extract_features", "--config", str(tmp_path / "cfg.yaml"), "--synthetic", "10",
+                        "--image_size", "64", "--batch_size", "2", "--num_workers", "0"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = tmp_path / "ds" / "vmae_feature_imagenet_train_64_sample"
+    files = sorted(f for f in os.listdir(out) if f.endswith(".safetensors"))
+    assert files == ["latents_rank00_shard000.safetensors", "latents_rank01_shard000.safetensors"] and os.path.exists(out / "latents_stats.pt")
+    sys.path.insert(0, ROOT)
+    from ldmae_amd.extract_features import _SyntheticImages
+    ds = _SyntheticImages(10, 64, False)
+    for rank, f in enumerate(files):
+        with safe_open(str(out / f), framework="pt") as h:
+            lat, labels = h.get_tensor("latents"), h.get_tensor("labels")
+            assert h.metadata()["total_size"] == "5"
+        assert lat.shape == (5, 32, 8, 8) and labels.tolist() == [ds[i][1] for i in range(rank, 10, 2)]      # rank-strided, in order
+    from ldmae_amd.datasets.img_latent_dataset import ImgLatentDataset
+    assert len(ImgLatentDataset(str(out), latent_norm=True, sample=True)) == 10
