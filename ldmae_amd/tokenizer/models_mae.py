@@ -12,6 +12,7 @@ pred_with_conv, perceptual loss) raise NotImplementedError.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from functools import partial
 from typing import Optional
@@ -315,7 +316,7 @@ class MaskedAutoencoderViT(nn.Module):
             self.decoder_pred = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
         self.norm_pix_loss = norm_pix_loss
         self.precision = None
-        self.fused_encoder = True          # False: always the per-layer kernels (A/B and parity tests)
+        self.fused_encoder = os.environ.get("LDMAE_VMAE_FUSED", "1") != "0"      # False / LDMAE_VMAE_FUSED=0: always the per-layer kernels (A/B and parity tests)
         self.initialize_weights()
 
     def initialize_weights(self):
