@@ -74,6 +74,10 @@ int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, fl
 /* f32 master weight [R,C] -> dst[R,C] (dtype) and, if dstT != NULL, dstT[C,R] (the [in,out] copy) */
 int ldmae_cast_weight(int dst_dtype, const float* src, void* dst, void* dstT, int R, int C, void* stream);
 int ldmae_cast(int src_dtype, int dst_dtype, const void* src, void* dst, long n, void* stream);
+/* `count` (<= 64) f32 device tensors of n_each elements each -> dst[count * n_each] in dst_dtype, one launch; srcs is a HOST array of device
+ * pointers (16-B aligned; n_each % 8 == 0).  Used to stack the adaLN_modulation weights of all blocks (lightningdit.py:233-236) into the
+ * [depth * 6D, D] operand of one GEMM. */
+int ldmae_cast_stack(int dst_dtype, const void* const* srcs, int count, long n_each, void* dst, void* stream);
 
 /* ---- adaLN-modulated RMSNorm (rmsnorm.py:51-77 + lightningdit.py:26-30) ----------------------- */
 /* out = rmsnorm(x; w, eps) * (1 + scale[b]) + shift[b];  rstd[M] saved for backward.

@@ -929,6 +929,38 @@ extern "C" int ldmae_cast(int src_dtype, int dst_dtype, const void* src, void* d
   return LDMAE_OK;
 }
 
+// `count` equally sized f32 tensors -> one stacked tensor in the activation type with ONE launch (the adaLN weights of all blocks become the
+// [depth * 6D, D] operand of a single GEMM: models/lightningdit.py:_AdaLNAllFn).  The source pointers travel by value in the kernel arguments.
+constexpr int CAST_STACK_MAX = 64;
+struct CastStackArgs { const float* src[CAST_STACK_MAX]; };
+template <typename Dt>
+__global__ void cast_stack_kernel(CastStackArgs a, Dt* __restrict__ dst, long n_each) {
+  const float* s = a.src[blockIdx.y];
+  Dt* d = dst + (size_t)blockIdx.y * n_each;
+  const long n8 = n_each / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    Vec8<float>::load(s + i * 8, v);
+    Vec8<Dt>::store(d + i * 8, v);
+  }
+}
+extern "C" int ldmae_cast_stack(int dst_dtype, const void* const* srcs, int count, long n_each, void* dst, void* stream) {
+  LDMAE_REQUIRE(srcs && dst && count > 0 && count <= CAST_STACK_MAX, "cast_stack: count=%d must be 1..%d", count, CAST_STACK_MAX);
+  LDMAE_REQUIRE(n_each > 0 && n_each % 8 == 0, "cast_stack: n_each=%ld must be a positive multiple of 8", n_each);
+  LDMAE_REQUIRE(((uintptr_t)dst & 15) == 0, "cast_stack: dst must be 16-B aligned");
+  CastStackArgs a{};
+  for (int i = 0; i < count; ++i) {
+    LDMAE_REQUIRE(srcs[i] && ((uintptr_t)srcs[i] & 15) == 0, "cast_stack: source %d is null or not 16-B aligned", i);
+    a.src[i] = (const float*)srcs[i];
+  }
+  const unsigned gx = (unsigned)min((long)1024, (n_each / 8 + 255) / 256);
+  if (dst_dtype == LDMAE_BF16) hipLaunchKernelGGL(cast_stack_kernel<bf16>, dim3(gx, count), dim3(256), 0, as_stream(stream), a, (bf16*)dst, n_each);
+  else if (dst_dtype == LDMAE_F32) hipLaunchKernelGGL(cast_stack_kernel<float>, dim3(gx, count), dim3(256), 0, as_stream(stream), a, (float*)dst, n_each);
+  else LDMAE_FAIL(LDMAE_ERR_INVALID, "cast_stack: unsupported dst dtype %d", dst_dtype);
+  LDMAE_CHECK_LAUNCH("cast_stack");
+  return LDMAE_OK;
+}
+
 // f32 [R,C] -> T [R,C] and T [C,R] through a 32x33 LDS tile
 template <typename T>
 __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, T* __restrict__ dstT, int R, int C) {

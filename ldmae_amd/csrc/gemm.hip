@@ -648,7 +648,9 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
   const int ntiles = cdiv(M, 256) * cdiv(N, 256);
   // launch mode, a per-call argument (LDMAE_EPI_TILE_LAUNCH or'ed into `epi` by the caller): one 256x256 tile per workgroup instead of
   // one persistent workgroup per CU -- what a data-parallel caller asks for while RCCL's collective kernels hold some CUs
-  const bool pers = !tile_launch && ldmae_tune_get(8) != 2;
+  // the persistent mapping gives every XCD a contiguous range of A row-blocks: with fewer than 8 row-blocks (the batched adaLN GEMM: M = batch
+  // = 256, N = depth * 6D) whole XCDs would idle, so such shapes take the tile launch, which deals tiles to all XCDs
+  const bool pers = !tile_launch && ldmae_tune_get(8) != 2 && cdiv(M, 256) >= 8;
   const int pgrid = (pers && ntiles != ncu) ? ncu : ntiles;
 #ifdef LDMAE_DIAG
   // tune key 0: 1 / 2 = the experimental kernels of probe/gemm_w4.hip (diagnostic build only)
@@ -778,8 +780,10 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   hipStream_t st = as_stream(stream);
   LDMAE_REQUIRE(workspace && workspace_bytes >= (long)splits * ((long)N * K + N) * 4, "gemm_tn: workspace too small (%ld < %ld)",
                 workspace_bytes, (long)splits * ((long)N * K + N) * 4);
-  float* P = workspace;
-  float* Pb = workspace + (size_t)splits * N * K;
+  // one split and nothing to accumulate into: the GEMM writes C (and the bias gradient) itself -- no partial slab, no reduce pass
+  const bool direct = splits == 1 && beta == 0.f;
+  float* P = direct ? C : workspace;
+  float* Pb = direct ? dbias : workspace + (size_t)splits * N * K;
   if (ring) {
     constexpr int lds = 5 * 32768;   // ring (4 x 32 KiB) and the 139 KiB epilogue region share it
     if (ldmae_tune_get(4) == 3) hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -804,7 +808,7 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
     hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(grid), dim3(256), 0, st, (const float*)A, (const float*)B, P, M, N, K, lda, ldb, rows);
   }
   LDMAE_CHECK_LAUNCH("gemm_tn");
-  {
+  if (!direct) {
     const long n = (long)N * K;
     const unsigned grid = (unsigned)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, P, C, n, splits, beta);

@@ -169,6 +169,17 @@ class _GradChain:
 
     def __init__(self):
         self.up, self.pre = {}, {}
+        self.dmod_all, self.mod_cols = None, 0      # batched adaLN (_AdaLNAllFn): ONE [B, depth * 6D] gradient buffer, a column slice per block
+
+    def dmod(self, j, mod):
+        """Gradient buffer of member j's modulation vectors `mod` [B, 6D]: a private tensor, or member j's column slice of the shared
+        buffer when the adaLN Linears of all blocks run as one GEMM (their backward then is one GEMM over the whole buffer)."""
+        if self.mod_cols == 0:
+            return torch.empty(mod.shape, dtype=mod.dtype, device=mod.device)
+        if self.dmod_all is None:
+            self.dmod_all = torch.empty(mod.shape[0], self.mod_cols, dtype=torch.float32, device=mod.device)
+        w = mod.shape[1]
+        return self.dmod_all[:, j * w:(j + 1) * w]
 
     def norm_bwd(self, j, dout, x, w, scale, rstd, dx, dshift, dscale, N, dtype, accumulate=True):
         """norm backward of member j (accumulating into dx); fused with member j-1's gate backward when that member is registered."""
@@ -179,24 +190,62 @@ class _GradChain:
         if prev is None:
             return ops.rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx, dshift, dscale, N, accumulate)
         y2p, modp = prev
-        dmodp = torch.empty_like(modp)
+        dmodp = self.dmod(j - 1, modp)
         dw, dy2p, db3p = ops.rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx, dshift, dscale, y2p, modp[:, 5 * D:6 * D],
                                                        dmodp[:, 5 * D:6 * D], N, dtype, accumulate)
         self.pre[j - 1] = (dx.data_ptr(), dy2p, db3p, dmodp)
         return dw
 
 
+class _AdaLNAllFn(torch.autograd.Function):
+    """The adaLN_modulation Linears (:233-236) of ALL blocks as one GEMM on the shared SiLU(c): mod_all [B, depth * 6D] = sc @ W_all^T +
+    b_all, W_all = the depth weights stacked (one cast launch), bf16 operands with f32 accumulation and f32 output -- what the
+    reference's autocast Linear computes (its output is bf16 on top).  Per block these were a 40-us f32 GEMM forward and, backward, two
+    46-51-us f32 GEMMs, a transpose, two split reductions, a column sum and three AccumulateGrad adds (2.8 ms per B/1 step in ~190
+    launches); batched: one NT GEMM forward, two TN GEMMs + a column sum backward.  The blocks write their modulation gradients into
+    column slices of ONE buffer (_GradChain.dmod) and block 0 -- whose backward runs last -- hands that buffer to autograd as the
+    gradient of mod_all; every block lists mod_all as an input, so this backward cannot start before all of them are done."""
+
+    @staticmethod
+    def forward(ctx, sc, fwd_only, *wb):
+        n = len(wb) // 2
+        ws, bs = wb[:n], wb[n:]
+        scb = ops.cast(sc.contiguous(), torch.bfloat16)
+        stack = ops.cached_stack_copy if fwd_only else ops.cast_stack       # sampling re-runs the same weights: keep the stacked copies
+        W_all = stack(ws, torch.bfloat16)                           # [n * 6D, D]
+        b_all = stack(bs, torch.float32)                            # [n * 6D]
+        mod_all = ops.gemm_nt(scb, W_all, b_all, out_dtype=torch.float32)
+        ctx.save_for_backward(scb, W_all)
+        ctx.n, ctx.rows = n, ws[0].shape[0]
+        return mod_all
+
+    @staticmethod
+    def backward(ctx, g):
+        scb, W_all = ctx.saved_tensors
+        n, rows = ctx.n, ctx.rows
+        g = g.contiguous()
+        gb = ops.cast(g, torch.bfloat16)
+        dW_all = ops.gemm_tn(gb, scb)                               # [n * 6D, D] f32: contraction over the batch
+        db_all = ops.colsum(g)
+        dsc = ops.gemm_tn(gb.t().contiguous(), W_all) if ctx.needs_input_grad[0] else None      # [B, D]: contraction over all n * 6D outputs
+        return (dsc, None) + tuple(dW_all[i * rows:(i + 1) * rows] for i in range(n)) + tuple(db_all[i * rows:(i + 1) * rows] for i in range(n))
+
+
 class _DiTBlockFn(torch.autograd.Function):
     """LightningDiTBlock.forward (:239-250) with RMSNorm, QK-norm, RoPE, SwiGLU, shift."""
 
     @staticmethod
-    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace, chain, idx, direct, fwd_only,
+    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace, chain, idx, direct, fwd_only, mod_all,
                 n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12, b12, w3, b3, adaw, adab):
         B, N, D = x.shape
         M, hd = B * N, D // H
         x2 = x.contiguous().view(M, D)
         sc = sc.contiguous()
-        mod = ops.gemm_nt(sc, adaw, adab, out_dtype=torch.float32)                       # [B, 6D] f32
+        ctx.batched_ada = mod_all is not None
+        if mod_all is not None:                                                          # _AdaLNAllFn ran the Linear of every block at once
+            mod = mod_all[:, idx * 6 * D:(idx + 1) * 6 * D]
+        else:
+            mod = ops.gemm_nt(sc, adaw, adab, out_dtype=torch.float32)                   # [B, 6D] f32
         sh1, s1, g1, sh2, s2, g2 = (mod[:, i * D:(i + 1) * D] for i in range(6))          # :246 chunk order
         # forward-only calls (torch.no_grad sampling: forward_with_cfg) skip everything only the backward pass reads: the transposed
         # weight copies, the pre-gate branch outputs y1 / y2 and h12 = [x1 | x2] of the SwiGLU (1.6 GB per XL/1 block at batch 128).
@@ -253,7 +302,7 @@ class _DiTBlockFn(torch.autograd.Function):
         if pre is not None and pre[0] == dx.data_ptr():      # the next member's backward already gated this dx (see _GradChain)
             _, dy2, db3, dmod = pre
         else:
-            dmod = torch.empty_like(mod)
+            dmod = chain.dmod(idx, mod) if chain is not None else torch.empty(mod.shape, dtype=mod.dtype, device=mod.device)
             dy2, db3 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype, with_bias=True)   # bias grads where dy is produced
         qkvw_p, pw_p, w12_p, w3_p = ctx.wparams
         notify = []
@@ -282,14 +331,20 @@ class _DiTBlockFn(torch.autograd.Function):
             dn1 = chain.norm_bwd(idx, dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N, dtype)
         else:
             dn1 = ops.rmsnorm_modulate_bwd(dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N)
-        # ---- adaLN (f32 in both modes)
-        dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
-        dsc = _dmod_times_w(dmod, adaw)
+        # ---- adaLN: per block in f32, or (batched) nothing here -- block 0, the last to run, returns the shared dmod buffer for mod_all
+        dmod_all = None
+        if ctx.batched_ada:
+            dadaw = dadab = dsc = None
+            if idx == 0:
+                dmod_all = chain.dmod_all
+        else:
+            dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
+            dsc = _dmod_times_w(dmod, adaw)
         sg.join()
         for r, p_ in notify:          # gradients written straight into .grad: tell the reducer (no-op without one)
             if r is not None:
                 r(p_)
-        return (dx.view(B, N, D), dsc, None, None, None, None, None, None, None, None, None, None,
+        return (dx.view(B, N, D), dsc, None, None, None, None, None, None, None, None, None, None, dmod_all,
                 dn1, dWqkv, dbqkv, dqn, dkn, dWp, dbp, dn2, dW12, db12, dW3, db3, dadaw, dadab)
 
 
@@ -497,14 +552,14 @@ class LightningDiTBlock(nn.Module):
         self.wo_shift = wo_shift
         self.precision = None
 
-    def forward(self, x, c, feat_rope=None, _silu_c=None, _dtype=None, _inplace_grad=False, _chain=None, _idx=0, _direct=False):
+    def forward(self, x, c, feat_rope=None, _silu_c=None, _dtype=None, _inplace_grad=False, _chain=None, _idx=0, _direct=False, _mod_all=None):
         if feat_rope is None:
             raise NotImplementedError("ldmae_amd LightningDiTBlock needs feat_rope (use_rope=True)")
         sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
         a, m = self.attn, self.mlp
         return _DiTBlockFn.apply(
             x.float(), sc, feat_rope.freqs_cos, feat_rope.freqs_sin, a.num_heads, self.norm1.eps, _dtype or _act_dtype(self.precision),
-            _inplace_grad, _chain, _idx, _direct, not torch.is_grad_enabled(),
+            _inplace_grad, _chain, _idx, _direct, not torch.is_grad_enabled(), _mod_all,
             self.norm1.weight, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.k_norm.weight, a.proj.weight, a.proj.bias,
             self.norm2.weight, m.w12.weight, m.w12.bias, m.w3.weight, m.w3.bias,
             self.adaLN_modulation[1].weight, self.adaLN_modulation[1].bias)
@@ -542,6 +597,7 @@ class LightningDiT(nn.Module):
         # opt-in of the training driver (which owns a gradient slab and calls plain loss.backward()): the four Linear weight gradients
         # of every block are accumulated straight into param.grad by the GEMM's reduce instead of through autograd's AccumulateGrad
         self.direct_param_grads = False
+        self.batched_adaln = os.environ.get("LDMAE_BATCHED_ADALN", "1") != "0"      # False / LDMAE_BATCHED_ADALN=0: per-block f32 adaLN GEMMs (A/B and parity tests)
         self.learn_sigma = learn_sigma
         self.in_channels = in_channels
         self.out_channels = in_channels if not learn_sigma else in_channels * 2
@@ -627,11 +683,21 @@ class LightningDiT(nn.Module):
             if torch.is_grad_enabled() and not self.use_checkpoint and not any(hooked) and \
                     not (fl._forward_hooks or fl._forward_pre_hooks or fl._backward_hooks):
                 chain = _GradChain()
+            # the adaLN Linears of all blocks as ONE bf16 GEMM (_AdaLNAllFn): training needs the chain (its shared gradient buffer),
+            # inference just takes the forward.  f32 mode, checkpointing, hooked blocks and batches that are not a multiple of 8 (the
+            # bf16 TN GEMM's alignment) keep the per-block f32 GEMMs.
+            mod_all = None
+            if self.batched_adaln and dtype == torch.bfloat16 and not self.use_checkpoint and len(self.blocks) <= 64 and sc.shape[0] % 8 == 0 and \
+                    (chain is not None or not torch.is_grad_enabled()):
+                lins = [b.adaLN_modulation[1] for b in self.blocks]
+                mod_all = _AdaLNAllFn.apply(sc, not torch.is_grad_enabled(), *[l.weight for l in lins], *[l.bias for l in lins])
+                if chain is not None:
+                    chain.mod_cols = mod_all.shape[1]
             for i, block in enumerate(self.blocks):
                 if self.use_checkpoint:
                     x = checkpoint(block, x, c, self.feat_rope, sc, dtype, not hooked[i], use_reentrant=True)
                 else:
-                    x = block(x, c, self.feat_rope, sc, dtype, not hooked[i], chain, i, self.direct_param_grads and chain is not None)
+                    x = block(x, c, self.feat_rope, sc, dtype, not hooked[i], chain, i, self.direct_param_grads and chain is not None, mod_all)
             x = self.final_layer(x, c, sc, dtype, chain, len(self.blocks))
             x = self.unpatchify(x)
             if self.learn_sigma:

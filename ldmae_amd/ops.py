@@ -209,6 +209,20 @@ def cast(x, dtype):
     return out
 
 
+def cast_stack(tensors, dtype):
+    """Equally shaped contiguous f32 tensors -> one stacked [len * rows, cols] tensor in `dtype`, one launch."""
+    import ctypes
+    t0 = tensors[0]
+    n_each = t0.numel()
+    out = torch.empty((len(tensors) * t0.shape[0],) + tuple(t0.shape[1:]), dtype=dtype, device=t0.device)
+    srcs = [_c(t) for t in tensors]
+    if any(t.dtype != torch.float32 or t.numel() != n_each for t in srcs):
+        raise RuntimeError("cast_stack: f32 tensors of one size expected")
+    arr = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+    call("ldmae_cast_stack", dt(dtype), arr, len(srcs), n_each, ptr(out), stream())
+    return out
+
+
 # ----------------------------------------------------------------------------- norms / elementwise
 def rmsnorm_modulate_fwd(x, w, shift, scale, rows_per_batch, out_dtype, eps=1e-6):
     M, D = x.shape
@@ -437,6 +451,22 @@ def cached_weight_copy(w, dtype):
     if len(_WCACHE) > 4096:
         _WCACHE.clear()
     c = cast_weight(w, dtype, transposed=False, straight=True)[0]
+    _WCACHE[key] = (weakref.ref(w), stamp, c)
+    return c
+
+
+def cached_stack_copy(tensors, dtype):
+    """cast_stack for FORWARD-ONLY use (sampling re-runs the same weights hundreds of times): valid while every source's storage pointer and
+    version counter and WEIGHT_EPOCH are unchanged.  Keyed by the first tensor (weak reference, like cached_weight_copy)."""
+    w = tensors[0]
+    key = (id(w), dtype, "stack", len(tensors))
+    stamp = (tuple((t.data_ptr(), t._version) for t in tensors), WEIGHT_EPOCH)
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == stamp:
+        return hit[2]
+    if len(_WCACHE) > 4096:
+        _WCACHE.clear()
+    c = cast_stack(tensors, dtype)
     _WCACHE[key] = (weakref.ref(w), stamp, c)
     return c
 

@@ -419,3 +419,37 @@ def test_forward_only_weight_copy_cache_tracks_weight_changes():
     assert not torch.equal(b, c)
     ref = build(TINY, {k: v.detach().clone() for k, v in m.state_dict().items()}).eval()     # fresh model, same weights, no cache entries
     assert torch.equal(c, fwd(ref))
+
+
+def test_batched_adaln_matches_per_block_and_oracle():
+    """The adaLN_modulation Linears of all blocks as ONE bf16 GEMM (_AdaLNAllFn; batch a multiple of 8) against the per-block f32 GEMMs
+    (batched_adaln = False) and the f32 oracle: prediction, and EVERY gradient -- the adaLN weights / biases come out of the two batched
+    TN GEMMs, the conditioning path (t / y embedders) out of their dsc, everything else must not notice."""
+    sd = tiny_sd()
+    B = 8
+    x1, x0 = det_randn("ba_x1", (B, 16, 8, 8), 5), det_randn("ba_x0", (B, 16, 8, 8), 6)
+    t = torch.linspace(0.1, 0.9, B)
+    y = torch.arange(B) % 10
+    drop = torch.tensor([0, 1, 0, 0, 0, 0, 1, 0], dtype=torch.bool)
+    _, xt, ut = otr.plan(t, x0, x1)
+    res = {}
+    for batched in (True, False):
+        m = build(TINY, sd)
+        m.batched_adaln = batched
+        force_drop(m, drop.numpy())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = m(xt.cuda(), t.cuda(), y.cuda())
+        ((pred - ut.cuda()) ** 2).mean().backward()
+        res[batched] = (pred.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None})
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):      # the forward-only (sampling) path takes the batched GEMM too
+            assert rel_err(m(xt.cuda(), t.cuda(), y.cuda()).cpu(), res[batched][0]) < 1e-6
+    assert rel_err(res[True][0], res[False][0]) < 2e-2
+    assert set(res[True][1]) == set(res[False][1])
+    _, ograds, opred = otrain.loss_and_grads(sd, TINY, x1, y, t, x0, drop)
+    assert rel_err(res[True][0], opred) < 3e-2
+    for k, gb in res[True][1].items():
+        for other, name in ((res[False][1][k], "per-block"), (ograds[k], "oracle")):
+            a, b = gb.double().flatten(), other.double().flatten()
+            cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+            assert cos > 0.99, (k, name, cos)
+        assert abs(float(gb.norm() / (ograds[k].norm() + 1e-30)) - 1.0) < 0.1, k
