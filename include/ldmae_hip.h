@@ -74,6 +74,16 @@ int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, fl
 /* f32 master weight [R,C] -> dst[R,C] (dtype) and, if dstT != NULL, dstT[C,R] (the [in,out] copy) */
 int ldmae_cast_weight(int dst_dtype, const float* src, void* dst, void* dstT, int R, int C, void* stream);
 int ldmae_cast(int src_dtype, int dst_dtype, const void* src, void* dst, long n, void* stream);
+/* Thin f32 products with a contraction of K = 16 or 32 over M = batch * tokens rows -- the DiT's PatchEmbed at patch size 1
+ * (lightningdit.py:309, 402: K = C * p * p) and dX of the FinalLayer's Linear (:270): HBM streaming, one pass over the big tensor.
+ *   ldmae_thin_nt: out[M,N] (out_dtype) = T[M,K] . W[N,K]^T + bias[N] (+ pos[m % rows_per_batch, :] when pos != NULL); N % 4 == 0.
+ *   ldmae_thin_tn: dW[N,K] = beta * dW + G[M,N]^T . T[M,K]; dbias[N] (may be NULL) = beta * dbias + column sums of G; partial sums per
+ *                  512 rows, reduced in fixed order (deterministic); workspace >= ldmae_thin_tn_workspace_bytes(M, N, K). */
+int ldmae_thin_nt(int out_dtype, const float* T, const float* W, const float* bias, const float* pos, void* out, int M, int N, int K,
+                  int rows_per_batch, void* stream);
+long ldmae_thin_tn_workspace_bytes(int M, int N, int K);
+int ldmae_thin_tn(const float* G, const float* T, float* dW, float* dbias, int M, int N, int K, float beta, float* workspace,
+                  long workspace_bytes, void* stream);
 /* `count` (<= 64) f32 device tensors of n_each elements each -> dst[count * n_each] in dst_dtype, one launch; srcs is a HOST array of device
  * pointers (16-B aligned; n_each % 8 == 0).  Used to stack the adaLN_modulation weights of all blocks (lightningdit.py:233-236) into the
  * [depth * 6D, D] operand of one GEMM. */

@@ -33,6 +33,9 @@ SIGNATURES = {
     "ldmae_cast_weight": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
     "ldmae_cast": (_i, [_i, _i, _vp, _vp, _l, _vp]),
     "ldmae_cast_stack": (_i, [_i, _vp, _i, _l, _vp, _vp]),
+    "ldmae_thin_nt": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ldmae_thin_tn_workspace_bytes": (_l, [_i, _i, _i]),
+    "ldmae_thin_tn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _l, _vp]),
     "ldmae_rmsnorm_modulate_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
     "ldmae_rmsnorm_modulate_bwd_workspace_bytes": (_l, [_i, _i, _i]),
     "ldmae_rmsnorm_modulate_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _f, _i, _i, _i, _vp, _vp]),

@@ -929,6 +929,133 @@ extern "C" int ldmae_cast(int src_dtype, int dst_dtype, const void* src, void* d
   return LDMAE_OK;
 }
 
+// ------------------------------------------------------------------ thin GEMMs: contraction length K <= 32 over M = batch * tokens rows
+// The DiT's PatchEmbed at patch 1 (lightningdit.py:309, 402: K = C * p * p = 16) and the dX of the FinalLayer's 16-column Linear (:270)
+// are [M, 768] <-> [M, 16] products at M = 262144: 0.02 FLOP per byte, pure HBM streaming.  As 64x64-tile MFMA GEMMs they ran at
+// 2.2 TB/s (358 us forward, 366 + 34 + 146 us for weight gradient + split reduce + bias column sum: two passes over the 805-MB
+// gradient).  Here a thread owns one output column, the K-vectors of the workgroup's rows sit in LDS (broadcast reads) and the weights / partial sums
+// live in registers: one pass over the big tensor, 256-B runs per wave.
+//   thin_nt: out[m, n] = sum_k T[m, k] W[n, k] + bias[n] (+ pos[m % rows_per_batch, n])
+//   thin_tn: dW[n, k] = sum_m G[m, n] T[m, k], dbias[n] = sum_m G[m, n]   (per-chunk partials, summed in fixed order by splitk_reduce)
+template <int K, typename OutT, bool POS>
+__global__ __launch_bounds__(256) void thin_nt_kernel(const float* __restrict__ T, const float* __restrict__ W, const float* __restrict__ bias,
+                                                      const float* __restrict__ pos, OutT* __restrict__ out, int M, int N, int rows_per_batch,
+                                                      int rows_per_wg) {
+  // one column per thread (17 registers of state): 4 waves per workgroup x (M / 512) x (N / 256) workgroups keep ~6 waves per SIMD in flight,
+  // which is what hides the HBM latency of a loop that does 16 FMAs per 4 bytes stored
+  // the workgroup's rows of T (512 x K floats) are staged in LDS once (coalesced 16-B loads) and read back at a wave-uniform address
+  // (LDS broadcast): as per-row scalar loads every wave paid a scalar-cache miss per row
+  __shared__ __attribute__((aligned(16))) float ts[512 * K];
+  const int m0 = blockIdx.x * rows_per_wg, m1 = min(M, m0 + rows_per_wg);
+  for (int i = threadIdx.x * 4; i < (m1 - m0) * K; i += 256 * 4) *(float4*)(ts + i) = *(const float4*)(T + (size_t)m0 * K + i);
+  __syncthreads();
+  const int n = blockIdx.y * 256 + threadIdx.x;
+  if (n >= N) return;
+  float w[K];
+#pragma unroll
+  for (int k = 0; k < K; k += 4) {
+    const float4 v = *(const float4*)(W + (size_t)n * K + k);
+    w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+  }
+  const float b = bias ? bias[n] : 0.f;
+#pragma unroll 4
+  for (int m = m0; m < m1; ++m) {
+    const float* t = ts + (m - m0) * K;
+    float a = b;
+#pragma unroll
+    for (int k = 0; k < K; ++k) a = fmaf(t[k], w[k], a);
+    if (POS) a += pos[(size_t)(m % rows_per_batch) * N + n];
+    out[(size_t)m * N + n] = from_f<OutT>(a);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void thin_tn_kernel(const float* __restrict__ G, const float* __restrict__ T, float* __restrict__ P,
+                                                      float* __restrict__ Pb, int M, int N, int rows_per_wg) {
+  __shared__ __attribute__((aligned(16))) float ts[512 * K];
+  const int m0 = blockIdx.x * rows_per_wg, m1 = min(M, m0 + rows_per_wg);
+  for (int i = threadIdx.x * 4; i < (m1 - m0) * K; i += 256 * 4) *(float4*)(ts + i) = *(const float4*)(T + (size_t)m0 * K + i);
+  __syncthreads();
+  const int n = blockIdx.y * 256 + threadIdx.x;
+  if (n >= N) return;
+  float acc[K], accb = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+#pragma unroll 4
+  for (int m = m0; m < m1; ++m) {
+    const float g = G[(size_t)m * N + n];
+    const float* t = ts + (m - m0) * K;                 // wave-uniform LDS address: broadcast reads
+    accb += g;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = fmaf(g, t[k], acc[k]);
+  }
+  float* p = P + ((size_t)blockIdx.x * N + n) * K;
+#pragma unroll
+  for (int k = 0; k < K; k += 4) *(float4*)(p + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+  if (Pb) Pb[(size_t)blockIdx.x * N + n] = accb;
+}
+// out[i] = beta * out[i] + sum_c P[c][i], i < n, in a FIXED order (deterministic): one wave per 4 consecutive outputs, lane l sums chunks
+// l, l + 64, ... and the 64 lane sums are folded by a butterfly -- few outputs (12288) x many chunks (512) needs its parallelism across chunks
+__global__ __launch_bounds__(256) void thin_reduce_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int chunks, float beta) {
+  const int lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  if (i >= n) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = lane; c < chunks; c += 64) {
+    const float4 t = *(const float4*)(P + (size_t)c * n + i);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+  }
+  if (lane == 0) {
+    if (beta != 0.f) { const float4 o = *(const float4*)(out + i); s.x += beta * o.x; s.y += beta * o.y; s.z += beta * o.z; s.w += beta * o.w; }
+    *(float4*)(out + i) = s;
+  }
+}
+constexpr int THIN_ROWS = 512;      // rows of M per workgroup (the kernels' LDS image of T is sized for it)
+static bool thin_ok(int N, int K) { return (K == 16 || K == 32) && N % 4 == 0 && N >= 4; }
+
+extern "C" int ldmae_thin_nt(int out_dtype, const float* T, const float* W, const float* bias, const float* pos, void* out, int M, int N, int K,
+                             int rows_per_batch, void* stream) {
+  LDMAE_REQUIRE(T && W && out && M > 0, "thin_nt: null pointer or empty input");
+  LDMAE_REQUIRE(thin_ok(N, K), "thin_nt: K=%d must be 16 or 32 and N=%d a multiple of 4 (use ldmae_gemm_nt otherwise)", K, N);
+  LDMAE_REQUIRE(!pos || rows_per_batch > 0, "thin_nt: pos needs rows_per_batch");
+  LDMAE_REQUIRE(out_dtype == LDMAE_F32 || out_dtype == LDMAE_BF16, "thin_nt: bad out dtype %d", out_dtype);
+  const dim3 grid(cdiv(M, THIN_ROWS), cdiv(N, 256));
+  hipStream_t st = as_stream(stream);
+#define THIN_NT(KK, OT, PP) hipLaunchKernelGGL((thin_nt_kernel<KK, OT, PP>), grid, dim3(256), 0, st, T, W, bias, pos, (OT*)out, M, N, rows_per_batch, THIN_ROWS)
+#define THIN_NT_K(KK)                                                                                 \
+  if (out_dtype == LDMAE_F32) { if (pos) THIN_NT(KK, float, true); else THIN_NT(KK, float, false); }  \
+  else { if (pos) THIN_NT(KK, bf16, true); else THIN_NT(KK, bf16, false); }
+  if (K == 16) { THIN_NT_K(16) } else { THIN_NT_K(32) }
+#undef THIN_NT_K
+#undef THIN_NT
+  LDMAE_CHECK_LAUNCH("thin_nt");
+  return LDMAE_OK;
+}
+extern "C" long ldmae_thin_tn_workspace_bytes(int M, int N, int K) { return (long)cdiv(M, THIN_ROWS) * ((long)N * K + N) * 4; }
+extern "C" int ldmae_thin_tn(const float* G, const float* T, float* dW, float* dbias, int M, int N, int K, float beta, float* workspace,
+                             long workspace_bytes, void* stream) {
+  LDMAE_REQUIRE(G && T && dW && M > 0, "thin_tn: null pointer or empty input");
+  LDMAE_REQUIRE(thin_ok(N, K), "thin_tn: K=%d must be 16 or 32 and N=%d a multiple of 4 (use ldmae_gemm_tn otherwise)", K, N);
+  LDMAE_REQUIRE(beta == 0.f || beta == 1.f, "thin_tn: beta must be 0 or 1");
+  LDMAE_REQUIRE(workspace && workspace_bytes >= ldmae_thin_tn_workspace_bytes(M, N, K), "thin_tn: workspace too small");
+  const int chunks = cdiv(M, THIN_ROWS);
+  float* P = workspace;
+  float* Pb = dbias ? workspace + (size_t)chunks * N * K : nullptr;
+  const dim3 grid(chunks, cdiv(N, 256));
+  hipStream_t st = as_stream(stream);
+  if (K == 16) hipLaunchKernelGGL(thin_tn_kernel<16>, grid, dim3(256), 0, st, G, T, P, Pb, M, N, THIN_ROWS);
+  else hipLaunchKernelGGL(thin_tn_kernel<32>, grid, dim3(256), 0, st, G, T, P, Pb, M, N, THIN_ROWS);
+  const long n = (long)N * K;
+  hipLaunchKernelGGL(thin_reduce_kernel, dim3((unsigned)((n / 4 + 3) / 4)), dim3(256), 0, st, P, dW, n, chunks, beta);
+  if (dbias) hipLaunchKernelGGL(thin_reduce_kernel, dim3(cdiv(N / 4, 4)), dim3(256), 0, st, Pb, dbias, (long)N, chunks, beta);
+  LDMAE_CHECK_LAUNCH("thin_tn");
+  return LDMAE_OK;
+}
+
 // `count` equally sized f32 tensors -> one stacked tensor in the activation type with ONE launch (the adaLN weights of all blocks become the
 // [depth * 6D, D] operand of a single GEMM: models/lightningdit.py:_AdaLNAllFn).  The source pointers travel by value in the kernel arguments.
 constexpr int CAST_STACK_MAX = 64;

@@ -124,6 +124,8 @@ class _PatchEmbedFn(torch.autograd.Function):
             ctx.save_for_backward(tok, w2d)
             return ops.gemm_nt_pos(tok, ops.cast(w2d.contiguous(), torch.bfloat16), b, pos, T)
         ctx.save_for_backward(tok, w2d)
+        if tok.dtype == torch.float32 and ops.thin_ok(w2d.shape[0], tok.shape[1]):      # K = C*p*p = 16 / 32: one streaming pass (ldmae_thin_nt)
+            return ops.thin_nt(tok, w2d.float(), b, pos, T)
         return ops.gemm_nt_pos(tok, w2d, b, pos, T)
 
     @staticmethod
@@ -131,6 +133,9 @@ class _PatchEmbedFn(torch.autograd.Function):
         tok, w2d = ctx.saved_tensors
         g = g.contiguous()
         dtok = ops.gemm_nt(g, ops.cast_weight(w2d, torch.float32, True, False)[1]) if ctx.needs_input_grad[0] else None
+        if not ctx.lowp and g.dtype == torch.float32 and tok.dtype == torch.float32 and ops.thin_ok(g.shape[1], tok.shape[1]):
+            dw, db = ops.thin_tn(g, tok)            # weight and bias gradient in ONE pass over the 805-MB gradient
+            return dtok, dw, db, None, None, None
         dw = ops.gemm_tn(ops.cast(g, torch.bfloat16), tok) if ctx.lowp else ops.gemm_tn(g, tok)
         return dtok, dw, ops.colsum(g), None, None, None
 
@@ -416,7 +421,10 @@ class _FinalLayerFn(torch.autograd.Function):
         g = gout.contiguous().view(M, -1)
         ga = ops.cast(g, dtype)
         dlw, dlb = ops.gemm_tn(ga, xf), ops.colsum(g)
-        dxf = ops.gemm_nt(g, ops.cast_weight(lw, torch.float32, True, False)[1], out_dtype=dtype)     # K = p*p*C (16): f32 MFMA
+        if g.dtype == torch.float32 and ops.thin_ok(lw.shape[1], lw.shape[0]):                        # K = p*p*C = 16 / 32: ldmae_thin_nt
+            dxf = ops.thin_nt(g, lw.float().t().contiguous(), out_dtype=dtype)
+        else:
+            dxf = ops.gemm_nt(g, ops.cast_weight(lw, torch.float32, True, False)[1], out_dtype=dtype)     # f32 MFMA
         dx = torch.empty(M, D, dtype=torch.float32, device=g.device)     # written, not accumulated into: no 805 MB memset + read
         dmod = torch.empty_like(mod)
         if ctx.chain is not None:

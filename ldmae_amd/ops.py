@@ -209,6 +209,35 @@ def cast(x, dtype):
     return out
 
 
+_THIN = os.environ.get("LDMAE_THIN_GEMM", "1") != "0"       # 0: the generic f32 MFMA GEMMs for these shapes too (A/B)
+
+
+def thin_ok(N, K):
+    """Shapes the thin (K = 16 / 32) f32 products take: see ldmae_thin_nt / ldmae_thin_tn."""
+    return _THIN and K in (16, 32) and N % 4 == 0
+
+
+def thin_nt(t, w, bias=None, pos=None, rows_per_batch=0, out_dtype=torch.float32):
+    """out[M,N] = t[M,K] @ w[N,K]^T + bias (+ pos[row % rows_per_batch]) for K = 16 / 32, f32 inputs; one streaming pass."""
+    M, K = t.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=out_dtype, device=t.device)
+    call("ldmae_thin_nt", dt(out_dtype), ptr(_c(t)), ptr(_c(w)), ptr(bias), ptr(_c(pos)) if pos is not None else None, ptr(out), M, N, K,
+         int(rows_per_batch), stream())
+    return out
+
+
+def thin_tn(g, t, with_bias=True):
+    """(dW[N,K] = g[M,N]^T @ t[M,K], column sums of g or None) for K = 16 / 32, f32; one pass over g."""
+    M, N = g.shape
+    K = t.shape[1]
+    dW = torch.empty(N, K, dtype=torch.float32, device=g.device)
+    db = torch.empty(N, dtype=torch.float32, device=g.device) if with_bias else None
+    ws = workspace(L.load().ldmae_thin_tn_workspace_bytes(M, N, K), g.device)
+    call("ldmae_thin_tn", ptr(_c(g)), ptr(_c(t)), ptr(dW), ptr(db), M, N, K, 0.0, ptr(ws), ws.numel() * 4, stream())
+    return dW, db
+
+
 def cast_stack(tensors, dtype):
     """Equally shaped contiguous f32 tensors -> one stacked [len * rows, cols] tensor in `dtype`, one launch."""
     import ctypes

@@ -467,3 +467,28 @@ def test_errors_are_loud(ops):
         ops.gemm_nt(a, a)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gemm_nt(torch.zeros(4, 16), torch.zeros(4, 16))
+
+
+@pytest.mark.parametrize("K", [16, 32])
+def test_thin_products_vs_float64(ops, K):
+    """ldmae_thin_nt / ldmae_thin_tn (contraction 16 / 32: the DiT patch embedding at patch 1 and the final layer's dX) against float64,
+    incl. bias, the position table, bf16 output, a ragged row count and bitwise run-to-run equality of the chunked reduction."""
+    g = torch.Generator(device="cuda").manual_seed(K)
+    M, N, Tn = 2 * 520 + 8, 772, 520                      # not a multiple of the 512-row chunk; N % 4 == 0 only
+    t, w, b = (torch.randn(*s, device="cuda", generator=g) for s in ((M, K), (N, K), (N,)))
+    pos = torch.randn(Tn + 4, N, device="cuda", generator=g)[:Tn]
+    ref = t.double() @ w.double().t() + b.double()
+    out = ops.thin_nt(t, w, b)
+    assert float((out.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    rows = torch.arange(M, device="cuda") % Tn
+    outp = ops.thin_nt(t, w, b, pos, Tn)
+    assert float((outp.double() - (ref + pos.double()[rows])).abs().max()) < 1e-4 * float(ref.abs().max())
+    outb = ops.thin_nt(t, w, None, None, 0, torch.bfloat16)
+    assert outb.dtype == torch.bfloat16 and float((outb.double() - (ref - b.double())).abs().max()) < 1e-2 * float(ref.abs().max())
+    gr = torch.randn(M, N, device="cuda", generator=g)
+    dW, db = ops.thin_tn(gr, t)
+    rW, rb = gr.double().t() @ t.double(), gr.double().sum(0)
+    assert float((dW.double() - rW).abs().max()) < 1e-4 * float(rW.abs().max()) and float((db.double() - rb).abs().max()) < 1e-4 * float(rb.abs().max())
+    dW2, db2 = ops.thin_tn(gr, t)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    assert not ops.thin_ok(770, 16) and not ops.thin_ok(768, 24)
