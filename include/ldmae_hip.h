@@ -84,6 +84,9 @@ int ldmae_thin_nt(int out_dtype, const float* T, const float* W, const float* bi
 long ldmae_thin_tn_workspace_bytes(int M, int N, int K);
 int ldmae_thin_tn(const float* G, const float* T, float* dW, float* dbias, int M, int N, int K, float beta, float* workspace,
                   long workspace_bytes, void* stream);
+/* dst[i][0..n[i]) += src[i][0..n[i]) (f32) for `count` (<= 32) triples in one launch; dst / src / n are HOST arrays.  The host side uses it
+ * to add a block's small parameter gradients into their .grad views in place of one AccumulateGrad add each (train_accum.py:236 backward). */
+int ldmae_multi_add(int count, void* const* dst, const void* const* src, const long* n, void* stream);
 /* `count` (<= 64) f32 device tensors of n_each elements each -> dst[count * n_each] in dst_dtype, one launch; srcs is a HOST array of device
  * pointers (16-B aligned; n_each % 8 == 0).  Used to stack the adaLN_modulation weights of all blocks (lightningdit.py:233-236) into the
  * [depth * 6D, D] operand of one GEMM. */

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ldmae_cast_weight": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp]),
     "ldmae_cast": (_i, [_i, _i, _vp, _vp, _l, _vp]),
     "ldmae_cast_stack": (_i, [_i, _vp, _i, _l, _vp, _vp]),
+    "ldmae_multi_add": (_i, [_i, _vp, _vp, _vp, _vp]),
     "ldmae_thin_nt": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_thin_tn_workspace_bytes": (_l, [_i, _i, _i]),
     "ldmae_thin_tn": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _l, _vp]),

@@ -1056,6 +1056,31 @@ extern "C" int ldmae_thin_tn(const float* G, const float* T, float* dW, float* d
   return LDMAE_OK;
 }
 
+// dst[i] += src[i] for up to 32 (dst, src, n) f32 triples in ONE launch: the small parameter gradients of a block (norm weights, biases, QK-norm
+// weights) added into their .grad views of the optimizer's slab -- as separate AccumulateGrad adds they were 8 launches of ~5 us per block.
+constexpr int MULTI_ADD_MAX = 32;
+struct MultiAddArgs { float* dst[MULTI_ADD_MAX]; const float* src[MULTI_ADD_MAX]; long n[MULTI_ADD_MAX]; };
+__global__ void multi_add_kernel(MultiAddArgs a) {
+  float* d = a.dst[blockIdx.y];
+  const float* s = a.src[blockIdx.y];
+  const long n = a.n[blockIdx.y];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] += s[i];
+}
+extern "C" int ldmae_multi_add(int count, void* const* dst, const void* const* src, const long* n, void* stream) {
+  LDMAE_REQUIRE(dst && src && n && count > 0 && count <= MULTI_ADD_MAX, "multi_add: count=%d must be 1..%d", count, MULTI_ADD_MAX);
+  MultiAddArgs a{};
+  long nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    LDMAE_REQUIRE(dst[i] && src[i] && n[i] > 0, "multi_add: entry %d is null or empty", i);
+    a.dst[i] = (float*)dst[i]; a.src[i] = (const float*)src[i]; a.n[i] = n[i];
+    nmax = n[i] > nmax ? n[i] : nmax;
+  }
+  const unsigned gx = (unsigned)min((long)256, (nmax + 255) / 256);
+  hipLaunchKernelGGL(multi_add_kernel, dim3(gx, count), dim3(256), 0, as_stream(stream), a);
+  LDMAE_CHECK_LAUNCH("multi_add");
+  return LDMAE_OK;
+}
+
 // `count` equally sized f32 tensors -> one stacked tensor in the activation type with ONE launch (the adaLN weights of all blocks become the
 // [depth * 6D, D] operand of a single GEMM: models/lightningdit.py:_AdaLNAllFn).  The source pointers travel by value in the kernel arguments.
 constexpr int CAST_STACK_MAX = 64;

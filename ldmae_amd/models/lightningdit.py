@@ -282,6 +282,7 @@ class _DiTBlockFn(torch.autograd.Function):
         ctx.inplace = bool(inplace)
         ctx.chain, ctx.idx = chain, idx
         ctx.direct, ctx.wparams = bool(direct), (qkvw, pw, w12, w3)
+        ctx.sparams = (n1w, qkvb, qnw, knw, pb, n2w, b12, b3) if direct else None
         if chain is not None:
             chain.up[idx] = (y2, mod)
         return xout.view(B, N, D)
@@ -346,6 +347,14 @@ class _DiTBlockFn(torch.autograd.Function):
             dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
             dsc = _dmod_times_w(dmod, adaw)
         sg.join()
+        # the eight small gradients of the block (norm weights, biases, QK-norm weights): with `direct`, ONE launch adds them into their .grad
+        # views instead of one AccumulateGrad add each
+        small = [dn1, dbqkv, dqn, dkn, dbp, dn2, db12, db3]
+        if ctx.sparams is not None and all(g_ is not None and p_.grad is not None and p_.grad.dtype == torch.float32 and
+                                           p_.grad.is_contiguous() and p_.grad.shape == g_.shape for p_, g_ in zip(ctx.sparams, small)):
+            ops.multi_add_([p_.grad for p_ in ctx.sparams], small)
+            notify.extend((getattr(p_, "_ldmae_grad_ready", None), p_) for p_ in ctx.sparams)
+            dn1 = dbqkv = dqn = dkn = dbp = dn2 = db12 = db3 = None
         for r, p_ in notify:          # gradients written straight into .grad: tell the reducer (no-op without one)
             if r is not None:
                 r(p_)

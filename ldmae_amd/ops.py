@@ -238,6 +238,20 @@ def thin_tn(g, t, with_bias=True):
     return dW, db
 
 
+def multi_add_(dsts, srcs):
+    """dsts[i] += srcs[i] (contiguous f32 tensors of equal sizes pairwise), one launch."""
+    import ctypes
+    k = len(dsts)
+    srcs = [_c(s_) for s_ in srcs]
+    for d_, s_ in zip(dsts, srcs):
+        if d_.dtype != torch.float32 or s_.dtype != torch.float32 or d_.numel() != s_.numel() or not d_.is_contiguous():
+            raise RuntimeError("multi_add_: contiguous f32 pairs of equal size expected")
+    da = (ctypes.c_void_p * k)(*[d_.data_ptr() for d_ in dsts])
+    sa = (ctypes.c_void_p * k)(*[s_.data_ptr() for s_ in srcs])
+    na = (ctypes.c_long * k)(*[d_.numel() for d_ in dsts])
+    call("ldmae_multi_add", k, da, sa, na, stream())
+
+
 def cast_stack(tensors, dtype):
     """Equally shaped contiguous f32 tensors -> one stacked [len * rows, cols] tensor in `dtype`, one launch."""
     import ctypes
