@@ -49,6 +49,11 @@ def build(device, per_gpu_batch):
     model = model.to(device).train()
     opt = AdamWEMA(model, lr=2e-4, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9999)
     reducer = GradBucketReducer(opt.flat)
+    if reducer.world > 1:
+        # batched adaLN (models.lightningdit._AdaLNAllFn) finishes the adaLN weight gradients of EVERY block at the very end of backward; every
+        # 64-MiB bucket of the slab holds one of them, so no bucket could start its all-reduce under backward.  Data-parallel runs keep the
+        # per-block form (the gradients of a block complete with the block), single-GPU runs take the 1.5 ms.
+        model.batched_adaln = False
     model.direct_param_grads = os.environ.get("LDMAE_DIRECT_GRADS", "1") != "0"       # every .grad is a slab view and backward is a plain loss.backward(): dW goes straight into the slab
     reducer.broadcast_params(0)
     opt.ema.copy_(opt.flat.params)

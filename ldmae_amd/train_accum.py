@@ -131,6 +131,11 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
     o = cfg['optimizer']
     opt = AdamWEMA(model, lr=o['lr'], betas=(0.9, o['beta2']), weight_decay=0.0, ema_decay=0.9999)
     reducer = GradBucketReducer(opt.flat)
+    if reducer.world > 1:
+        # batched adaLN (models.lightningdit._AdaLNAllFn) finishes the adaLN weight gradients of EVERY block at the very end of backward; every
+        # 64-MiB bucket of the slab holds one of them, so no bucket could start its all-reduce under backward.  Data-parallel runs keep the
+        # per-block form (the gradients of a block complete with the block), single-GPU runs take the 1.5 ms.
+        model.batched_adaln = False
     ops.set_gemm_launch_mode(reducer.recommended_gemm_launch_mode())     # world > 1: one tile per workgroup (RCCL kernels share the chip)
     model.direct_param_grads = True       # every .grad is a slab view and backward is a plain loss.backward(): dW goes straight into the slab
     reducer.broadcast_params(0)
