@@ -933,39 +933,47 @@ extern "C" int ldmae_cast(int src_dtype, int dst_dtype, const void* src, void* d
 // The DiT's PatchEmbed at patch 1 (lightningdit.py:309, 402: K = C * p * p = 16) and the dX of the FinalLayer's 16-column Linear (:270)
 // are [M, 768] <-> [M, 16] products at M = 262144: 0.02 FLOP per byte, pure HBM streaming.  As 64x64-tile MFMA GEMMs they ran at
 // 2.2 TB/s (358 us forward, 366 + 34 + 146 us for weight gradient + split reduce + bias column sum: two passes over the 805-MB
-// gradient).  Here a thread owns one output column, the K-vectors of the workgroup's rows sit in LDS (broadcast reads) and the weights / partial sums
-// live in registers: one pass over the big tensor, 256-B runs per wave.
+// gradient).  Here the K-vectors of a workgroup's rows sit in LDS (broadcast reads) and the weights / partial sums live in registers: one
+// pass over the big tensor.
 //   thin_nt: out[m, n] = sum_k T[m, k] W[n, k] + bias[n] (+ pos[m % rows_per_batch, n])
 //   thin_tn: dW[n, k] = sum_m G[m, n] T[m, k], dbias[n] = sum_m G[m, n]   (per-chunk partials, summed in fixed order by splitk_reduce)
 template <int K, typename OutT, bool POS>
 __global__ __launch_bounds__(256) void thin_nt_kernel(const float* __restrict__ T, const float* __restrict__ W, const float* __restrict__ bias,
                                                       const float* __restrict__ pos, OutT* __restrict__ out, int M, int N, int rows_per_batch,
                                                       int rows_per_wg) {
-  // one column per thread (17 registers of state): 4 waves per workgroup x (M / 512) x (N / 256) workgroups keep ~6 waves per SIMD in flight,
-  // which is what hides the HBM latency of a loop that does 16 FMAs per 4 bytes stored
-  // the workgroup's rows of T (512 x K floats) are staged in LDS once (coalesced 16-B loads) and read back at a wave-uniform address
-  // (LDS broadcast): as per-row scalar loads every wave paid a scalar-cache miss per row
-  __shared__ __attribute__((aligned(16))) float ts[512 * K];
+  // the workgroup's rows of T (128 x K floats) are staged in LDS once (coalesced 16-B loads) and read back at a wave-uniform address
+  // (LDS broadcast); a thread owns FOUR adjacent columns, so a wave stores whole 1-KiB runs (one column per thread moved 4 B per lane:
+  // 2.5 TB/s); 128 rows per workgroup keep ~6 waves per SIMD in flight
+  __shared__ __attribute__((aligned(16))) float ts[128 * K];
   const int m0 = blockIdx.x * rows_per_wg, m1 = min(M, m0 + rows_per_wg);
   for (int i = threadIdx.x * 4; i < (m1 - m0) * K; i += 256 * 4) *(float4*)(ts + i) = *(const float4*)(T + (size_t)m0 * K + i);
   __syncthreads();
-  const int n = blockIdx.y * 256 + threadIdx.x;
+  const int n = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (n >= N) return;
-  float w[K];
+  float w[4][K];
 #pragma unroll
-  for (int k = 0; k < K; k += 4) {
-    const float4 v = *(const float4*)(W + (size_t)n * K + k);
-    w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
-  }
-  const float b = bias ? bias[n] : 0.f;
-#pragma unroll 4
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < K; k += 4) {
+      const float4 v = *(const float4*)(W + (size_t)(n + j) * K + k);
+      w[j][k] = v.x; w[j][k + 1] = v.y; w[j][k + 2] = v.z; w[j][k + 3] = v.w;
+    }
+  const float4 b = bias ? *(const float4*)(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
   for (int m = m0; m < m1; ++m) {
     const float* t = ts + (m - m0) * K;
-    float a = b;
+    float a0 = b.x, a1 = b.y, a2 = b.z, a3 = b.w;
 #pragma unroll
-    for (int k = 0; k < K; ++k) a = fmaf(t[k], w[k], a);
-    if (POS) a += pos[(size_t)(m % rows_per_batch) * N + n];
-    out[(size_t)m * N + n] = from_f<OutT>(a);
+    for (int k = 0; k < K; ++k) {
+      const float tk = t[k];
+      a0 = fmaf(tk, w[0][k], a0); a1 = fmaf(tk, w[1][k], a1); a2 = fmaf(tk, w[2][k], a2); a3 = fmaf(tk, w[3][k], a3);
+    }
+    if (POS) {
+      const float4 q = *(const float4*)(pos + (size_t)(m % rows_per_batch) * N + n);
+      a0 += q.x; a1 += q.y; a2 += q.z; a3 += q.w;
+    }
+    if constexpr (sizeof(OutT) == 4) *(float4*)((float*)out + (size_t)m * N + n) = make_float4(a0, a1, a2, a3);
+    else { bf16x4 o; o[0] = (bf16)a0; o[1] = (bf16)a1; o[2] = (bf16)a2; o[3] = (bf16)a3; *(bf16x4*)((bf16*)out + (size_t)m * N + n) = o; }
   }
 }
 
@@ -1023,9 +1031,9 @@ extern "C" int ldmae_thin_nt(int out_dtype, const float* T, const float* W, cons
   LDMAE_REQUIRE(thin_ok(N, K), "thin_nt: K=%d must be 16 or 32 and N=%d a multiple of 4 (use ldmae_gemm_nt otherwise)", K, N);
   LDMAE_REQUIRE(!pos || rows_per_batch > 0, "thin_nt: pos needs rows_per_batch");
   LDMAE_REQUIRE(out_dtype == LDMAE_F32 || out_dtype == LDMAE_BF16, "thin_nt: bad out dtype %d", out_dtype);
-  const dim3 grid(cdiv(M, THIN_ROWS), cdiv(N, 256));
+  const dim3 grid(cdiv(M, 128), cdiv(N / 4, 256));
   hipStream_t st = as_stream(stream);
-#define THIN_NT(KK, OT, PP) hipLaunchKernelGGL((thin_nt_kernel<KK, OT, PP>), grid, dim3(256), 0, st, T, W, bias, pos, (OT*)out, M, N, rows_per_batch, THIN_ROWS)
+#define THIN_NT(KK, OT, PP) hipLaunchKernelGGL((thin_nt_kernel<KK, OT, PP>), grid, dim3(256), 0, st, T, W, bias, pos, (OT*)out, M, N, rows_per_batch, 128)
 #define THIN_NT_K(KK)                                                                                 \
   if (out_dtype == LDMAE_F32) { if (pos) THIN_NT(KK, float, true); else THIN_NT(KK, float, false); }  \
   else { if (pos) THIN_NT(KK, bf16, true); else THIN_NT(KK, bf16, false); }
