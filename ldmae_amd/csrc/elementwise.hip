@@ -1204,20 +1204,22 @@ __global__ void label_embed_fwd_kernel(const float* __restrict__ table, const lo
 }
 __global__ void label_embed_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ y, const unsigned char* __restrict__ drop,
                                        float* __restrict__ dtable, int B, int D, int num_classes) {
-  // one workgroup per table row; the samples that hit the row are found cooperatively (one sample per thread and pass) and summed in
-  // ascending sample order (deterministic).  (Every thread used to scan all B labels itself: 140 us for a 3 MB result.)
-  __shared__ int hit[256];
-  const int row = blockIdx.x;
+  // one workgroup per table row; the samples that hit the row are found cooperatively (one sample per thread and pass: a ballot per wave) and
+  // summed in ascending sample order (deterministic) by walking the set bits.  (Every thread used to scan all B labels itself: 140 us for a
+  // 3 MB result; then a 256-step loop over a hit array in LDS: 84 us.)
+  __shared__ unsigned long long mask[4];
+  const int row = blockIdx.x, wave = threadIdx.x >> 6;
   for (int b0 = 0; b0 < B; b0 += blockDim.x) {
     const int b = b0 + threadIdx.x;
     const bool mine = b < B && ((drop && drop[b]) ? num_classes : y[b]) == row;
-    hit[threadIdx.x] = mine ? 1 : 0;
-    const int nhit = __syncthreads_count(mine);          // (a serial count by thread 0 made this 84 us for 1001 rows)
-    if (nhit > 0) {
+    const unsigned long long m = __ballot(mine);
+    if ((threadIdx.x & 63) == 0) mask[wave] = m;
+    __syncthreads();
+    if ((mask[0] | mask[1] | mask[2] | mask[3]) != 0ull) {
       for (int d = threadIdx.x; d < D; d += blockDim.x) {
         float s = 0.f;
-        for (int i = 0; i < (int)blockDim.x && b0 + i < B; ++i)
-          if (hit[i]) s += dout[(size_t)(b0 + i) * D + d];
+        for (int w = 0; w < 4; ++w)
+          for (unsigned long long mm = mask[w]; mm; mm &= mm - 1) s += dout[(size_t)(b0 + w * 64 + __builtin_ctzll(mm)) * D + d];
         dtable[(size_t)row * D + d] += s;
       }
     }
