@@ -28,8 +28,11 @@ __device__ __forceinline__ float hsum(float4 a) { return (a.x + a.y) + (a.z + a.
 // partial sums are combined in a fixed order (bitwise reproducible).
 template <int RL>
 __global__ __launch_bounds__(32 * RL) void group_reduce_kernel(const float* __restrict__ P, int p_ld, int nout, int cols, int group,
-                                                              float* __restrict__ out, int out_ld, float beta) {
+                                                              float* __restrict__ out, int out_ld, float beta,
+                                                              const float* __restrict__ P2 = nullptr, float* __restrict__ out2 = nullptr,
+                                                              float beta2 = 0.f) {
   __shared__ float red[RL][33];
+  if (blockIdx.z == 1) { P = P2; out = out2; beta = beta2; }        // a second reduction of the same shape in the same launch
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, o = blockIdx.y;
   float s = 0.f;
@@ -47,12 +50,15 @@ __global__ __launch_bounds__(32 * RL) void group_reduce_kernel(const float* __re
     *q = (beta != 0.f ? beta * *q : 0.f) + t;
   }
 }
-static void group_reduce(const float* P, int p_ld, int nout, int cols, int group, float* out, int out_ld, float beta, hipStream_t st) {
-  // long groups (thousands of per-workgroup partial rows into one output row): 32 row lanes, otherwise 8
+static void group_reduce(const float* P, int p_ld, int nout, int cols, int group, float* out, int out_ld, float beta, hipStream_t st,
+                         const float* P2 = nullptr, float* out2 = nullptr, float beta2 = 0.f) {
+  // long groups (thousands of per-workgroup partial rows into one output row): 32 row lanes, otherwise 8.  P2 / out2: a second reduction
+  // of the same shape rides in the same launch (grid z = 2), with exactly the arithmetic it would have on its own
+  const unsigned gz = P2 ? 2 : 1;
   if (group >= 256)
-    hipLaunchKernelGGL(group_reduce_kernel<32>, dim3(cdiv(cols, 32), nout), dim3(1024), 0, st, P, p_ld, nout, cols, group, out, out_ld, beta);
+    hipLaunchKernelGGL(group_reduce_kernel<32>, dim3(cdiv(cols, 32), nout, gz), dim3(1024), 0, st, P, p_ld, nout, cols, group, out, out_ld, beta, P2, out2, beta2);
   else
-    hipLaunchKernelGGL(group_reduce_kernel<8>, dim3(cdiv(cols, 32), nout), dim3(256), 0, st, P, p_ld, nout, cols, group, out, out_ld, beta);
+    hipLaunchKernelGGL(group_reduce_kernel<8>, dim3(cdiv(cols, 32), nout, gz), dim3(256), 0, st, P, p_ld, nout, cols, group, out, out_ld, beta, P2, out2, beta2);
 }
 
 // rows per workgroup for the per-sample reductions: largest of 64/32/16/8/4 dividing rows_per_batch
@@ -295,19 +301,36 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
   }
 }
 
-// per-sample reduce of the partials: dshift/dscale [B, dmod_ld], dwb [B, D]
+// per-sample reduce of the per-workgroup partials, every set optional: P [G][3][D] -> dshift / dscale [B, dmod_ld] and dwb [B, D] (the norm
+// weight gradient per sample); Pg [G][D] -> dgate [B, dgate_ld]; Pb [G][D] -> dbb [B, D] (the bias gradient per sample).  One launch for
+// what used to be a reduce kernel + a grouped reduce + the first stage of a column sum; dwb and dbb are then summed over the samples by
+// ONE group_reduce launch (grid z = 2).
 __global__ void mod_partials_reduce_kernel(const float* __restrict__ P, int D, int gps, float* __restrict__ dshift,
-                                           float* __restrict__ dscale, int dmod_ld, float* __restrict__ dwb) {
+                                           float* __restrict__ dscale, int dmod_ld, float* __restrict__ dwb,
+                                           const float* __restrict__ Pg = nullptr, float* __restrict__ dgate = nullptr, int dgate_ld = 0,
+                                           const float* __restrict__ Pb = nullptr, float* __restrict__ dbb = nullptr) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (d >= D) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int g = 0; g < gps; ++g) {
-    const float* p = P + ((size_t)b * gps + g) * 3 * D + d;
-    s0 += p[0]; s1 += p[D]; s2 += p[2 * D];
+  if (P) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int g = 0; g < gps; ++g) {
+      const float* p = P + ((size_t)b * gps + g) * 3 * D + d;
+      s0 += p[0]; s1 += p[D]; s2 += p[2 * D];
+    }
+    if (dshift) dshift[(size_t)b * dmod_ld + d] = s0;
+    if (dscale) dscale[(size_t)b * dmod_ld + d] = s1;
+    dwb[(size_t)b * D + d] = s2;
   }
-  if (dshift) dshift[(size_t)b * dmod_ld + d] = s0;
-  if (dscale) dscale[(size_t)b * dmod_ld + d] = s1;
-  dwb[(size_t)b * D + d] = s2;
+  if (Pg) {
+    float s = 0.f;
+    for (int g = 0; g < gps; ++g) s += Pg[((size_t)b * gps + g) * D + d];
+    dgate[(size_t)b * dgate_ld + d] = s;
+  }
+  if (Pb) {
+    float s = 0.f;
+    for (int g = 0; g < gps; ++g) s += Pb[((size_t)b * gps + g) * D + d];
+    dbb[(size_t)b * D + d] = s;
+  }
 }
 
 #define DISPATCH_NCH(D, CALL)                                   \
@@ -376,14 +399,17 @@ static int rmsnorm_modulate_bwd_core(int dtype, const void* dout, const float* x
 #undef LAUNCH
 #undef LAUNCH_FULL
   LDMAE_CHECK_LAUNCH("rmsnorm_modulate_bwd");
+  if (gate) {        // two launches: every per-sample sum, then dw and dbias over the samples together
+    float* dbb = ga.Pb + (size_t)G * D;                 // [B][D], behind the gate partials (ldmae_gate_bwd_workspace_bytes reserves it)
+    hipLaunchKernelGGL(mod_partials_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, P, D, gps, dshift, dscale, dmod_ld, dwb,
+                       (const float*)ga.Pg, dgate, dgate_ld, (const float*)ga.Pb, dbb);
+    group_reduce(dwb, D, 1, D, B, dw, D, beta_w, st, dbb, dbias, 0.f);
+    LDMAE_CHECK_LAUNCH("rmsnorm_modulate_bwd_gate reduce");
+    return LDMAE_OK;
+  }
   hipLaunchKernelGGL(mod_partials_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, P, D, gps, dshift, dscale, dmod_ld, dwb);
   group_reduce(dwb, D, 1, D, B, dw, D, beta_w, st);
   LDMAE_CHECK_LAUNCH("rmsnorm_modulate_bwd reduce");
-  if (gate) {
-    group_reduce(ga.Pg, D, B, D, gps, dgate, dgate_ld, 0.f, st);
-    LDMAE_CHECK_LAUNCH("rmsnorm_modulate_bwd gate reduce");
-    return ldmae_colsum(LDMAE_F32, ga.Pb, D, G, D, dbias, 0.f, ga.Pb + (size_t)G * D, stream);
-  }
   return LDMAE_OK;
 }
 
@@ -836,8 +862,9 @@ extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, flo
 extern "C" long ldmae_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch) {
   const int rw = pick_rows_per_wg(rows_per_batch);
   if (rw <= 0) return 0;
-  const int G = M / rw;                                // dgate partials + bias-gradient partials + their column-sum scratch
-  return 2L * G * D * 4 + ldmae_colsum_workspace_bytes(G, D);
+  const int G = M / rw;                                // dgate partials + bias-gradient partials + max(column-sum scratch, per-sample bias sums)
+  const long tail = ldmae_colsum_workspace_bytes(G, D), dbb = (long)(M / rows_per_batch) * D * 4;
+  return 2L * G * D * 4 + (tail > dbb ? tail : dbb);
 }
 extern "C" int ldmae_gate_bwd(int dtype, const float* dxout, const void* y, const float* gate, int gate_ld, void* dy, float* dgate,
                               int dgate_ld, float* dbias, int M, int D, int rows_per_batch, float* workspace, void* stream) {
@@ -858,6 +885,15 @@ extern "C" int ldmae_gate_bwd(int dtype, const float* dxout, const void* y, cons
     DISPATCH_NCH(D, hipLaunchKernelGGL((gate_bwd_kernel<NCH, float>), dim3(G), dim3(256), lds, st, dxout, (const float*)y, gate, gate_ld, (float*)dy, P, Pb, M, D, rows_per_batch, rw));
   }
   LDMAE_CHECK_LAUNCH("gate_bwd");
+  if (dgate && dbias) {      // the same two reduce launches, in the same order of summation, as the fused rmsnorm_modulate_bwd_gate (bitwise equal)
+    const int B = M / rows_per_batch;
+    float* dbb = Pb + (size_t)G * D;
+    hipLaunchKernelGGL(mod_partials_reduce_kernel, dim3(cdiv(D, 256), B), dim3(256), 0, st, (const float*)nullptr, D, rows_per_batch / rw,
+                       (float*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)P, dgate, dgate_ld, (const float*)Pb, dbb);
+    group_reduce(dbb, D, 1, D, B, dbias, D, 0.f, st);
+    LDMAE_CHECK_LAUNCH("gate_bwd reduce");
+    return LDMAE_OK;
+  }
   if (dgate) group_reduce(P, D, M / rows_per_batch, D, rows_per_batch / rw, dgate, dgate_ld, 0.f, st);
   if (dbias) return ldmae_colsum(LDMAE_F32, Pb, D, G, D, dbias, 0.f, Pb + (size_t)G * D, stream);   // two-stage column sum of the G partial rows
   LDMAE_CHECK_LAUNCH("gate_bwd reduce");
