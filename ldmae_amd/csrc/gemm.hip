@@ -182,6 +182,13 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
   }
 }
 
+#ifdef LDMAE_DIAG
+// launch-gap probes (tools/, diagnostic build): the persistent NT kernel's launch configuration and arguments around an empty body
+__global__ __launch_bounds__(512) void gemm_nt_dummy_kernel(const bf16* A, const bf16* B, int M, int N, int K, int lda, int ldb, EpiArgs e, int ntiles,
+                                                            int delay, unsigned long long* stamps) {
+  if (M < 0) stamps[0] = (unsigned long long)(size_t)A + (size_t)B + N + K + lda + ldb + ntiles + delay + (size_t)e.C;
+}
+#endif
 // ------------------------------------------------------------------------------------------------
 // f32 NT GEMM: 64x64 tile, 256 threads (2x2 waves, 32x32 per wave), BK = 16, register staged.
 // ------------------------------------------------------------------------------------------------
@@ -646,6 +653,15 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
     ncu = n >= 8 ? n / 8 * 8 : 8;
   }
   const int ntiles = cdiv(M, 256) * cdiv(N, 256);
+#ifdef LDMAE_DIAG
+  // tune key 11 (launch-gap probes): 1 = an empty kernel with the same launch configuration, 2 = the real kernel with ntiles = 0 (every
+  // workgroup returns at once)
+#define NT_DUMMY_BRANCHES(E)                                                                                                       \
+    else if (ldmae_tune_get(11) == 1) { hipFuncSetAttribute((const void*)gemm_nt_dummy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048); hipLaunchKernelGGL(gemm_nt_dummy_kernel, dim3(pgrid), dim3(512), lds + 2048, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e, ntiles, 0, (unsigned long long*)nullptr); } \
+    else if (ldmae_tune_get(11) == 2) { PERS_ATTR(3, E, OutT); hipLaunchKernelGGL((gemm_nt_persist_kernel<3, E, OutT>), dim3(pgrid), dim3(512), lds + 2048, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, e, 0, 0, (unsigned long long*)nullptr); }
+#else
+#define NT_DUMMY_BRANCHES(E)
+#endif
   // launch mode, a per-call argument (LDMAE_EPI_TILE_LAUNCH or'ed into `epi` by the caller): one 256x256 tile per workgroup instead of
   // one persistent workgroup per CU -- what a data-parallel caller asks for while RCCL's collective kernels hold some CUs
   // the persistent mapping gives every XCD a contiguous range of A row-blocks: with fewer than 8 row-blocks (the batched adaLN GEMM: M = batch
@@ -674,6 +690,7 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
     /* the LDS opt-in is per device and cheap: set it at every launch (no process-wide "done" flag) */                            \
     if (E == LDMAE_EPI_BIAS && ldmae_tune_get(7) == 1) { PERS_ATTR(3, LDMAE_EPI_BIAS, OutT, true); PERS_GO(3, LDMAE_EPI_BIAS, OutT, true); }     \
     else if (E == LDMAE_EPI_SWIGLU && ldmae_tune_get(7) == 1) { PERS_ATTR(3, LDMAE_EPI_SWIGLU, OutT, true); PERS_GO(3, LDMAE_EPI_SWIGLU, OutT, true); } \
+    NT_DUMMY_BRANCHES(E)                                                                                                          \
     else { PERS_ATTR(3, E, OutT); PERS_GO(3, E, OutT); }                                                                          \
   }
 #define NT_LAUNCH(E)                                                                                                             \
