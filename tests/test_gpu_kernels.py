@@ -492,3 +492,30 @@ def test_thin_products_vs_float64(ops, K):
     dW2, db2 = ops.thin_tn(gr, t)
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
     assert not ops.thin_ok(770, 16) and not ops.thin_ok(768, 24)
+
+
+def test_round3_entry_points_reject_bad_arguments(ops):
+    """Error behaviour of the entry points added in round 3: a negative status + message (RuntimeError through the wrappers), never a launch."""
+    f = lambda *s: torch.randn(*s, device="cuda")
+    with pytest.raises(RuntimeError, match="K=24"):
+        ops.thin_nt(f(64, 24), f(32, 24))
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        ops.thin_nt(f(64, 16), f(30, 16))
+    with pytest.raises(RuntimeError, match="K=8"):
+        ops.thin_tn(f(64, 32), f(64, 8))
+    with pytest.raises(RuntimeError, match="count=65"):
+        ops.cast_stack([f(8, 8) for _ in range(65)], torch.bfloat16)
+    with pytest.raises(RuntimeError, match="one size"):
+        ops.cast_stack([f(8, 8), f(8, 16)], torch.bfloat16)
+    with pytest.raises(RuntimeError, match="equal size"):
+        ops.multi_add_([f(16)], [f(8)])
+    with pytest.raises(RuntimeError, match="H\\*W=6"):
+        ops.latent_prologue(f(2, 8, 2, 3), f(2, 4, 2, 3))
+    # and the happy paths of the two small helpers
+    a, b = [f(5), f(1000, 3)], [f(5), f(1000, 3)]
+    want = [x + y for x, y in zip(a, b)]
+    ops.multi_add_(a, b)
+    assert all(torch.equal(x, w) for x, w in zip(a, want))
+    ws = [f(16, 24) for _ in range(3)]
+    st = ops.cast_stack(ws, torch.bfloat16)
+    assert st.shape == (48, 24) and torch.equal(st, torch.cat(ws).to(torch.bfloat16))
