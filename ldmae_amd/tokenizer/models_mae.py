@@ -408,8 +408,13 @@ class MaskedAutoencoderViT(nn.Module):
             x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x, mask, ids_restore
 
-    def forward_decoder(self, x, ids_restore):
-        """:525-554 (no cls token)."""
+    def forward_decoder(self, x, ids_restore, dtype=None):
+        """:525-554 (no cls token).  `dtype`: activation type of the decoder blocks; a caller that has switched autocast off around this call
+        (forward) passes the type it read BEFORE doing so -- the blocks would otherwise see "no autocast" and run their f32 kernels (the
+        1024-token decoder of the pre-training step did: 250 of its 304 ms)."""
+        dtype = dtype if dtype is not None else _act_dtype(self.precision)
+        for blk in self.decoder_blocks:
+            blk.precision = dtype
         x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias)
         mask_tokens = self.mask_token.repeat(x.shape[0], ids_restore.shape[1] - x.shape[1], 1)
         x_ = torch.cat([x, mask_tokens], dim=1)
@@ -438,6 +443,7 @@ class MaskedAutoencoderViT(nn.Module):
         posterior-sample noise instead of the device RNG draws the reference makes at the same two places."""
         if self.ldmae_mode:
             raise NotImplementedError("ldmae_amd: ldmae_mode (decoder fine-tuning with LPIPS) is out of scope")
+        dtype = _act_dtype(self.precision)           # read before autocast is switched off below
         latent, mask, ids_restore = self.forward_encoder(imgs, mask_ratio, noise=_noise)
         with torch.autocast(device_type="cuda", enabled=False):
             latent = _LinearFn.apply(latent, self.to_latent.weight, self.to_latent.bias)
@@ -449,7 +455,7 @@ class MaskedAutoencoderViT(nn.Module):
                 kl_loss = torch.sum(kl) / kl.shape[0] / N
                 latent = (posterior.sample() if _eps is None else posterior.mean + posterior.std * _eps).permute(0, 2, 1)
             latent = _LinearFn.apply(latent.contiguous(), self.from_latent.weight, self.from_latent.bias)
-            pred = self.forward_decoder(latent, ids_restore)
+            pred = self.forward_decoder(latent, ids_restore, dtype)
             loss, vis_loss, mask_loss = self.forward_loss(imgs, pred, mask, visible_loss_ratio)
             if kl_loss is not None:
                 loss = loss + self.kl_loss_weight * kl_loss
