@@ -57,6 +57,19 @@ template <> __device__ __forceinline__ float from_f<float>(float v) { return v; 
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32, RNE, NaN-safe
 
 // 8-element vector load/store as floats (16 B for bf16, 2 x 16 B for f32); pointers 16-B aligned
+// Exact-erf GELU (timm Mlp act, models_mae.py:172).  f32 activations: libm's erff.  bf16 activations: erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, three orders below the bf16 rounding of the result): 2 transcendental + ~12 plain instructions, no branches, against
+// ~40 instructions with three branches -- the GELU epilogue of the fc1 GEMM and the GELU backward pass were bound by that arithmetic.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  return copysignf(fmaf(-poly, __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f), 1.f), x);
+}
+template <typename T> __device__ __forceinline__ float erf_act(float x) { return erff(x); }
+template <> __device__ __forceinline__ float erf_act<bf16>(float x) { return erf_as(x); }
+template <typename T> __device__ __forceinline__ float gelu_act(float y) { return 0.5f * y * (1.f + erf_act<T>(y * 0.70710678118654752f)); }
+
 template <typename T> struct Vec8;
 template <> struct Vec8<float> {
   static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {

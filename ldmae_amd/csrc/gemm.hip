@@ -630,6 +630,36 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, float* __restr
   }
 }
 
+// the same sum for MANY splits of a SMALL output (VMAE weight gradients: 192 x 192 outputs from up to 128 row splits): one wave per 4
+// adjacent outputs, lane l sums splits l, l + 64, ... and a butterfly folds the lane sums -- fixed order, so still deterministic; the
+// per-thread loop above left 36 workgroups walking 100 partial slabs one after the other (24 us, 197 times per VMAE step)
+__global__ __launch_bounds__(256) void splitk_reduce_wave_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int splits, float beta) {
+  const int lane = threadIdx.x & 63;
+  const long i = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  if (i >= n) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = lane; k < splits; k += 64) {
+    const float4 t = *(const float4*)(P + (size_t)k * n + i);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+  }
+  if (lane == 0) {
+    if (beta != 0.f) { const float4 o = *(const float4*)(out + i); s.x += beta * o.x; s.y += beta * o.y; s.z += beta * o.z; s.w += beta * o.w; }
+    *(float4*)(out + i) = s;
+  }
+}
+static void splitk_reduce(const float* P, float* out, long n, int splits, float beta, hipStream_t st) {
+  if (splits >= 16 && n % 4 == 0 && n <= (1L << 20))
+    hipLaunchKernelGGL(splitk_reduce_wave_kernel, dim3((unsigned)((n / 4 + 3) / 4)), dim3(256), 0, st, P, out, n, splits, beta);
+  else {
+    const unsigned grid = (unsigned)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, P, out, n, splits, beta);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -826,10 +856,8 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   }
   LDMAE_CHECK_LAUNCH("gemm_tn");
   if (!direct) {
-    const long n = (long)N * K;
-    const unsigned grid = (unsigned)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, P, C, n, splits, beta);
-    if (dbias && ring) hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(N / 4, 256)), dim3(256), 0, st, Pb, dbias, (long)N, splits, beta);
+    splitk_reduce(P, C, (long)N * K, splits, beta, st);
+    if (dbias && ring) splitk_reduce(Pb, dbias, (long)N, splits, beta, st);
     LDMAE_CHECK_LAUNCH("splitk_reduce");
   }
   if (dbias && !ring) {   // non-ring paths: separate column-sum pass (elementwise.hip), re-using the workspace

@@ -42,7 +42,7 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M,
     ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
   } else if (EPI == LDMAE_EPI_BIAS_GELU) {
     if (e.C2) ((OutT*)e.C2)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
-    ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(0.5f * y * (1.f + erff(y * 0.70710678118654752f)));
+    ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(gelu_act<OutT>(y));
   } else {  // LDMAE_EPI_GATE_RES
     if (e.C) ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
     const size_t o = (size_t)m * N + n;
@@ -89,7 +89,7 @@ template <int EPI, typename OutT> struct Epi4 {
       const float4 q = *(const float4*)(e.xin + (size_t)(m % e.rows_per_batch) * N + n);
       c = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
     } else if (EPI == LDMAE_EPI_BIAS_GELU) {
-      auto g = [](float y) { return 0.5f * y * (1.f + erff(y * 0.70710678118654752f)); };
+      auto g = [](float y) { return gelu_act<OutT>(y); };
       c = make_float4(g(a.x), g(a.y), g(a.z), g(a.w));
     } else if (EPI == LDMAE_EPI_GATE_RES) {
       const size_t o = (size_t)m * N + n;
@@ -111,7 +111,7 @@ template <int EPI, typename OutT> struct Epi4 {
       put(e.C, oc, make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w));
     } else if (EPI == LDMAE_EPI_BIAS_GELU) {
       if (e.C2) put(e.C2, oc, a);
-      auto g = [](float y) { return 0.5f * y * (1.f + erff(y * 0.70710678118654752f)); };
+      auto g = [](float y) { return gelu_act<OutT>(y); };
       put(e.C, oc, make_float4(g(a.x), g(a.y), g(a.z), g(a.w)));
     } else {
       if (e.C) put(e.C, oc, a);
@@ -364,7 +364,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
             *(float4*)(wb + xoff + 16) = make_float4(x1.x + g1.x * q.x, x1.y + g1.y * q.y, x1.z + g1.z * q.z, x1.w + g1.w * q.w);
             if (e.C) put8(e.C, oc, p, q);
           } else if constexpr (EPI == LDMAE_EPI_BIAS_GELU) {
-            auto g = [](float y) { return 0.5f * y * (1.f + erff(y * 0.70710678118654752f)); };
+            auto g = [](float y) { return gelu_act<OutT>(y); };
             put8(e.C, oc, make_float4(g(p.x), g(p.y), g(p.z), g(p.w)), make_float4(g(q.x), g(q.y), g(q.z), g(q.w)));
             if (e.C2) put8(e.C2, oc, p, q);
           } else {

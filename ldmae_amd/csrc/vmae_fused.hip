@@ -53,16 +53,8 @@ __device__ __forceinline__ f32x16 zero16() {
   for (int t = 0; t < 16; ++t) o[t] = 0.f;
   return o;
 }
-// exact-erf GELU (timm Mlp act, models_mae.py:172) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, three orders below the bf16
-// rounding of the result): 2 transcendental + ~12 plain instructions, no branches.  libm's erff is ~40 instructions with three
-// branches, and 16 of them per lane per MLP step made the step VALU-bound (1.50 -> see profiles/r03 notes).
-__device__ __forceinline__ float gelu_erf(float y) {
-  const float x = y * 0.70710678118654752f, ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
-  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-  const float er = fmaf(-poly, __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f), 1.f);      // erf(|x|)
-  return 0.5f * y * (1.f + copysignf(er, x));
-}
+// exact-erf GELU with erf by Abramowitz-Stegun 7.1.26 (common.h: erf_as -- the bf16 per-layer kernels use the same function)
+__device__ __forceinline__ float gelu_erf(float y) { return gelu_act<bf16>(y); }
 }  // namespace
 
 // x, out: [B, 256, 192] f32.  blob: nblk * 36 slots of SLOTB bytes (ldmae_amd/tokenizer/fused_encoder.py packs it; layout in the header).
