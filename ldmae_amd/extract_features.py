@@ -89,7 +89,7 @@ def extract(tokenizer, loaders, output_dir, rank=0, batch_size=64, sample=True, 
 
     for batch_idx, pair in enumerate(zip(*loaders)):
         run_images += pair[0][0].shape[0]
-        if run_images % 100 == 0 and rank == 0:
+        if rank == 0 and (run_images % 100 == 0 or batch_idx % 8 == 7):      # the reference's rule (:147) never fires at batch sizes like 64 / 256
             log(f"{datetime.now()} processing {run_images} of {total} images")
         for which, (x, y) in enumerate(pair):
             with torch.no_grad():
@@ -124,6 +124,9 @@ class _SyntheticImages(Dataset):
 
 
 def main(args, cfg):
+    if os.environ.get("LDMAE_DUMP_AFTER"):            # debugging aid: all thread stacks after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LDMAE_DUMP_AFTER"]), exit=True)
     if not torch.cuda.is_available():
         raise RuntimeError("extract_features needs a GPU: there is no CPU path in this package")
     if "RANK" in os.environ:                                           # launched by torchrun / accelerate (:27-41)
@@ -160,9 +163,14 @@ def main(args, cfg):
     else:
         root = os.path.join(cfg["data"]["origin_path"], args.data_split)
         sets = [ImageFolder(root, transform=tokenizer.img_transform(p_hflip=p, img_size=args.image_size)) for p in (0.0, 1.0)]
+    # workers from a FORK SERVER, not forked from this process: it has the GPU runtime, its helper threads and (from the first loader on) a
+    # pin-memory thread running, and a child forked while one of them holds a lock inherits that lock forever -- seen as loader workers that
+    # never deliver a batch (2 of 6 runs with 2 x 8 workers).  Datasets and transforms are plain picklable objects.
+    mp_ctx = "forkserver" if args.num_workers > 0 else None
     loaders = [DataLoader(ds, batch_size=args.batch_size, shuffle=False,
                           sampler=DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=False, seed=args.seed),
-                          num_workers=args.num_workers, pin_memory=True, drop_last=False) for ds in sets]
+                          num_workers=args.num_workers, pin_memory=True, drop_last=False, multiprocessing_context=mp_ctx,
+                          persistent_workers=False) for ds in sets]
     if rank == 0:
         print(f"Total data in one loop: {len(sets[0])}")
     files = extract(tokenizer, loaders, output_dir, rank=rank, batch_size=args.batch_size, sample=sample)

@@ -95,7 +95,11 @@ def make_loader(cfg, per_gpu, rank, world, synthetic):
         ds_ = ImgLatentDataset(data_dir=path, latent_norm=d.get('latent_norm', False), latent_multiplier=d.get('latent_multiplier', 0.18215),
                                sample=d.get('sample', False), raw=bool(d.get('gpu_prologue', False)))
     sampler = DistributedSampler(ds_, num_replicas=world, rank=rank, shuffle=True, seed=cfg['train'].get('global_seed', 0)) if world > 1 else None
-    return ds_, DataLoader(ds_, batch_size=per_gpu, shuffle=sampler is None, sampler=sampler, num_workers=d.get('num_workers', 0),
+    # workers come from a fork server: forking THIS process (GPU runtime threads, pin-memory thread, RCCL threads) can hand a child a lock
+    # that is held at the moment of the fork and never released in the child (extract_features.py saw such workers hang)
+    nw = d.get('num_workers', 0)
+    return ds_, DataLoader(ds_, batch_size=per_gpu, shuffle=sampler is None, sampler=sampler, num_workers=nw,
+                           multiprocessing_context="forkserver" if nw > 0 else None,
                            pin_memory=True, drop_last=True)
 
 
