@@ -515,7 +515,10 @@ class MaskedAutoencoderViT(nn.Module):
         """:963-973 -> uint8 NHWC numpy."""
         with torch.no_grad():
             images = self.decode(z.cuda(), return_dict=False)[0]
-            return torch.clamp(127.5 * images + 128.0, 0, 255).permute(0, 2, 3, 1).to("cpu", dtype=torch.uint8).numpy()
+            # clamp, convert to uint8 and go to NHWC ON THE DEVICE, then copy 1 byte per value (the reference's .to("cpu", dtype=uint8) moves
+            # the f32 image and converts / permutes on the host: 30 of 36 ms per 64 images); same truncation toward zero for values in [0, 255]
+            img8 = torch.clamp(127.5 * images.float() + 128.0, 0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+            return img8.cpu().numpy()
 
 
 def _ln(**kw):
