@@ -519,3 +519,20 @@ def test_round3_entry_points_reject_bad_arguments(ops):
     ws = [f(16, 24) for _ in range(3)]
     st = ops.cast_stack(ws, torch.bfloat16)
     assert st.shape == (48, 24) and torch.equal(st, torch.cat(ws).to(torch.bfloat16))
+
+
+def test_thin_products_at_the_bench_shape_match_the_generic_gemms(ops):
+    """At the real patch-embedding shape (M = 256 x 1024 rows, N = 768, K = 16) the thin kernels against the generic f32 MFMA GEMMs they
+    replaced on this shape (same inputs; f32 summation order differs: 1e-5)."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M, N, K, T = 256 * 1024, 768, 16, 1024
+    t, w, b, pos = (torch.randn(*s, device="cuda", generator=g) for s in ((M, K), (N, K), (N,), (T, N)))
+    a, ref = ops.thin_nt(t, w, b, pos, T), ops.gemm_nt_pos(t, w, b, pos, T)
+    assert float((a - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    gr = torch.randn(M, N, device="cuda", generator=g)
+    dW, db = ops.thin_tn(gr, t)
+    rW, rb = ops.gemm_tn(gr, t), ops.colsum(gr)
+    assert float((dW - rW).abs().max()) < 1e-5 * float(rW.abs().max()) and float((db - rb).abs().max()) < 1e-5 * float(rb.abs().max())
+    wt = torch.randn(N, K, device="cuda", generator=g)            # final layer dX: [M, 16] @ [16, 768] -> bf16
+    dx, rx = ops.thin_nt(t, wt, out_dtype=torch.bfloat16), ops.gemm_nt(t, wt, out_dtype=torch.bfloat16)
+    assert float((dx.float() - rx.float()).abs().max()) <= 2 ** -7 * float(rx.float().abs().max())
