@@ -1176,8 +1176,45 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
     if (r < R && c < C) dstT[(size_t)c * R + r] = from_f<T>(tile[tx][j]);
   }
 }
+// The same for shapes whose sides are multiples of 64 (every Linear weight of the shipped models): 64x64 tiles, 16-B loads, 8-B stores of the
+// straight copy and 32-B runs of the transposed one (the 4-byte-per-lane form above ran at ~2 TB/s: 48 launches = 0.34 ms per train step)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_weight64_kernel(const float* __restrict__ src, T* __restrict__ dst, T* __restrict__ dstT, int R, int C) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 4;          // 16 rows x 16 float4 per pass
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = p * 16 + lr;
+    const float4 v = *(const float4*)(src + (size_t)(r0 + r) * C + c0 + lc);
+    if (dst) {
+      T* d = dst + (size_t)(r0 + r) * C + c0 + lc;
+      if constexpr (sizeof(T) == 4) *(float4*)d = v;
+      else { bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w; *(bf16x4*)d = o; }
+    }
+    tile[r][lc] = v.x; tile[r][lc + 1] = v.y; tile[r][lc + 2] = v.z; tile[r][lc + 3] = v.w;
+  }
+  __syncthreads();
+  if (!dstT) return;
+  const int c = threadIdx.x >> 2, rq = (threadIdx.x & 3) * 16;            // output row c of the transposed tile, 16 of its 64 values
+  T* d = dstT + (size_t)(c0 + c) * R + r0 + rq;
+#pragma unroll
+  for (int k = 0; k < 16; k += 4) {
+    const float a0 = tile[rq + k][c], a1 = tile[rq + k + 1][c], a2 = tile[rq + k + 2][c], a3 = tile[rq + k + 3][c];
+    if constexpr (sizeof(T) == 4) *(float4*)(d + k) = make_float4(a0, a1, a2, a3);
+    else { bf16x4 o; o[0] = (bf16)a0; o[1] = (bf16)a1; o[2] = (bf16)a2; o[3] = (bf16)a3; *(bf16x4*)(d + k) = o; }
+  }
+}
 extern "C" int ldmae_cast_weight(int dst_dtype, const float* src, void* dst, void* dstT, int R, int C, void* stream) {
   LDMAE_REQUIRE(src && (dst || dstT) && R > 0 && C > 0, "cast_weight: null pointer or empty");
+  const bool al = ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0 && ((uintptr_t)dstT & 15) == 0;
+  if (R % 64 == 0 && C % 64 == 0 && al) {
+    dim3 grid(C / 64, R / 64);
+    if (dst_dtype == LDMAE_BF16) hipLaunchKernelGGL(cast_weight64_kernel<bf16>, grid, dim3(256), 0, as_stream(stream), src, (bf16*)dst, (bf16*)dstT, R, C);
+    else hipLaunchKernelGGL(cast_weight64_kernel<float>, grid, dim3(256), 0, as_stream(stream), src, (float*)dst, (float*)dstT, R, C);
+    LDMAE_CHECK_LAUNCH("cast_weight");
+    return LDMAE_OK;
+  }
   dim3 grid(cdiv(C, 32), cdiv(R, 32));
   if (dst_dtype == LDMAE_BF16) hipLaunchKernelGGL(cast_weight_kernel<bf16>, grid, dim3(256), 0, as_stream(stream), src, (bf16*)dst, (bf16*)dstT, R, C);
   else hipLaunchKernelGGL(cast_weight_kernel<float>, grid, dim3(256), 0, as_stream(stream), src, (float*)dst, (float*)dstT, R, C);

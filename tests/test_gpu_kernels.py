@@ -536,3 +536,15 @@ def test_thin_products_at_the_bench_shape_match_the_generic_gemms(ops):
     wt = torch.randn(N, K, device="cuda", generator=g)            # final layer dX: [M, 16] @ [16, 768] -> bf16
     dx, rx = ops.thin_nt(t, wt, out_dtype=torch.bfloat16), ops.gemm_nt(t, wt, out_dtype=torch.bfloat16)
     assert float((dx.float() - rx.float()).abs().max()) <= 2 ** -7 * float(rx.float().abs().max())
+
+
+@pytest.mark.parametrize("R,C", [(768, 2304), (4096, 768), (192, 576), (100, 36), (64, 64)])
+def test_cast_weight_straight_and_transposed(ops, R, C):
+    """ldmae_cast_weight: bf16 / f32 copies of an f32 master weight, straight and transposed, on the 64x64-tile path (sides % 64 == 0) and
+    the 32x32 fallback -- exact (one rounding per element)."""
+    w = torch.randn(R, C, device="cuda", generator=torch.Generator(device="cuda").manual_seed(R + C))
+    for dtype in (torch.bfloat16, torch.float32):
+        a, at = ops.cast_weight(w, dtype, transposed=True, straight=True)
+        assert torch.equal(a, w.to(dtype)) and torch.equal(at, w.t().contiguous().to(dtype))
+        _, only_t = ops.cast_weight(w, dtype, transposed=True, straight=False)
+        assert torch.equal(only_t, at)
