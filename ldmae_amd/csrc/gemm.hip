@@ -709,6 +709,14 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
     return LDMAE_OK;
   }
 #endif
+  // fused epilogues whose elementwise part can run inside the next tile's main loop (gemm_nt_defer.hip); tune key 12 = 1 (diagnostic
+  // build) keeps them on gemm_nt_persist_kernel for A/B runs
+  if (dtype == LDMAE_BF16 && sizeof(OutT) == 2 && pers && pgrid != ntiles && (epi == LDMAE_EPI_GATE_RES || epi == LDMAE_EPI_SWIGLU || epi == LDMAE_EPI_SWIGLU_BWD) &&
+      ldmae_tune_get(12) != 1 && ldmae_launch_nt_defer(epi, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st)) {
+    if (pi >= 0) ldmae_prof_end(pi, st);
+    LDMAE_CHECK_LAUNCH("gemm_nt_defer");
+    return LDMAE_OK;
+  }
   // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup (A/B knob),
   // key 7 = diagnostic per-K-step stamp build.
 #define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048)

@@ -21,6 +21,11 @@ struct EpiArgs {
   float beta;           // EPI_BIAS with f32 out: C = acc + bias + beta*C   (beta 0 or 1: gradient accumulation)
 };
 
+// gemm_nt_defer.hip: persistent bf16 NT kernel whose fused epilogue (gated residual / SwiGLU) runs inside the NEXT tile's main loop.
+// Returns 0 when the shape or the arguments are outside what it covers (the caller then launches gemm_nt_persist_kernel).
+int ldmae_launch_nt_defer(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid, int ntiles,
+                          hipStream_t st);
+
 #ifdef LDMAE_DIAG
 // probe/gemm_w4.hip (diagnostic build): experimental NT kernels; return 0 if they have no instantiation for `epi`
 int ldmae_launch_nt_w4(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
@@ -28,6 +33,17 @@ int ldmae_launch_nt_w4(int epi, int out_bf16, const void* A, const void* B, int 
 int ldmae_launch_nt_p8(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
                        int ntiles, hipStream_t st);
 #endif
+
+// The gated residual adds gate * y with y AS STORED in the activation type (the reference's autocast Linear returns bf16:
+// lightningdit.py:248-249); every kernel that forms it -- the fused epilogues here, the deferred units of gemm_nt_defer.hip --
+// uses this one definition, so they agree bit for bit.
+template <typename OutT> __device__ __forceinline__ float act_round(float y) { return to_f<OutT>(from_f<OutT>(y)); }
+__device__ __forceinline__ float4 gate_res4(float4 x, float4 g, float4 y) {
+  return make_float4(fmaf(g.x, y.x, x.x), fmaf(g.y, y.y, x.y), fmaf(g.z, y.z, x.z), fmaf(g.w, y.w, x.w));
+}
+template <typename OutT> __device__ __forceinline__ float4 act_round4(float4 y) {
+  return make_float4(act_round<OutT>(y.x), act_round<OutT>(y.y), act_round<OutT>(y.z), act_round<OutT>(y.w));
+}
 
 template <int EPI, typename OutT>
 __device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M, int N, float acc) {
@@ -47,7 +63,7 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M,
     if (e.C) ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
     const size_t o = (size_t)m * N + n;
     const float gt = e.gate ? e.gate[(size_t)(m / e.rows_per_batch) * e.gate_ld + n] : 1.f;
-    e.xout[o] = e.xin[o] + gt * y;
+    e.xout[o] = fmaf(gt, act_round<OutT>(y), e.xin[o]);
   }
 }
 
@@ -94,7 +110,7 @@ template <int EPI, typename OutT> struct Epi4 {
     } else if (EPI == LDMAE_EPI_GATE_RES) {
       const size_t o = (size_t)m * N + n;
       const float4 xi = *(const float4*)(e.xin + o);
-      *(float4*)(e.xout + o) = make_float4(xi.x + gate.x * a.x, xi.y + gate.y * a.y, xi.z + gate.z * a.z, xi.w + gate.w * a.w);
+      *(float4*)(e.xout + o) = gate_res4(xi, gate, act_round4<OutT>(a));
     }
   }
   __device__ __forceinline__ void apply(int m, float4 a) const {
@@ -117,7 +133,7 @@ template <int EPI, typename OutT> struct Epi4 {
       if (e.C) put(e.C, oc, a);
       const size_t o = (size_t)m * N + n;
       const float4 xi = *(const float4*)(e.xin + o);
-      *(float4*)(e.xout + o) = make_float4(xi.x + gate.x * a.x, xi.y + gate.y * a.y, xi.z + gate.z * a.z, xi.w + gate.w * a.w);
+      *(float4*)(e.xout + o) = gate_res4(xi, gate, act_round4<OutT>(a));
     }
   }
 };
@@ -360,8 +376,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
           if constexpr (EPI == LDMAE_EPI_GATE_RES) {
             char* wb = (char*)e.xout + (size_t)(mw + i * 16 + it * 8) * (size_t)N * 4;
             const float4 x0 = xi[i][it][0], x1 = xi[i][it][1];
-            *(float4*)(wb + xoff) = make_float4(x0.x + g0.x * p.x, x0.y + g0.y * p.y, x0.z + g0.z * p.z, x0.w + g0.w * p.w);
-            *(float4*)(wb + xoff + 16) = make_float4(x1.x + g1.x * q.x, x1.y + g1.y * q.y, x1.z + g1.z * q.z, x1.w + g1.w * q.w);
+            *(float4*)(wb + xoff) = gate_res4(x0, g0, act_round4<OutT>(p));
+            *(float4*)(wb + xoff + 16) = gate_res4(x1, g1, act_round4<OutT>(q));
             if (e.C) put8(e.C, oc, p, q);
           } else if constexpr (EPI == LDMAE_EPI_BIAS_GELU) {
             auto g = [](float y) { return gelu_act<OutT>(y); };

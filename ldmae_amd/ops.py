@@ -99,14 +99,17 @@ def gemm_nt(a, b, bias=None, out_dtype=None, out=None, beta=0.0):
     return out
 
 
-def gemm_nt_gate_res(a, b, bias, xin, gate, rows_per_batch, save_y=True, xout=None):
-    """y = a @ b^T + bias ; xout = xin + gate[batch] * y.  Returns (xout, y or None).  gate: [B, D] view (any row stride)."""
+def gemm_nt_gate_res(a, b, bias, xin, gate, rows_per_batch, save_y=True, xout=None, y_dtype=None):
+    """y = a @ b^T + bias ; xout = xin + gate[batch] * y.  Returns (xout, y or None).  gate: [B, D] view (any row stride).
+    The residual adds y ROUNDED to `y_dtype` (default: the activation type -- what the reference's autocast Linear hands to
+    `x + gate * branch`, lightningdit.py:248-249); y_dtype=float32 with save_y=False adds the unrounded product."""
     M, K = a.shape
     N = b.shape[0]
-    y = torch.empty(M, N, dtype=a.dtype, device=a.device) if save_y else None
+    y_dtype = y_dtype or a.dtype
+    y = torch.empty(M, N, dtype=y_dtype, device=a.device) if save_y else None
     if xout is None:
         xout = torch.empty_like(xin)
-    call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_GATE_RES | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(y), N,
+    call("ldmae_gemm_nt", dt(a.dtype), dt(y_dtype), EPI_GATE_RES | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(y), N,
          M, N, K, ptr(bias), 0.0, ptr(xin), ptr(xout), ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch, stream())
     return xout, y
 
@@ -546,7 +549,7 @@ def patch_embed_kept(img, ids_keep, pos, w2d, bias, patch, dtype):
     posg = torch.empty(N * keep, D, dtype=torch.float32, device=img.device)
     call("ldmae_patch_gather", dt(dtype), ptr(_c(img.float())), ptr(ids_keep), ptr(pos), ptr(tok), ptr(posg), N, keep, C, S, patch, D, stream())
     wb = cast(_c(w2d), dtype)          # 192 x 192: one tiny launch (w2d is a fresh view per call, so the id-keyed weight cache does not apply)
-    out, _ = gemm_nt_gate_res(tok, wb, bias, posg, None, keep, save_y=False, xout=posg)
+    out, _ = gemm_nt_gate_res(tok, wb, bias, posg, None, keep, save_y=False, xout=posg, y_dtype=torch.float32)   # unrounded, as gemm_nt_pos
     return out.view(N, keep, D)
 
 
