@@ -118,6 +118,9 @@ def load():
         for kv in filter(None, os.environ.get("LDMAE_TUNE", "").split(",")):
             k, v = kv.split("=")
             lib.ldmae_tune(int(k), int(v))
+    elif os.environ.get("LDMAE_TUNE"):
+        raise RuntimeError("LDMAE_TUNE is set but the loaded library has no A/B knobs: point LDMAE_HIP_LIB at "
+                           "ldmae_amd/libldmae_hip_diag.so (make -C ldmae_amd/csrc diag)")
     _lib = lib
     return lib
 

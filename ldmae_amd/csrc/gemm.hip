@@ -36,11 +36,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const unsigned tiles_n = (N + BN - 1) / BN;
-  float* ew = (float*)(smem + STAGES * STAGE_BYTES) + wave * (16 * 68);
-  // per-wave column-sum scratch of the SwiGLU-bwd epilogue (1024 floats): ring stage STAGES-1.  The prologue of the next tile fills stages
-  // 0 .. STAGES-2 only, and stage STAGES-1 is first written by the K-step-0 load phase, behind the tile-start barrier every wave reaches
-  // after its epilogue -- so during an epilogue that stage is free
-  float* ex = (float*)(smem + (STAGES - 1) * STAGE_BYTES) + wave * 1024;
+  // LDS map.  3-deep ring: the epilogue strips behind the ring (96 KiB ..), the SwiGLU-bwd column-sum scratch `ex` (1024 floats per wave) on
+  // ring stage 2, which is free during an epilogue (the prologue of the next tile fills stages 0 and 1 only).  4-deep ring (128 KiB): the
+  // strips (34 KiB) are ALIASED onto stages 2 and 3 -- free during an epilogue for the same reason: stage 2 of the next tile is requested
+  // behind the tile-start barrier, which every wave reaches after its epilogue -- and `ex` sits behind the ring (.. 160 KiB).
+  float* ew = (float*)(smem + (STAGES == 3 ? 3 : 2) * STAGE_BYTES) + wave * (16 * 68);
+  float* ex = (float*)(smem + (STAGES == 3 ? 2 : 4) * STAGE_BYTES) + wave * 1024;
   static_assert(STAGE_BYTES >= 8 * 1024 * 4, "epilogue scratch does not fit a ring stage");
   // workgroup b sits on XCD b % 8 (256 workgroups, one per CU): give each XCD a contiguous run of 32 tiles per round so the
   // workgroups that share an A row-block (and the whole of B) share an L2
@@ -85,17 +86,16 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
   const int a_off = (wm * TM + (lane & 15)) * 64 + fpos, b_off = (BM + wn * TNn + (lane & 15)) * 64 + fpos;
   const int nk = K / 32;
   const bool grpB = wm >= WM / 2;
-  static_assert(STAGES == 3, "wait accounting below is written for a 3-deep ring");
-  // own pieces of stage kt+1 landed; stage kt+2's may stay in flight (all PPW of them after the MFMA phase, only the PL issued
-  // so far when the wait sits between load and MFMA phase, i.e. for group B)
-  auto wait_next = [&](int kt, bool after_mfma) {
-    if (kt + 2 < nk) {
-      if (after_mfma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL) : "memory");
-    } else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  static_assert(STAGES == 3 || STAGES == 4, "wait accounting below is written for a 3- or 4-deep ring");
+  // own pieces of stage kt+1 landed; the stages requested after it (kt+2 .. kt+STAGES-1, as far as the tile has them) may stay in flight
+  auto wait_next = [&](int kt, bool) {
+    const int after = nk - kt - 2;                 // stages of this tile behind stage kt+1
+    if (after >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PPW) : "memory");
+    else if (STAGES == 4 && after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else if (after == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
-  constexpr int PRO = STAGES - 1;   // K-steps put in flight ahead of a tile's main loop
+  constexpr int PRO = 2;            // K-steps put in flight ahead of a tile's epilogue (a 4-deep ring requests its third at the tile start)
   int t = first;
   if (t < tend) {
     set_tile(t);
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
     // have landed too, and the previous tile's stores are drained (~0.2 us per tile).
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __builtin_amdgcn_s_barrier();
+    if constexpr (STAGES == 4) { if (PRO < nk) issue(PRO); }       // behind the barrier: every wave has left the strips that alias this stage
     if (grpB) __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; ++kt) {
       tstamp(kt, 0);
@@ -709,21 +710,38 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
     return LDMAE_OK;
   }
 #endif
-  // fused epilogues whose elementwise part can run inside the next tile's main loop (gemm_nt_defer.hip); tune key 12 = 1 (diagnostic
-  // build) keeps them on gemm_nt_persist_kernel for A/B runs
-  if (dtype == LDMAE_BF16 && sizeof(OutT) == 2 && pers && pgrid != ntiles && (epi == LDMAE_EPI_GATE_RES || epi == LDMAE_EPI_SWIGLU || epi == LDMAE_EPI_SWIGLU_BWD) &&
-      ldmae_tune_get(12) != 1 && ldmae_launch_nt_defer(epi, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st)) {
+#ifdef LDMAE_DIAG
+  // tune key 12 = 1 (diagnostic build only): the fused epilogue's elementwise part runs inside the next tile's main loop
+  // (probe/gemm_nt_defer.hip).  Built, bitwise equal, and 5-9 % SLOWER than the fused epilogues (profiles/r04_defer_ab.txt).
+  if (dtype == LDMAE_BF16 && sizeof(OutT) == 2 && pers && pgrid != ntiles && (epi == LDMAE_EPI_GATE_RES || epi == LDMAE_EPI_SWIGLU) &&
+      ldmae_tune_get(12) == 1 && ldmae_launch_nt_defer(epi, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st)) {
     if (pi >= 0) ldmae_prof_end(pi, st);
     LDMAE_CHECK_LAUNCH("gemm_nt_defer");
     return LDMAE_OK;
   }
+#endif
   // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup (A/B knob),
   // key 7 = diagnostic per-K-step stamp build.
 #define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048)
 #define PERS_GO(...)                                                                                                             \
   hipLaunchKernelGGL((gemm_nt_persist_kernel<__VA_ARGS__>), dim3(pgrid), dim3(512), lds + 2048, st, (const bf16*)A, (const bf16*)B, \
                      M, N, K, lda, ldb, e, ntiles, ldmae_tune_get(5), (unsigned long long*)g_nt_stamps)
+  // tune key 14 = 1 (diagnostic build only): 4-deep ring, 128 KiB, strips aliased onto it, the SwiGLU-bwd scratch behind it (160 KiB in all).
+  // Measured neutral (profiles/r04_ring4_ab.txt: block total 8.158 -> 8.118 ms): the L2 read latency seen by the CU is ~360 cycles
+  // (TCP_TCC_READ_REQ_LATENCY / READ_REQ, profiles/r04_pmc_ta.md), far inside what two stages in flight cover.
+#ifdef LDMAE_DIAG
+#define PERS_RING4(E)                                                                                                             \
+  if (ldmae_tune_get(14) == 1) {                                                                                                  \
+    constexpr int lds4 = 4 * 512 * 64 + (E == LDMAE_EPI_SWIGLU_BWD ? 8 * 1024 * 4 : 0);                                            \
+    hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<4, E, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);       \
+    hipLaunchKernelGGL((gemm_nt_persist_kernel<4, E, OutT>), dim3(pgrid), dim3(512), lds4, st, (const bf16*)A, (const bf16*)B,      \
+                       M, N, K, lda, ldb, e, ntiles, ldmae_tune_get(5), (unsigned long long*)g_nt_stamps);                       \
+  } else
+#else
+#define PERS_RING4(E)
+#endif
 #define PERS(E)                                                                                                                  \
+  PERS_RING4(E)                                                                                                                   \
   {                                                                                                                               \
     constexpr int lds = 3 * 512 * 64 + 8 * 16 * 68 * 4;                                                                           \
     /* the LDS opt-in is per device and cheap: set it at every launch (no process-wide "done" flag) */                            \
@@ -748,6 +766,7 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
 #undef NT_LAUNCH
 #undef PERS
 #undef PERS_GO
+#undef PERS_RING4
 #undef PERS_ATTR
   if (pi >= 0) ldmae_prof_end(pi, st);
   LDMAE_CHECK_LAUNCH("gemm_nt");

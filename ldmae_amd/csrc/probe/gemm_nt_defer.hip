@@ -31,8 +31,8 @@
 // between every DMA and its ring wait.
 #include <type_traits>
 
-#include "common.h"
-#include "gemm_nt_common.h"
+#include "../common.h"
+#include "../gemm_nt_common.h"
 
 namespace {
 

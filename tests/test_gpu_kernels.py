@@ -102,7 +102,10 @@ def test_gemm_nt_persistent_multi_tile_ragged(ops):
         gate = torch.randn(M // T, N, device="cuda", generator=g)
         xo, y = ops.gemm_nt_gate_res(a, w, bias, xin, gate, T)
         assert torch.equal(y, out)
-        assert rel_err(xo.cpu(), (xin + gate.repeat_interleave(T, 0) * ref).cpu()) < 1e-5      # residual uses the unrounded f32 product
+        # the residual adds y AS STORED (bf16) -- what the reference's autocast Linear hands to `x + gate * branch` (lightningdit.py:248-249)
+        assert rel_err(xo.cpu(), torch.addcmul(xin, gate.repeat_interleave(T, 0), y.float()).cpu()) < 1e-6
+        xo32, _ = ops.gemm_nt_gate_res(a, w, bias, xin, gate, T, save_y=False, y_dtype=torch.float32)      # y_dtype f32: the unrounded product
+        assert rel_err(xo32.cpu(), (xin + gate.repeat_interleave(T, 0) * ref).cpu()) < 1e-5
     ops.set_gemm_launch_mode("persistent")
     assert not hasattr(_lib.load(), "ldmae_tune")    # the product library has no process-wide knobs (csrc/probe/ldmae_diag.h is a separate build)
     assert torch.equal(outs[0], outs[2])             # persistent and one-tile-per-workgroup launches (the multi-rank mode): bitwise equal

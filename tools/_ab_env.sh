@@ -1,6 +1,8 @@
 #!/bin/bash
 # usage: tools/_ab_env.sh "LDMAE_TUNE=10=64" "LDMAE_TUNE=10=16" ... -> per-kernel ms/step of bench.py under rocprofv3 for each env setting (same box)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# LDMAE_TUNE knobs exist in the diagnostic build only
+export LDMAE_HIP_LIB=${LDMAE_HIP_LIB:-$GRAFT_REPO_ROOT/ldmae_amd/libldmae_hip_diag.so}
 i=0
 for e in "$@"; do
   i=$((i+1)); rm -rf gpurun_out/abe_$i

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Audit of the deferred-epilogue NT GEMM kernels' ISA (ldmae_amd/csrc/gemm_nt_defer.hip), after every edit of that file:
+"""Audit of the deferred-epilogue NT GEMM kernels' ISA (ldmae_amd/csrc/probe/gemm_nt_defer.hip), after every edit of that file:
 
   1. vector-register spills / scratch traffic: where they sit relative to the K loops (inside = a VMEM instruction the hand-written
      vmcnt counts do not know, and a compiler vmcnt wait that drains the DMA ring);
@@ -14,7 +14,7 @@ loop): a register pending at the loop's back edge is checked against the code up
 import os, re, subprocess, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "ldmae_amd", "csrc", "gemm_nt_defer.hip")
+src = os.path.join(root, "ldmae_amd", "csrc", "probe", "gemm_nt_defer.hip")
 out = "/tmp/defer_audit.s"
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-inline-asm",
                 "-Wno-unused-value", "-S", "--cuda-device-only", "-o", out, src], check=True, stderr=subprocess.DEVNULL)
