@@ -720,6 +720,18 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
     return LDMAE_OK;
   }
 #endif
+#ifdef LDMAE_DIAG
+  // tune key 15 = 1 (diagnostic build only): whole-line ring DMA (probe/gemm_nt_wl.hip: 128-B LDS rows, pieces of 8 rows x 128 B).  Built,
+  // bitwise equal on every epilogue, 6.5 % SLOWER over the block's eight GEMMs (profiles/r04_wl_ab.txt): the CU's DMA path is limited in
+  // BYTES per cycle, not in line requests.
+  if (ldmae_tune_get(15) == 1 && dtype == LDMAE_BF16 && sizeof(OutT) == 2 && M % 8 == 0 && N % 8 == 0 && M >= 8 && N >= 8 && K % 64 == 0 && lda % 64 == 0 &&
+      ldb % 64 == 0 && ((uintptr_t)A & 127) == 0 && ((uintptr_t)B & 127) == 0 && (epi != LDMAE_EPI_SWIGLU || N % 256 == 0) &&
+      ldmae_launch_nt_wl(epi, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st)) {
+    if (pi >= 0) ldmae_prof_end(pi, st);
+    LDMAE_CHECK_LAUNCH("gemm_nt_wl");
+    return LDMAE_OK;
+  }
+#endif
   // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup (A/B knob),
   // key 7 = diagnostic per-K-step stamp build.
 #define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048)

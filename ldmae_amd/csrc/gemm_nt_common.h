@@ -26,6 +26,9 @@ struct EpiArgs {
 // tile's main loop.  Returns 0 when the shape or the arguments are outside what it covers.
 int ldmae_launch_nt_defer(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid, int ntiles,
                           hipStream_t st);
+// probe/gemm_nt_wl.hip (diagnostic build): the same tile with a whole-line ring DMA (128-B LDS rows); bf16 outputs, epilogues 0 / 1 / 4 / 5
+int ldmae_launch_nt_wl(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid, int ntiles,
+                       hipStream_t st);
 // probe/gemm_w4.hip (diagnostic build): experimental NT kernels; return 0 if they have no instantiation for `epi`
 int ldmae_launch_nt_w4(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
                        int ntiles, hipStream_t st);

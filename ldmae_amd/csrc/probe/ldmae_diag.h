@@ -8,7 +8,9 @@ extern "C" {
 #endif
 /* kernel-variant selection for A/B measurements.  key 0: bf16 NT GEMM variant (1 / 2 = probe/gemm_w4.hip kernels), 1: TN fallback kernel,
  * 4: TN wave layout, 5: NT start delay, 7: per-K-step stamp build, 8: NT launch mode (2 = one tile per workgroup; the product library
- * takes this per call through LDMAE_EPI_TILE_LAUNCH), 9: TN split target, 10: row-kernel grid cap.  0 = shipped behaviour. */
+ * takes this per call through LDMAE_EPI_TILE_LAUNCH), 9: TN split target, 10: row-kernel grid cap, 12: 1 = deferred-epilogue NT kernel (probe/gemm_nt_defer.hip), 13: its timing-only
+ * ablations (1 no deferred work, 2 loads only, 3 loads + arithmetic), 14: 1 = 4-deep NT ring, 15: 1 = whole-line NT ring (probe/gemm_nt_wl.hip).
+ * 0 = shipped behaviour. */
 int ldmae_tune(int key, int value);
 int ldmae_tune_query(int key);
 /* device buffer (>= 64 B x 256 workgroups x tiles-per-workgroup) that receives s_memrealtime stamps of the persistent NT GEMM
