@@ -31,10 +31,10 @@ FLOPS_PER_IMAGE = 638.22e9        # 212.74 GFLOP fwd x 3 (fwd+bwd)
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md chip table)
 
 
-def build(device, per_gpu_batch):
+def build(device, per_gpu_batch, force_hooks=False):
     from ldmae_amd.distributed import GradBucketReducer
     from ldmae_amd.models.lightningdit import LightningDiT_models
-    from ldmae_amd.optim import AdamWEMA
+    from ldmae_amd.optim import AdamWEMA, adaln_first
     from ldmae_amd.transport import create_transport
     # configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml: model / optimizer / transport sections
     model = LightningDiT_models["LightningDiT-B/1"](input_size=32, num_classes=1000, use_qknorm=True, use_swiglu=True, use_rope=True,
@@ -47,13 +47,11 @@ def build(device, per_gpu_batch):
             if "adaLN_modulation" in n or n.startswith("final_layer.linear"):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)
     model = model.to(device).train()
-    opt = AdamWEMA(model, lr=2e-4, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9999)
-    reducer = GradBucketReducer(opt.flat)
-    if reducer.world > 1:
-        # batched adaLN (models.lightningdit._AdaLNAllFn) finishes the adaLN weight gradients of EVERY block at the very end of backward; every
-        # 64-MiB bucket of the slab holds one of them, so no bucket could start its all-reduce under backward.  Data-parallel runs keep the
-        # per-block form (the gradients of a block complete with the block), single-GPU runs take the 1.5 ms.
-        model.batched_adaln = False
+    # the adaLN weights FIRST in the slab: the batched adaLN backward finishes them at the very end of backward, and the reducer's buckets are
+    # cut from the end of the slab backwards -- so N > 1 runs the same program as N = 1 (ldmae_amd/train_accum.py does the same)
+    opt = AdamWEMA(model, lr=2e-4, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9999, front_fn=adaln_first)
+    model.batched_adaln = os.environ.get("LDMAE_BATCHED_ADALN", "1") != "0"
+    reducer = GradBucketReducer(opt.flat, force_hooks=force_hooks)
     model.direct_param_grads = os.environ.get("LDMAE_DIRECT_GRADS", "1") != "0"       # every .grad is a slab view and backward is a plain loss.backward(): dW goes straight into the slab
     reducer.broadcast_params(0)
     opt.ema.copy_(opt.flat.params)
@@ -324,10 +322,48 @@ def gemm_roofline(lib, fn, steps=2):
             "measured": f"{steps} profiled steps after the timed region (HIP events per launch on the launch stream)"}
 
 
+def bench_dp_config(args, device, launch_modes=("tile", "persistent")):
+    """The DATA-PARALLEL program on one GPU: a world of ONE RCCL rank (init_process_group("nccl"), librccl loaded), the gradient reducer
+    with its hooks, side stream and per-bucket all-reduce launches live (force_hooks), adaLN weights first in the slab, batched adaLN on --
+    timed with both GEMM launch modes.  What the first 8-GPU run adds to this is the collectives' own time and their CU share."""
+    from ldmae_amd import ops
+    import socket
+    own = not dist.is_initialized()
+    if own:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=device)
+    res = {}
+    try:
+        model, opt, reducer, transport = build(device, args.batch, force_hooks=True)
+        reducer.measure_exposed = True
+        torch.manual_seed(0); np.random.seed(0)
+        x = torch.randn(args.batch, 16, 32, 32, device=device)
+        y = torch.randint(0, 1000, (args.batch,), device=device)
+        step = lambda: train_step(model, opt, reducer, transport, x, y)
+        for mode in launch_modes:
+            ops.set_gemm_launch_mode(mode)
+            for _ in range(2):
+                step()
+            reducer.exposed_comm_ms()
+            el, loss = timed_loop(step, args.steps, 1, 1)
+            res[mode] = {"ms_per_step": round(el / args.steps * 1e3, 3), "exposed_reduce_wait_ms": round(reducer.exposed_comm_ms() / (args.steps + 1), 3)}
+        res.update({"buckets": len(reducer.buckets), "adaln_params_first": opt.flat.n_front, "batched_adaln": bool(model.batched_adaln),
+                    "backend": "rccl, world of 1 rank", "steps": args.steps, "loss": round(float(loss.item()), 5)})
+        del model, opt, reducer
+    finally:
+        ops.set_gemm_launch_mode("auto")
+        if own:
+            dist.destroy_process_group()
+    return res
+
+
 def bench_dit(args, world, rank, device, lib, backend):
     from ldmae_amd import ops
     model, opt, reducer, transport = build(device, args.batch)
-    ops.set_gemm_launch_mode(reducer.recommended_gemm_launch_mode())      # world > 1: one tile per workgroup, a per-call flag of the C ABI
+    # world > 1: one tile per workgroup or persistent, a per-call flag of the C ABI (LDMAE_DP_GEMM_LAUNCH; default = what --dp-config measured)
+    ops.set_gemm_launch_mode(os.environ.get("LDMAE_DP_GEMM_LAUNCH", reducer.recommended_gemm_launch_mode()) if world > 1 else "persistent")
     reducer.measure_exposed = True
     seed = 0 * world + rank                      # inference.py:87 convention
     torch.manual_seed(seed)
@@ -514,7 +550,8 @@ def main():
                     help="dit = the headline train step (BASELINE config 2/3); vmae = config 4 encoder; xl_sample = config 5 CFG forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="do not sample package power / clock (sysfs) during the timed loop")
-    ap.add_argument("--no-extra", action="store_true", help="dit workload at N=1: skip the vmae / xl_sample lines under extra_workloads")
+    ap.add_argument("--no-extra", action="store_true", help="dit workload at N=1: skip the vmae / xl_sample / dp_config lines under extra_workloads")
+    ap.add_argument("--dp-config", action="store_true", help="N=1: time the data-parallel program (world-1 RCCL group, reducer hooks + side stream live) and print that line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -542,7 +579,11 @@ def main():
 
     from ldmae_amd import _lib
     lib = _lib.load()
-    if args.workload == "dit":
+    if args.dp_config:
+        if world != 1:
+            sys.exit("--dp-config is the data-parallel program on ONE GPU")
+        out = {"metric": "DiT-B train step in the data-parallel configuration on one MI355X (ms per step)", "dp_config": bench_dp_config(args, device)}
+    elif args.workload == "dit":
         out = bench_dit(args, world, rank, device, lib, backend)
         if world == 1 and not args.no_extra and args.batch == 256:
             # BASELINE configs 4 and 5 on the same box, AFTER the timed headline region (its model and activations are freed first), so
@@ -554,6 +595,13 @@ def main():
             free_gpu_memory()
             extra.steps, extra.warmup = 6, 2
             out["extra_workloads"]["xl_sample"] = bench_xl_sample(extra, world, rank, device, lib)
+            free_gpu_memory()
+            extra.steps, extra.warmup = 8, 2
+            try:
+                out["extra_workloads"]["dp_config"] = bench_dp_config(extra, device)
+                out["extra_workloads"]["dp_config"]["headline_ms_per_step"] = out["ms_per_step"]
+            except Exception as ex:          # a box without a usable RCCL must not cost the headline line
+                out["extra_workloads"]["dp_config"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     elif args.workload == "vmae":
         out = bench_vmae(args, world, rank, device, lib)
     else:

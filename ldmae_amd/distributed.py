@@ -23,10 +23,13 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, flat, process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True):
+    def __init__(self, flat, process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True, force_hooks: bool = False):
+        """force_hooks: arm the hooks / side stream / bucket launches for a world of ONE rank too (bench.py --dp-config and the world-1
+        RCCL test: the data-parallel program on a single GPU; needs an initialised process group)."""
         self.flat = flat
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_hooks and dist.is_initialized())
         self.is_cuda = flat.grads.is_cuda
         self.overlap = overlap and self.is_cuda
         self.stream = torch.cuda.Stream() if self.overlap else None
@@ -57,14 +60,14 @@ class GradBucketReducer:
         # all-reduced once, on the last micro-step (`sync = True` before that backward).  All-reducing the accumulating slab on
         # every micro-step would re-sum earlier micro-steps across ranks (world * g1 + g2).
         self.sync = True
-        if self.world > 1:
+        if self.active:
             for n, p in flat.trainable:
                 h = self._make_hook(n)
                 self._hooks.append(p.register_post_accumulate_grad_hook(h))
                 p._ldmae_grad_ready = h          # for gradients written into .grad without AccumulateGrad (models.lightningdit._dw_into_grad)
 
     def recommended_gemm_launch_mode(self) -> str:
-        return "tile" if (self.world > 1 and self.is_cuda) else "persistent"
+        return "tile" if (self.active and self.is_cuda) else "persistent"
 
     def _make_hook(self, name):
         def hook(_p):
@@ -94,7 +97,7 @@ class GradBucketReducer:
     def finish(self) -> float:
         """Call after backward: launches buckets whose hooks did not all fire (unused parameters), waits for the
         collectives, re-arms the counters.  Returns the grad scale (1/world) to hand to ``AdamWEMA.step``."""
-        if self.world > 1 and self.sync:
+        if self.active and self.sync:
             for bi, pend in enumerate(self._pending):
                 if pend > 0:
                     self._launch(bi)

@@ -614,7 +614,13 @@ class LightningDiT(nn.Module):
         # opt-in of the training driver (which owns a gradient slab and calls plain loss.backward()): the four Linear weight gradients
         # of every block are accumulated straight into param.grad by the GEMM's reduce instead of through autograd's AccumulateGrad
         self.direct_param_grads = False
-        self.batched_adaln = os.environ.get("LDMAE_BATCHED_ADALN", "1") != "0"      # False / LDMAE_BATCHED_ADALN=0: per-block f32 adaLN GEMMs (A/B and parity tests)
+        # batched adaLN (_AdaLNAllFn).  None = automatic: on, except in a process of a torch.distributed world of more than one rank -- the
+        # weight gradients of the batched form complete at the very END of backward, which delays every gradient bucket that holds one of
+        # them (the reference's train_accum.py under accelerate / DDP through the drop-in: DDP's buckets interleave them with everything
+        # else).  A driver that lays the adaLN weights out FIRST in its gradient slab (optim.adaln_first) sets True.  LDMAE_BATCHED_ADALN=0 / 1
+        # overrides (A/B and parity tests).
+        env = os.environ.get("LDMAE_BATCHED_ADALN")
+        self.batched_adaln = None if env is None else env != "0"
         self.learn_sigma = learn_sigma
         self.in_channels = in_channels
         self.out_channels = in_channels if not learn_sigma else in_channels * 2
@@ -704,7 +710,7 @@ class LightningDiT(nn.Module):
             # inference just takes the forward.  f32 mode, checkpointing, hooked blocks and batches that are not a multiple of 8 (the
             # bf16 TN GEMM's alignment) keep the per-block f32 GEMMs.
             mod_all = None
-            if self.batched_adaln and dtype == torch.bfloat16 and not self.use_checkpoint and len(self.blocks) <= 64 and sc.shape[0] % 8 == 0 and \
+            if self._use_batched_adaln() and dtype == torch.bfloat16 and not self.use_checkpoint and len(self.blocks) <= 64 and sc.shape[0] % 8 == 0 and \
                     (chain is not None or not torch.is_grad_enabled()):
                 lins = [b.adaLN_modulation[1] for b in self.blocks]
                 mod_all = _AdaLNAllFn.apply(sc, not torch.is_grad_enabled(), *[l.weight for l in lins], *[l.bias for l in lins])
@@ -720,6 +726,12 @@ class LightningDiT(nn.Module):
             if self.learn_sigma:
                 x, _ = x.chunk(2, dim=1)
         return x
+
+    def _use_batched_adaln(self) -> bool:
+        if self.batched_adaln is not None:
+            return bool(self.batched_adaln)
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and torch.is_grad_enabled())
 
     def forward_with_cfg(self, x, t, y, cfg_scale, cfg_interval=None, cfg_interval_start=None):
         """:420-442 (CFG on the first three channels only; interval gate on t[0])."""

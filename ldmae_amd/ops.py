@@ -72,19 +72,35 @@ class SideGemms:
 # ----------------------------------------------------------------------------- GEMMs
 # Launch mode of the bf16 GEMMs, owned by the CALLER (a train driver that knows it shares the chip with RCCL's collective kernels sets
 # "tile"; everything else keeps "persistent") and handed to the library PER CALL as a flag in `epi` -- the C ABI keeps no mode.
-_GEMM_LAUNCH = 0
+# Until a driver says otherwise ("auto"): persistent, except in a process that belongs to a torch.distributed world of more than one rank
+# (the reference's own train_accum.py under accelerate / DDP through the drop-in: nobody there calls set_gemm_launch_mode) -> tile.
+_GEMM_MODE = "auto"
+_AUTO_FLAG = None          # resolved once torch.distributed is initialised (the world does not change afterwards)
 
 
 def set_gemm_launch_mode(mode: str) -> None:
-    """"persistent" (default: one workgroup per CU walks the tiles) or "tile" (one 256x256 tile per workgroup; bitwise-equal results)."""
-    global _GEMM_LAUNCH
-    if mode not in ("persistent", "tile"):
-        raise ValueError(f"gemm launch mode {mode!r}: 'persistent' or 'tile'")
-    _GEMM_LAUNCH = EPI_TILE_LAUNCH if mode == "tile" else 0
+    """"persistent" (one workgroup per CU walks the tiles), "tile" (one 256x256 tile per workgroup; bitwise-equal results) or "auto"."""
+    global _GEMM_MODE
+    if mode not in ("persistent", "tile", "auto"):
+        raise ValueError(f"gemm launch mode {mode!r}: 'persistent', 'tile' or 'auto'")
+    _GEMM_MODE = mode
+
+
+def _launch_flag() -> int:
+    global _AUTO_FLAG
+    if _GEMM_MODE != "auto":
+        return EPI_TILE_LAUNCH if _GEMM_MODE == "tile" else 0
+    if _AUTO_FLAG is not None:
+        return _AUTO_FLAG
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    _AUTO_FLAG = EPI_TILE_LAUNCH if dist.get_world_size() > 1 else 0
+    return _AUTO_FLAG
 
 
 def gemm_launch_mode() -> str:
-    return "tile" if _GEMM_LAUNCH else "persistent"
+    return "tile" if _launch_flag() else "persistent"
 
 
 def gemm_nt(a, b, bias=None, out_dtype=None, out=None, beta=0.0):
@@ -94,7 +110,7 @@ def gemm_nt(a, b, bias=None, out_dtype=None, out=None, beta=0.0):
     out_dtype = out_dtype or a.dtype
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
-    call("ldmae_gemm_nt", dt(a.dtype), dt(out.dtype), EPI_BIAS | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
+    call("ldmae_gemm_nt", dt(a.dtype), dt(out.dtype), EPI_BIAS | _launch_flag(), ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
          M, N, K, ptr(bias), float(beta), None, None, None, 0, 0, stream())
     return out
 
@@ -109,7 +125,7 @@ def gemm_nt_gate_res(a, b, bias, xin, gate, rows_per_batch, save_y=True, xout=No
     y = torch.empty(M, N, dtype=y_dtype, device=a.device) if save_y else None
     if xout is None:
         xout = torch.empty_like(xin)
-    call("ldmae_gemm_nt", dt(a.dtype), dt(y_dtype), EPI_GATE_RES | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(y), N,
+    call("ldmae_gemm_nt", dt(a.dtype), dt(y_dtype), EPI_GATE_RES | _launch_flag(), ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(y), N,
          M, N, K, ptr(bias), 0.0, ptr(xin), ptr(xout), ptr(gate), gate.stride(0) if gate is not None else 0, rows_per_batch, stream())
     return xout, y
 
@@ -119,7 +135,7 @@ def gemm_nt_pos(a, b, bias, pos, rows_per_batch):
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    call("ldmae_gemm_nt", dt(a.dtype), F32, EPI_BIAS_POS | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
+    call("ldmae_gemm_nt", dt(a.dtype), F32, EPI_BIAS_POS | _launch_flag(), ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
          M, N, K, ptr(bias), 0.0, ptr(pos), None, None, 0, rows_per_batch, stream())
     return out
 
@@ -130,7 +146,7 @@ def gemm_nt_gelu(a, b, bias, save_pre=True):
     N = b.shape[0]
     out = torch.empty(M, N, dtype=a.dtype, device=a.device)
     pre = torch.empty_like(out) if save_pre else None
-    call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_BIAS_GELU | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
+    call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_BIAS_GELU | _launch_flag(), ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
          M, N, K, ptr(bias), 0.0, None, ptr(pre), None, 0, 0, stream())
     return out, pre
 
@@ -144,7 +160,7 @@ def gemm_nt_swiglu(a, w12, b12, save_h12=True):
     if a.dtype == torch.bfloat16 and N % 256 == 0 and K % 64 == 0:
         h12 = torch.empty(M, N, dtype=a.dtype, device=a.device) if save_h12 else None
         hid = torch.empty(M, N // 2, dtype=a.dtype, device=a.device)
-        call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU | _GEMM_LAUNCH, ptr(a), a.stride(0), ptr(w12), w12.stride(0), ptr(h12), N, M, N, K, ptr(b12), 0.0,
+        call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU | _launch_flag(), ptr(a), a.stride(0), ptr(w12), w12.stride(0), ptr(h12), N, M, N, K, ptr(b12), 0.0,
              None, ptr(hid), None, 0, 0, stream())
         return h12, hid
     h12 = gemm_nt(a, w12, b12)
@@ -161,7 +177,7 @@ def gemm_nt_swiglu_bwd(dy, w3t, h12, with_bias=False):
         # every (128-row group, column) of the partial-sum matrix is written by exactly one wave when the tile grid is whole: no 33 MB fill
         whole = M % 128 == 0 and Hs % 64 == 0
         part = (torch.empty if whole else torch.zeros)((M + 127) // 128, 2 * Hs, dtype=torch.float32, device=dy.device) if with_bias else None
-        call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU_BWD | _GEMM_LAUNCH, ptr(dy), dy.stride(0), ptr(w3t), w3t.stride(0), ptr(dh12), 2 * Hs, M, Hs, K, None, 0.0,
+        call("ldmae_gemm_nt", BF16, BF16, EPI_SWIGLU_BWD | _launch_flag(), ptr(dy), dy.stride(0), ptr(w3t), w3t.stride(0), ptr(dh12), 2 * Hs, M, Hs, K, None, 0.0,
              ptr(h12), ptr(part), None, 0, 0, stream())
         return (dh12, colsum(part)) if with_bias else dh12
     dh12 = swiglu_bwd(gemm_nt(dy, w3t), h12)

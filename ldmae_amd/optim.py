@@ -22,14 +22,18 @@ class FlatParams:
     and gives trainable parameters ``.grad`` views into a second one.  Names / shapes / state_dict are
     unchanged; ``module.to(device)`` must happen BEFORE this."""
 
-    def __init__(self, module: torch.nn.Module, group_fn=None):
+    def __init__(self, module: torch.nn.Module, group_fn=None, front_fn=None):
         """group_fn(name, param) -> int (optional): trainable parameters are laid out group by group (stable inside a group), so every
         group is ONE contiguous slice ``self.groups[g] = (lo, hi)`` -- per-group optimizer hyper-parameters (timm-style weight-decay
-        groups of the VMAE pre-training) still cost one fused launch per group, not one per parameter."""
+        groups of the VMAE pre-training) still cost one fused launch per group, not one per parameter.
+        front_fn(name) -> bool (optional): matching trainable parameters are laid out FIRST (stable).  The gradient reducer cuts its buckets
+        from the END of the slab backwards, in the order backward completes them, so parameters whose gradients only complete at the very end
+        of backward belong at the front: the adaLN weights of a LightningDiT with batched adaLN (`adaln_first`)."""
         named = [(n, p) for n, p in module.named_parameters()]
         self.trainable = [(n, p) for n, p in named if p.requires_grad]
         gid = {n: (group_fn(n, p) if group_fn else 0) for n, p in self.trainable}
-        self.trainable.sort(key=lambda np_: gid[np_[0]])
+        self.trainable.sort(key=lambda np_: (gid[np_[0]], 0 if (front_fn and front_fn(np_[0])) else 1))
+        self.n_front = sum(1 for n, _ in self.trainable if front_fn and front_fn(n))
         self.frozen = [(n, p) for n, p in named if not p.requires_grad]
         dev = named[0][1].device
         self.offsets = OrderedDict()
@@ -64,15 +68,21 @@ class FlatParams:
         return flat[o:o + k].view(shape)
 
 
+def adaln_first(name: str) -> bool:
+    """front_fn for a LightningDiT trained with batched adaLN (models.lightningdit._AdaLNAllFn): the modulation Linears of the blocks, whose
+    weight gradients are two GEMMs over ALL blocks at the end of backward."""
+    return name.startswith("blocks.") and ".adaLN_modulation." in name
+
+
 class AdamWEMA:
     """AdamW(lr, betas, eps, weight_decay) on the trainable slice + EMA(decay) over ALL parameters (the
     reference's EMA includes the frozen ``pos_embed``, train_accum.py:343-347)."""
 
     def __init__(self, module, lr=2e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, ema_decay=0.9999, flat: FlatParams = None,
-                 group_weight_decay=None):
+                 group_weight_decay=None, front_fn=None):
         """group_weight_decay: {group id: weight decay} for a ``FlatParams(module, group_fn)`` layout (default: `weight_decay` everywhere)."""
         self.module = module
-        self.flat = flat or FlatParams(module)
+        self.flat = flat or FlatParams(module, front_fn=front_fn)
         self.lr, self.betas, self.eps, self.weight_decay, self.ema_decay = lr, betas, eps, weight_decay, ema_decay
         self.group_weight_decay = group_weight_decay
         f = self.flat

@@ -29,7 +29,7 @@ if os.path.dirname(_HERE) not in sys.path:
 from ldmae_amd import ops                                 # noqa: E402
 from ldmae_amd.distributed import GradBucketReducer      # noqa: E402
 from ldmae_amd.models.lightningdit import LightningDiT_models  # noqa: E402
-from ldmae_amd.optim import AdamWEMA                      # noqa: E402
+from ldmae_amd.optim import AdamWEMA, adaln_first                      # noqa: E402
 from ldmae_amd.transport import create_transport         # noqa: E402
 
 
@@ -133,14 +133,15 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
         load_weights_with_shape_check(model, ck, rank)
     model = model.to(device).train()
     o = cfg['optimizer']
-    opt = AdamWEMA(model, lr=o['lr'], betas=(0.9, o['beta2']), weight_decay=0.0, ema_decay=0.9999)
+    # Batched adaLN (models.lightningdit._AdaLNAllFn) finishes the adaLN weight gradients of EVERY block at the very end of backward, so those
+    # weights sit at the FRONT of the gradient slab (optim.adaln_first): the reducer cuts its buckets from the end backwards, the front ones
+    # are the last to be all-reduced anyway, and every other bucket still starts under backward.  The data-parallel step is then the same
+    # program as the single-GPU one (round 3 switched the batched form off for world > 1).
+    opt = AdamWEMA(model, lr=o['lr'], betas=(0.9, o['beta2']), weight_decay=0.0, ema_decay=0.9999, front_fn=adaln_first)
+    model.batched_adaln = os.environ.get("LDMAE_BATCHED_ADALN", "1") != "0"
     reducer = GradBucketReducer(opt.flat)
-    if reducer.world > 1:
-        # batched adaLN (models.lightningdit._AdaLNAllFn) finishes the adaLN weight gradients of EVERY block at the very end of backward; every
-        # 64-MiB bucket of the slab holds one of them, so no bucket could start its all-reduce under backward.  Data-parallel runs keep the
-        # per-block form (the gradients of a block complete with the block), single-GPU runs take the 1.5 ms.
-        model.batched_adaln = False
-    ops.set_gemm_launch_mode(reducer.recommended_gemm_launch_mode())     # world > 1: one tile per workgroup (RCCL kernels share the chip)
+    # world > 1: LDMAE_DP_GEMM_LAUNCH=tile|persistent (default: what bench.py --dp-config measured faster with the reducer's hooks live)
+    ops.set_gemm_launch_mode(os.environ.get("LDMAE_DP_GEMM_LAUNCH", reducer.recommended_gemm_launch_mode()) if reducer.world > 1 else "persistent")
     model.direct_param_grads = True       # every .grad is a slab view and backward is a plain loss.backward(): dW goes straight into the slab
     reducer.broadcast_params(0)
     opt.ema.copy_(opt.flat.params)                               # update_ema(ema, model, decay=0), train_accum.py:166

@@ -60,14 +60,23 @@ def _worker(rank, world, port, q):
     m, x, t, y, tgt = _tiny()
     from ldmae_amd import _lib
     from ldmae_amd.distributed import GradBucketReducer
-    from ldmae_amd.optim import AdamWEMA
-    opt = AdamWEMA(m, lr=1e-3)
+    from ldmae_amd.optim import AdamWEMA, adaln_first
+    from ldmae_amd import ops
+    # what a model gets when NOBODY configures it (the reference's own train_accum.py under accelerate / DDP through the drop-in): in a world
+    # of two ranks the per-block adaLN (its weight gradients complete with their block) and one-tile-per-workgroup GEMM launches
+    assert m.batched_adaln is None and not m._use_batched_adaln() and ops.gemm_launch_mode() == "tile"
+    with torch.no_grad():
+        assert m._use_batched_adaln()                                    # forward-only calls keep the batched form
+    opt = AdamWEMA(m, lr=1e-3, front_fn=adaln_first)                     # the drivers' layout: adaLN weights first in the slab ...
+    m.batched_adaln = True                                               # ... so the batched form stays on under the reducer
+    names = [n for n, _ in opt.flat.trainable]
+    assert opt.flat.n_front == 4 and all(adaln_first(n) for n in names[:4]) and not any(adaln_first(n) for n in names[4:])
     red = GradBucketReducer(opt.flat, bucket_bytes=256 << 10)            # several buckets, launched from the hooks on the side stream
     red.broadcast_params(0)
     m.direct_param_grads = True      # as the train drivers do: block weight gradients go straight into the slab and notify the reducer by callback
     assert len(red.buckets) >= 3 and red.overlap
-    from ldmae_amd import ops
-    assert ops.gemm_launch_mode() == "persistent" and red.recommended_gemm_launch_mode() == "tile"   # the reducer only recommends
+    assert all(adaln_first(n) for n in red.buckets[-1][2][-4:])          # the adaLN weights sit in the bucket that is reduced last
+    assert red.recommended_gemm_launch_mode() == "tile"                  # the reducer only recommends
     ops.set_gemm_launch_mode(red.recommended_gemm_launch_mode())         # ... the driver sets it: one tile per workgroup, per call
     red.measure_exposed = True
     sl = slice(rank * 4, rank * 4 + 4)
@@ -94,13 +103,81 @@ def test_two_ranks_one_gpu_reduced_grads_equal_concatenated_batch():
         p.join(120)
         assert p.exitcode == 0
     m, x, t, y, tgt = _tiny()
-    from ldmae_amd.optim import AdamWEMA
-    opt = AdamWEMA(m, lr=1e-3)
+    from ldmae_amd.optim import AdamWEMA, adaln_first
+    opt = AdamWEMA(m, lr=1e-3, front_fn=adaln_first)                      # same slab layout as the ranks
     _grad_slab(m, opt.flat, x, t, y, tgt)                                 # single process, all 8 samples: mean loss = mean of the halves' means
     ref = opt.flat.grads.cpu()
     err = float((got - ref).norm() / ref.norm())
     print("2-rank reduced slab vs single-process slab: rel err", err, "exposed comm ms", exposed)
     assert err < 1e-5 and exposed >= 0.0
+
+
+def _world1_rccl_worker(port, q):
+    """One RCCL rank: librccl loads, the reducer's hooks fire, every bucket is all-reduced on the side stream and finish() joins it."""
+    os.environ.pop("LDMAE_TUNE", None)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    m, x, t, y, tgt = _tiny()
+    from ldmae_amd.distributed import GradBucketReducer
+    from ldmae_amd.optim import AdamWEMA, adaln_first
+    opt = AdamWEMA(m, lr=1e-3, front_fn=adaln_first)
+    m.batched_adaln = True
+    m.direct_param_grads = True
+
+    def slab():
+        opt.flat.grads.zero_()
+        with torch.autocast("cuda", dtype=torch.bfloat16):               # batch 8, bf16: the batched adaLN path runs
+            loss = ((m(x.cuda(), t.cuda(), y.cuda()).float() - tgt.cuda()) ** 2).mean()
+        loss.backward()
+        return opt.flat.grads.clone()
+    ref = slab()                                                          # no process group, no hooks
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    red = GradBucketReducer(opt.flat, bucket_bytes=256 << 10, force_hooks=True)
+    assert red.active and red.world == 1 and len(red.buckets) >= 3 and red.overlap and red.recommended_gemm_launch_mode() == "tile"
+    red.broadcast_params(0)
+    red.measure_exposed = True
+    launched = []
+    orig = red._launch
+    red._launch = lambda bi: (launched.append(bi), orig(bi))[1]
+    got = None
+    for _ in range(2):                                                    # twice: the counters re-arm
+        launched.clear()
+        got = slab()
+        scale = red.finish()
+        assert sorted(launched) == list(range(len(red.buckets))) and scale == 1.0
+    torch.cuda.synchronize()
+    front = sorted({red.param_bucket[n] for n, _ in opt.flat.trainable if adaln_first(n)})
+    q.put((bool(torch.equal(got, ref)), list(launched), front, red.exposed_comm_ms()))
+    dist.destroy_process_group()
+
+
+def test_world_of_one_rccl_rank_walks_the_reducer():
+    """init_process_group("nccl") with a world of ONE rank on the test GPU (RCCL itself executes: the 8-GPU node is the driver's), the
+    reducer armed with force_hooks: every bucket goes through dist.all_reduce on the side stream, the bucket with the adaLN weights (front of
+    the slab) is launched LAST, and the slab equals the hook-free gradient bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_world1_rccl_worker, args=(_free_port(), q))
+    p.start()
+    same, launched, front, exposed = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    # the buckets that hold adaLN weights (front of the slab = highest bucket indices) are the ones launched last
+    assert same and exposed >= 0.0 and front == list(range(front[0], len(launched))) and sorted(launched[-len(front):]) == front, (launched, front)
+
+
+def test_bench_dp_config_line():
+    """`bench.py --dp-config`: the data-parallel program (world-1 RCCL group, hooks + side stream, adaLN weights first, batched adaLN) timed
+    with both GEMM launch modes on one GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LDMAE_TUNE")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dp-config", "--steps", "2", "--batch", "8", "--no-power"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["dp_config"]
+    assert d["tile"]["ms_per_step"] > 0 and d["persistent"]["ms_per_step"] > 0 and d["buckets"] >= 2 and d["batched_adaln"] and d["adaln_params_first"] == 24
 
 
 def test_train_driver_comes_up_under_two_process_launch(tmp_path):
@@ -150,7 +227,7 @@ def test_extract_features_two_ranks_share_the_dataset(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(LDMAE_DIST_BACKEND="gloo", LDMAE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29631", "-m", "ldmae_amd.extract_features", "--config", str(tmp_path / "cfg.yaml"), "--synthetic", "10",
+                        "--master-port", str(_free_port()), "-m", "ldmae_amd.extract_features", "--config", str(tmp_path / "cfg.yaml"), "--synthetic", "10",
                         "--image_size", "64", "--batch_size", "2", "--num_workers", "0"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     out = tmp_path / "ds" / "vmae_feature_imagenet_train_64_sample"
