@@ -470,7 +470,8 @@ def bench_xl_sample(args, world, rank, device, lib):
     """BASELINE config 5 kernel reuse: LightningDiT-XL/1 (depth 28, width 1152, 16 heads, head_dim 72) CFG forward in bf16, inference
     only.  One step = one forward_with_cfg on a doubled batch (what every Euler step of run_inference.sh costs; 250 of them per image)."""
     from ldmae_amd.models.lightningdit import LightningDiT_models
-    n = args.batch if args.batch != 256 else 64                  # per-GPU images per sampling batch (doubled for CFG)
+    n = args.batch                                               # per-GPU images per sampling batch (doubled for CFG): 256 -> CFG batch 512,
+                                                                 # the reference's `per_proc_batch_size: 256` (lightningdit_b_vmae_f8d16_cfg.yaml:77)
     model = LightningDiT_models["LightningDiT-XL/1"](input_size=32, num_classes=1000, use_qknorm=True, use_swiglu=True, use_rope=True,
                                                       use_rmsnorm=True, wo_shift=False, in_channels=16, class_dropout_prob=0.1)
     gsd = torch.Generator().manual_seed(0)
@@ -511,6 +512,66 @@ def bench_xl_sample(args, world, rank, device, lib):
     }
 
 
+def bench_do_sample(args, device, batches=1):
+    """BASELINE config 5 end to end, as run_inference.sh drives it (inference.py:264-299) at the reference's per-process batch: LightningDiT-B/1
+    (the yaml's model), 250 shifted Euler steps with CFG 10 / interval 0.10 on a doubled batch of 2 x 256 -> de-normalise -> VMAE
+    decode_to_images (1024 tokens) -> PNG files written by the host thread of ldmae_amd.inference.PngWriter.  Random-init weights, synthetic
+    latent statistics.  Reports images/s over the whole loop and how long the GPU had nothing enqueued."""
+    import shutil
+    import tempfile
+    import yaml
+    from ldmae_amd import inference as inf
+    from ldmae_amd.tokenizer import models_mae
+    from ldmae_amd.train_accum import build_model
+    root = os.path.dirname(os.path.abspath(__file__))
+    cfg = yaml.safe_load(open(os.path.join(root, "ldmae_amd/configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml")))
+    model = build_model(cfg)
+    gsd = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for nm, p in model.named_parameters():
+            if "adaLN_modulation" in nm or nm.startswith("final_layer.linear"):
+                p.copy_(torch.randn(p.shape, generator=gsd) * 0.02)
+    model = model.to(device).eval()
+    vae = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=True, no_cls=True, kl_loss_weight=True, smooth_output=True, img_size=cfg["data"]["image_size"]).to(device).eval()
+    sample_fn = inf.build_sampler(cfg)
+    s = cfg["sample"]
+    n = s["per_proc_batch_size"] if args.batch == 256 else args.batch
+    mean, std, mult = torch.zeros(1, 16, 1, 1, device=device), torch.ones(1, 16, 1, 1, device=device), cfg["data"].get("latent_multiplier", 0.18215)
+    out_dir = tempfile.mkdtemp(prefix="ldmae_bench_png_")
+    gen = torch.Generator(device=device).manual_seed(0)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_png = [0.0]
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        writer = inf.PngWriter()
+        gpu_ms = dec_ms = 0.0
+        for it in range(batches):
+            ev[0].record()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                lat, _ = inf.sample_latents(model, sample_fn, n, s["cfg_scale"], s.get("cfg_interval_start", 0), device, cfg["data"]["num_classes"], generator=gen)
+            ev[1].record()
+            imgs = vae.decode_to_images(lat * std / mult + mean)
+            ev[2].record()
+            writer.put(imgs, [f"{out_dir}/{it * n + i:06d}.png" for i in range(len(imgs))])
+            torch.cuda.synchronize()
+            gpu_ms += ev[0].elapsed_time(ev[2]); dec_ms += ev[1].elapsed_time(ev[2])
+        t1 = time.perf_counter()
+        writer.close()
+        t2 = time.perf_counter()
+        npng = len(os.listdir(out_dir))
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+    wall = t2 - t0
+    return {"metric": "LightningDiT-B/1 CFG sampling to PNG files, images/s on one MI355X (250 Euler steps, per-process batch of the reference)",
+            "value": round(batches * n / wall, 3), "unit": "images/s", "images": batches * n, "png_files": npng, "wall_s": round(wall, 2),
+            "euler_250_steps_s": round((gpu_ms - dec_ms) / 1e3 / batches, 2), "ms_per_cfg_forward": round((gpu_ms - dec_ms) / batches / (s["num_sampling_steps"] - 1), 2),
+            "decode_to_images_s": round(dec_ms / 1e3 / batches, 3), "png_drain_after_last_batch_s": round(t2 - t1, 2),
+            "gpu_idle_share": round(max(0.0, 1.0 - gpu_ms / 1e3 / wall), 4),
+            "config": {"workload": "inference.py:264-299 loop: sample_latents (CFG batch 2 x %d, cfg 10.0, interval 0.10, timestep_shift 0.3) -> "
+                                   "de-normalise -> decode_to_images -> PngWriter" % n, "batches": batches}}
+
+
 def spawn_ranks(args, argv):
     """--gpus N > 1 without a launcher around us: start the N ranks (fresh processes, torch.distributed.run on 127.0.0.1) as a CHILD of
     this process -- which has not touched, and never touches, the GPU -- relay rank 0's JSON line and return the child's exit code
@@ -546,7 +607,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
-    ap.add_argument("--workload", default="dit", choices=["dit", "vmae", "xl_sample"],
+    ap.add_argument("--workload", default="dit", choices=["dit", "vmae", "xl_sample", "do_sample"],
                     help="dit = the headline train step (BASELINE config 2/3); vmae = config 4 encoder; xl_sample = config 5 CFG forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="do not sample package power / clock (sysfs) during the timed loop")
@@ -593,8 +654,10 @@ def main():
             extra.steps, extra.warmup = 30, 5
             out["extra_workloads"] = {"vmae": bench_vmae(extra, world, rank, device, lib)}
             free_gpu_memory()
-            extra.steps, extra.warmup = 6, 2
+            extra.steps, extra.warmup = 4, 1
             out["extra_workloads"]["xl_sample"] = bench_xl_sample(extra, world, rank, device, lib)
+            free_gpu_memory()
+            out["extra_workloads"]["do_sample"] = bench_do_sample(extra, device, batches=1)
             free_gpu_memory()
             extra.steps, extra.warmup = 8, 2
             try:
@@ -604,6 +667,8 @@ def main():
                 out["extra_workloads"]["dp_config"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     elif args.workload == "vmae":
         out = bench_vmae(args, world, rank, device, lib)
+    elif args.workload == "do_sample":
+        out = bench_do_sample(args, device, batches=max(1, args.steps if args.steps < 10 else 1))
     else:
         out = bench_xl_sample(args, world, rank, device, lib)
     if rank == 0:

@@ -557,3 +557,45 @@ def mae_for_ldmae_16d(**kwargs):
 def mae_for_ldmae_f16d32(**kwargs):
     return MaskedAutoencoderViT(img_size=128, patch_size=16, embed_dim=192, depth=12, num_heads=12, decoder_embed_dim=192, decoder_depth=12,
                                 decoder_num_heads=12, mlp_ratio=4, norm_layer=_ln(), latent_dim=32, **kwargs)
+
+
+# The rest of the reference's registry (:1006-1083), as thin entries over the same class: geometries only.  `down_nonlinear` (the f8d16 /
+# f8d16_flexible archs) is a flag the class does not implement -- those two raise NotImplementedError naming it, from the constructor.
+def mae_for_ldmae_f8d16(**kwargs):
+    return MaskedAutoencoderViT(patch_size=8, embed_dim=192, depth=12, num_heads=12, decoder_embed_dim=384, decoder_depth=12,
+                                decoder_num_heads=24, mlp_ratio=4, norm_layer=_ln(), latent_dim=16, down_nonlinear=True, **kwargs)
+
+
+mae_for_ldmae_f8d16_flexible = mae_for_ldmae_f8d16
+
+
+def mae_for_ldmae_f16d32_large(**kwargs):
+    # finetune_downsample_layer only acts with gradual_resol (:351), which is not implemented (and raises when asked for)
+    return MaskedAutoencoderViT(img_size=128, patch_size=16, embed_dim=384, depth=12, num_heads=12, decoder_embed_dim=384, decoder_depth=12,
+                                decoder_num_heads=12, mlp_ratio=4, norm_layer=_ln(), latent_dim=32, finetune_downsample_layer=4, **kwargs)
+
+
+def mae_vit_base_patch16_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(patch_size=16, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512, decoder_depth=8,
+                                decoder_num_heads=16, mlp_ratio=4, norm_layer=_ln(), **kwargs)
+
+
+def mae_vit_base_patch16_dec128d8b(**kwargs):
+    return MaskedAutoencoderViT(patch_size=16, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=128, decoder_depth=8,
+                                decoder_num_heads=16, mlp_ratio=4, norm_layer=_ln(), **kwargs)
+
+
+def mae_vit_large_patch16_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(patch_size=16, embed_dim=1024, depth=24, num_heads=16, decoder_embed_dim=512, decoder_depth=8,
+                                decoder_num_heads=16, mlp_ratio=4, norm_layer=_ln(), **kwargs)
+
+
+def mae_vit_huge_patch14_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(patch_size=14, embed_dim=1280, depth=32, num_heads=16, decoder_embed_dim=512, decoder_depth=8,
+                                decoder_num_heads=16, mlp_ratio=4, norm_layer=_ln(), **kwargs)
+
+
+mae_vit_base_patch16 = mae_vit_base_patch16_dec512d8b
+mae_vit_large_patch16 = mae_vit_large_patch16_dec512d8b
+mae_vit_huge_patch14 = mae_vit_huge_patch14_dec512d8b
+mae_vit_base_patch16_128 = mae_vit_base_patch16_dec128d8b

@@ -140,3 +140,32 @@ def test_image_folder_order_and_labels(tmp_path):
     assert rel == [("n01/z.png", 0), ("n02/a.JPEG", 1), ("n02/b.png", 1), ("n10/c.png", 2), ("n10/sub/k.bmp", 2)]
     img, t = ds[3]
     assert img.size == (20, 12) and img.mode == "RGB" and t == 2
+
+
+def test_mae_arch_registry_has_every_reference_constructor():
+    """tokenizer/models_mae.py:977-1083: sixteen constructor names + four aliases.  All build (on the meta device: geometry only) except the
+    two `down_nonlinear` archs, which raise naming the flag."""
+    import pytest
+    from ldmae_amd.tokenizer import models_mae as mm
+    names = ["mae_for_ldmae", "mae_for_ldmae_f8d32", "mae_for_ldmae_f8d16_prev", "mae_for_ldmae_f8d16_prev_large", "mae_for_ldmae_f8d16",
+             "mae_for_ldmae_f8d16_flexible", "mae_for_ldmae_f16d32", "mae_for_ldmae_f16d32_large", "mae_for_ldmae_f8d32_flexible", "mae_for_ldmae_16d",
+             "mae_vit_base_patch16_dec512d8b", "mae_vit_base_patch16_dec128d8b", "mae_vit_large_patch16_dec512d8b", "mae_vit_huge_patch14_dec512d8b",
+             "mae_vit_base_patch16", "mae_vit_large_patch16", "mae_vit_huge_patch14", "mae_vit_base_patch16_128"]
+    geo = {"mae_for_ldmae_f16d32_large": (384, 12, 384, 64), "mae_vit_base_patch16_dec128d8b": (768, 12, 128, 196), "mae_vit_large_patch16": (1024, 24, 512, 196),
+           "mae_for_ldmae_f8d16_prev": (192, 12, 192, 784)}
+    for n in names:
+        f = getattr(mm, n)
+        if n in ("mae_for_ldmae_f8d16", "mae_for_ldmae_f8d16_flexible"):
+            with pytest.raises(NotImplementedError, match="down_nonlinear"):
+                f()
+            continue
+        if n in geo:
+            with torch.device("meta"):
+                try:
+                    m = f()
+                except Exception:            # initialize_weights fills real tensors: geometry checked on the CPU for the small ones only
+                    m = None
+            if m is None and geo[n][0] <= 384:
+                m = f()
+            if m is not None:
+                assert (m.pos_embed.shape[-1], len(m.blocks), m.decoder_pos_embed.shape[-1], m.pos_embed.shape[1]) == geo[n]

@@ -329,6 +329,25 @@ def test_xl1_real_width_forward_vs_oracle():
         assert lo.shape == (2, 16, 32, 32) and torch.isfinite(lo).all()
 
 
+def test_xl1_cfg_batch_512_is_the_sum_of_its_samples():
+    """BASELINE config 5 at the reference's per-process batch (per_proc_batch_size 256 -> CFG batch 512, lightningdit_b_vmae_f8d16_cfg.yaml:77):
+    524 288 token rows -- qkv alone is 3.6 GB, past 2^31 bytes.  A forward of the whole batch must equal, bit for bit, the forwards of its
+    halves (no index arithmetic wraps at this size), at the XL/1 width (depth 2)."""
+    cfg = odit.DiTConfig(input_size=32, patch_size=1, in_channels=16, hidden_size=1152, depth=2, num_heads=16, num_classes=1000,
+                         class_dropout_prob=0.1)
+    sd = det_weights(odit.param_shapes(cfg), 7)
+    sd.update(odit.fixed_tables(cfg))
+    m = build(cfg, sd).eval()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    z = torch.randn(512, 16, 32, 32, device="cuda", generator=g)
+    t = torch.rand(512, device="cuda", generator=g)
+    y = torch.randint(0, 1001, (512,), device="cuda", generator=g)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        full = m(z, t, y)
+        halves = torch.cat([m(z[:256], t[:256], y[:256]), m(z[256:], t[256:], y[256:])])
+    assert torch.isfinite(full).all() and torch.equal(full, halves)
+
+
 def test_three_optimizer_steps_match_oracle_fp32():
     """model + fused AdamW/EMA vs the oracle's train_steps on the tiny geometry (host-drawn x0, t, label-drop)."""
     from ldmae_amd.optim import AdamWEMA

@@ -176,6 +176,40 @@ def test_vmae_pretrain_driver_steps():
     assert all(b.precision == torch.float32 for b in list(m.blocks) + list(m.decoder_blocks))
 
 
+def test_vmae_pretrain_bf16_tracks_f32_over_50_steps():
+    """Row f4's precision statement, with evidence.  The reference pre-trains under fp16 autocast + GradScaler (VMAE/engine_pretrain.py:51-57,
+    util/misc.py:406-435); the kernels here have no fp16 path and run bf16 (8 significant bits against fp16's 11, f32's exponent range).
+    What that costs over an optimisation trajectory: 50 optimizer steps of the pre-training driver on the mae_train geometry (128 px,
+    depth 2 + 2, batch 8, a fresh batch per step, identical initial weights, masking noise and posterior draws) in bf16 and in f32 --
+    the loss curves stay within 2 % of each other at EVERY step (measured: 0.6 % worst step, 0.2 % over the last ten), no step is skipped
+    by the loss scaler, and both fall by the same amount."""
+    import argparse
+    from ldmae_amd import vmae_pretrain as vp
+    from ldmae_amd.tokenizer import models_mae
+    curves = {}
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192, decoder_depth=2,
+                                            decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
+                                            kl_loss_weight=1e-6, smooth_output=True).cuda()
+        opt = vp.build_optimizer(m, 1e-3, 0.05)
+        args = argparse.Namespace(accum_iter=1, lr=1e-3, min_lr=0.0, warmup_epochs=0, epochs=100, fixed_lr=True, precision=prec, mask_ratio=0.75,
+                                  visible_loss_ratio=0.5, print_freq=1)
+        g = torch.Generator().manual_seed(5)
+        loader = [(torch.rand(8, 3, 128, 128, generator=g) * 2 - 1, 0) for _ in range(50)]
+        scaler = vp.LossScaler(enabled=prec == "bf16")
+        losses = []
+        torch.manual_seed(123)                       # the device RNG behind the masking noise and the posterior sample
+        vp.train_one_epoch(m, loader, opt, 0, args, log=lambda s: losses.append(float(s.split("loss: ")[1].split()[0])), scaler=scaler)
+        assert len(losses) == 50 and opt.step_count == 50 and scaler.skipped == 0
+        curves[prec] = np.array(losses)
+    f, b = curves["fp32"], curves["bf16"]
+    rel = np.abs(b - f) / f
+    print("bf16 vs f32 pre-training loss: worst step", rel.max(), "last ten", abs(b[-10:].mean() - f[-10:].mean()) / f[-10:].mean(), "f32 first/last", f[0], f[-1])
+    assert f[-10:].mean() < 0.8 * f[:5].mean()                                  # it trains
+    assert rel.max() < 2e-2 and abs(b[-10:].mean() - f[-10:].mean()) / f[-10:].mean() < 1e-2
+
+
 def test_pretraining_forward_and_grads_vs_reference_golden(golden):
     """The product's pre-training forward + backward against the REFERENCE's own MaskedAutoencoderViT.forward outputs and gradient
     norms (tests/golden/mae_train.npz, generated by importing tokenizer/models_mae.py:733-790, 811-815), on the recorded draws."""
