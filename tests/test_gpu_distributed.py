@@ -163,8 +163,10 @@ def test_world_of_one_rccl_rank_walks_the_reducer():
     same, launched, front, exposed = q.get(timeout=600)
     p.join(120)
     assert p.exitcode == 0
-    # the buckets that hold adaLN weights (front of the slab = highest bucket indices) are the ones launched last
-    assert same and exposed >= 0.0 and front == list(range(front[0], len(launched))) and sorted(launched[-len(front):]) == front, (launched, front)
+    # the buckets that hold adaLN weights (front of the slab = highest bucket indices) are among the last launched: only the bucket with the
+    # embedders' parameters, whose gradients complete after the batched adaLN backward, may come between / after them
+    assert same and exposed >= 0.0 and front == list(range(front[0], len(launched))), (launched, front)
+    assert set(front) <= set(launched[-(len(front) + 1):]) and launched[0] == 0, (launched, front)
 
 
 def test_bench_dp_config_line():
