@@ -512,6 +512,53 @@ def bench_xl_sample(args, world, rank, device, lib):
     }
 
 
+def bench_vmae_paths(device, batch=256):
+    """The tokenizer calls the reference's drivers actually make, per 256 images (the encoder line above is BASELINE config 4 as written:
+    masked forward_encoder, no gradients): `_encode` over all 1024 tokens (extract_features.py:150 -> models_mae.py:819-833), `decode_to_images`
+    (1024-token decoder + uint8 / NHWC + D2H, inference.py:290-292 -> :963-973), in the f32 the reference runs them in and in bf16
+    (set_precision), and one optimizer step of VMAE pre-training (engine_pretrain.py:51-76: masked encoder + 1024-token decoder, loss,
+    backward, fused AdamW; bf16 autocast + loss scaler)."""
+    import argparse as _ap
+    from ldmae_amd import vmae_pretrain as vp
+    from ldmae_amd.tokenizer import models_mae
+    out = {"images": batch}
+    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=True, no_cls=True, kl_loss_weight=True, smooth_output=True, img_size=256).to(device).eval()
+    g = torch.Generator(device=device).manual_seed(0)
+    x = torch.rand(batch, 3, 256, 256, device=device, generator=g) * 2 - 1
+    z = torch.randn(batch, 16, 32, 32, device=device, generator=g)
+
+    def ms(fn, iters=3):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / iters * 1e3, 2)
+    for tag, prec in (("f32", None), ("bf16", torch.bfloat16)):
+        m.set_precision(prec)
+        with torch.no_grad():
+            out[f"encode_all_tokens_ms_{tag}"] = ms(lambda: m._encode(x))
+        out[f"decode_to_images_ms_{tag}"] = ms(lambda: m.decode_to_images(z))
+    del m
+    free_gpu_memory()
+    torch.manual_seed(0)
+    pm = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).to(device)
+    opt = vp.build_optimizer(pm, 1.5e-4, 0.05)
+    a = _ap.Namespace(accum_iter=1, lr=1.5e-4, min_lr=0.0, warmup_epochs=0, epochs=10, fixed_lr=True, precision="bf16", mask_ratio=0.75,
+                      visible_loss_ratio=0.5, print_freq=10 ** 9)
+    scaler = vp.LossScaler(enabled=True)
+    loader = [(x, 0)]
+    stats = None
+
+    def step():
+        nonlocal stats
+        stats = vp.train_one_epoch(pm, loader, opt, 0, a, log=lambda s_: None, scaler=scaler)
+    out["pretrain_step_ms_bf16"] = ms(step, iters=4)
+    out["pretrain_loss"] = round(float(stats["loss"]), 5)
+    out["note"] = "wall time per call with a device synchronise at both ends; f32 = what the reference's drivers run these calls in"
+    return out
+
+
 def bench_do_sample(args, device, batches=1):
     """BASELINE config 5 end to end, as run_inference.sh drives it (inference.py:264-299) at the reference's per-process batch: LightningDiT-B/1
     (the yaml's model), 250 shifted Euler steps with CFG 10 / interval 0.10 on a doubled batch of 2 x 256 -> de-normalise -> VMAE
@@ -607,7 +654,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
-    ap.add_argument("--workload", default="dit", choices=["dit", "vmae", "xl_sample", "do_sample"],
+    ap.add_argument("--workload", default="dit", choices=["dit", "vmae", "xl_sample", "do_sample", "vmae_paths"],
                     help="dit = the headline train step (BASELINE config 2/3); vmae = config 4 encoder; xl_sample = config 5 CFG forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="do not sample package power / clock (sysfs) during the timed loop")
@@ -657,6 +704,8 @@ def main():
             extra.steps, extra.warmup = 4, 1
             out["extra_workloads"]["xl_sample"] = bench_xl_sample(extra, world, rank, device, lib)
             free_gpu_memory()
+            out["extra_workloads"]["vmae_paths"] = bench_vmae_paths(device)
+            free_gpu_memory()
             out["extra_workloads"]["do_sample"] = bench_do_sample(extra, device, batches=1)
             free_gpu_memory()
             extra.steps, extra.warmup = 8, 2
@@ -667,6 +716,8 @@ def main():
                 out["extra_workloads"]["dp_config"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     elif args.workload == "vmae":
         out = bench_vmae(args, world, rank, device, lib)
+    elif args.workload == "vmae_paths":
+        out = bench_vmae_paths(device, args.batch)
     elif args.workload == "do_sample":
         out = bench_do_sample(args, device, batches=max(1, args.steps if args.steps < 10 else 1))
     else:

@@ -239,6 +239,17 @@ int ldmae_conv3x3_bwd(const float* dout, const float* x, const float* w, float* 
 /* When enabled, ldmae_gemm_nt brackets each launch with HIP events on the launch stream. */
 int ldmae_prof_enable(int on);
 int ldmae_prof_collect(double* total_ms, double* total_flops, long* launches);   /* syncs the events; resets */
+/* Launch counts by kernel family since the last reset, always on (one relaxed atomic add per entry-point call): which ARITHMETIC TYPE a
+ * model's calls were dispatched to -- a bf16 forward that silently runs the f32 kernels (round 3: the VMAE decoder under autocast, 250 of
+ * 304 ms) shows up as f32 counts.  counts[0..5] = NT GEMM bf16 / f32, TN GEMM bf16 / f32, attention (fwd or bwd entry) bf16 / f32;
+ * n = how many to copy (<= 6).  reset != 0 zeroes them after the copy. */
+#define LDMAE_COUNT_NT_BF16 0
+#define LDMAE_COUNT_NT_F32 1
+#define LDMAE_COUNT_TN_BF16 2
+#define LDMAE_COUNT_TN_F32 3
+#define LDMAE_COUNT_ATTN_BF16 4
+#define LDMAE_COUNT_ATTN_F32 5
+int ldmae_launch_counts(long* counts, int n, int reset);
 
 #ifdef __cplusplus
 }

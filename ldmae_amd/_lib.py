@@ -84,6 +84,7 @@ SIGNATURES = {
     "ldmae_conv3x3_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldmae_prof_enable": (_i, [_i]),
     "ldmae_prof_collect": (_i, [C.POINTER(_d), C.POINTER(_d), C.POINTER(_l)]),
+    "ldmae_launch_counts": (_i, [C.POINTER(_l), _i, _i]),
 }
 # csrc/probe/ldmae_diag.h: present only in the diagnostic build (LDMAE_HIP_LIB=.../libldmae_hip_diag.so, used by tools/)
 DIAG_SIGNATURES = {
@@ -155,3 +156,13 @@ def dt(dtype) -> int:
     if dtype == torch.bfloat16:
         return BF16
     raise RuntimeError(f"unsupported activation dtype {dtype} (float32 or bfloat16)")
+
+
+COUNT_NAMES = ("nt_bf16", "nt_f32", "tn_bf16", "tn_f32", "attn_bf16", "attn_f32")
+
+
+def launch_counts(reset: bool = False) -> dict:
+    """Launch counts by kernel family since the last reset (ldmae_launch_counts): which arithmetic type the calls were dispatched to."""
+    arr = (C.c_long * 6)()
+    call("ldmae_launch_counts", arr, 6, 1 if reset else 0)
+    return dict(zip(COUNT_NAMES, [int(v) for v in arr]))

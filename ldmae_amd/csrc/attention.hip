@@ -999,6 +999,7 @@ static int attn_lds(int hd, int extra) {
 }
 
 static int attn_check(const char* who, int dtype, int B, int H, int N, int hd) {
+  ldmae_count(dtype == LDMAE_BF16 ? LDMAE_COUNT_ATTN_BF16 : LDMAE_COUNT_ATTN_F32);
   LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "%s: bad dtype %d", who, dtype);
   LDMAE_REQUIRE(B > 0 && H > 0 && N > 0 && hd > 0, "%s: empty problem", who);
   return LDMAE_OK;      // any N: the last 64-row tile of a sweep may be ragged (mask_rows_past)

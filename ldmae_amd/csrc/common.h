@@ -143,6 +143,8 @@ int ldmae_tune_get(int key);
 #else
 static inline constexpr int ldmae_tune_get(int) { return 0; }
 #endif
+// launch counts by kernel family (core.hip; LDMAE_COUNT_* of the public header)
+void ldmae_count(int family);
 // timing hook (core.hip)
 bool ldmae_prof_is_on();
 long ldmae_prof_begin(hipStream_t st, double flops);

@@ -825,6 +825,7 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
   } else {
     LDMAE_FAIL(LDMAE_ERR_INVALID, "gemm_nt: unknown epilogue %d", epi);
   }
+  ldmae_count(dtype == LDMAE_BF16 ? LDMAE_COUNT_NT_BF16 : LDMAE_COUNT_NT_F32);
   return out_dtype == LDMAE_BF16 ? launch_nt<bf16>(dtype, epi, tile_launch, A, B, M, N, K, lda, ldb, e, as_stream(stream))
                                  : launch_nt<float>(dtype, epi, tile_launch, A, B, M, N, K, lda, ldb, e, as_stream(stream));
 }
@@ -865,6 +866,7 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   const int splits = tn_plan(dtype, M, N, K, &rows);
   const bool ring = dtype == LDMAE_BF16 && ldmae_tune_get(1) == 0 && M % 32 == 0;
   hipStream_t st = as_stream(stream);
+  ldmae_count(dtype == LDMAE_BF16 ? LDMAE_COUNT_TN_BF16 : LDMAE_COUNT_TN_F32);
   LDMAE_REQUIRE(workspace && workspace_bytes >= (long)splits * ((long)N * K + N) * 4, "gemm_tn: workspace too small (%ld < %ld)",
                 workspace_bytes, (long)splits * ((long)N * K + N) * 4);
   // one split and nothing to accumulate into: the GEMM writes C (and the bias gradient) itself -- no partial slab, no reduce pass

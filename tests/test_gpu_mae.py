@@ -176,6 +176,64 @@ def test_vmae_pretrain_driver_steps():
     assert all(b.precision == torch.float32 for b in list(m.blocks) + list(m.decoder_blocks))
 
 
+def test_bf16_calls_are_dispatched_to_the_bf16_kernels():
+    """Which kernel FAMILY every path of the tokenizer runs, by count (ldmae_launch_counts).  Under bf16 autocast / set_precision(bf16) no
+    block GEMM and no attention call may fall to the f32 kernels -- the pre-training decoder once did, silently (304 instead of 79 ms per
+    step); the only f32 GEMMs left are the thin latent projections (to_latent / from_latent / decoder_embed / decoder_pred), which are f32
+    by policy.  Counted on the shipped geometry with depth 2 + 2 at 128 px."""
+    from ldmae_amd import _lib
+    from ldmae_amd.tokenizer import models_mae
+    torch.manual_seed(0)
+    m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192, decoder_depth=2,
+                                        decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
+                                        kl_loss_weight=1e-6, smooth_output=True).cuda()
+    x = torch.rand(8, 3, 128, 128, device="cuda") * 2 - 1
+    nblk = len(m.blocks) + len(m.decoder_blocks)
+
+    def counted(fn):
+        _lib.launch_counts(reset=True)
+        fn()
+        torch.cuda.synchronize()
+        return _lib.launch_counts(reset=True)
+
+    def train_step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = m(x, mask_ratio=0.75, visible_loss_ratio=0.5)[0]
+        loss.backward()
+    c = counted(train_step)
+    # per block: 4 forward Linears + 4 dX GEMMs (NT), 4 dW GEMMs (TN), attention forward + backward -- all bf16
+    assert c["nt_bf16"] >= 8 * nblk and c["tn_bf16"] >= 4 * nblk and c["attn_bf16"] == 2 * nblk and c["attn_f32"] == 0, c
+    assert c["nt_f32"] <= 12 and c["tn_f32"] <= 8, c                     # the latent / embedding / prediction Linears only
+    m.eval().set_precision(torch.bfloat16)
+    with torch.no_grad():
+        c = counted(lambda: m._encode(x))
+        assert c["nt_bf16"] >= 4 * len(m.blocks) and c["attn_bf16"] == len(m.blocks) and c["attn_f32"] == 0 and c["nt_f32"] <= 2, c
+        z = torch.randn(8, 16, 16, 16, device="cuda")
+        c = counted(lambda: m.decode(z))
+        assert c["nt_bf16"] >= 4 * len(m.decoder_blocks) and c["attn_bf16"] == len(m.decoder_blocks) and c["attn_f32"] == 0 and c["nt_f32"] <= 4, c
+    m.set_precision(None)
+    with torch.no_grad():
+        c = counted(lambda: m._encode(x))                                # no autocast, no precision: the f32 family, and only it
+        assert c["nt_bf16"] == 0 and c["attn_bf16"] == 0 and c["attn_f32"] == len(m.blocks), c
+
+
+def test_fused_encoder_is_independent_of_the_batch_at_full_size():
+    """The one-kernel encoder at the bench size: 256 images = one workgroup per CU, every CU busy.  Each image's tokens must equal, bit for
+    bit, what the kernel gives for that image alone / in a small batch (no cross-workgroup state, no dependence on the grid)."""
+    from ldmae_amd.tokenizer import models_mae
+    torch.manual_seed(1)
+    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.rand(256, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+    noise = torch.rand(256, 1024, device="cuda", generator=g)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        full = m.forward_encoder(x, 0.75, noise=noise)[0]
+        assert full.shape == (256, 256, 192) and torch.isfinite(full).all()
+        for sl in (slice(0, 1), slice(97, 102), slice(251, 256)):
+            part = m.forward_encoder(x[sl], 0.75, noise=noise[sl])[0]
+            assert torch.equal(part, full[sl]), sl
+
+
 def test_vmae_pretrain_bf16_tracks_f32_over_50_steps():
     """Row f4's precision statement, with evidence.  The reference pre-trains under fp16 autocast + GradScaler (VMAE/engine_pretrain.py:51-57,
     util/misc.py:406-435); the kernels here have no fp16 path and run bf16 (8 significant bits against fp16's 11, f32's exponent range).
