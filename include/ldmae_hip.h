@@ -41,6 +41,8 @@ extern "C" {
 #define LDMAE_EPI_SWIGLU 4     /* bf16 only: B = w12 [2Hs,K]; C = h12 [M,2Hs] = acc+bias (NULL: not stored -- forward-only), xout(as bf16*) = hid [M,Hs] = silu(x1)*x2 */
 #define LDMAE_EPI_SWIGLU_BWD 5 /* bf16 only: acc = dhid [M,Hs]; xin(as bf16*) = h12 [M,2Hs]; C = dh12 [M,2Hs]; xout (optional) =
                                   [ceil(M/128)][2Hs] f32 partial column sums of dh12 as stored (bias gradient; caller sums the rows) */
+#define LDMAE_EPI_GELU_BWD 6   /* C = dpre [M,N] = g * gelu_erf'(pre), g = acc (+ bias) rounded to out_dtype first; xin (read as out_dtype*) = pre [M, ldc]:
+                                  the input gradient of fc2 with the GELU backward of the VMAE Mlp fused (models_mae.py:172: timm Mlp) */
 /* launch mode, or'ed into `epi` per call (bf16 GEMMs): one 256x256 tile per workgroup instead of one persistent workgroup per CU.  A
    data-parallel caller sets it while RCCL's collective kernels share the chip with backward (ldmae_amd/distributed.py); results are
    bitwise equal to the persistent launch */

@@ -38,10 +38,16 @@ class _AliasLoader(importlib.abc.Loader):
         self.target = target
 
     def create_module(self, spec):
-        return importlib.import_module(self.target)      # the runtime module itself: `models.x is ldmae_amd.models.x`
+        mod = importlib.import_module(self.target)       # the runtime module itself: `models.x is ldmae_amd.models.x`
+        self._spec = getattr(mod, "__spec__", None)      # importlib is about to overwrite it with the ALIAS spec ...
+        return mod
 
     def exec_module(self, module):
-        pass
+        # ... put the module's own spec back: with __spec__.parent = 'models' and __package__ = 'ldmae_amd.models' a later relative import
+        # inside the aliased module warns (ImportWarning; an error under -W error) or, on interpreters that resolve relative imports through
+        # __spec__.parent, looks in the wrong package
+        if getattr(self, "_spec", None) is not None:
+            module.__spec__ = self._spec
 
 
 class _Finder(importlib.abc.MetaPathFinder):

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libldmae_hip.so")
 LIB_PATH = os.environ.get("LDMAE_HIP_LIB", LIB_PATH)      # A/B builds of the same library (tools/); unset = the in-tree build
 
 F32, BF16 = 0, 1
-EPI_BIAS, EPI_GATE_RES, EPI_BIAS_POS, EPI_BIAS_GELU, EPI_SWIGLU, EPI_SWIGLU_BWD = 0, 1, 2, 3, 4, 5
+EPI_BIAS, EPI_GATE_RES, EPI_BIAS_POS, EPI_BIAS_GELU, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_GELU_BWD = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 

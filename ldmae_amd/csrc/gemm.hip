@@ -773,6 +773,7 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
     case LDMAE_EPI_BIAS_POS: NT_LAUNCH(LDMAE_EPI_BIAS_POS); break;
     case LDMAE_EPI_SWIGLU: PERS(LDMAE_EPI_SWIGLU); break;
     case LDMAE_EPI_SWIGLU_BWD: PERS(LDMAE_EPI_SWIGLU_BWD); break;
+    case LDMAE_EPI_GELU_BWD: NT_LAUNCH(LDMAE_EPI_GELU_BWD); break;
     default: NT_LAUNCH(LDMAE_EPI_BIAS_GELU); break;
   }
 #undef NT_LAUNCH
@@ -813,6 +814,9 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
   } else if (epi == LDMAE_EPI_BIAS_GELU) {
     LDMAE_REQUIRE(C && ldc >= N, "gemm_nt: gelu epilogue needs C");
     e.C2 = xout;   /* pre-activation copy, same dtype/ld as C */
+  } else if (epi == LDMAE_EPI_GELU_BWD) {
+    LDMAE_REQUIRE(C && ldc >= N && xin && out_dtype == dtype, "gemm_nt: gelu-bwd epilogue needs C, the pre-activation in xin (same type and row stride as C) and out_dtype == dtype");
+    e.xin = xin;
   } else if (epi == LDMAE_EPI_SWIGLU) {
     LDMAE_REQUIRE(dtype == LDMAE_BF16 && out_dtype == LDMAE_BF16, "gemm_nt: swiglu epilogue is bf16 only");
     LDMAE_REQUIRE(xout && N % 256 == 0 && K % 32 == 0 && (!C || ldc == N), "gemm_nt: swiglu epilogue needs hid (xout), N %% 256 == 0 (N=%d); h12 (C, ldc = N) may be NULL in forward-only calls", N);

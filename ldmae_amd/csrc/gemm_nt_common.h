@@ -47,6 +47,13 @@ template <typename OutT> __device__ __forceinline__ float4 act_round4(float4 y) 
   return make_float4(act_round<OutT>(y.x), act_round<OutT>(y.y), act_round<OutT>(y.z), act_round<OutT>(y.w));
 }
 
+// d/dx of the exact-erf GELU times the incoming gradient AS STORED (vmae.hip: gelu_bwd_kernel computes the same expression on the stored
+// fc2 input gradient, so the fused epilogue and GEMM + ldmae_gelu_bwd agree bit for bit)
+template <typename OutT> __device__ __forceinline__ float gelu_bwd_val(float acc, float v) {
+  const float cdf = 0.5f * (1.f + erf_act<OutT>(v * 0.70710678118654752f)), pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+  return act_round<OutT>(acc) * (cdf + v * pdf);
+}
+
 template <int EPI, typename OutT>
 __device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M, int N, float acc) {
   if (m >= M || n >= N) return;
@@ -61,6 +68,9 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M,
   } else if (EPI == LDMAE_EPI_BIAS_GELU) {
     if (e.C2) ((OutT*)e.C2)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
     ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(gelu_act<OutT>(y));
+  } else if (EPI == LDMAE_EPI_GELU_BWD) {
+    const size_t o = (size_t)m * e.ldc + n;
+    ((OutT*)e.C)[o] = from_f<OutT>(gelu_bwd_val<OutT>(y, to_f<OutT>(((const OutT*)e.xin)[o])));
   } else {  // LDMAE_EPI_GATE_RES
     if (e.C) ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
     const size_t o = (size_t)m * N + n;
@@ -109,6 +119,10 @@ template <int EPI, typename OutT> struct Epi4 {
     } else if (EPI == LDMAE_EPI_BIAS_GELU) {
       auto g = [](float y) { return gelu_act<OutT>(y); };
       c = make_float4(g(a.x), g(a.y), g(a.z), g(a.w));
+    } else if (EPI == LDMAE_EPI_GELU_BWD) {
+      const OutT* p = (const OutT*)e.xin + (size_t)m * e.ldc + n;
+      c = make_float4(gelu_bwd_val<OutT>(a.x, to_f<OutT>(p[0])), gelu_bwd_val<OutT>(a.y, to_f<OutT>(p[1])), gelu_bwd_val<OutT>(a.z, to_f<OutT>(p[2])),
+                      gelu_bwd_val<OutT>(a.w, to_f<OutT>(p[3])));
     } else if (EPI == LDMAE_EPI_GATE_RES) {
       const size_t o = (size_t)m * N + n;
       const float4 xi = *(const float4*)(e.xin + o);
@@ -131,6 +145,10 @@ template <int EPI, typename OutT> struct Epi4 {
       if (e.C2) put(e.C2, oc, a);
       auto g = [](float y) { return gelu_act<OutT>(y); };
       put(e.C, oc, make_float4(g(a.x), g(a.y), g(a.z), g(a.w)));
+    } else if (EPI == LDMAE_EPI_GELU_BWD) {
+      const OutT* p = (const OutT*)e.xin + oc;
+      put(e.C, oc, make_float4(gelu_bwd_val<OutT>(a.x, to_f<OutT>(p[0])), gelu_bwd_val<OutT>(a.y, to_f<OutT>(p[1])),
+                               gelu_bwd_val<OutT>(a.z, to_f<OutT>(p[2])), gelu_bwd_val<OutT>(a.w, to_f<OutT>(p[3]))));
     } else {
       if (e.C) put(e.C, oc, a);
       const size_t o = (size_t)m * N + n;
@@ -352,7 +370,16 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
           xi[i][it][0] = *(const float4*)(rb + xoff); xi[i][it][1] = *(const float4*)(rb + xoff + 16);
         }
       };
+      // GELU backward: the pre-activation rows of a strip (8 values per lane and row) are requested one strip ahead, like the residual rows
+      float pv[MI][2][8];
+      const unsigned poff = ((unsigned)(lane >> 3) * (unsigned)e.ldc + (unsigned)(nb + c8)) * (unsigned)sizeof(OutT);
+      auto ldp = [&](int i) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+          Vec8<OutT>::load((const OutT*)((const char*)e.xin + (size_t)(mw + i * 16 + it * 8) * (size_t)e.ldc * sizeof(OutT) + poff), pv[i][it]);
+      };
       if constexpr (EPI == LDMAE_EPI_GATE_RES) ldx(0);
+      if constexpr (EPI == LDMAE_EPI_GELU_BWD) ldp(0);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         fill(i, cblk);
@@ -370,6 +397,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
           else if (i == 1) { ldx(2); ldx(3); }
           else if (i + 2 < MI) ldx(i + 2);
         }
+        if constexpr (EPI == LDMAE_EPI_GELU_BWD) { if (i + 1 < MI) ldp(i + 1); }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int m = mw + i * 16 + it * 8 + (lane >> 3);
@@ -385,6 +413,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
             auto g = [](float y) { return gelu_act<OutT>(y); };
             put8(e.C, oc, make_float4(g(p.x), g(p.y), g(p.z), g(p.w)), make_float4(g(q.x), g(q.y), g(q.z), g(q.w)));
             if (e.C2) put8(e.C2, oc, p, q);
+          } else if constexpr (EPI == LDMAE_EPI_GELU_BWD) {
+            const float* v = pv[i][it];
+            put8(e.C, oc, make_float4(gelu_bwd_val<OutT>(p.x, v[0]), gelu_bwd_val<OutT>(p.y, v[1]), gelu_bwd_val<OutT>(p.z, v[2]), gelu_bwd_val<OutT>(p.w, v[3])),
+                 make_float4(gelu_bwd_val<OutT>(q.x, v[4]), gelu_bwd_val<OutT>(q.y, v[5]), gelu_bwd_val<OutT>(q.z, v[6]), gelu_bwd_val<OutT>(q.w, v[7])));
           } else {
             put8(e.C, oc, p, q);
           }

@@ -12,7 +12,7 @@ import weakref
 import torch
 
 from . import _lib as L
-from ._lib import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_GATE_RES, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_TILE_LAUNCH, F32, call, dt,
+from ._lib import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_GATE_RES, EPI_GELU_BWD, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_TILE_LAUNCH, F32, call, dt,
                    ptr, stream)
 
 _ws = {}
@@ -149,6 +149,17 @@ def gemm_nt_gelu(a, b, bias, save_pre=True):
     call("ldmae_gemm_nt", dt(a.dtype), dt(a.dtype), EPI_BIAS_GELU | _launch_flag(), ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), N,
          M, N, K, ptr(bias), 0.0, None, ptr(pre), None, 0, 0, stream())
     return out, pre
+
+
+def gemm_nt_gelu_bwd(dy, w2t, pre):
+    """dpre = gelu_bwd(dy @ w2t^T, pre): the input gradient of fc2 with the GELU backward in the GEMM's epilogue (w2t = [hidden, D] transposed
+    copy of fc2's weight; pre = fc1's pre-activation as gemm_nt_gelu saved it).  Same bits as gelu_bwd(gemm_nt(dy, w2t), pre)."""
+    M, K = dy.shape
+    N = w2t.shape[0]
+    out = torch.empty(M, N, dtype=dy.dtype, device=dy.device)
+    call("ldmae_gemm_nt", dt(dy.dtype), dt(dy.dtype), EPI_GELU_BWD | _launch_flag(), ptr(dy), dy.stride(0), ptr(w2t), w2t.stride(0), ptr(out), N,
+         M, N, K, None, 0.0, ptr(pre), None, None, 0, 0, stream())
+    return out
 
 
 def gemm_nt_swiglu(a, w12, b12, save_h12=True):

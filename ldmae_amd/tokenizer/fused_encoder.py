@@ -81,8 +81,13 @@ def pack_encoder(blocks, final_norm) -> torch.Tensor:
 def supported(model, tokens: int, dim: int) -> bool:
     """The fused kernel covers exactly the shipped encoder geometry on a 256-token sequence (mask_ratio 0.75 of 1024 patches)."""
     b0 = model.blocks[0]
+
+    def packable(blk):          # _pack_block reads every bias: a model built with qkv_bias=False (or on another device / type) keeps the per-layer kernels
+        ts = (blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+              blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias)
+        return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in ts)
     return (tokens == TOKENS and dim == DIM and b0.attn.num_heads == HEADS and b0.mlp.fc1.weight.shape[0] == HIDDEN and
-            isinstance(model.norm, torch.nn.LayerNorm) and
+            isinstance(model.norm, torch.nn.LayerNorm) and model.norm.bias is not None and all(packable(blk) for blk in model.blocks) and
             all(abs(blk.norm1.eps - model.norm.eps) < 1e-12 and abs(blk.norm2.eps - model.norm.eps) < 1e-12 for blk in model.blocks))
 
 

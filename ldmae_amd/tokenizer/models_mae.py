@@ -86,7 +86,7 @@ class _ViTBlockFn(torch.autograd.Function):
     """Block.forward (:176-187): x += proj(attn(LN1(x))); x += fc2(gelu(fc1(LN2(x))))."""
 
     @staticmethod
-    def forward(ctx, x, H, eps, dtype, inplace, fwd_only, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
+    def forward(ctx, x, H, eps, dtype, inplace, fwd_only, direct, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
         B, N, D = x.shape
         M, hd = B * N, D // H
         x2 = x.contiguous().view(M, D)
@@ -116,6 +116,11 @@ class _ViTBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2, h1, mu1, rs1, qkv, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T)
         ctx.dims = (B, N, D, H, hd, dtype)
         ctx.inplace = bool(inplace)
+        # opt-in of the training driver (MaskedAutoencoderViT.direct_param_grads; every .grad is a view of its gradient slab): the block's
+        # twelve parameter gradients are ADDED into their .grad by the producing kernels (the TN GEMM's reduce with beta = 1; one
+        # ldmae_multi_add for the eight vectors) instead of by twelve AccumulateGrad passes -- as models/lightningdit.py does for the DiT
+        plist = (n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b)
+        ctx.plist = plist if direct and all(p_.grad is not None and p_.grad.dtype == torch.float32 and p_.grad.is_contiguous() for p_ in plist) else None
         return xout.view(B, N, D)
 
     @staticmethod
@@ -126,24 +131,38 @@ class _ViTBlockFn(torch.autograd.Function):
         dx = gout.contiguous().view(M, D)
         if not ctx.inplace and dx.data_ptr() == gout.data_ptr():
             dx = dx.clone()                   # the incoming gradient may have other consumers: never modify it (see _DiTBlockFn)
+        pl = ctx.plist
+
+        def dw(dy, xin, i):           # weight + bias gradient of Linear i (index of its weight in plist)
+            if pl is not None:
+                return None, ops.gemm_tn(dy, xin, out=pl[i].grad, beta=1.0, with_bias=True)[1]
+            return ops.gemm_tn(dy, xin, with_bias=True)
         # MLP branch
         dy2 = ops.cast(dx, dtype)
-        dW2, db2 = ops.gemm_tn(dy2, act, with_bias=True)
-        dpre = ops.gelu_bwd(ops.gemm_nt(dy2, W2T), pre)
-        dW1, db1 = ops.gemm_tn(dpre, h2, with_bias=True)
+        dW2, db2 = dw(dy2, act, 10)
+        dpre = ops.gemm_nt_gelu_bwd(dy2, W2T, pre)                 # fc2's input gradient with the GELU backward in the GEMM epilogue
+        dW1, db1 = dw(dpre, h2, 8)
         dn2w, dn2b = ops.layernorm_bwd(ops.gemm_nt(dpre, W1T), xmid, n2w, mu2, rs2, dx)
         # attention branch
         dy1 = ops.cast(dx, dtype)
-        dWp, dbp = ops.gemm_tn(dy1, oa, with_bias=True)
+        dWp, dbp = dw(dy1, oa, 4)
         do = ops.gemm_nt(dy1, WpT)
         if qkv is not None:
             dqkv = ops.attention_bwd_qkv(qkv, o, do, lse, B, N, H, hd, hd ** -0.5)
         else:
             dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
             dqkv = ops.heads_merge(dq, dk, dv, B, N, H, hd)
-        dWqkv, dbqkv = ops.gemm_tn(dqkv, h1, with_bias=True)
+        dWqkv, dbqkv = dw(dqkv, h1, 2)
         dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT), x2, n1w, mu1, rs1, dx)
-        return (dx.view(B, N, D), None, None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
+        if pl is not None:
+            small = [(0, dn1w), (1, dn1b), (3, dbqkv), (5, dbp), (6, dn2w), (7, dn2b), (9, db1), (11, db2)]
+            ops.multi_add_([pl[i].grad for i, _ in small], [g_ for _, g_ in small])
+            for p_ in pl:              # a data-parallel reducer's post-accumulate hook does not fire for these: tell it (no-op without one)
+                r = getattr(p_, "_ldmae_grad_ready", None)
+                if r is not None:
+                    r(p_)
+            dn1w = dn1b = dbqkv = dbp = dn2w = dn2b = db1 = db2 = None
+        return (dx.view(B, N, D), None, None, None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -249,10 +268,15 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
         self.precision = None
 
-    def forward(self, x, _inplace_grad=False):
+    def forward(self, x, _inplace_grad=False, dtype=None):
+        """dtype: the activation type of THIS call (the model's encoder / decoder loops pass the type they resolved -- a caller that has
+        switched autocast off around the stack passes what it read before doing so); None: the block's own `precision` setting / autocast.
+        `last_dtype` records what the call ran in (tests)."""
         a, m = self.attn, self.mlp
-        return _ViTBlockFn.apply(x.float(), a.num_heads, self.norm1.eps, _act_dtype(self.precision), _inplace_grad,
-                                 not torch.is_grad_enabled(), self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+        dtype = dtype if dtype is not None else _act_dtype(self.precision)
+        self.last_dtype = dtype
+        return _ViTBlockFn.apply(x.float(), a.num_heads, self.norm1.eps, dtype, _inplace_grad,
+                                 not torch.is_grad_enabled(), bool(getattr(self, "direct_param_grads", False)), self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                  self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
 
 
@@ -317,6 +341,7 @@ class MaskedAutoencoderViT(nn.Module):
         self.norm_pix_loss = norm_pix_loss
         self.precision = None
         self.fused_encoder = os.environ.get("LDMAE_VMAE_FUSED", "1") != "0"      # False / LDMAE_VMAE_FUSED=0: always the per-layer kernels (A/B and parity tests)
+        self.direct_param_grads = False
         self.initialize_weights()
 
     def initialize_weights(self):
@@ -338,6 +363,14 @@ class MaskedAutoencoderViT(nn.Module):
                 nn.init.constant_(m.bias, 0)
                 nn.init.constant_(m.weight, 1.0)
         self.apply(_init)
+
+    def set_direct_param_grads(self, on=True):
+        """Opt-in of a training driver whose optimizer keeps every .grad as a view of one gradient slab (vmae_pretrain.build_optimizer): the
+        blocks add their parameter gradients into .grad themselves (see _ViTBlockFn)."""
+        self.direct_param_grads = bool(on)
+        for b in list(self.blocks) + list(self.decoder_blocks):
+            b.direct_param_grads = bool(on)
+        return self
 
     def set_precision(self, dtype):
         self.precision = dtype
@@ -377,9 +410,9 @@ class MaskedAutoencoderViT(nn.Module):
         gradient buffer it hands on) unless a module hook taps it: only then may its backward re-use the incoming gradient."""
         return not (blk._forward_hooks or blk._forward_pre_hooks or blk._backward_hooks)
 
-    def _run(self, blocks, x):
+    def _run(self, blocks, x, dtype=None):
         for blk in blocks:
-            x = blk(x, self._chain_ok(blk))
+            x = blk(x, self._chain_ok(blk), dtype)
         return x
 
     def forward_encoder(self, x, mask_ratio, noise=None):
@@ -402,9 +435,7 @@ class MaskedAutoencoderViT(nn.Module):
                 return fused_encoder.encoder_forward(self, xk), mask, ids_restore
             x = self._embed(x, dtype)
             x, mask, ids_restore = self.random_masking(x, mask_ratio, noise)
-            for blk in self.blocks:
-                blk.precision = dtype
-                x = blk(x, self._chain_ok(blk))
+            x = self._run(self.blocks, x, dtype)
             x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x, mask, ids_restore
 
@@ -413,14 +444,12 @@ class MaskedAutoencoderViT(nn.Module):
         (forward) passes the type it read BEFORE doing so -- the blocks would otherwise see "no autocast" and run their f32 kernels (the
         1024-token decoder of the pre-training step did: 250 of its 304 ms)."""
         dtype = dtype if dtype is not None else _act_dtype(self.precision)
-        for blk in self.decoder_blocks:
-            blk.precision = dtype
         x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias)
         mask_tokens = self.mask_token.repeat(x.shape[0], ids_restore.shape[1] - x.shape[1], 1)
         x_ = torch.cat([x, mask_tokens], dim=1)
         x = torch.gather(x_, dim=1, index=ids_restore.unsqueeze(-1).repeat(1, 1, x.shape[2]))
         x = x + self.decoder_pos_embed
-        x = self._run(self.decoder_blocks, x)
+        x = self._run(self.decoder_blocks, x, dtype)
         x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
         return self.decoder_pred(x) if not isinstance(self.decoder_pred, nn.Linear) else \
             _LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)
@@ -466,9 +495,7 @@ class MaskedAutoencoderViT(nn.Module):
         dtype = _act_dtype(self.precision)
         with torch.autocast(device_type="cuda", enabled=False):
             x = self._embed(x, dtype)
-            for blk in self.blocks:
-                blk.precision = dtype
-                x = blk(x, self._chain_ok(blk))
+            x = self._run(self.blocks, x, dtype)
             x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
             x = _LinearFn.apply(x, self.to_latent.weight, self.to_latent.bias)
         g = self.latent_resolution
@@ -486,9 +513,7 @@ class MaskedAutoencoderViT(nn.Module):
             x = z.float().permute(0, 2, 3, 1).reshape(B, -1, z.shape[1]).contiguous()
             x = _LinearFn.apply(x, self.from_latent.weight, self.from_latent.bias)
             x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias) + self.decoder_pos_embed
-            for blk in self.decoder_blocks:
-                blk.precision = dtype
-                x = blk(x, self._chain_ok(blk))
+            x = self._run(self.decoder_blocks, x, dtype)
             x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
             x = self.decoder_pred(x) if not isinstance(self.decoder_pred, nn.Linear) else \
                 _LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)

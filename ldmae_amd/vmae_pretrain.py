@@ -47,6 +47,8 @@ def no_decay(name, param):
 
 def build_optimizer(model, lr, weight_decay):
     flat = FlatParams(model, group_fn=no_decay)
+    if hasattr(model, "set_direct_param_grads") and os.environ.get("LDMAE_DIRECT_GRADS", "1") != "0":
+        model.set_direct_param_grads(True)        # every .grad is a slab view from here on: the blocks add their gradients into it themselves
     return AdamWEMA(model, lr=lr, betas=(0.9, 0.95), weight_decay=weight_decay, ema_decay=0.0, flat=flat,
                     group_weight_decay={0: weight_decay, 1: 0.0})
 

@@ -78,6 +78,9 @@ def test_gemm_nt_gate_res_pos_gelu(ops, dtype):
     g, pre = ops.gemm_nt_gelu(dev(a, dtype), dev(w, dtype), dev(bias))
     assert rel_err(pre.float().cpu(), y) < TOL[dtype]
     assert rel_err(g.float().cpu(), torch.nn.functional.gelu(y)) < TOL[dtype]
+    # GELU backward fused into the dX GEMM of the next Linear: same bits as the GEMM followed by ldmae_gelu_bwd
+    dy2, w2t = dev(rnd(M, 64, seed=9), dtype), dev(rnd(D, 64, seed=10, scale=0.125), dtype)
+    assert torch.equal(ops.gemm_nt_gelu_bwd(dy2, w2t, pre), ops.gelu_bwd(ops.gemm_nt(dy2, w2t), pre))
 
 
 def test_gemm_nt_persistent_multi_tile_ragged(ops):
@@ -115,6 +118,9 @@ def test_gemm_nt_persistent_multi_tile_ragged(ops):
     h12, hid = ops.gemm_nt_swiglu(a, w12, b12)
     h12_ref = ops.gemm_nt(a, w12, b12)
     assert torch.equal(h12, h12_ref) and torch.equal(hid, ops.swiglu_fwd(h12_ref))
+    pre = ops.gemm_nt(a, w, bias)                       # [M, N] ragged multi-tile: the GELU-backward epilogue on the persistent path
+    w2t = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(BF16)
+    assert torch.equal(ops.gemm_nt_gelu_bwd(a, w2t, pre), ops.gelu_bwd(ops.gemm_nt(a, w2t), pre))
     w3t = (torch.randn(Hs, K, device="cuda", generator=g) * K ** -0.5).to(BF16)
     dh12, db12 = ops.gemm_nt_swiglu_bwd(a, w3t, h12, with_bias=True)
     unf = ops.swiglu_bwd(ops.gemm_nt(a, w3t), h12)

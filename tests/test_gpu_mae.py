@@ -170,10 +170,10 @@ def test_vmae_pretrain_driver_steps():
     assert 0 < last["lr"] < 1e-3 and torch.isfinite(m.norm.weight).all() and not torch.equal(m.norm.weight, ln_w)
     # under bf16 autocast BOTH stacks run their bf16 kernels: forward() switches autocast off around the decoder, whose blocks must be
     # told the activation type read before that (they once saw "no autocast" and ran the f32 kernels: 250 of 304 ms per step at batch 256)
-    assert all(b.precision == torch.bfloat16 for b in list(m.blocks) + list(m.decoder_blocks))
+    assert all(b.last_dtype == torch.bfloat16 and b.precision is None for b in list(m.blocks) + list(m.decoder_blocks))
     with torch.no_grad():
         m(x.cuda())                                # no autocast: everything back on the f32 path
-    assert all(b.precision == torch.float32 for b in list(m.blocks) + list(m.decoder_blocks))
+    assert all(b.last_dtype == torch.float32 and b.precision is None for b in list(m.blocks) + list(m.decoder_blocks))
 
 
 def test_bf16_calls_are_dispatched_to_the_bf16_kernels():
@@ -232,6 +232,33 @@ def test_fused_encoder_is_independent_of_the_batch_at_full_size():
         for sl in (slice(0, 1), slice(97, 102), slice(251, 256)):
             part = m.forward_encoder(x[sl], 0.75, noise=noise[sl])[0]
             assert torch.equal(part, full[sl]), sl
+
+
+def test_vmae_direct_param_grads_equal_autograd_accumulation():
+    """The pre-training driver's opt-in (set_direct_param_grads: the blocks add their twelve parameter gradients into the slab views
+    themselves -- TN GEMM reduce with beta = 1, one multi_add for the vectors) gives the same gradient slab, bit for bit, as autograd's
+    AccumulateGrad, over two accumulated micro-steps, bf16."""
+    from ldmae_amd import vmae_pretrain as vp
+    from ldmae_amd.tokenizer import models_mae
+    slabs = {}
+    for direct in (False, True):
+        torch.manual_seed(0)
+        m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192, decoder_depth=2,
+                                            decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
+                                            kl_loss_weight=1e-6, smooth_output=True).cuda()
+        opt = vp.build_optimizer(m, 1e-3, 0.05)
+        m.set_direct_param_grads(direct)
+        opt.zero_grad()
+        g = torch.Generator().manual_seed(3)
+        for _ in range(2):
+            x = (torch.rand(8, 3, 128, 128, generator=g) * 2 - 1).cuda()
+            torch.manual_seed(11)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = m(x, mask_ratio=0.75, visible_loss_ratio=0.5)[0]
+            loss.backward()
+        slabs[direct] = opt.flat.grads.clone()
+        assert all(b.direct_param_grads == direct for b in m.blocks)
+    assert float(slabs[True].abs().sum()) > 0 and torch.equal(slabs[True], slabs[False])
 
 
 def test_vmae_pretrain_bf16_tracks_f32_over_50_steps():
