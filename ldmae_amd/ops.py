@@ -203,7 +203,8 @@ def gemm_tn(a, b, out=None, beta=0.0, with_bias=False, ws_slot="tn"):
     if out is None:
         out = torch.empty(N, K, dtype=torch.float32, device=a.device)
         beta = 0.0
-    dbias = torch.empty(N, dtype=torch.float32, device=a.device) if with_bias else None
+    # the C entry applies ONE beta to C and to dbias: a fresh bias-gradient buffer must be zero when the caller accumulates into `out`
+    dbias = (torch.zeros if beta != 0.0 else torch.empty)(N, dtype=torch.float32, device=a.device) if with_bias else None
     d = dt(a.dtype)
     nb = max(L.load().ldmae_gemm_tn_workspace_bytes(d, M, N, K), L.load().ldmae_colsum_workspace_bytes(M, N) if with_bias else 0)
     ws = workspace(nb, a.device, ws_slot)
