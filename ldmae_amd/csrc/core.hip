@@ -81,11 +81,11 @@ extern "C" int ldmae_launch_counts(long* counts, int n, int reset) {
 
 #ifdef LDMAE_DIAG
 // ---------------------------------------------------------------- tuning knobs (kernel variant selection; not part of the reference seam)
-static int g_tune[16] = {0};
-int ldmae_tune_get(int key) { return (key >= 0 && key < 16) ? g_tune[key] : 0; }
+static int g_tune[32] = {0};
+int ldmae_tune_get(int key) { return (key >= 0 && key < 32) ? g_tune[key] : 0; }
 extern "C" int ldmae_tune_query(int key) { return ldmae_tune_get(key); }
 extern "C" int ldmae_tune(int key, int value) {
-  if (key < 0 || key >= 16) LDMAE_FAIL(LDMAE_ERR_INVALID, "tune: key %d out of range", key);
+  if (key < 0 || key >= 32) LDMAE_FAIL(LDMAE_ERR_INVALID, "tune: key %d out of range", key);
   g_tune[key] = value;
   return LDMAE_OK;
 }

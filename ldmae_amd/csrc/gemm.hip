@@ -55,13 +55,22 @@ __global__ __launch_bounds__(512) void gemm_nt_persist_kernel(const bf16* __rest
   const int first = persistent ? xcd * rbx * (int)tiles_n + slot : (int)xcd_remap(blockIdx.x, gridDim.x);
   const int tend = persistent ? min(ntiles, (xcd + 1) * rbx * (int)tiles_n) : ntiles;
   const int tstride = persistent ? per_xcd : ntiles;
+  const int cgrp = delay >> 16;                 // (diagnostic knob, see set_tile)
+  delay &= 0xffff;
   if (delay > 0 && (slot & 1) && persistent)
     for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(127);
 
   const bf16* src[PPW];
   int m0 = 0, n0 = 0;
+  // column-group walk (diagnostic A/B, tune key 16 = g, passed in the high bits of `delay`): an XCD takes its tiles g column tiles at a time
+  // over ALL its row-blocks instead of all column tiles of one row-block after the other -- fewer B-tile refetches per round, more A refetches
   auto set_tile = [&](int t) {
     m0 = (t / tiles_n) * BM; n0 = (t % tiles_n) * BN;
+    if (persistent && cgrp > 0 && tiles_n % cgrp == 0) {
+      const int rb0 = xcd * rbx, rbe = min(rbx, (M + BM - 1) / BM - rb0), u = t - rb0 * (int)tiles_n;
+      const int grp = u / (rbe * cgrp), v = u % (rbe * cgrp);
+      m0 = (rb0 + v / cgrp) * BM; n0 = (grp * cgrp + v % cgrp) * BN;
+    }
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int piece = wave * PPW + i;
@@ -737,7 +746,7 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
 #define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048)
 #define PERS_GO(...)                                                                                                             \
   hipLaunchKernelGGL((gemm_nt_persist_kernel<__VA_ARGS__>), dim3(pgrid), dim3(512), lds + 2048, st, (const bf16*)A, (const bf16*)B, \
-                     M, N, K, lda, ldb, e, ntiles, ldmae_tune_get(5), (unsigned long long*)g_nt_stamps)
+                     M, N, K, lda, ldb, e, ntiles, ldmae_tune_get(5) | (ldmae_tune_get(16) << 16), (unsigned long long*)g_nt_stamps)
   // tune key 14 = 1 (diagnostic build only): 4-deep ring, 128 KiB, strips aliased onto it, the SwiGLU-bwd scratch behind it (160 KiB in all).
   // Measured neutral (profiles/r04_ring4_ab.txt: block total 8.158 -> 8.118 ms): the L2 read latency seen by the CU is ~360 cycles
   // (TCP_TCC_READ_REQ_LATENCY / READ_REQ, profiles/r04_pmc_ta.md), far inside what two stages in flight cover.
