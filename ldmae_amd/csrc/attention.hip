@@ -40,10 +40,13 @@ template <int HD> __device__ __forceinline__ void tile_inv(int off, int& row, in
 // columns add 0 to every score, zero v / dO columns produce output columns that are never stored.  Padded 16-B chunks of an
 // LDS tile are fetched from this 16 zero bytes (the DMA source address is per lane).
 __device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+// 1.0 (bf16) in the first of eight columns: as the first PADDED chunk of a V row it makes column HD of the V image a column of ones, and
+// the P.V product then delivers the softmax row sums in accumulator row HD of the (padded) output -- for free, on the matrix pipe
+__device__ __attribute__((aligned(16))) unsigned g_one16[4] = {0x00003F80u, 0u, 0u, 0u};
 constexpr int hd_pad(int hd) { return (hd + 31) / 32 * 32; }
 
 // stage a [ROWS][HD] bf16 tile (global row stride ld elements) into the [ROWS][HDP] LDS image with global_load_lds; 256 threads
-template <int HD, int ROWS>
+template <int HD, int ROWS, bool ONES = false>      // ONES: the first padded chunk of every row comes from g_one16 (the forward kernel's V tile)
 __device__ __forceinline__ void stage_tile(const bf16* __restrict__ g, long ld, int row_limit, char* lds, int wave, int lane) {
   constexpr int HDP = hd_pad(HD), PIECES = ROWS * HDP * 2 / 1024;
   static_assert(PIECES % 4 == 0 || PIECES == 2 || PIECES == 1, "tile too small");
@@ -54,34 +57,54 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ g, long ld, 
       int row, ch;
       tile_inv<HDP>(pi * 1024 + lane * 16, row, ch);
       row = min(row, row_limit);
-      const void* src = (HD == HDP || ch * 8 < HD) ? (const void*)(g + (long)row * ld + ch * 8) : (const void*)g_zero16;
+      const void* src = (HD == HDP || ch * 8 < HD) ? (const void*)(g + (long)row * ld + ch * 8)
+                                                    : ((ONES && ch * 8 == HD) ? (const void*)g_one16 : (const void*)g_zero16);
       glds16(src, lds + pi * 1024);
     }
   }
 }
-// The same staging with the addressing hoisted out of the tile loop (head dims that need no padding): per-lane byte offsets of this
-// wave's pieces, computed once; a tile is then (uniform base pointer, uniform LDS address) + one LDS-DMA instruction per piece.  Head
-// dims with padded chunks keep the per-lane-pointer form above (their zero source is not base-relative).
+// The same staging with the addressing hoisted out of the tile loop: per-lane byte offsets of this wave's pieces, computed once; a tile is
+// then (uniform base pointer, uniform LDS address) + one LDS-DMA instruction per piece.  Padded head dims (16, 72): the lanes whose chunk
+// lies past the true head dim take NO part in the DMA (the instruction runs under an EXEC mask: the hardware writes LDS bytes base + 16 *
+// lane for active lanes only), and their sixteen bytes of every LDS image are written ONCE, by `prefill`, before the first tile: zeros, or
+// (ONES) the ones column of the forward kernel's V tile.  Round 3 fetched those chunks from 16 zero bytes with a per-lane POINTER, which
+// put the whole address computation (~70 vector instructions per tile) back into the tile loop of kernels that are bound by vector issue.
+// Every piece has real lanes (checked at compile time for the instantiated head dims), so every wave still issues the same number of
+// DMA instructions per tile and the counted vmcnt waits hold.
 template <int HD, int ROWS> struct TileMap {
   static constexpr int HDP = hd_pad(HD), PIECES = ROWS * HDP * 2 / 1024, NPW = (PIECES + 3) / 4;
   unsigned voff[NPW];
+  unsigned real;                 // bit i: this lane's chunk of piece i lies inside the true head dim
   __device__ __forceinline__ void init(long ld, int wave, int lane) {
+    real = 0;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       int row, ch;
       tile_inv<HDP>((wave * NPW + i) * 1024 + lane * 16, row, ch);
       voff[i] = (unsigned)((row * ld + ch * 8) * 2);
+      if (ch * 8 < HD) real |= 1u << i;
     }
   }
-  // g: first element of the tile (wave-uniform); lds: the tile's LDS image; lds_addr: its LDS byte address (wave-uniform)
-  __device__ __forceinline__ void issue(const bf16* g, long ld, char* lds, unsigned lds_addr, int wave, int lane) const {
-    if constexpr (HD == HDP) {
+  // the padded chunks of one LDS tile image (call once per image, then lgkmcnt(0) + a barrier before the first read)
+  template <bool ONES = false> __device__ __forceinline__ void prefill(char* lds, int wave, int lane) const {
+    if constexpr (HD != HDP) {
 #pragma unroll
       for (int i = 0; i < NPW; ++i)
-        if (wave * NPW + i < PIECES) glds16_s(g, voff[i], lds_addr + (wave * NPW + i) * 1024);
-    } else {
-      stage_tile<HD, ROWS>(g, ld, ROWS - 1, lds, wave, lane);
+        if (wave * NPW + i < PIECES && !((real >> i) & 1u)) {
+          int row, ch;
+          tile_inv<HDP>((wave * NPW + i) * 1024 + lane * 16, row, ch);
+          *(uint4*)(lds + (wave * NPW + i) * 1024 + lane * 16) = make_uint4((ONES && ch * 8 == HD) ? 0x00003F80u : 0u, 0u, 0u, 0u);
+        }
     }
+  }
+  // g: first element of the tile (wave-uniform); lds_addr: LDS byte address of the tile's image (wave-uniform)
+  __device__ __forceinline__ void issue(const bf16* g, long, char*, unsigned lds_addr, int wave, int) const {
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+      if (wave * NPW + i < PIECES) {
+        if constexpr (HD == HDP) glds16_s(g, voff[i], lds_addr + (wave * NPW + i) * 1024);
+        else if ((real >> i) & 1u) glds16_s(g, voff[i], lds_addr + (wave * NPW + i) * 1024);       // EXEC-masked
+      }
   }
 };
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) { return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(void, p)); }
@@ -373,12 +396,23 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   TileMap<HD, 64> mk, mv;
   mk.init(ld, wave, lane);
   mv.init(ldv, wave, lane);
+  // padded head dims: the row sums come out of the P.V product (ones column in the V image, see g_one16) instead of 32 vector adds per tile
+  constexpr bool LSUM = HD != HDP;
+  constexpr int LROW = HD % 32, LREG = (LROW & 3) + 4 * (LROW >> 3), LHALF = (LROW >> 2) & 1;
+  if constexpr (HD != HDP) {
+#pragma unroll
+    for (int st = 0; st < ATT_STAGES; ++st) {
+      mk.prefill(smem + st * 2 * TB, wave, lane);
+      mv.template prefill<true>(smem + st * 2 * TB + TB, wave, lane);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): in LDS before this wave reaches the first tile barrier
+  }
   const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int kt) {
     const int so = (kt % ATT_STAGES) * 2 * TB;
     if (ragged && kt == nt - 1) {          // same number of LDS-DMA instructions per wave as the hoisted form: the vmcnt counts hold
       stage_tile<HD, 64>(kp + (size_t)kt * 64 * ld, ld, N - 1 - kt * 64, smem + so, wave, lane);
-      stage_tile<HD, 64>(vp + (size_t)kt * 64 * ldv, ldv, N - 1 - kt * 64, smem + so + TB, wave, lane);
+      stage_tile<HD, 64, LSUM>(vp + (size_t)kt * 64 * ldv, ldv, N - 1 - kt * 64, smem + so + TB, wave, lane);
       return;
     }
     mk.issue(kp + (size_t)kt * 64 * ld, ld, smem + so, lds0 + so, wave, lane);
@@ -451,7 +485,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) { const float p = EXP2(s[kb][t]); s[kb][t] = p; rs += p; }
+      for (int t = 0; t < 16; ++t) { const float p = EXP2(s[kb][t]); s[kb][t] = p; if constexpr (!LSUM) rs += p; }
     l += rs;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -468,7 +502,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     if (kt + 1 < nt) body(IC<1>{}, kt + 1);
     if (kt + 2 < nt) body(IC<2>{}, kt + 2);
   }
-  l += __shfl_xor(l, 32, 64);
+  if constexpr (LSUM) l = __shfl(oacc[HD / 32][LREG], (lane & 31) + 32 * LHALF, 64);      // row HD of O^T = sum over the keys of P (as rounded to bf16)
+  else l += __shfl_xor(l, 32, 64);
   __syncthreads();                                   // every wave is past its last K/V read: the ring becomes store scratch
   if (!active) return;
   const float inv = 1.f / l;
@@ -540,6 +575,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   TileMap<HD, 64> mq, mo;
   mq.init(ld, wave, lane);
   mo.init(dold, wave, lane);
+  if constexpr (HD != HDP) {                   // zero padding of every Q / dO image, once (TileMap)
+#pragma unroll
+    for (int st = 0; st < ATT_STAGES; ++st) { mq.prefill(smem + st * BUF, wave, lane); mo.prefill(smem + st * BUF + TB, wave, lane); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
   const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int qt) {
     const int so = (qt % ATT_STAGES) * BUF;
@@ -686,6 +726,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   TileMap<HD, 64> mk, mv;
   mk.init(ld, wave, lane);
   mv.init(ldv, wave, lane);
+  if constexpr (HD != HDP) {                   // zero padding of every K / V image, once (TileMap)
+#pragma unroll
+    for (int st = 0; st < ATT_STAGES; ++st) { mk.prefill(smem + st * 2 * TB, wave, lane); mv.prefill(smem + st * 2 * TB + TB, wave, lane); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
   const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int kt) {
     const int so = (kt % ATT_STAGES) * 2 * TB;

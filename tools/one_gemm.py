@@ -21,6 +21,11 @@ elif kind == "tn":
     b = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     for _ in range(3):
         ops.gemm_tn(a, b)
+elif kind == "attn16":        # VMAE attention forward at 1024 tokens: packed qkv, 12 heads of 16 (the decoder / _encode shape)
+    B, H, NN, hd = 256, 12, 1024, 16
+    qkv = torch.randn(B * NN, 3 * H * hd, device="cuda", generator=g).to(torch.bfloat16)
+    for _ in range(3):
+        ops.attention_fwd_qkv(qkv, B, NN, H, hd, hd ** -0.5)
 elif kind == "vmae":          # the one-kernel VMAE encoder, 256 images (one workgroup per CU)
     from ldmae_amd.tokenizer import fused_encoder, models_mae
     m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).cuda().eval()
