@@ -311,26 +311,30 @@ __global__ void mod_partials_reduce_kernel(const float* __restrict__ P, int D, i
                                            const float* __restrict__ Pb = nullptr, float* __restrict__ dbb = nullptr) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (d >= D) return;
-  if (P) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int g = 0; g < gps; ++g) {
-      const float* p = P + ((size_t)b * gps + g) * 3 * D + d;
-      s0 += p[0]; s1 += p[D]; s2 += p[2 * D];
+  // The partials of a sample are added in their fixed order (bitwise equal to the stand-alone gate_bwd path), but LOADED eight at a time: the
+  // rolled loop had one load in flight per accumulator and the launch was a chain of dependent L2 round trips (29 us for 31 MB)
+  auto sum = [&](const float* p, size_t stride) {
+    float s = 0.f;
+    int g = 0;
+    for (; g + 8 <= gps; g += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(g + j) * stride];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
     }
+    for (; g < gps; ++g) s += p[(size_t)g * stride];
+    return s;
+  };
+  if (P) {
+    const float* p = P + (size_t)b * gps * 3 * D + d;
+    const float s0 = sum(p, (size_t)3 * D), s1 = sum(p + D, (size_t)3 * D), s2 = sum(p + 2 * D, (size_t)3 * D);
     if (dshift) dshift[(size_t)b * dmod_ld + d] = s0;
     if (dscale) dscale[(size_t)b * dmod_ld + d] = s1;
     dwb[(size_t)b * D + d] = s2;
   }
-  if (Pg) {
-    float s = 0.f;
-    for (int g = 0; g < gps; ++g) s += Pg[((size_t)b * gps + g) * D + d];
-    dgate[(size_t)b * dgate_ld + d] = s;
-  }
-  if (Pb) {
-    float s = 0.f;
-    for (int g = 0; g < gps; ++g) s += Pb[((size_t)b * gps + g) * D + d];
-    dbb[(size_t)b * D + d] = s;
-  }
+  if (Pg) dgate[(size_t)b * dgate_ld + d] = sum(Pg + (size_t)b * gps * D + d, (size_t)D);
+  if (Pb) dbb[(size_t)b * D + d] = sum(Pb + (size_t)b * gps * D + d, (size_t)D);
 }
 
 #define DISPATCH_NCH(D, CALL)                                   \
