@@ -259,23 +259,15 @@ __device__ __forceinline__ void qk_prefetch(QkPref<HD>& p, const QkNormBwd& a, i
     p.x[it] = *(const bf16x8*)(a.qkv + (((size_t)b * N + n0 + row) * 3 + which) * H * HD + (size_t)hh * HD + ch * 8);
   }
 }
-// aw / ab: this wave's column sums (norm-weight gradient, bias gradient) for columns ch*8 .. +7, valid on lanes < CPR
-template <int HD>
-__device__ __forceinline__ void qknorm_rows_bwd(const f32x16 (&acc)[HD / 32], float mul, char* lds_wave, int lane, const QkNormBwd& a, int which,
-                                                int b, int hh, int H, int N, int n0, const QkPref<HD>& pf, float (&aw)[8], float (&ab)[8]) {
+// The row math of the fused QK-norm / RoPE backward: lane = (row, 16-B chunk) of a wave's 32 rows, `grad(it)` = the lane's 8 incoming
+// gradients (already rounded to bf16) of iteration `it`.  aw / ab: this wave's column sums (norm-weight gradient, bias gradient) for
+// columns ch*8 .. +7, valid on lanes < CPR
+template <int HD, typename GRAD>
+__device__ __forceinline__ void qknorm_rows_math(GRAD&& grad, int lane, const QkNormBwd& a, int which, int b, int hh, int H, int N, int n0,
+                                                 const QkPref<HD>& pf, float (&aw)[8], float (&ab)[8]) {
   static_assert(HD == 64 || HD == 128, "fused QK-norm backward: 8 or 16 chunks per row");
-  constexpr int PITCH = HD * 2 + 16, CPR = HD / 8, NIT = 32 * CPR / 64;
-  const int r = lane & 31, h = lane >> 5;
+  constexpr int CPR = HD / 8, NIT = 32 * CPR / 64;
   const int ch = lane % CPR;                      // 64 % CPR == 0: a lane keeps its chunk column in every iteration
-#pragma unroll
-  for (int d = 0; d < HD / 32; ++d)
-#pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-      bf16x4 w;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = (bf16)(acc[d][4 * t4 + j] * mul);
-      *(bf16x4*)(lds_wave + r * PITCH + (d * 32 + 8 * t4 + 4 * h) * 2) = w;
-    }
   const float* wsrc = (which ? a.wk : a.wq) + ch * 8;
   float w8[8];
 #pragma unroll
@@ -283,7 +275,7 @@ __device__ __forceinline__ void qknorm_rows_bwd(const f32x16 (&acc)[HD / 32], fl
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = (it * 64 + lane) / CPR, n = n0 + row;
-    const bf16x8 gv = *(const bf16x8*)(lds_wave + row * PITCH + ch * 16);
+    const bf16x8 gv = grad(it);
     const size_t so = (((size_t)b * N + n) * 3 + which) * H * HD + (size_t)hh * HD + ch * 8;
     const float c8[8] = {pf.cs[it][0].x, pf.cs[it][0].y, pf.cs[it][0].z, pf.cs[it][0].w, pf.cs[it][1].x, pf.cs[it][1].y, pf.cs[it][1].z, pf.cs[it][1].w};
     const float s8[8] = {pf.sn[it][0].x, pf.sn[it][0].y, pf.sn[it][0].z, pf.sn[it][0].w, pf.sn[it][1].x, pf.sn[it][1].y, pf.sn[it][1].z, pf.sn[it][1].w};
@@ -308,6 +300,24 @@ __device__ __forceinline__ void qknorm_rows_bwd(const f32x16 (&acc)[HD / 32], fl
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) { aw[j] = col_sum<CPR>(aw[j]); ab[j] = col_sum<CPR>(ab[j]); }
+}
+// the dq (dk) tile held as (result)^T accumulators: through the wave's bf16 row image (as store_rows_t), then the row math
+template <int HD>
+__device__ __forceinline__ void qknorm_rows_bwd(const f32x16 (&acc)[HD / 32], float mul, char* lds_wave, int lane, const QkNormBwd& a, int which,
+                                                int b, int hh, int H, int N, int n0, const QkPref<HD>& pf, float (&aw)[8], float (&ab)[8]) {
+  constexpr int PITCH = HD * 2 + 16, CPR = HD / 8;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      bf16x4 w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (bf16)(acc[d][4 * t4 + j] * mul);
+      *(bf16x4*)(lds_wave + r * PITCH + (d * 32 + 8 * t4 + 4 * h) * 2) = w;
+    }
+  qknorm_rows_math<HD>([&](int it) { return *(const bf16x8*)(lds_wave + ((it * 64 + lane) / CPR) * PITCH + (lane % CPR) * 16); },
+                       lane, a, which, b, hh, H, N, n0, pf, aw, ab);
 }
 // store_rows_t that also returns the column sums of the rows AS STORED (the v part of the qkv bias gradient): ab, valid on lanes < CPR
 template <int HD>
@@ -805,6 +815,235 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   }
 }
 
+#ifdef LDMAE_DIAG
+// ================================================================================================ backward in ONE pass, bf16
+// DIAGNOSTIC BUILD ONLY (tune key 17 = 1; A/B and ablations: tools/bench_attn.py --fused, profiles/r04_attn_onepass_ab.txt).  Built to
+// settle the question the two-kernel backward leaves open -- it executes 7 products for the 5 the backward has -- and it LOSES on this
+// shape: 4.41 ms against 1.74 + 1.35 ms.  Without its dQ stores / atomics the kernel runs 2.38 ms (the two saved products are worth
+// 0.7 ms), but the dQ sum over the N / 128 key blocks is 3.2 GB of f32 adds per layer at bs 256: float atomics execute at the memory
+// side at ~1.3 TB/s chip-wide (MI355X_MICROARCH 'Global float atomics'; measured here: +2.0 ms), and every store-based alternative
+// (f32 read-modify-write by the owning wave, bf16 slabs + a reduce pass) moves at least as many bytes through the fabric, because stores
+// never stay in L2.  With 256 keys per workgroup the sum still costs >= 1 ms -- more than the 0.7 ms the products save.
+// Shape: (LightningDiT block shape: hd 64, N a multiple of 128, QK-norm / RoPE backward fused.)  The two-pass form executes 7 products for the 5 the
+// backward has (S and dP are formed in both kernels).  Here a workgroup owns one (batch, head) and walks its key blocks of 128 (wave = 32 keys,
+// dK / dV stationary in registers, as in the dK/dV kernel); for every 64-query tile the dS block [128 keys][64 queries] goes through LDS once
+// (bf16, the dual-use image: written by rows, read transposed) and each wave forms one 32 x 32 block of dQ[q, d] = dS[q, :] . K[:, d] over all
+// 128 keys, with its K^T fragments stationary in registers.  dQ is accumulated in an f32 scratch [B*H][N][64]: plain stores in the first
+// key block, f32 atomic adds at L2 in the others -- every element is only ever touched by ONE wave (same (tile, block) -> same wave in every
+// key block), in program order, so the sum order is fixed and the result bitwise reproducible.  attn_dq_finish_kernel then runs the
+// QK-norm / RoPE backward on the finished rows.  -delta / -lse*log2(e) come from attn_rowc_kernel (the dQ kernel that used to publish them is gone).
+template <int PPW> __device__ __forceinline__ void onepass_wait(int ahead, int batches) {
+  // in flight behind the stage that must have landed: `ahead` later stages (PPW DMA pieces each) and `batches` x 16 dQ stores / atomics
+  if (ahead) {
+    if (batches >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 32) : "memory");
+    else if (batches == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 16) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+  } else {
+    if (batches >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (batches == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+template <int HD, int DBG = 0>       // DBG (diagnostic build, timing only): 1 = no dQ stores / atomics, 2 = no dQ product and no second barrier, 3 = no dS image either
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_onepass_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                                    const bf16* __restrict__ dO, const float* __restrict__ ROWC, long rc_stride,
+                                                                    bf16* __restrict__ dV, float* __restrict__ DQ,
+                                                                    int H, int N, float scale, QkvLayout L, QkvLayout Lv, QkNormBwd qn) {
+  static_assert(HD == 64, "one-pass backward: head dim 64");
+  constexpr int KS = HD / 16, DB = HD / 32, TB = 64 * HD * 2, BUF = 2 * TB + 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [STAGES][Q tile | dO tile | -lse2[64] -delta[64] scratch[128]] | dS image [128][64]
+  char* const dsimg = smem + ATT_STAGES * BUF;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+  const float c = scale * 1.4426950408889634f;
+  const int kblocks = N / 128, nt = N / 64;
+  const int bh = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = bh / H, hh = bh % H;
+  const size_t hb = (size_t)b * L.sb + (size_t)hh * L.sh, hbv = (size_t)b * Lv.sb + (size_t)hh * Lv.sh;
+  const long ld = L.ld;
+  const bf16* qp = Q + hb;
+  const bf16* dop = dO + ((size_t)b * N * H + hh) * HD;     // row stride H*HD
+  const long dold = (long)H * HD;
+  constexpr int PPW = 2 * (TB / 1024) / 4 + 1;
+  const float* rowc = ROWC + (size_t)bh * N + ((wave & 1) ? 0 : rc_stride);     // wave 0/2: -lse2, wave 1/3: -delta
+  TileMap<HD, 64> mq, mo;
+  mq.init(ld, wave, lane);
+  mo.init(dold, wave, lane);
+  const unsigned lds0 = lds_addr_of(smem);
+  auto stage = [&](int qt) {
+    const int so = (qt % ATT_STAGES) * BUF;
+    mq.issue(qp + (size_t)qt * 64 * ld, ld, smem + so, lds0 + so, wave, lane);
+    mo.issue(dop + (size_t)qt * 64 * dold, dold, smem + so + TB, lds0 + so + TB, wave, lane);
+    glds4_s(rowc + qt * 64, lane * 4, lds0 + so + 2 * TB + wave * 256);
+  };
+  // this lane's 8-byte slots in the dS image: row = its key, chunk (4 qb + c) of the row at dsw + 512 qb + wx[c] (tile_off, + the half h)
+  const int krow = wave * 32 + r;
+  char* const dsw = dsimg + (HD * 16) * (krow >> 3) + 64 * (krow & 7) + 8 * h;
+  int wx[4];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) wx[cc] = 16 * (cc ^ ((krow >> 2) & 3));
+  const int qbi = wave >> 1, dbi = wave & 1;       // this wave's block of the tile's dQ: queries 32 qbi.., columns 32 dbi..
+  // dQ scratch: element t of the block is row acc_row(t, h) = (t & 3) + 8 (t >> 2) + 4 h, this lane's column is 32 dbi + r
+  float* const dqw = DQ + ((size_t)bh * N + qbi * 32 + 4 * h) * HD + dbi * 32 + r;
+
+  for (int kb = 0; kb < kblocks; ++kb) {
+    const int k0 = kb * 128 + wave * 32;
+    if (kb) __syncthreads();                       // the epilogue's scratch (and its column-sum rows) -> ring
+    // the key block's 128 rows into the first ring stage (two 64-row images), for the transposed fragments of the dQ product
+    stage_tile<HD, 64>(K + hb + (size_t)(kb * 128) * ld, ld, 63, smem, wave, lane);
+    stage_tile<HD, 64>(K + hb + (size_t)(kb * 128 + 64) * ld, ld, 63, smem + TB, wave, lane);
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[ks] = frag_scale(gfrag<HD>(K + hb + (size_t)(k0 + r) * ld, ks * 16 + 8 * h), c);
+      vf[ks] = gfrag<HD>(V + hbv + (size_t)(k0 + r) * Lv.ld, ks * 16 + 8 * h);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0), visible to the compiler (see the dK/dV kernel)
+    __syncthreads();
+    bf16x8 kT[8];                                  // K^T fragments: keys 16 s .. 16 s + 15 of the block x this wave's 32 columns
+#pragma unroll
+    for (int s = 0; s < 8; ++s) kT[s] = frag_tr<HD>(smem + (s >> 2) * TB, 16 * (s & 3), dbi * 32, lane);
+    __syncthreads();                               // every wave has its fragments: the ring may overwrite the images
+    f32x16 dkacc[DB], dvacc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) { dkacc[d] = splat16(0.f); dvacc[d] = splat16(0.f); }
+#pragma unroll
+    for (int st = 0; st < ATT_STAGES - 1; ++st) stage(st);
+    auto body = [&](auto ST, int qt) {
+      constexpr int st = decltype(ST)::value;
+      onepass_wait<PPW>(qt + 1 < nt ? 1 : 0, DBG ? 0 : min(qt, 2));
+      __builtin_amdgcn_s_barrier();
+      if (qt + ATT_STAGES - 1 < nt) stage(qt + ATT_STAGES - 1);
+      const char* Qt = smem + st * BUF;
+      const char* dOt = Qt + TB;
+      const float* nl = (const float*)(Qt + 2 * TB);
+      const float* nd = nl + 64;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {              // accumulator element 4g+j <-> query row qb*32 + 8g + 4h + j
+          const f32x4 a = *(const f32x4*)(nl + qb * 32 + 8 * g + 4 * h), e = *(const f32x4*)(nd + qb * 32 + 8 * g + 4 * h);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s[4 * g + j] = a[j]; dp[4 * g + j] = e[j]; }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = MFMA_BF16(frag_row<HD>(Qt, qb * 32, ks, lane), kf[ks], s);
+          dp = MFMA_BF16(frag_row<HD>(dOt, qb * 32, ks, lane), vf[ks], dp);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float p = EXP2(s[t]);
+          s[t] = p;
+          dp[t] *= p;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = acc_frag(s, s2), dsf = acc_frag(dp, s2);
+          union { bf16x8 v; uint2 u[2]; } w;
+          w.v = dsf;                               // queries qb*32 + 16 s2 + 4h + 0..3 | + 8 + 4h + 0..3 of this lane's key
+          if (DBG < 3) {
+            *(uint2*)(dsw + 512 * qb + wx[2 * s2]) = w.u[0];
+            *(uint2*)(dsw + 512 * qb + wx[2 * s2 + 1]) = w.u[1];
+          }
+#pragma unroll
+          for (int d = 0; d < DB; ++d) {
+            dvacc[d] = MFMA_BF16(frag_tr<HD>(dOt, qb * 32 + 16 * s2, d * 32, lane), pf, dvacc[d]);
+            dkacc[d] = MFMA_BF16(frag_tr<HD>(Qt, qb * 32 + 16 * s2, d * 32, lane), dsf, dkacc[d]);
+          }
+        }
+      }
+      if (DBG >= 2) return;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                // dS of all 128 keys is in LDS (the next tile's first barrier keeps it until every wave has read it)
+      f32x16 dq = splat16(0.f);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) dq = MFMA_BF16(frag_tr<HD>(dsimg, 16 * s, qbi * 32, lane), kT[s], dq);
+      float* const dst = dqw + (size_t)qt * 64 * HD;
+      if (DBG == 1) {
+        if (dq[0] + dq[5] + dq[10] + dq[15] == 123.456f) dst[0] = dq[3];      // keeps the product alive
+      } else if (kb == 0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dst[((t & 3) + 8 * (t >> 2)) * HD] = dq[t] * scale;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)(dst + ((t & 3) + 8 * (t >> 2)) * HD), dq[t] * scale);
+      }
+    };
+    for (int qt = 0; qt < nt; qt += ATT_STAGES) {
+      body(IC<0>{}, qt);
+      if (qt + 1 < nt) body(IC<1>{}, qt + 1);
+      if (qt + 2 < nt) body(IC<2>{}, qt + 2);
+    }
+    // dk -> k slot of dqkv through the QK-norm / RoPE backward; dv + its column sums (qkv bias gradient): as the dK/dV kernel
+    QkPref<HD> pf;
+    qk_prefetch<HD>(pf, qn, 1, b, hh, H, N, k0, lane);
+    __syncthreads();                               // ring -> store scratch
+    char* sw = smem + wave * 32 * (HD * 2 + 16);
+    float cs3[3][8];
+    qk_prefetch_cs<HD>(pf, qn, k0, lane);
+    qknorm_rows_bwd<HD>(dkacc, scale, sw, lane, qn, 1, b, hh, H, N, k0, pf, cs3[0], cs3[1]);
+    store_rows_t_colsum<HD>(dvacc, 1.f, sw, dV + hbv + (size_t)k0 * Lv.ld, Lv.ld, lane, cs3[2]);
+    const size_t blk = (size_t)b * kblocks + kb;
+    float* const dst[3] = {qn.Pw + (blk * H + hh) * (2 * HD) + HD, qn.Pb + blk * (3 * H * HD) + ((size_t)H + hh) * HD,
+                           qn.Pb + blk * (3 * H * HD) + ((size_t)2 * H + hh) * HD};
+    wg_colsums<HD, 3>(cs3, (float*)(smem + 4 * 32 * (HD * 2 + 16)), wave, lane, true, 4, dst);
+  }
+}
+
+// ROWC for the one-pass kernel: [0] = -delta = -rowsum(dO * O), [1] = -lse * log2(e); o / do token-major [B,N,H,hd], rows of ROWC head-major
+template <int HD>
+__global__ __launch_bounds__(256) void attn_rowc_kernel(const bf16* __restrict__ O, const bf16* __restrict__ dO, const float* __restrict__ LSE,
+                                                        float* __restrict__ ROWC, long rc_stride, int H, int N, long items) {
+  constexpr int LPR = HD / 8;                      // lanes per (b, n, h) row, 16 B each
+  const long it = ((long)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int sub = threadIdx.x % LPR;
+  if (it >= items) return;
+  const int hh = it % H, n = (it / H) % N;
+  const long b = it / ((long)H * N);
+  const bf16x8 o = *(const bf16x8*)(O + (size_t)it * HD + sub * 8), g = *(const bf16x8*)(dO + (size_t)it * HD + sub * 8);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += (float)g[j] * (float)o[j];
+  s = group_sum<LPR>(s);
+  if (sub == 0) {
+    const size_t dst = ((size_t)b * H + hh) * N + n;
+    ROWC[dst] = -s;
+    ROWC[rc_stride + dst] = -LSE[dst] * 1.4426950408889634f;
+  }
+}
+
+// dQ scratch (f32, already scaled) -> q slot of dqkv through the QK-norm / RoPE backward, + the per-block column sums (as the dQ kernel's epilogue)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_dq_finish_kernel(const float* __restrict__ DQ, int H, int N, QkNormBwd qn) {
+  constexpr int CPR = HD / 8, NIT = 32 * CPR / 64;
+  __shared__ float red[4 * 2 * HD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qblocks = N / 128;
+  const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks, q0 = qb * 128 + wave * 32;
+  const int b = bh / H, hh = bh % H;
+  QkPref<HD> pf;
+  qk_prefetch<HD>(pf, qn, 0, b, hh, H, N, q0, lane);
+  qk_prefetch_cs<HD>(pf, qn, q0, lane);
+  float4 g4[NIT][2];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const float* src = DQ + ((size_t)bh * N + q0 + (it * 64 + lane) / CPR) * HD + (lane % CPR) * 8;
+    g4[it][0] = *(const float4*)src; g4[it][1] = *(const float4*)(src + 4);
+  }
+  float cs2[2][8];
+  qknorm_rows_math<HD>([&](int it) {
+    bf16x8 v;
+    v[0] = (bf16)g4[it][0].x; v[1] = (bf16)g4[it][0].y; v[2] = (bf16)g4[it][0].z; v[3] = (bf16)g4[it][0].w;
+    v[4] = (bf16)g4[it][1].x; v[5] = (bf16)g4[it][1].y; v[6] = (bf16)g4[it][1].z; v[7] = (bf16)g4[it][1].w;
+    return v; }, lane, qn, 0, b, hh, H, N, q0, pf, cs2[0], cs2[1]);
+  const size_t blk = (size_t)b * qblocks + qb;
+  float* const dst[2] = {qn.Pw + (blk * H + hh) * (2 * HD), qn.Pb + blk * (3 * H * HD) + (size_t)hh * HD};
+  wg_colsums<HD, 2>(cs2, red, wave, lane, true, 4, dst);
+}
+#endif  // LDMAE_DIAG
+
 // ================================================================================================ f32 path (parity)
 // Tiles are f32 [rows][LD] with LD = HD + 1 (odd stride: conflict-free row reads); operands are single
 // floats: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31] per 32x32x2 step.
@@ -1175,10 +1414,17 @@ extern "C" int ldmae_attention_bwd_pv(int dtype, const void* q, const void* k, c
 // and the qkv bias gradient.  Replaces ldmae_attention_bwd_pv + ldmae_qknorm_rope_bwd for head dims 64 / 128.
 extern "C" long ldmae_colsum_workspace_bytes(int M, int N);
 extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, float beta, float* workspace, void* stream);
+// the diagnostic build's one-pass kernel: its shapes (f32 dQ scratch [B*H][N][hd] at the end of the workspace)
+#ifdef LDMAE_DIAG
+static bool attn_onepass_shape(int N, int hd) { return hd == 64 && N % 128 == 0; }
+#else
+static constexpr bool attn_onepass_shape(int, int) { return false; }
+#endif
 extern "C" long ldmae_attention_bwd_pv_qknorm_workspace_bytes(int B, int H, int N, int hd) {
   const long blk = (long)B * ((N + 127) / 128);
   const long cw = ldmae_colsum_workspace_bytes((int)(blk * H), 2 * hd), cb = ldmae_colsum_workspace_bytes((int)blk, 3 * H * hd);
-  return (2L * B * H * N + blk * H * 2 * hd + blk * 3 * H * hd + 2L * hd) * 4 + (cw > cb ? cw : cb);
+  const long cmax = ((cw > cb ? cw : cb) + 15) / 16 * 16;
+  return (2L * B * H * N + blk * H * 2 * hd + blk * 3 * H * hd + 2L * hd) * 4 + cmax + (attn_onepass_shape(N, hd) ? 4L * B * H * N * hd : 0);
 }
 extern "C" int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const void* k, const void* qkv, const void* o, const void* do_,
                                              const float* lse, const float* wq, const float* wk, const float* cos, const float* sin, float eps,
@@ -1201,6 +1447,20 @@ extern "C" int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const voi
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const bf16* v = (const bf16*)qkv + 2 * hw;
   bf16* dv = (bf16*)dqkv + 2 * hw;
+#ifdef LDMAE_DIAG
+  if (attn_onepass_shape(N, hd) && ldmae_tune_get(17) == 1) {
+    const long cw = ldmae_colsum_workspace_bytes((int)(blk * H), 2 * hd), cb = ldmae_colsum_workspace_bytes((int)blk, 3 * H * hd);
+    float* dqs = (float*)((char*)cws + ((cw > cb ? cw : cb) + 15) / 16 * 16);
+    constexpr int LDS1 = ATT_STAGES * (2 * 64 * 64 * 2 + 1024) + 128 * 64 * 2;
+    hipLaunchKernelGGL(attn_rowc_kernel<64>, dim3((unsigned)((items * 8 + 255) / 256)), dim3(256), 0, st, (const bf16*)o, (const bf16*)do_, lse, rowc, items, H, N, items);
+#define LOP(D) { hipFuncSetAttribute((const void*)attn_bwd_onepass_bf16_kernel<64, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1); \
+    hipLaunchKernelGGL((attn_bwd_onepass_bf16_kernel<64, D>), dim3((unsigned)B * H), dim3(256), LDS1, st, (const bf16*)q, (const bf16*)k, v, (const bf16*)do_, rowc, items, \
+                       dv, dqs, H, N, scale, hm, pk, qn); }
+    switch (ldmae_tune_get(18)) { case 1: LOP(1); break; case 2: LOP(2); break; case 3: LOP(3); break; default: LOP(0); }
+#undef LOP
+    hipLaunchKernelGGL(attn_dq_finish_kernel<64>, dim3(grid), dim3(256), 0, st, (const float*)dqs, H, N, qn);
+  } else
+#endif
 #define L(HD) { \
     hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
     hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \

@@ -9,7 +9,9 @@ extern "C" {
 /* kernel-variant selection for A/B measurements.  key 0: bf16 NT GEMM variant (1 / 2 = probe/gemm_w4.hip kernels), 1: TN fallback kernel,
  * 4: TN wave layout, 5: NT start delay, 7: per-K-step stamp build, 8: NT launch mode (2 = one tile per workgroup; the product library
  * takes this per call through LDMAE_EPI_TILE_LAUNCH), 9: TN split target, 10: row-kernel grid cap, 12: 1 = deferred-epilogue NT kernel (probe/gemm_nt_defer.hip), 13: its timing-only
- * ablations (1 no deferred work, 2 loads only, 3 loads + arithmetic), 14: 1 = 4-deep NT ring, 15: 1 = whole-line NT ring (probe/gemm_nt_wl.hip).
+ * ablations (1 no deferred work, 2 loads only, 3 loads + arithmetic), 14: 1 = 4-deep NT ring, 15: 1 = whole-line NT ring (probe/gemm_nt_wl.hip),
+ * 16: NT column-group tile walk (column tiles per group), 17: 1 = one-pass attention backward (attention.hip, hd 64, N % 128 == 0) instead of the
+ * dQ + dK/dV kernels, 18: its timing-only ablations (1 no dQ stores / atomics, 2 no dQ product, 3 no dS image).
  * 0 = shipped behaviour. */
 int ldmae_tune(int key, int value);
 int ldmae_tune_query(int key);

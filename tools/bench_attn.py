@@ -53,10 +53,45 @@ def main():
         def two_pass():
             dq, dk, dqkv = ops.attention_bwd_pv(q2, k2, qkv, o2, do, lse2, scale)
             return ops.qknorm_rope_bwd(dq, dk, None, qkv, wq, wk, cos, sin, B, N, H, hd, with_bias=True, dqkv=dqkv)
+        from ldmae_amd import _lib
+        lib = _lib.load()
+        diag = hasattr(lib, "ldmae_tune")           # diagnostic build: key 17 = 1 = the one-pass backward kernel instead of the two kernels (dQ, then dK/dV)
         for r in range(3):
             ta = timed(two_pass)
             tb = timed(lambda: ops.attention_bwd_pv_qknorm(q2, k2, qkv, o2, do, lse2, scale, wq, wk, cos, sin))
-            print(f"round {r}: attention_bwd_pv + qknorm_rope_bwd {ta:.3f} ms | attention_bwd_pv_qknorm {tb:.3f} ms")
+            line = f"round {r}: attention_bwd_pv + qknorm_rope_bwd {ta:.3f} ms | attention_bwd_pv_qknorm {tb:.3f} ms (two kernels)"
+            if diag:
+                lib.ldmae_tune(17, 1)
+                tc = timed(lambda: ops.attention_bwd_pv_qknorm(q2, k2, qkv, o2, do, lse2, scale, wq, wk, cos, sin))
+                lib.ldmae_tune(17, 0)
+                line += f" | {tc:.3f} ms (one pass: rowc + main + dq finish)"
+            print(line)
+        if diag:
+            lib.ldmae_tune(17, 1)
+            for dbg in (1, 2, 3):                   # timing-only ablations of the one-pass kernel (results are wrong)
+                lib.ldmae_tune(18, dbg)
+                td = timed(lambda: ops.attention_bwd_pv_qknorm(q2, k2, qkv, o2, do, lse2, scale, wq, wk, cos, sin))
+                print(f"one pass, ablation {dbg} (1 no dQ stores / atomics, 2 no dQ product / barrier, 3 no dS image): {td:.3f} ms")
+            lib.ldmae_tune(18, 0)
+            # the two forms against each other and run to run
+            a1 = ops.attention_bwd_pv_qknorm(q2, k2, qkv, o2, do, lse2, scale, wq, wk, cos, sin)
+            a2 = ops.attention_bwd_pv_qknorm(q2, k2, qkv, o2, do, lse2, scale, wq, wk, cos, sin)
+            lib.ldmae_tune(17, 0)
+            b1 = ops.attention_bwd_pv_qknorm(q2, k2, qkv, o2, do, lse2, scale, wq, wk, cos, sin)
+            print("one pass bitwise reproducible:", all(torch.equal(x, y) for x, y in zip(a1, a2)))
+            for name, x, y in zip(("dqkv", "dwq", "dwk", "dbias"), a1, b1):
+                print(f"  {name}: rel diff one pass vs two kernels {float((x.float() - y.float()).norm() / y.float().norm()):.3e}")
+            print("  dq / dk / dv slots differing elements:", [float((a1[0][:, :, i] != b1[0][:, :, i]).float().mean()) for i in range(3)])
+            # both against the f32 kernels (exact-f32 MFMA) on the first two images, from the same bf16 q / k / v / o / lse
+            n2 = 2
+            qf, kf = q2[:n2].float(), k2[:n2].float()
+            vf = qkv[:n2, :, 2].float().permute(0, 2, 1, 3).contiguous()
+            of, lf = ops.attention_fwd(qf, kf, vf, scale)
+            dqf, dkf, dvf = ops.attention_bwd(qf, kf, vf, of, do[:n2].float(), lf, scale)
+            ref = ops.qknorm_rope_bwd(dqf, dkf, dvf, qkv[:n2].float(), wq, wk, cos, sin, n2, N, H, hd)[0]
+            for name, x in (("one pass", a1[0]), ("two kernels", b1[0])):
+                print(f"  {name} vs the f32 kernels, per slot (dq, dk, dv):",
+                      [f"{float((x[:n2, :, i].float() - ref[:, :, i]).norm() / ref[:, :, i].norm()):.3e}" for i in range(3)])
     if args.ref:
         qq, kk, vv = (x.clone().requires_grad_(True) for x in (q, k, v))
         t = timed(lambda: torch.nn.functional.scaled_dot_product_attention(qq, kk, vv))
