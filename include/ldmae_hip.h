@@ -221,6 +221,14 @@ int ldmae_scatter_rows(const float* dout, const long long* ids, float* dx, int N
 long ldmae_vmae_encoder_blob_bytes(int nblocks);
 int ldmae_vmae_encoder_fwd(const float* x, float* out, const void* blob, int B, int tokens, int dim, int heads, int hidden, int nblocks,
                            float eps, void* stream);
+/* The same stack on sequences of SEVERAL whole 256-token tiles per image (tokens % 256 == 0; the docking encoder `_encode` runs all 1024
+ * patches: models_mae.py:819-833): the same blob, three launches per block -- LayerNorm + q|k|v of a tile (tokens on the lanes, weights
+ * through the LDS ring) -> ldmae_attention_fwd_qkv on the packed qkv -> proj + residual + LayerNorm + MLP + residual of a tile with the
+ * residual stream in registers.  workspace: ldmae_vmae_encoder_fwd_tiled_workspace_bytes(B, tokens) bytes, 16-B aligned (qkv, attention
+ * output, lse).  x may equal out. */
+long ldmae_vmae_encoder_fwd_tiled_workspace_bytes(int B, int tokens);
+int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const void* blob, void* workspace, int B, int tokens, int dim, int heads,
+                                 int hidden, int nblocks, float eps, void* stream);
 /* LayerNorm with affine (models_mae.py:163,171,369; eps 1e-6).  mean/rstd [M] saved. */
 int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w, const float* b, void* out, float* mean, float* rstd,
                         int M, int D, float eps, void* stream);

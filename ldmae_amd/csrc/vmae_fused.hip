@@ -57,17 +57,34 @@ __device__ __forceinline__ f32x16 zero16() {
 __device__ __forceinline__ float gelu_erf(float y) { return gelu_act<bf16>(y); }
 }  // namespace
 
-// x, out: [B, 256, 192] f32.  blob: nblk * 36 slots of SLOTB bytes (ldmae_amd/tokenizer/fused_encoder.py packs it; layout in the header).
-__global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, const char* __restrict__ blob,
-                                                               int nblk, float eps, float qscale) {
+// Sequences LONGER than one workgroup's 256 tokens (the docking encoder `_encode` runs all 1024 patches of an image, models_mae.py:819-833)
+// keep the same machinery -- tokens on the lanes, residual stream in registers, weights through the ring from the SAME blob -- but a block
+// becomes three launches, because every token needs every other tile's K and V:
+//   MODE 1 (per 256-token tile): LayerNorm -> q^T, k^T, v^T of the block (the blob's twelve attention steps), staged through LDS and
+//           written as whole 64-B segments into the packed token-major qkv [tokens][3][12][16] that the flash kernel reads
+//           (ldmae_attention_fwd_qkv: attention.hip, any N);
+//   MODE 2 (per tile): attention output rows -> operand fragments straight from global memory, proj (+ bias) into the residual stream,
+//           LayerNorm -> fc1 -> GELU -> fc2 exactly as MODE 0, x written back (or the closing LayerNorm after the last block).
+// Per block the activations that reach HBM are x (f32, read twice, written once), qkv and the attention output: 1.4 GB at 256 images
+// against 3.2 GB for the per-layer kernels, in 3 launches instead of 7.
+constexpr int STG_PITCH = 144;                                     // bytes per token row of the MODE 1 staging image (64 features + pad)
+constexpr int LDS_BYTES_QKV = NSLOT * SLOTB + VTOK * STG_PITCH;    // 143,360 B
+
+// MODE 0: x, out: [B, 256, 192] f32, nblk = number of blocks.  MODE 1 / 2: x, out [tiles * 256, 192] f32, nblk = INDEX of the block.
+// blob: 36 slots of SLOTB bytes per block (ldmae_amd/tokenizer/fused_encoder.py packs it; layout in the header).
+template <int MODE>
+__global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restrict__ x, float* __restrict__ out, const char* __restrict__ blob,
+                                                           int nblk, float eps, float qscale, bf16* __restrict__ qkv, const bf16* __restrict__ oatt, int last) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kv = smem + NSLOT * SLOTB;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
-  const int total = nblk * STEPS;
+  const int total = MODE == 0 ? nblk * STEPS : (MODE == 1 ? 12 : 30);
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(void, smem));
   const bool extra = wave < PIECES - 24;                            // waves 0, 1 carry the two vector pieces
+  // ring step g -> slot of the blob: MODE 1 walks the block's attention steps, MODE 2 the proj halves (odd attention steps) and the MLP
+  auto slot_of = [&](int g) { return MODE == 0 ? g : nblk * STEPS + (MODE == 1 ? g : (g < 6 ? 2 * g + 1 : g + 6)); };
   auto issue = [&](int g) {
-    const char* src = blob + (size_t)g * SLOTB;
+    const char* src = blob + (size_t)slot_of(g) * SLOTB;
     const unsigned dst = lds0 + (g % NSLOT) * SLOTB;
 #pragma unroll
     for (int i = 0; i < 3; ++i) glds16_s(src, (unsigned)((wave + 8 * i) * 1024 + lane * 16), dst + (wave + 8 * i) * 1024);
@@ -89,6 +106,19 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
       for (int g = 0; g < 4; ++g) {
         const float4 v = *(const float4*)(xr + 32 * d + 8 * g + 4 * h);
         xacc[d][4 * g] = v.x; xacc[d][4 * g + 1] = v.y; xacc[d][4 * g + 2] = v.z; xacc[d][4 * g + 3] = v.w;
+      }
+  }
+  bf16x8 of2[MODE == 2 ? 6 : 1][2];            // MODE 2: the attention output rows of this lane's token as proj operand fragments (k-order: see `of` below)
+  if constexpr (MODE == 2) {
+    const bf16* orow = oatt + ((size_t)blockIdx.x * VTOK + wave * 32 + r) * VD + 4 * h;
+#pragma unroll
+    for (int hp = 0; hp < 6; ++hp)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        union { bf16x8 v; bf16x4 q[2]; } u;
+        u.q[0] = *(const bf16x4*)(orow + (2 * hp + e) * 16);
+        u.q[1] = *(const bf16x4*)(orow + (2 * hp + e) * 16 + 8);
+        of2[hp][e] = u.v;
       }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);          // the x loads have landed (and with them the two prologue slots): no compiler-counted wait inside the loop
@@ -184,7 +214,15 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
   // tells that every wave is done with slot g - 1, which the DMA of slot g + 2 overwrites.  Returns this lane's fragment base in slot g.
   int g = 0;
   auto next_slot = [&]() -> const char* {
-    if (g + 1 < total) {
+    if constexpr (MODE == 1) {
+      // behind slot g's pieces in the (in-order) vector-memory queue: the qkv stores of step g - 2, the pieces of slot g + 1, the stores of
+      // step g - 1 (4 per thread after a q | k step, 2 after a v step: 6 per pair of steps)
+      if (g + 1 < total) {
+        if (g >= 2) { if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
+        else if (g == 1) { if (extra) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+        else { if (extra) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+      } else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (g + 1 < total) {
       if (extra) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -193,9 +231,73 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
     ++g;
     return slot;
   };
-  for (int blk = 0; blk < nblk; ++blk) {
-    // ================= attention branch: six pairs of heads, two ring steps each
+  if constexpr (MODE == 1) {
+    // ================= q | k | v of the block for this tile's 256 tokens -> packed qkv (natural feature order: the weight rows are not permuted)
+    char* const stg = kv;
+    auto stage_t = [&](const f32x16& a, int byteoff) {        // element 4g + j = feature 8g + 4h + j of the 32-row block, this lane's token
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        bf16x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (bf16)a[4 * gq + j];
+        *(bf16x4*)(stg + (wave * 32 + r) * STG_PITCH + byteoff + (8 * gq + 4 * h) * 2) = w;
+      }
+    };
+    bf16* const qrow = qkv + (size_t)blockIdx.x * VTOK * (3 * VD);
+    const char* slot0 = next_slot();
+    layernorm((const float*)(slot0 + 2 * PANEL), (const float*)(slot0 + 2 * PANEL) + VD, to_frags);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
     for (int hp = 0; hp < 6; ++hp) {
+      {
+        const char* slot = hp ? next_slot() : slot0;
+        const char* p0 = slot + lane * 16;
+        const char* p1 = p0 + PANEL;
+        const float* vec = (const float*)(slot + 2 * PANEL);
+        f32x16 qT = mm12(zero16(), p0, std::false_type{});
+        add_rows32(qT, vec + 384);
+        stage_t(qT, 0);
+        f32x16 kT = mm12(zero16(), p1, std::false_type{});
+        add_rows32(kT, vec + 416);
+        stage_t(kT, 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                          // 256 rows x (4 chunks of q | 4 of k): 64-B segments of the token's q and k slots
+          const int idx = i * 512 + threadIdx.x, row = idx >> 3, ch = idx & 7;
+          *(bf16x8*)(qrow + (size_t)row * (3 * VD) + (ch >> 2) * VD + hp * 32 + (ch & 3) * 8) = *(const bf16x8*)(stg + row * STG_PITCH + ch * 16);
+        }
+      }
+      {
+        const char* slot = next_slot();                        // (its barrier: every wave has read the q | k image)
+        const char* p0 = slot + lane * 16;
+        const float* vec = (const float*)(slot + 2 * PANEL);
+        f32x16 vT = mm12(zero16(), p0, std::false_type{});
+        add_rows32(vT, vec + 384);
+        stage_t(vT, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int idx = i * 512 + threadIdx.x, row = idx >> 2, ch = idx & 3;
+          *(bf16x8*)(qrow + (size_t)row * (3 * VD) + 2 * VD + hp * 32 + ch * 8) = *(const bf16x8*)(stg + row * STG_PITCH + ch * 16);
+        }
+      }
+    }
+    return;
+  }
+  for (int blk = 0; blk < (MODE == 0 ? nblk : 1); ++blk) {
+    // ================= attention branch: six pairs of heads, two ring steps each
+    if constexpr (MODE == 2) {
+      // the attention ran as its own launch: proj of its output rows, one pair of heads per ring step (the blob's odd attention steps)
+      for (int hp = 0; hp < 6; ++hp) {
+        const char* slot = next_slot();
+        const float* vec = (const float*)(slot + 2 * PANEL);
+        mm_out(slot + lane * 16 + PANEL, of2[hp][0], of2[hp][1]);
+        if (hp == 5) add_rowvec(vec);                          // + proj bias
+      }
+    }
+    for (int hp = 0; hp < (MODE == 0 ? 6 : 0); ++hp) {
       bf16x8 qf[2];                            // this wave's queries of the head pair (operand fragments, scale * log2(e) folded in)
       {
         // ---- step A: q^T and k^T of heads 2hp, 2hp+1 (panel rows = Wqkv rows 32hp.. and 192 + 32hp..)
@@ -336,6 +438,14 @@ __global__ __launch_bounds__(512) void vmae_encoder_fwd_kernel(const float* __re
   // closing LayerNorm (models_mae.py:369, 521): its weight / bias ride in the second-to-last slot, which nothing has overwritten
   const float* nv = (const float*)(smem + ((total - 2) % NSLOT) * SLOTB + 2 * PANEL);
   float* orow = out + ((size_t)blockIdx.x * VTOK + wave * 32 + r) * VD;
+  if (MODE == 2 && !last) {                    // not the last block: the residual stream goes back as it is
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *(float4*)(orow + 32 * d + 8 * g4 + 4 * h) = make_float4(xacc[d][4 * g4], xacc[d][4 * g4 + 1], xacc[d][4 * g4 + 2], xacc[d][4 * g4 + 3]);
+    return;
+  }
   layernorm(nv, nv + VD, [&](int d, int g, float4 y) { *(float4*)(orow + 32 * d + 8 * g + 4 * h) = y; });
 #if VF_TL
   if (lane == 0 && (wave == 0 || wave == 4)) {          // timing build only: the stamps overwrite the head of this wave's output rows
@@ -355,9 +465,45 @@ extern "C" int ldmae_vmae_encoder_fwd(const float* x, float* out, const void* bl
                 VTOK, VD, VH, VHID, tokens, dim, heads, hidden);
   LDMAE_REQUIRE(nblocks >= 1, "vmae_encoder_fwd: nblocks=%d", nblocks);
   LDMAE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)blob & 15) == 0, "vmae_encoder_fwd: pointers must be 16-B aligned");
-  hipFuncSetAttribute((const void*)vmae_encoder_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipFuncSetAttribute((const void*)vmae_encoder_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   const float qscale = 0.25f * 1.4426950408889634f;          // head_dim^-0.5 (models_mae.py:123) * log2(e)
-  hipLaunchKernelGGL(vmae_encoder_fwd_kernel, dim3(B), dim3(512), LDS_BYTES, as_stream(stream), x, out, (const char*)blob, nblocks, eps, qscale);
+  hipLaunchKernelGGL(vmae_encoder_kernel<0>, dim3(B), dim3(512), LDS_BYTES, as_stream(stream), x, out, (const char*)blob, nblocks, eps, qscale, (bf16*)nullptr,
+                     (const bf16*)nullptr, 1);
   LDMAE_CHECK_LAUNCH("vmae_encoder_fwd");
+  return LDMAE_OK;
+}
+
+// ---- the same encoder on sequences of several 256-token tiles (docking `_encode`: all 1024 patches): per block qkv kernel -> flash attention
+// on the packed qkv -> proj / MLP kernel.  workspace: qkv [B*tokens][576] bf16 | attention output [B*tokens][192] bf16 | lse [B][12][tokens] f32.
+extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream);
+extern "C" long ldmae_vmae_encoder_fwd_tiled_workspace_bytes(int B, int tokens) {
+  return (long)B * tokens * (3 * VD + VD) * 2 + (long)B * VH * tokens * 4;
+}
+extern "C" int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const void* blob, void* workspace, int B, int tokens, int dim, int heads,
+                                            int hidden, int nblocks, float eps, void* stream) {
+  LDMAE_REQUIRE(x && out && blob && workspace && B > 0, "vmae_encoder_fwd_tiled: null pointer or empty batch");
+  LDMAE_REQUIRE(tokens > 0 && tokens % VTOK == 0 && dim == VD && heads == VH && hidden == VHID,
+                "vmae_encoder_fwd_tiled: built for whole %d-token tiles of width %d, %d heads, hidden %d (got %d, %d, %d, %d): use the per-layer entry points",
+                VTOK, VD, VH, VHID, tokens, dim, heads, hidden);
+  LDMAE_REQUIRE(nblocks >= 1, "vmae_encoder_fwd_tiled: nblocks=%d", nblocks);
+  LDMAE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)blob & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+                "vmae_encoder_fwd_tiled: pointers must be 16-B aligned");
+  LDMAE_REQUIRE((long)B * tokens / VTOK < (1L << 31), "vmae_encoder_fwd_tiled: too many tiles");
+  hipFuncSetAttribute((const void*)vmae_encoder_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_QKV);
+  hipFuncSetAttribute((const void*)vmae_encoder_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  bf16* qkv = (bf16*)workspace;
+  bf16* oatt = qkv + (size_t)B * tokens * 3 * VD;
+  float* lse = (float*)(oatt + (size_t)B * tokens * VD);
+  const unsigned tiles = (unsigned)((long)B * tokens / VTOK);
+  for (int blk = 0; blk < nblocks; ++blk) {
+    const float* xin = blk == 0 ? x : out;                    // the residual stream lives in `out` from the first block on (a tile rewrites only its own rows)
+    hipLaunchKernelGGL(vmae_encoder_kernel<1>, dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), xin, (float*)nullptr, (const char*)blob, blk, eps, 0.f, qkv,
+                       (const bf16*)nullptr, 0);
+    LDMAE_CHECK_LAUNCH("vmae_encoder_fwd_tiled(qkv)");
+    if (int e = ldmae_attention_fwd_qkv(LDMAE_BF16, qkv, oatt, lse, B, VH, tokens, VD / VH, 0.25f, stream)) return e;      // head_dim^-0.5 (models_mae.py:123)
+    hipLaunchKernelGGL(vmae_encoder_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, as_stream(stream), xin, out, (const char*)blob, blk, eps, 0.f, (bf16*)nullptr,
+                       (const bf16*)oatt, blk == nblocks - 1 ? 1 : 0);
+    LDMAE_CHECK_LAUNCH("vmae_encoder_fwd_tiled(post)");
+  }
   return LDMAE_OK;
 }

@@ -78,15 +78,16 @@ def pack_encoder(blocks, final_norm) -> torch.Tensor:
     return blob
 
 
-def supported(model, tokens: int, dim: int) -> bool:
-    """The fused kernel covers exactly the shipped encoder geometry on a 256-token sequence (mask_ratio 0.75 of 1024 patches)."""
+def supported(model, tokens: int, dim: int, tiled: bool = False) -> bool:
+    """The fused kernel covers exactly the shipped encoder geometry on a 256-token sequence (mask_ratio 0.75 of 1024 patches); `tiled`:
+    the three-launches-per-block form, any whole number of 256-token tiles (the docking encoder on all 1024 patches)."""
     b0 = model.blocks[0]
 
     def packable(blk):          # _pack_block reads every bias: a model built with qkv_bias=False (or on another device / type) keeps the per-layer kernels
         ts = (blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
               blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias)
         return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in ts)
-    return (tokens == TOKENS and dim == DIM and b0.attn.num_heads == HEADS and b0.mlp.fc1.weight.shape[0] == HIDDEN and
+    return ((tokens % TOKENS == 0 and tokens > 0 if tiled else tokens == TOKENS) and dim == DIM and b0.attn.num_heads == HEADS and b0.mlp.fc1.weight.shape[0] == HIDDEN and
             isinstance(model.norm, torch.nn.LayerNorm) and model.norm.bias is not None and all(packable(blk) for blk in model.blocks) and
             all(abs(blk.norm1.eps - model.norm.eps) < 1e-12 and abs(blk.norm2.eps - model.norm.eps) < 1e-12 for blk in model.blocks))
 
@@ -112,3 +113,8 @@ def encoder_blob(model) -> torch.Tensor:
 def encoder_forward(model, x: torch.Tensor) -> torch.Tensor:
     """x [B, 256, 192] f32 (gathered kept tokens) -> LayerNorm(blocks(x)) [B, 256, 192] f32, one launch."""
     return ops.vmae_encoder_fwd(x, encoder_blob(model), len(model.blocks), DIM, HEADS, HIDDEN, model.norm.eps)
+
+
+def encoder_forward_tiled(model, x: torch.Tensor) -> torch.Tensor:
+    """x [B, k * 256, 192] f32 (every patch of the image) -> LayerNorm(blocks(x)), three launches per block from the same blob."""
+    return ops.vmae_encoder_fwd_tiled(x, encoder_blob(model), len(model.blocks), DIM, HEADS, HIDDEN, model.norm.eps)

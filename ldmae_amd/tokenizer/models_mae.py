@@ -495,8 +495,14 @@ class MaskedAutoencoderViT(nn.Module):
         dtype = _act_dtype(self.precision)
         with torch.autocast(device_type="cuda", enabled=False):
             x = self._embed(x, dtype)
-            x = self._run(self.blocks, x, dtype)
-            x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
+            if (self.fused_encoder and dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.dim() == 3 and
+                    fused_encoder.supported(self, x.shape[1], x.shape[2], tiled=True) and all(self._chain_ok(blk) for blk in self.blocks)):
+                # bf16 inference on the shipped geometry: per block three launches instead of seven, the residual stream of a 256-token tile
+                # in registers through proj / LayerNorm / MLP (csrc/vmae_fused.hip, MODE 1 / 2), the closing LayerNorm in the last of them
+                x = fused_encoder.encoder_forward_tiled(self, x.float())
+            else:
+                x = self._run(self.blocks, x, dtype)
+                x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
             x = _LinearFn.apply(x, self.to_latent.weight, self.to_latent.bias)
         g = self.latent_resolution
         return x.reshape(x.shape[0], g, g, -1).permute(0, 3, 1, 2)

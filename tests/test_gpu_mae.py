@@ -234,6 +234,22 @@ def test_fused_encoder_is_independent_of_the_batch_at_full_size():
             assert torch.equal(part, full[sl]), sl
 
 
+def test_tiled_encoder_is_independent_of_the_batch_at_full_size():
+    """The docking encoder (`_encode`: all 1024 patches) in bf16 at the bench size -- 256 images = 1024 tiles of 256 tokens through the
+    q|k|v and proj / MLP kernels of csrc/vmae_fused.hip and the flash kernel between them: an image's latent must equal, bit for bit, what
+    the same kernels give for that image alone / in a small batch."""
+    from ldmae_amd.tokenizer import models_mae
+    torch.manual_seed(1)
+    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.rand(256, 3, 256, 256, device="cuda", generator=g) * 2 - 1
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        full = m._encode(x)
+        assert full.shape[0] == 256 and torch.isfinite(full).all()
+        for sl in (slice(0, 1), slice(97, 102), slice(251, 256)):
+            assert torch.equal(m._encode(x[sl]), full[sl]), sl
+
+
 def test_vmae_direct_param_grads_equal_autograd_accumulation():
     """The pre-training driver's opt-in (set_direct_param_grads: the blocks add their twelve parameter gradients into the slab views
     themselves -- TN GEMM reduce with beta = 1, one multi_add for the vectors) gives the same gradient slab, bit for bit, as autograd's
@@ -350,6 +366,38 @@ def test_loss_scaler_protocol_skips_non_finite_steps():
     (lin(x).pow(2).mean() * sc.scale).backward()
     sc.step(opt)
     assert sc.scale == 1024.0                      # two clean steps: growth
+
+
+def test_tiled_encoder_kernels_match_per_layer_path(golden):
+    """`_encode` (models_mae.py:819-833: every patch, no masking) in bf16 through the tiled form of the fused encoder -- per block: q|k|v
+    kernel, flash attention, proj / MLP kernel with the residual stream in registers -- against the per-layer bf16 kernels and the f32 path on
+    the reference-pinned weights; under autograd and in f32 the per-layer kernels stay."""
+    from ldmae_amd.tokenizer import fused_encoder
+    cfg = omae.MAEConfig()
+    m = build({}, full_sd(cfg), 256)
+    imgs = det_randn("mae_img", (5, 3, 256, 256), 2).clamp(-1, 1).cuda()
+    calls = []
+    orig = fused_encoder.encoder_forward_tiled
+    fused_encoder.encoder_forward_tiled = lambda model, x: (calls.append(tuple(x.shape)), orig(model, x))[1]
+    try:
+        with torch.no_grad():
+            lat32 = m._encode(imgs)                                                          # f32: never the fused kernels
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                fused = m._encode(imgs)
+                m.fused_encoder = False
+                layered = m._encode(imgs)
+                m.fused_encoder = True
+                one = m._encode(imgs[3:4])
+        assert calls == [(5, 1024, 192), (1, 1024, 192)]
+        assert fused.shape == lat32.shape and fused.dtype == torch.float32
+        assert rel_err(fused.cpu(), lat32.cpu()) < 3e-2 and rel_err(layered.cpu(), lat32.cpu()) < 3e-2
+        assert rel_err(fused.cpu(), layered.cpu()) < 2e-2
+        assert torch.equal(one[0], fused[3])
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            lat_g = m._encode(imgs[:1])
+        assert lat_g.requires_grad and len(calls) == 2
+    finally:
+        fused_encoder.encoder_forward_tiled = orig
 
 
 def test_fused_encoder_kernel_matches_per_layer_path(golden):
