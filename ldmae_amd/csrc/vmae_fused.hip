@@ -65,8 +65,10 @@ __device__ __forceinline__ float gelu_erf(float y) { return gelu_act<bf16>(y); }
 //           (ldmae_attention_fwd_qkv: attention.hip, any N);
 //   MODE 2 (per tile): attention output rows -> operand fragments straight from global memory, proj (+ bias) into the residual stream,
 //           LayerNorm -> fc1 -> GELU -> fc2 exactly as MODE 0, x written back (or the closing LayerNorm after the last block).
-// Per block the activations that reach HBM are x (f32, read twice, written once), qkv and the attention output: 1.4 GB at 256 images
-// against 3.2 GB for the per-layer kernels, in 3 launches instead of 7.
+//   MODE 3 = MODE 2 followed, with the residual stream still in registers, by MODE 1 for the NEXT block (its twelve steps are simply the
+//           ring's next slots): per block one launch of it and one of the flash kernel; MODE 1 alone only opens the stack, MODE 2 closes it.
+// Per block the activations that reach HBM are x (f32, read once, written once), qkv and the attention output: 1.2 GB at 256 images
+// against 3.2 GB for the per-layer kernels, in 2 launches instead of 7.
 constexpr int STG_PITCH = 144;                                     // bytes per token row of the MODE 1 staging image (64 features + pad)
 constexpr int LDS_BYTES_QKV = NSLOT * SLOTB + VTOK * STG_PITCH;    // 143,360 B
 
@@ -78,11 +80,12 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kv = smem + NSLOT * SLOTB;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
-  const int total = MODE == 0 ? nblk * STEPS : (MODE == 1 ? 12 : 30);
+  const int total = MODE == 0 ? nblk * STEPS : (MODE == 1 ? 12 : (MODE == 2 ? 30 : 42));
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(void, smem));
   const bool extra = wave < PIECES - 24;                            // waves 0, 1 carry the two vector pieces
   // ring step g -> slot of the blob: MODE 1 walks the block's attention steps, MODE 2 the proj halves (odd attention steps) and the MLP
-  auto slot_of = [&](int g) { return MODE == 0 ? g : nblk * STEPS + (MODE == 1 ? g : (g < 6 ? 2 * g + 1 : g + 6)); };
+  // (MODE 3: then the next block's attention steps)
+  auto slot_of = [&](int g) { return MODE == 0 ? g : nblk * STEPS + (MODE == 1 ? g : (g < 6 ? 2 * g + 1 : g + 6)); };      // g + 6 >= 36: the next block
   auto issue = [&](int g) {
     const char* src = blob + (size_t)slot_of(g) * SLOTB;
     const unsigned dst = lds0 + (g % NSLOT) * SLOTB;
@@ -108,8 +111,8 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
         xacc[d][4 * g] = v.x; xacc[d][4 * g + 1] = v.y; xacc[d][4 * g + 2] = v.z; xacc[d][4 * g + 3] = v.w;
       }
   }
-  bf16x8 of2[MODE == 2 ? 6 : 1][2];            // MODE 2: the attention output rows of this lane's token as proj operand fragments (k-order: see `of` below)
-  if constexpr (MODE == 2) {
+  bf16x8 of2[MODE >= 2 ? 6 : 1][2];            // MODE 2 / 3: the attention output rows of this lane's token as proj operand fragments (k-order: see `of` below)
+  if constexpr (MODE >= 2) {
     const bf16* orow = oatt + ((size_t)blockIdx.x * VTOK + wave * 32 + r) * VD + 4 * h;
 #pragma unroll
     for (int hp = 0; hp < 6; ++hp)
@@ -214,12 +217,13 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
   // tells that every wave is done with slot g - 1, which the DMA of slot g + 2 overwrites.  Returns this lane's fragment base in slot g.
   int g = 0;
   auto next_slot = [&]() -> const char* {
-    if constexpr (MODE == 1) {
+    constexpr int Q0 = MODE == 3 ? 30 : 0;       // first q | k | v step of MODE 1 / 3
+    if (MODE == 1 || (MODE == 3 && g >= Q0)) {
       // behind slot g's pieces in the (in-order) vector-memory queue: the qkv stores of step g - 2, the pieces of slot g + 1, the stores of
       // step g - 1 (4 per thread after a q | k step, 2 after a v step: 6 per pair of steps)
       if (g + 1 < total) {
-        if (g >= 2) { if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
-        else if (g == 1) { if (extra) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+        if (g >= Q0 + 2) { if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
+        else if (g == Q0 + 1) { if (extra) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
         else { if (extra) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
       } else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else if (g + 1 < total) {
@@ -231,8 +235,8 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
     ++g;
     return slot;
   };
-  if constexpr (MODE == 1) {
-    // ================= q | k | v of the block for this tile's 256 tokens -> packed qkv (natural feature order: the weight rows are not permuted)
+  // ================= q | k | v of a block for this tile's 256 tokens -> packed qkv (natural feature order: the weight rows are not permuted)
+  auto qkv_phase = [&]() {
     char* const stg = kv;
     auto stage_t = [&](const f32x16& a, int byteoff) {        // element 4g + j = feature 8g + 4h + j of the 32-row block, this lane's token
 #pragma unroll
@@ -284,11 +288,11 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
         }
       }
     }
-    return;
-  }
+  };
+  if constexpr (MODE == 1) { qkv_phase(); return; }
   for (int blk = 0; blk < (MODE == 0 ? nblk : 1); ++blk) {
     // ================= attention branch: six pairs of heads, two ring steps each
-    if constexpr (MODE == 2) {
+    if constexpr (MODE >= 2) {
       // the attention ran as its own launch: proj of its output rows, one pair of heads per ring step (the blob's odd attention steps)
       for (int hp = 0; hp < 6; ++hp) {
         const char* slot = next_slot();
@@ -438,7 +442,8 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
   // closing LayerNorm (models_mae.py:369, 521): its weight / bias ride in the second-to-last slot, which nothing has overwritten
   const float* nv = (const float*)(smem + ((total - 2) % NSLOT) * SLOTB + 2 * PANEL);
   float* orow = out + ((size_t)blockIdx.x * VTOK + wave * 32 + r) * VD;
-  if (MODE == 2 && !last) {                    // not the last block: the residual stream goes back as it is
+  if constexpr (MODE == 3) qkv_phase();        // q | k | v of the next block while x is here
+  if (MODE == 3 || (MODE == 2 && !last)) {     // not the last block: the residual stream goes back as it is
 #pragma unroll
     for (int d = 0; d < 6; ++d)
 #pragma unroll
@@ -491,18 +496,23 @@ extern "C" int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const vo
   LDMAE_REQUIRE((long)B * tokens / VTOK < (1L << 31), "vmae_encoder_fwd_tiled: too many tiles");
   hipFuncSetAttribute((const void*)vmae_encoder_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_QKV);
   hipFuncSetAttribute((const void*)vmae_encoder_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipFuncSetAttribute((const void*)vmae_encoder_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_QKV);
   bf16* qkv = (bf16*)workspace;
   bf16* oatt = qkv + (size_t)B * tokens * 3 * VD;
   float* lse = (float*)(oatt + (size_t)B * tokens * VD);
   const unsigned tiles = (unsigned)((long)B * tokens / VTOK);
+  hipLaunchKernelGGL(vmae_encoder_kernel<1>, dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), x, (float*)nullptr, (const char*)blob, 0, eps, 0.f, qkv,
+                     (const bf16*)nullptr, 0);
+  LDMAE_CHECK_LAUNCH("vmae_encoder_fwd_tiled(qkv)");
   for (int blk = 0; blk < nblocks; ++blk) {
     const float* xin = blk == 0 ? x : out;                    // the residual stream lives in `out` from the first block on (a tile rewrites only its own rows)
-    hipLaunchKernelGGL(vmae_encoder_kernel<1>, dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), xin, (float*)nullptr, (const char*)blob, blk, eps, 0.f, qkv,
-                       (const bf16*)nullptr, 0);
-    LDMAE_CHECK_LAUNCH("vmae_encoder_fwd_tiled(qkv)");
     if (int e = ldmae_attention_fwd_qkv(LDMAE_BF16, qkv, oatt, lse, B, VH, tokens, VD / VH, 0.25f, stream)) return e;      // head_dim^-0.5 (models_mae.py:123)
-    hipLaunchKernelGGL(vmae_encoder_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, as_stream(stream), xin, out, (const char*)blob, blk, eps, 0.f, (bf16*)nullptr,
-                       (const bf16*)oatt, blk == nblocks - 1 ? 1 : 0);
+    if (blk + 1 < nblocks)      // proj / MLP of this block, then q | k | v of the next one (the attention has consumed this block's)
+      hipLaunchKernelGGL(vmae_encoder_kernel<3>, dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), xin, out, (const char*)blob, blk, eps, 0.f, qkv,
+                         (const bf16*)oatt, 0);
+    else
+      hipLaunchKernelGGL(vmae_encoder_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, as_stream(stream), xin, out, (const char*)blob, blk, eps, 0.f, (bf16*)nullptr,
+                         (const bf16*)oatt, 1);
     LDMAE_CHECK_LAUNCH("vmae_encoder_fwd_tiled(post)");
   }
   return LDMAE_OK;
