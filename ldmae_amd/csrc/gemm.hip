@@ -624,9 +624,10 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restric
       }
 }
 
-// sum the split-K partial slabs in fixed order (deterministic): out = beta*out + sum_s P[s]
-__global__ void splitk_reduce_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int splits, float beta) {
-  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+// sum the split-K partial slabs in fixed order (deterministic): out = beta*out + sum_s P[s].  `bid` of `nblk` workgroups of 256 threads.
+__device__ __forceinline__ void splitk_reduce_threads(const float* __restrict__ P, float* __restrict__ out, long n, int splits, float beta,
+                                                      unsigned bid, unsigned nblk) {
+  for (long i = ((long)bid * 256 + threadIdx.x) * 4; i < n; i += (long)nblk * 256 * 4) {
     float4 s = *(const float4*)(P + i);
     for (int k = 1; k < splits; ++k) {
       float4 t = *(const float4*)(P + (size_t)k * n + i);
@@ -639,13 +640,12 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, float* __restr
     *(float4*)(out + i) = s;
   }
 }
-
 // the same sum for MANY splits of a SMALL output (VMAE weight gradients: 192 x 192 outputs from up to 128 row splits): one wave per 4
 // adjacent outputs, lane l sums splits l, l + 64, ... and a butterfly folds the lane sums -- fixed order, so still deterministic; the
 // per-thread loop above left 36 workgroups walking 100 partial slabs one after the other (24 us, 197 times per VMAE step)
-__global__ __launch_bounds__(256) void splitk_reduce_wave_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int splits, float beta) {
+__device__ __forceinline__ void splitk_reduce_waves(const float* __restrict__ P, float* __restrict__ out, long n, int splits, float beta, unsigned bid) {
   const int lane = threadIdx.x & 63;
-  const long i = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  const long i = ((long)bid * 4 + (threadIdx.x >> 6)) * 4;
   if (i >= n) return;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int k = lane; k < splits; k += 64) {
@@ -661,14 +661,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_wave_kernel(const float* __
     *(float4*)(out + i) = s;
   }
 }
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int splits, float beta) {
+  splitk_reduce_threads(P, out, n, splits, beta, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void splitk_reduce_wave_kernel(const float* __restrict__ P, float* __restrict__ out, long n, int splits, float beta) {
+  splitk_reduce_waves(P, out, n, splits, beta, blockIdx.x);
+}
+// weight gradient AND bias gradient of one TN GEMM in one launch (they were two: ~200 launches of ~10 us per VMAE pre-training step): the
+// first g0 workgroups sum the first output, the rest the second, each in the form (w0 / w1: wave form) it would have had alone -- same bits
+struct ReducePart { const float* P; float* out; long n; int wave; };
+__global__ __launch_bounds__(256) void splitk_reduce_pair_kernel(ReducePart a, ReducePart b, unsigned g0, int splits, float beta) {
+  const bool first = blockIdx.x < g0;
+  const ReducePart& p = first ? a : b;
+  const unsigned bid = first ? blockIdx.x : blockIdx.x - g0, nblk = first ? g0 : gridDim.x - g0;
+  if (p.wave) splitk_reduce_waves(p.P, p.out, p.n, splits, beta, bid);
+  else splitk_reduce_threads(p.P, p.out, p.n, splits, beta, bid, nblk);
+}
+// (wave form for many splits only: with 28 splits of a 768 x 768 output it leaves half its lanes idle on 147K waves -- 40 us against 12)
+static bool reduce_wave_form(long n, int splits) { return splits >= 32 && n % 4 == 0 && n <= (1L << 18); }
+static unsigned reduce_grid(long n, int splits) {
+  return reduce_wave_form(n, splits) ? (unsigned)((n / 4 + 3) / 4) : (unsigned)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
+}
 static void splitk_reduce(const float* P, float* out, long n, int splits, float beta, hipStream_t st) {
-  // (many splits only: with 28 splits of a 768 x 768 output the wave form leaves half its lanes idle on 147K waves -- 40 us against 12)
-  if (splits >= 32 && n % 4 == 0 && n <= (1L << 18))
-    hipLaunchKernelGGL(splitk_reduce_wave_kernel, dim3((unsigned)((n / 4 + 3) / 4)), dim3(256), 0, st, P, out, n, splits, beta);
-  else {
-    const unsigned grid = (unsigned)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, P, out, n, splits, beta);
-  }
+  if (reduce_wave_form(n, splits)) hipLaunchKernelGGL(splitk_reduce_wave_kernel, dim3(reduce_grid(n, splits)), dim3(256), 0, st, P, out, n, splits, beta);
+  else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(reduce_grid(n, splits)), dim3(256), 0, st, P, out, n, splits, beta);
+}
+static void splitk_reduce_pair(const float* P, float* out, long n, const float* Pb, float* outb, long nb, int splits, float beta, hipStream_t st) {
+  const unsigned g0 = reduce_grid(n, splits), g1 = reduce_grid(nb, splits);
+  hipLaunchKernelGGL(splitk_reduce_pair_kernel, dim3(g0 + g1), dim3(256), 0, st, ReducePart{P, out, n, reduce_wave_form(n, splits) ? 1 : 0},
+                     ReducePart{Pb, outb, nb, reduce_wave_form(nb, splits) ? 1 : 0}, g0, splits, beta);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -911,8 +932,8 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   }
   LDMAE_CHECK_LAUNCH("gemm_tn");
   if (!direct) {
-    splitk_reduce(P, C, (long)N * K, splits, beta, st);
-    if (dbias && ring) splitk_reduce(Pb, dbias, (long)N, splits, beta, st);
+    if (dbias && ring) splitk_reduce_pair(P, C, (long)N * K, Pb, dbias, (long)N, splits, beta, st);
+    else splitk_reduce(P, C, (long)N * K, splits, beta, st);
     LDMAE_CHECK_LAUNCH("splitk_reduce");
   }
   if (dbias && !ring) {   // non-ring paths: separate column-sum pass (elementwise.hip), re-using the workspace

@@ -206,8 +206,12 @@ def test_bf16_calls_are_dispatched_to_the_bf16_kernels():
     assert c["nt_f32"] <= 12 and c["tn_f32"] <= 8, c                     # the latent / embedding / prediction Linears only
     m.eval().set_precision(torch.bfloat16)
     with torch.no_grad():
-        c = counted(lambda: m._encode(x))
+        c = counted(lambda: m._encode(x))            # whole 256-token tiles: the tiled fused kernels (no NT GEMM per block) around the bf16 flash kernel
+        assert c["attn_bf16"] == len(m.blocks) and c["attn_f32"] == 0 and c["nt_f32"] <= 2, c
+        m.fused_encoder = False
+        c = counted(lambda: m._encode(x))            # the per-layer kernels
         assert c["nt_bf16"] >= 4 * len(m.blocks) and c["attn_bf16"] == len(m.blocks) and c["attn_f32"] == 0 and c["nt_f32"] <= 2, c
+        m.fused_encoder = True
         z = torch.randn(8, 16, 16, 16, device="cuda")
         c = counted(lambda: m.decode(z))
         assert c["nt_bf16"] >= 4 * len(m.decoder_blocks) and c["attn_bf16"] == len(m.decoder_blocks) and c["attn_f32"] == 0 and c["nt_f32"] <= 4, c
