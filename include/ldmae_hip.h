@@ -155,6 +155,14 @@ int ldmae_attention_bwd_qkv(int dtype, const void* qkv, const void* o, const voi
  * ldmae_qknorm_rope_bwd(dv = NULL): v never gets a head-major copy. */
 int ldmae_attention_fwd_pv(int dtype, const void* q, const void* k, const void* qkv, void* o, float* lse, int B, int H, int N, int hd,
                            float scale, void* stream);
+/* The same with a STATIC softmax shift: score_bound = one float on the device, a proven upper bound of |q . k| * scale * log2(e) over all
+ * queries and keys.  Bounds up to 50 make the kernel skip the running maximum (exact: every exponent lies in [-2 bound, 0]; -8 % of the
+ * kernel at head_dim 64); larger ones fall back to the tracked form.  ldmae_qk_score_bound gives the bound for heads that went through
+ * QK-RMSNorm + RoPE (lightningdit.py:66-80) from the two norm weights alone: hd * max|wq| * max|wk| * scale * log2(e) * 1.02 (the RoPE
+ * tables must be rotations, cos^2 + sin^2 = 1, as models/pos_embed.py builds them). */
+int ldmae_attention_fwd_pv_bounded(int dtype, const void* q, const void* k, const void* qkv, void* o, float* lse, const float* score_bound,
+                                   int B, int H, int N, int hd, float scale, void* stream);
+int ldmae_qk_score_bound(const float* wq, const float* wk, int hd, float scale, float* out, void* stream);
 int ldmae_attention_bwd_pv(int dtype, const void* q, const void* k, const void* qkv, const void* o, const void* do_, const float* lse,
                            void* dq, void* dk, void* dqkv, float* delta, int B, int H, int N, int hd, float scale, void* stream);
 /* ldmae_attention_bwd_pv + ldmae_qknorm_rope_bwd in one (bf16, head_dim 64 / 128): the QK-RMSNorm / RoPE backward (lightningdit.py:70-75

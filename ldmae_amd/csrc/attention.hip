@@ -378,7 +378,8 @@ struct QkvLayout { long sb, sh, ld; };
 // moves in the (rare, wave-uniform) rescale branch, which shifts the tile's scores and refreshes nm; (iii) K / V tile addresses are scalar.
 template <int HD, bool RAGGED = false>      // RAGGED: N % 64 != 0 (its own instantiation: the masking costs the hot shapes no registers)
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
-                                                            bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L, QkvLayout Lv) {
+                                                            bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L, QkvLayout Lv,
+                                                            const float* __restrict__ SB) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   constexpr bool BATCH = HDP <= 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [STAGES][K tile | V tile]
@@ -417,6 +418,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): in LDS before this wave reaches the first tile barrier
   }
+  // A STATIC shift instead of the running maximum, when the caller can bound the scores (SB: one float on the device, an upper bound of
+  // |score * scale * log2(e)| over all queries and keys -- for the QK-normalised DiT heads it follows from the norm weights alone:
+  // ldmae_qk_score_bound).  With the shift bq every exponent s - bq lies in [-2 bq, 0]: no p overflows, and while 2 bq <= 100 none flushes
+  // to zero, so the softmax is exact without the per-tile 31-deep max chain, cross-half shuffle, ballot and rescale branch (a fifth of the
+  // loop's vector instructions: -8 % at head dim 64, -12 % at 16, profiles/r04_attn_static_shift.txt).  No bound, or one above 50: the
+  // tracked form below, as before.
+  const float bq = SB ? *SB : 0.f;
+  const bool stat = SB != nullptr && bq <= 50.f;       // wave- (and grid-) uniform
   const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int kt) {
     const int so = (kt % ATT_STAGES) * 2 * TB;
@@ -435,8 +444,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   // landed, so no compiler-counted wait for them ends up inside the tile loop, where -- the ring DMA being hidden in asm -- it
   // would drain the ring at every tile.  The prologue stages are in flight beside those loads, so this costs one round trip.
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  auto body = [&](auto ST, int kt) {
+  auto body = [&](auto ST, auto TRK, int kt) {
     constexpr int st = decltype(ST)::value;
+    constexpr bool track = decltype(TRK)::value != 0;
     ring_wait<PPW, ATT_STAGES>(min(ATT_STAGES - 2, nt - 1 - kt));
     __builtin_amdgcn_s_barrier();
     if (kt + ATT_STAGES - 1 < nt) stage(kt + ATT_STAGES - 1);
@@ -471,25 +481,27 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     }
     if (ragged && kt == nt - 1) { mask_rows_past(s[0], kt * 64, h, N); mask_rows_past(s[1], kt * 64 + 32, h, N); }
     // s = score * scale * log2(e) - ms
-    float mx = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-    for (int t = 1; t < 16; ++t) mx = fmaxf(mx, fmaxf(s[0][t], s[1][t]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const bool first = kt == 0;
-    if (first || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0) {      // wave-uniform: first tile, or some query's max grew a lot
-      const float d = first ? mx : fmaxf(mx, 0.f);
-      ms += d;
-      if (!first) {
-        const float alpha = EXP2(-d);
-        l *= alpha;
-#pragma unroll
-        for (int dd = 0; dd < DB; ++dd)
-#pragma unroll
-          for (int t = 0; t < 16; ++t) oacc[dd][t] *= alpha;
+    if constexpr (track) {
+      float mx = fmaxf(s[0][0], s[1][0]);
+  #pragma unroll
+      for (int t = 1; t < 16; ++t) mx = fmaxf(mx, fmaxf(s[0][t], s[1][t]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const bool first = kt == 0;
+      if (first || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0) {      // wave-uniform: first tile, or some query's max grew a lot
+        const float d = first ? mx : fmaxf(mx, 0.f);
+        ms += d;
+        if (!first) {
+          const float alpha = EXP2(-d);
+          l *= alpha;
+  #pragma unroll
+          for (int dd = 0; dd < DB; ++dd)
+  #pragma unroll
+            for (int t = 0; t < 16; ++t) oacc[dd][t] *= alpha;
+        }
+  #pragma unroll
+        for (int t = 0; t < 16; ++t) { s[0][t] -= d; s[1][t] -= d; }
+        nm = splat16(-ms);
       }
-#pragma unroll
-      for (int t = 0; t < 16; ++t) { s[0][t] -= d; s[1][t] -= d; }
-      nm = splat16(-ms);
     }
     float rs = 0.f;
 #pragma unroll
@@ -507,10 +519,20 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
           oacc[d] = MFMA_BF16(BATCH ? vfr[kb][s2][d] : frag_tr<HDP>(Vt, kb * 32 + 16 * s2, d * 32, lane), pf, oacc[d]);
       }
   };
-  for (int kt = 0; kt < nt; kt += ATT_STAGES) {
-    body(IC<0>{}, kt);
-    if (kt + 1 < nt) body(IC<1>{}, kt + 1);
-    if (kt + 2 < nt) body(IC<2>{}, kt + 2);
+  if (stat) {                               // the shift is the bound: no maximum to track
+    ms = bq;
+    nm = splat16(-bq);
+    for (int kt = 0; kt < nt; kt += ATT_STAGES) {
+      body(IC<0>{}, IC<0>{}, kt);
+      if (kt + 1 < nt) body(IC<1>{}, IC<0>{}, kt + 1);
+      if (kt + 2 < nt) body(IC<2>{}, IC<0>{}, kt + 2);
+    }
+  } else {
+    for (int kt = 0; kt < nt; kt += ATT_STAGES) {
+      body(IC<0>{}, IC<1>{}, kt);
+      if (kt + 1 < nt) body(IC<1>{}, IC<1>{}, kt + 1);
+      if (kt + 2 < nt) body(IC<2>{}, IC<1>{}, kt + 2);
+    }
   }
   if constexpr (LSUM) l = __shfl(oacc[HD / 32][LREG], (lane & 31) + 32 * LHALF, 64);      // row HD of O^T = sum over the keys of P (as rounded to bf16)
   else l += __shfl_xor(l, 32, 64);
@@ -1290,12 +1312,12 @@ static int attn_check(const char* who, int dtype, int B, int H, int N, int hd) {
 }
 
 static int attention_fwd_core(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N, int hd,
-                              float scale, QkvLayout Lq, QkvLayout Lv, hipStream_t st) {
+                              float scale, QkvLayout Lq, QkvLayout Lv, hipStream_t st, const float* score_bound = nullptr) {
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const float c = scale * 1.4426950408889634f;
   if (dtype == LDMAE_BF16) {
 #define LR(HD, R) { hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<HD, R>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
-    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, R>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq, Lv); }
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, R>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq, Lv, score_bound); }
 #define L(HD) if (N % 64 == 0) LR(HD, false) else LR(HD, true)
     ATTN_HD_DISPATCH(hd, L);
 #undef L
@@ -1396,6 +1418,34 @@ extern "C" int ldmae_attention_fwd_pv(int dtype, const void* q, const void* k, c
   const long hw = (long)H * hd;
   const QkvLayout hm{(long)H * N * hd, (long)N * hd, (long)hd}, pk{(long)N * 3 * hw, (long)hd, 3 * hw};
   return attention_fwd_core(dtype, q, k, (const bf16*)qkv + 2 * hw, o, lse, B, H, N, hd, scale, hm, pk, as_stream(stream));
+}
+// ldmae_attention_fwd_pv with a caller-supplied bound on |score * scale * log2(e)| (one float on the device; see the kernel): the softmax
+// then runs with that static shift.  A bound that does not hold makes the result wrong (overflow), so it has to be a proven one.
+extern "C" int ldmae_attention_fwd_pv_bounded(int dtype, const void* q, const void* k, const void* qkv, void* o, float* lse, const float* score_bound,
+                                              int B, int H, int N, int hd, float scale, void* stream) {
+  LDMAE_REQUIRE(q && k && qkv && o && lse && score_bound, "attention_fwd_pv_bounded: null pointer");
+  LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_fwd_pv_bounded: bf16 only");
+  if (int e = attn_check("attention_fwd_pv_bounded", dtype, B, H, N, hd)) return e;
+  LDMAE_REQUIRE(hd % 8 == 0, "attention_fwd_pv_bounded: head_dim %d must be a multiple of 8", hd);
+  const long hw = (long)H * hd;
+  const QkvLayout hm{(long)H * N * hd, (long)N * hd, (long)hd}, pk{(long)N * 3 * hw, (long)hd, 3 * hw};
+  return attention_fwd_core(dtype, q, k, (const bf16*)qkv + 2 * hw, o, lse, B, H, N, hd, scale, hm, pk, as_stream(stream), score_bound);
+}
+// The bound for heads that went through QK-RMSNorm + RoPE (lightningdit.py:66-80; elementwise.hip: q = x * rsqrt(mean(x^2) + eps) * w, then a
+// rotation): |q|^2 = sum w_i^2 xhat_i^2 <= max|w|^2 * hd, the same for k, RoPE preserves norms, so
+// |q . k| * scale * log2(e) <= hd * max|wq| * max|wk| * scale * log2(e); 2 % on top for the bf16 roundings of q, k and of the scaled q.
+__global__ void qk_score_bound_kernel(const float* __restrict__ wq, const float* __restrict__ wk, int hd, float c, float* __restrict__ out) {
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < hd; i += 64) { a = fmaxf(a, fabsf(wq[i])); b = fmaxf(b, fabsf(wk[i])); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o, 64)); b = fmaxf(b, __shfl_xor(b, o, 64)); }
+  if (threadIdx.x == 0) out[0] = (float)hd * a * b * c * 1.02f;
+}
+extern "C" int ldmae_qk_score_bound(const float* wq, const float* wk, int hd, float scale, float* out, void* stream) {
+  LDMAE_REQUIRE(wq && wk && out && hd > 0, "qk_score_bound: null pointer or empty head");
+  hipLaunchKernelGGL(qk_score_bound_kernel, dim3(1), dim3(64), 0, as_stream(stream), wq, wk, hd, scale * 1.4426950408889634f, out);
+  LDMAE_CHECK_LAUNCH("qk_score_bound");
+  return LDMAE_OK;
 }
 extern "C" int ldmae_attention_bwd_pv(int dtype, const void* q, const void* k, const void* qkv, const void* o, const void* do_, const float* lse,
                                       void* dq, void* dk, void* dqkv, float* delta, int B, int H, int N, int hd, float scale, void* stream) {

@@ -265,7 +265,9 @@ class _DiTBlockFn(torch.autograd.Function):
         qkv = ops.gemm_nt(xm1, Wqkv, qkvb)                                               # [M, 3D] == [B,N,3,H,hd]
         if dtype == torch.bfloat16:      # v is consumed where the qkv Linear wrote it: no head-major copy of v (nor of dv in backward)
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps, copy_v=False)
-            o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5)                          # [B,N,D]
+            # QK-RMSNorm bounds |q|, |k| by max|w| sqrt(hd) and the rotation keeps norms: a proven score bound, so the softmax runs with a
+            # static shift (no running maximum in the kernel)
+            o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5, bound=ops.qk_score_bound(qnw, knw, hd, hd ** -0.5))      # [B,N,D]
         else:
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
             o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)
@@ -376,7 +378,7 @@ class _AttentionFn(torch.autograd.Function):
         qkv = ops.gemm_nt(xa, Wqkv, qkvb)
         if dtype == torch.bfloat16:
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps, copy_v=False)
-            o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5)
+            o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5, bound=ops.qk_score_bound(qnw, knw, hd, hd ** -0.5))
         else:
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
             o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)

@@ -391,12 +391,24 @@ def attention_bwd(q, k, v, o, do, lse, scale):
     return dq, dk, dv
 
 
-def attention_fwd_pv(q, k, qkv, scale):
-    """q, k head-major [B,H,N,hd]; v read from the packed qkv [B*N, 3*H*hd] (bf16)."""
+def qk_score_bound(wq, wk, hd, scale):
+    """One float on the device: hd * max|wq| * max|wk| * scale * log2(e) * 1.02, an upper bound of every attention score (in the kernels'
+    log2 units) of heads that went through QK-RMSNorm with these weights and RoPE -- for attention_fwd_pv(bound=...)."""
+    out = torch.empty(1, dtype=torch.float32, device=wq.device)
+    call("ldmae_qk_score_bound", ptr(wq), ptr(wk), hd, float(scale), ptr(out), stream())
+    return out
+
+
+def attention_fwd_pv(q, k, qkv, scale, bound=None):
+    """q, k head-major [B,H,N,hd]; v read from the packed qkv [B*N, 3*H*hd] (bf16).  bound: a proven upper bound of the scores
+    (qk_score_bound): the softmax then runs with a static shift instead of a running maximum (same result, fewer vector instructions)."""
     B, H, N, hd = q.shape
     o = torch.empty(B, N, H * hd, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
-    call("ldmae_attention_fwd_pv", dt(q.dtype), ptr(q), ptr(k), ptr(qkv), ptr(o), ptr(lse), B, H, N, hd, float(scale), stream())
+    if bound is not None:
+        call("ldmae_attention_fwd_pv_bounded", dt(q.dtype), ptr(q), ptr(k), ptr(qkv), ptr(o), ptr(lse), ptr(bound), B, H, N, hd, float(scale), stream())
+    else:
+        call("ldmae_attention_fwd_pv", dt(q.dtype), ptr(q), ptr(k), ptr(qkv), ptr(o), ptr(lse), B, H, N, hd, float(scale), stream())
     return o, lse
 
 

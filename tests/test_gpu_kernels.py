@@ -256,6 +256,35 @@ def test_attention_bwd_pv_qknorm_fused(ops, hd, H, N):
     assert rel_err(db_b.cpu(), dqkv_b.float().cpu().reshape(B * N, 3 * H * hd).sum(0)) < 1e-5      # = column sums of dqkv as stored
 
 
+@pytest.mark.parametrize("hd,H,N", [(64, 3, 256), (72, 2, 192), (64, 2, 200)])
+def test_attention_fwd_static_shift_from_the_qknorm_bound(ops, hd, H, N):
+    """attention_fwd_pv with the score bound of QK-normalised heads (ldmae_qk_score_bound: hd max|wq| max|wk| scale log2e): the kernel then
+    shifts every exponent by that bound instead of tracking a running maximum.  Same softmax: o and lse against the f64 reference and
+    against the tracked form; the bound holds for the scores the kernel sees; a bound above 50 keeps the tracked form, bit for bit."""
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    qkv = (2 * torch.randn(B, N, 3, H, hd, generator=g)).to(BF16).cuda()
+    wq, wk = (1 + 0.2 * torch.randn(hd, generator=g)).cuda(), (1 + 0.2 * torch.randn(hd, generator=g)).cuda()
+    ang = torch.rand(N, hd // 2, generator=g) * 6.28
+    cos, sin = ang.cos().repeat_interleave(2, 1).cuda(), ang.sin().repeat_interleave(2, 1).cuda()      # a rotation per pair: norms are kept
+    scale = hd ** -0.5
+    q, k, _ = ops.qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, copy_v=False)
+    bound = ops.qk_score_bound(wq, wk, hd, scale)
+    assert abs(float(bound) - hd * float(wq.abs().max()) * float(wk.abs().max()) * scale * 1.4426950408889634 * 1.02) < 1e-3 * float(bound)
+    smax = float((q.double() @ k.double().transpose(-1, -2)).abs().max()) * scale * 1.4426950408889634
+    assert smax <= float(bound) <= 50
+    o_t, lse_t = ops.attention_fwd_pv(q, k, qkv, scale)
+    o_s, lse_s = ops.attention_fwd_pv(q, k, qkv, scale, bound=bound)
+    v = qkv[:, :, 2].permute(0, 2, 1, 3)
+    ro, rl = _attn_ref(q.double().cpu(), k.double().cpu(), v.double().cpu(), scale)
+    assert rel_err(o_s.float().cpu(), ro.float()) < 1e-2 and rel_err(o_t.float().cpu(), ro.float()) < 1e-2
+    assert (lse_s.cpu() - rl.float()).abs().max() < 2e-2 and (lse_s - lse_t).abs().max() < 2e-2
+    assert rel_err(o_s.float().cpu(), o_t.float().cpu()) < 5e-3
+    big = torch.full((1,), 80.0, device="cuda")
+    o_b, lse_b = ops.attention_fwd_pv(q, k, qkv, scale, bound=big)
+    assert torch.equal(o_b, o_t) and torch.equal(lse_b, lse_t)
+
+
 def _attn_ref(qq, kk, vv, scale):
     s = (qq @ kk.transpose(-2, -1)) * scale
     o = s.softmax(-1) @ vv
