@@ -59,7 +59,7 @@ __device__ __forceinline__ float gelu_erf(float y) { return gelu_act<bf16>(y); }
 
 // Sequences LONGER than one workgroup's 256 tokens (the docking encoder `_encode` runs all 1024 patches of an image, models_mae.py:819-833)
 // keep the same machinery -- tokens on the lanes, residual stream in registers, weights through the ring from the SAME blob -- but a block
-// becomes three launches, because every token needs every other tile's K and V:
+// is cut where the tiles have to meet, because every token needs every other tile's K and V:
 //   MODE 1 (per 256-token tile): LayerNorm -> q^T, k^T, v^T of the block (the blob's twelve attention steps), staged through LDS and
 //           written as whole 64-B segments into the packed token-major qkv [tokens][3][12][16] that the flash kernel reads
 //           (ldmae_attention_fwd_qkv: attention.hip, any N);
@@ -72,7 +72,7 @@ __device__ __forceinline__ float gelu_erf(float y) { return gelu_act<bf16>(y); }
 constexpr int STG_PITCH = 144;                                     // bytes per token row of the MODE 1 staging image (64 features + pad)
 constexpr int LDS_BYTES_QKV = NSLOT * SLOTB + VTOK * STG_PITCH;    // 143,360 B
 
-// MODE 0: x, out: [B, 256, 192] f32, nblk = number of blocks.  MODE 1 / 2: x, out [tiles * 256, 192] f32, nblk = INDEX of the block.
+// MODE 0: x, out: [B, 256, 192] f32, nblk = number of blocks.  MODE 1 / 2 / 3: x, out [tiles * 256, 192] f32, nblk = INDEX of the block.
 // blob: 36 slots of SLOTB bytes per block (ldmae_amd/tokenizer/fused_encoder.py packs it; layout in the header).
 template <int MODE>
 __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restrict__ x, float* __restrict__ out, const char* __restrict__ blob,
@@ -83,9 +83,9 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
   const int total = MODE == 0 ? nblk * STEPS : (MODE == 1 ? 12 : (MODE == 2 ? 30 : 42));
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(void, smem));
   const bool extra = wave < PIECES - 24;                            // waves 0, 1 carry the two vector pieces
-  // ring step g -> slot of the blob: MODE 1 walks the block's attention steps, MODE 2 the proj halves (odd attention steps) and the MLP
-  // (MODE 3: then the next block's attention steps)
-  auto slot_of = [&](int g) { return MODE == 0 ? g : nblk * STEPS + (MODE == 1 ? g : (g < 6 ? 2 * g + 1 : g + 6)); };      // g + 6 >= 36: the next block
+  // ring step g -> slot of the blob: MODE 1 walks the block's attention steps, MODE 2 the proj halves (odd attention steps) and the MLP,
+  // MODE 3 then runs on into the next block's attention steps (g + 6 >= 36)
+  auto slot_of = [&](int g) { return MODE == 0 ? g : nblk * STEPS + (MODE == 1 ? g : (g < 6 ? 2 * g + 1 : g + 6)); };
   auto issue = [&](int g) {
     const char* src = blob + (size_t)slot_of(g) * SLOTB;
     const unsigned dst = lds0 + (g % NSLOT) * SLOTB;
