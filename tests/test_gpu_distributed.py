@@ -88,7 +88,10 @@ def _worker(rank, world, port, q):
     if rank == 0:
         q.put((opt.flat.grads.cpu() * scale, exposed))
     dist.barrier()
-    dist.destroy_process_group()
+    try:                                  # the result is out and both ranks are past the barrier: a peer that closed its sockets first
+        dist.destroy_process_group()      # ("connection closed by peer" in gloo's teardown) is not a failure of what this test checks
+    except Exception as e:                # noqa: BLE001
+        print("destroy_process_group:", e)
 
 
 def test_two_ranks_one_gpu_reduced_grads_equal_concatenated_batch():
@@ -99,9 +102,9 @@ def test_two_ranks_one_gpu_reduced_grads_equal_concatenated_batch():
     for p in procs:
         p.start()
     got, exposed = q.get(timeout=300)
-    for p in procs:
+    for r, p in enumerate(procs):
         p.join(120)
-        assert p.exitcode == 0
+        assert p.exitcode == 0, f"rank {r} exit code {p.exitcode}"
     m, x, t, y, tgt = _tiny()
     from ldmae_amd.optim import AdamWEMA, adaln_first
     opt = AdamWEMA(m, lr=1e-3, front_fn=adaln_first)                      # same slab layout as the ranks
@@ -149,7 +152,10 @@ def _world1_rccl_worker(port, q):
     torch.cuda.synchronize()
     front = sorted({red.param_bucket[n] for n, _ in opt.flat.trainable if adaln_first(n)})
     q.put((bool(torch.equal(got, ref)), list(launched), front, red.exposed_comm_ms()))
-    dist.destroy_process_group()
+    try:
+        dist.destroy_process_group()
+    except Exception as e:                # noqa: BLE001  (teardown only: everything the test checks is in the queue)
+        print("destroy_process_group:", e)
 
 
 def test_world_of_one_rccl_rank_walks_the_reducer():
@@ -162,7 +168,7 @@ def test_world_of_one_rccl_rank_walks_the_reducer():
     p.start()
     same, launched, front, exposed = q.get(timeout=600)
     p.join(120)
-    assert p.exitcode == 0
+    assert p.exitcode == 0, f"exit code {p.exitcode}"
     # the buckets that hold adaLN weights (front of the slab = highest bucket indices) are among the last launched: only the bucket with the
     # embedders' parameters, whose gradients complete after the batched adaLN backward, may come between / after them
     assert same and exposed >= 0.0 and front == list(range(front[0], len(launched))), (launched, front)
