@@ -21,6 +21,16 @@ elif kind == "tn":
     b = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     for _ in range(3):
         ops.gemm_tn(a, b)
+elif kind in ("attnpv", "attnpvb"):      # the DiT block's forward attention (hd 64, QK-norm + RoPE): tracked maximum / static shift from the norm-weight bound
+    from ldmae_amd.models.pos_embed import VisionRotaryEmbeddingFast
+    B, H, NN, hd = 256, 12, 1024, 64
+    qkv = torch.randn(B, NN, 3, H, hd, device="cuda", generator=g).to(torch.bfloat16)
+    wq, wk = torch.ones(hd, device="cuda"), torch.ones(hd, device="cuda")
+    rope = VisionRotaryEmbeddingFast(dim=hd // 2, pt_seq_len=32).cuda()
+    q, k, _ = ops.qknorm_rope_fwd(qkv, wq, wk, rope.freqs_cos, rope.freqs_sin, B, NN, H, hd, copy_v=False)
+    bound = ops.qk_score_bound(wq, wk, hd, hd ** -0.5) if kind == "attnpvb" else None
+    for _ in range(3):
+        ops.attention_fwd_pv(q, k, qkv, hd ** -0.5, bound=bound)
 elif kind == "attn16":        # VMAE attention forward at 1024 tokens: packed qkv, 12 heads of 16 (the decoder / _encode shape)
     B, H, NN, hd = 256, 12, 1024, 16
     qkv = torch.randn(B * NN, 3 * H * hd, device="cuda", generator=g).to(torch.bfloat16)
