@@ -472,3 +472,21 @@ def test_batched_adaln_matches_per_block_and_oracle():
             cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
             assert cos > 0.99, (k, name, cos)
         assert abs(float(gb.norm() / (ograds[k].norm() + 1e-30)) - 1.0) < 0.1, k
+
+
+def test_train_steps_are_bitwise_identical_across_processes():
+    """tools/determinism_check.py in two fresh processes: three full B/1 train steps (bf16, batch 32; fwd + bwd + AdamW + EMA) from fixed
+    torch + numpy seeds print loss, gradient-slab sum and parameter sum at full precision -- the lines must agree to the last digit (fixed
+    reduction orders, no atomics, no uninitialised reads on the product path)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "determinism_check.py"), "32"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln[:2] in ("0 ", "1 ", "2 ") or ln.startswith("x ")]
+        assert len(lines) == 4, r.stdout
+        outs.append(lines)
+    assert outs[0] == outs[1], (outs[0], outs[1])
