@@ -303,6 +303,8 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
     }
     for (int hp = 0; hp < (MODE == 0 ? 6 : 0); ++hp) {
       bf16x8 qf[2];                            // this wave's queries of the head pair (operand fragments, scale * log2(e) folded in)
+      float qn2[2];                            // |q|^2 of this lane's query per head (of the scaled operand), for the score bound
+      const float* kmx = nullptr;              // [2 heads][8 waves] max |k|^2 over a wave's tokens, in step A's slot
       {
         // ---- step A: q^T and k^T of heads 2hp, 2hp+1 (panel rows = Wqkv rows 32hp.. and 192 + 32hp..)
         const char* slot = next_slot();
@@ -317,8 +319,22 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
         qf[0] = cvt8(qT, 0, qscale); qf[1] = cvt8(qT, 1, qscale);
         f32x16 kT = mm12(zero16(), p1, std::false_type{});
         add_rows32(kT, vec + 416);
-        *(bf16x8*)(kv + (0 * 8 + wave) * FRAG + lane * 16) = cvt8(kT, 0);
-        *(bf16x8*)(kv + (1 * 8 + wave) * FRAG + lane * 16) = cvt8(kT, 1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const bf16x8 kf = cvt8(kT, e);
+          *(bf16x8*)(kv + (e * 8 + wave) * FRAG + lane * 16) = kf;
+          // |k|^2 of this lane's token (as stored), maximum over the wave's 32 tokens -> the slot's spare vector floats (readable through
+          // the next step): with |q| it bounds every score of the head, and the softmax below needs no maximum pass (see `bq`)
+          float ks = 0.f, qs = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ks += (float)kf[j] * (float)kf[j]; qs += (float)qf[e][j] * (float)qf[e][j]; }
+          ks += __shfl_xor(ks, 32, 64);
+          qn2[e] = qs + __shfl_xor(qs, 32, 64);
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) ks = fmaxf(ks, __shfl_xor(ks, o, 64));
+          if (lane == 0) ((float*)vec)[448 + e * 8 + wave] = ks;
+        }
+        kmx = vec + 448;
       }
       {
         // ---- step B: v (un-transposed: rows = tokens, columns = 2 heads x 16), attention of both heads, proj into the residual stream
@@ -339,19 +355,26 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           if (VF_DBG == 2) { of[e] = qf[e]; continue; }
-          // two passes over the 8 key blocks (a score product is ONE MFMA at head dim 16, cheaper than an online rescale of O):
-          // pass 1 finds the row maximum; pass 2 starts every score chain from -max, so p = exp2(score) is one instruction
-          f32x16 mv = MFMA(*(const bf16x8*)(kv + (e * 8) * FRAG + lane * 16), qf[e], zero16());
+          // The shift of the softmax: bq = |q| max_j |k_j| (Cauchy-Schwarz; q carries scale * log2(e)) bounds every score of this query,
+          // so with it every exponent lies in [-2 bq, 0] -- nothing overflows, and up to bq = 50 nothing flushes to zero: exact, and no
+          // pass over the keys for the maximum.  A wave with a larger bound takes that pass (a score product is ONE MFMA at head dim 16,
+          // cheaper than an online rescale of O).  Either way the score chains start from -shift and p = exp2(score) is one instruction.
+          const float4 k0 = *(const float4*)(kmx + e * 8), k1 = *(const float4*)(kmx + e * 8 + 4);
+          const float km2 = fmaxf(fmaxf(fmaxf(k0.x, k0.y), fmaxf(k0.z, k0.w)), fmaxf(fmaxf(k1.x, k1.y), fmaxf(k1.z, k1.w)));
+          float mx = sqrtf(qn2[e] * km2) * 1.002f + 0.01f;
+          if (__builtin_amdgcn_ballot_w64(!(mx <= 50.f)) != 0) {
+            f32x16 mv = MFMA(*(const bf16x8*)(kv + (e * 8) * FRAG + lane * 16), qf[e], zero16());
 #pragma unroll
-          for (int kb = 1; kb < 8; ++kb) {
-            const f32x16 sc = MFMA(*(const bf16x8*)(kv + (e * 8 + kb) * FRAG + lane * 16), qf[e], zero16());
+            for (int kb = 1; kb < 8; ++kb) {
+              const f32x16 sc = MFMA(*(const bf16x8*)(kv + (e * 8 + kb) * FRAG + lane * 16), qf[e], zero16());
 #pragma unroll
-            for (int tt = 0; tt < 16; ++tt) mv[tt] = fmaxf(mv[tt], sc[tt]);
+              for (int tt = 0; tt < 16; ++tt) mv[tt] = fmaxf(mv[tt], sc[tt]);
+            }
+            mx = mv[0];
+#pragma unroll
+            for (int tt = 1; tt < 16; ++tt) mx = fmaxf(mx, mv[tt]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
           }
-          float mx = mv[0];
-#pragma unroll
-          for (int tt = 1; tt < 16; ++tt) mx = fmaxf(mx, mv[tt]);
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
           f32x16 nm;
 #pragma unroll
           for (int tt = 0; tt < 16; ++tt) nm[tt] = -mx;
