@@ -379,7 +379,7 @@ struct QkvLayout { long sb, sh, ld; };
 template <int HD, bool RAGGED = false>      // RAGGED: N % 64 != 0 (its own instantiation: the masking costs the hot shapes no registers)
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                             bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L, QkvLayout Lv,
-                                                            const float* __restrict__ SB) {
+                                                            const float* __restrict__ SB, int sb_heads) {
   constexpr int HDP = hd_pad(HD), KS = (HD + 15) / 16, DB = HDP / 32, TB = 64 * HDP * 2;
   constexpr bool BATCH = HDP <= 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [STAGES][K tile | V tile]
@@ -424,8 +424,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   // to zero, so the softmax is exact without the per-tile 31-deep max chain, cross-half shuffle, ballot and rescale branch (a fifth of the
   // loop's vector instructions: -8 % at head dim 64, -12 % at 16, profiles/r04_attn_static_shift.txt).  No bound, or one above 50: the
   // tracked form below, as before.
-  const float bq = SB ? *SB : 0.f;
-  const bool stat = SB != nullptr && bq <= 50.f;       // wave- (and grid-) uniform
+  // sb_heads: SB is [B*H][2] = (max_i |q_i|^2, max_j |k_j|^2) of each (batch, head) as STORED (unscaled): |q_i . k_j| <= |q_i| |k_j|
+  // (the fused VMAE q | k | v kernel leaves these maxima behind for free: csrc/vmae_fused.hip).
+  float bq = 0.f;
+  if (SB) bq = sb_heads ? sqrtf(SB[2 * bh] * SB[2 * bh + 1]) * c * 1.02f : *SB;
+  const bool stat = SB != nullptr && bq <= 50.f;       // workgroup-uniform
   const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int kt) {
     const int so = (kt % ATT_STAGES) * 2 * TB;
@@ -1312,12 +1315,12 @@ static int attn_check(const char* who, int dtype, int B, int H, int N, int hd) {
 }
 
 static int attention_fwd_core(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N, int hd,
-                              float scale, QkvLayout Lq, QkvLayout Lv, hipStream_t st, const float* score_bound = nullptr) {
+                              float scale, QkvLayout Lq, QkvLayout Lv, hipStream_t st, const float* score_bound = nullptr, int sb_heads = 0) {
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const float c = scale * 1.4426950408889634f;
   if (dtype == LDMAE_BF16) {
 #define LR(HD, R) { hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<HD, R>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
-    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, R>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq, Lv, score_bound); }
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, R>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq, Lv, score_bound, sb_heads); }
 #define L(HD) if (N % 64 == 0) LR(HD, false) else LR(HD, true)
     ATTN_HD_DISPATCH(hd, L);
 #undef L
@@ -1351,6 +1354,21 @@ extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, floa
   const long hw = (long)H * hd;
   const QkvLayout pk{(long)N * 3 * hw, (long)hd, 3 * hw};
   return attention_fwd_core(dtype, p, p + hw, p + 2 * hw, o, lse, B, H, N, hd, scale, pk, pk, as_stream(stream));
+}
+
+// ldmae_attention_fwd_qkv with the static softmax shift from per-(batch, head) norm maxima: qk_max2 [B*H][2] f32 on the device =
+// (max_i |q_i|^2, max_j |k_j|^2) of the q / k rows as stored in the packed qkv.  Heads whose bound |q|max |k|max scale log2(e) * 1.02 exceeds 50
+// keep the running maximum.  The maxima must be true maxima (or larger): a smaller value makes the result wrong.
+extern "C" int ldmae_attention_fwd_qkv_bounded(int dtype, const void* qkv, void* o, float* lse, const float* qk_max2, int B, int H, int N, int hd,
+                                               float scale, void* stream) {
+  LDMAE_REQUIRE(qkv && o && lse && qk_max2, "attention_fwd_qkv_bounded: null pointer");
+  LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_fwd_qkv_bounded: bf16 only");
+  if (int e = attn_check("attention_fwd_qkv_bounded", dtype, B, H, N, hd)) return e;
+  LDMAE_REQUIRE(hd % 8 == 0, "attention_fwd_qkv_bounded: head_dim %d must be a multiple of 8", hd);
+  const bf16* p = (const bf16*)qkv;
+  const long hw = (long)H * hd;
+  const QkvLayout pk{(long)N * 3 * hw, (long)hd, 3 * hw};
+  return attention_fwd_core(dtype, p, p + hw, p + 2 * hw, o, lse, B, H, N, hd, scale, pk, pk, as_stream(stream), qk_max2, 1);
 }
 
 static int attention_bwd_core(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,

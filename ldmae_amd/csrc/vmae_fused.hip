@@ -76,7 +76,8 @@ constexpr int LDS_BYTES_QKV = NSLOT * SLOTB + VTOK * STG_PITCH;    // 143,360 B
 // blob: 36 slots of SLOTB bytes per block (ldmae_amd/tokenizer/fused_encoder.py packs it; layout in the header).
 template <int MODE>
 __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restrict__ x, float* __restrict__ out, const char* __restrict__ blob,
-                                                           int nblk, float eps, float qscale, bf16* __restrict__ qkv, const bf16* __restrict__ oatt, int last) {
+                                                           int nblk, float eps, float qscale, bf16* __restrict__ qkv, const bf16* __restrict__ oatt, int last,
+                                                           unsigned* __restrict__ qkmax, int tpi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* kv = smem + NSLOT * SLOTB;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
@@ -219,13 +220,13 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
   auto next_slot = [&]() -> const char* {
     constexpr int Q0 = MODE == 3 ? 30 : 0;       // first q | k | v step of MODE 1 / 3
     if (MODE == 1 || (MODE == 3 && g >= Q0)) {
-      // behind slot g's pieces in the (in-order) vector-memory queue: the qkv stores of step g - 2, the pieces of slot g + 1, the stores of
-      // step g - 1 (4 per thread after a q | k step, 2 after a v step: 6 per pair of steps)
+      // behind slot g's pieces in the (in-order) vector-memory queue: the vector-memory instructions of step g - 2, the pieces of slot
+      // g + 1, those of step g - 1 (a q | k step: 4 norm-maximum atomics + 4 qkv stores per wave, a v step: 2 stores: 10 per pair of steps)
       if (g + 1 < total) {
-        if (g >= Q0 + 2) { if (extra) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
-        else if (g == Q0 + 1) { if (extra) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+        if (g >= Q0 + 2) { if (extra) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
+        else if (g == Q0 + 1) { if (extra) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
         else { if (extra) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-      } else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     } else if (g + 1 < total) {
       if (extra) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -264,6 +265,25 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
         f32x16 kT = mm12(zero16(), p1, std::false_type{});
         add_rows32(kT, vec + 416);
         stage_t(kT, 64);
+        // max |q|^2 and max |k|^2 over this tile's tokens, per head, as stored (bf16): they bound every score of the (image, head), and the
+        // flash kernel then needs no running maximum (attention.hip: ldmae_attention_fwd_qkv_bounded).  Non-negative floats order like their bits.
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float qs = 0.f, ks = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float a = (float)(bf16)qT[8 * e + j], b = (float)(bf16)kT[8 * e + j];
+            qs += a * a; ks += b * b;
+          }
+          qs += __shfl_xor(qs, 32, 64); ks += __shfl_xor(ks, 32, 64);
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) { qs = fmaxf(qs, __shfl_xor(qs, o, 64)); ks = fmaxf(ks, __shfl_xor(ks, o, 64)); }
+          if (lane == 0) {
+            unsigned* dst = qkmax + ((size_t)(blockIdx.x / tpi) * VH + 2 * hp + e) * 2;
+            atomicMax(dst, __float_as_uint(qs));
+            atomicMax(dst + 1, __float_as_uint(ks));
+          }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -496,16 +516,18 @@ extern "C" int ldmae_vmae_encoder_fwd(const float* x, float* out, const void* bl
   hipFuncSetAttribute((const void*)vmae_encoder_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   const float qscale = 0.25f * 1.4426950408889634f;          // head_dim^-0.5 (models_mae.py:123) * log2(e)
   hipLaunchKernelGGL(vmae_encoder_kernel<0>, dim3(B), dim3(512), LDS_BYTES, as_stream(stream), x, out, (const char*)blob, nblocks, eps, qscale, (bf16*)nullptr,
-                     (const bf16*)nullptr, 1);
+                     (const bf16*)nullptr, 1, (unsigned*)nullptr, 1);
   LDMAE_CHECK_LAUNCH("vmae_encoder_fwd");
   return LDMAE_OK;
 }
 
 // ---- the same encoder on sequences of several 256-token tiles (docking `_encode`: all 1024 patches): per block qkv kernel -> flash attention
-// on the packed qkv -> proj / MLP kernel.  workspace: qkv [B*tokens][576] bf16 | attention output [B*tokens][192] bf16 | lse [B][12][tokens] f32.
-extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream);
+// on the packed qkv -> proj / MLP kernel.  workspace: qkv [B*tokens][576] bf16 | attention output [B*tokens][192] bf16 | lse [B][12][tokens] f32 |
+// per block the norm maxima [B][12][2] f32 that give the flash kernel its static softmax shift.
+extern "C" int ldmae_attention_fwd_qkv_bounded(int dtype, const void* qkv, void* o, float* lse, const float* qk_max2, int B, int H, int N, int hd,
+                                               float scale, void* stream);
 extern "C" long ldmae_vmae_encoder_fwd_tiled_workspace_bytes(int B, int tokens) {
-  return (long)B * tokens * (3 * VD + VD) * 2 + (long)B * VH * tokens * 4;
+  return (long)B * tokens * (3 * VD + VD) * 2 + (long)B * VH * tokens * 4 + ((long)B * VH * 2 * 4 + 15) / 16 * 16 * 64;      // (up to 64 blocks)
 }
 extern "C" int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const void* blob, void* workspace, int B, int tokens, int dim, int heads,
                                             int hidden, int nblocks, float eps, void* stream) {
@@ -513,7 +535,7 @@ extern "C" int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const vo
   LDMAE_REQUIRE(tokens > 0 && tokens % VTOK == 0 && dim == VD && heads == VH && hidden == VHID,
                 "vmae_encoder_fwd_tiled: built for whole %d-token tiles of width %d, %d heads, hidden %d (got %d, %d, %d, %d): use the per-layer entry points",
                 VTOK, VD, VH, VHID, tokens, dim, heads, hidden);
-  LDMAE_REQUIRE(nblocks >= 1, "vmae_encoder_fwd_tiled: nblocks=%d", nblocks);
+  LDMAE_REQUIRE(nblocks >= 1 && nblocks <= 64, "vmae_encoder_fwd_tiled: nblocks=%d (1 .. 64)", nblocks);
   LDMAE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)blob & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
                 "vmae_encoder_fwd_tiled: pointers must be 16-B aligned");
   LDMAE_REQUIRE((long)B * tokens / VTOK < (1L << 31), "vmae_encoder_fwd_tiled: too many tiles");
@@ -523,19 +545,24 @@ extern "C" int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const vo
   bf16* qkv = (bf16*)workspace;
   bf16* oatt = qkv + (size_t)B * tokens * 3 * VD;
   float* lse = (float*)(oatt + (size_t)B * tokens * VD);
+  const size_t mxs = ((size_t)B * VH * 2 * 4 + 15) / 16 * 16;      // bytes of one block's norm maxima
+  char* mx = (char*)(lse + (size_t)B * VH * tokens);
+  hipMemsetAsync(mx, 0, mxs * nblocks, as_stream(stream));
+  const int tpi = tokens / VTOK;
   const unsigned tiles = (unsigned)((long)B * tokens / VTOK);
   hipLaunchKernelGGL(vmae_encoder_kernel<1>, dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), x, (float*)nullptr, (const char*)blob, 0, eps, 0.f, qkv,
-                     (const bf16*)nullptr, 0);
+                     (const bf16*)nullptr, 0, (unsigned*)mx, tpi);
   LDMAE_CHECK_LAUNCH("vmae_encoder_fwd_tiled(qkv)");
   for (int blk = 0; blk < nblocks; ++blk) {
     const float* xin = blk == 0 ? x : out;                    // the residual stream lives in `out` from the first block on (a tile rewrites only its own rows)
-    if (int e = ldmae_attention_fwd_qkv(LDMAE_BF16, qkv, oatt, lse, B, VH, tokens, VD / VH, 0.25f, stream)) return e;      // head_dim^-0.5 (models_mae.py:123)
+    if (int e = ldmae_attention_fwd_qkv_bounded(LDMAE_BF16, qkv, oatt, lse, (const float*)(mx + mxs * blk), B, VH, tokens, VD / VH, 0.25f, stream))
+      return e;                                                 // scale = head_dim^-0.5 (models_mae.py:123)
     if (blk + 1 < nblocks)      // proj / MLP of this block, then q | k | v of the next one (the attention has consumed this block's)
       hipLaunchKernelGGL(vmae_encoder_kernel<3>, dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), xin, out, (const char*)blob, blk, eps, 0.f, qkv,
-                         (const bf16*)oatt, 0);
+                         (const bf16*)oatt, 0, (unsigned*)(mx + mxs * (blk + 1)), tpi);
     else
       hipLaunchKernelGGL(vmae_encoder_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, as_stream(stream), xin, out, (const char*)blob, blk, eps, 0.f, (bf16*)nullptr,
-                         (const bf16*)oatt, 1);
+                         (const bf16*)oatt, 1, (unsigned*)nullptr, tpi);
     LDMAE_CHECK_LAUNCH("vmae_encoder_fwd_tiled(post)");
   }
   return LDMAE_OK;
