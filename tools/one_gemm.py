@@ -36,6 +36,13 @@ elif kind == "attn16":        # VMAE attention forward at 1024 tokens: packed qk
     qkv = torch.randn(B * NN, 3 * H * hd, device="cuda", generator=g).to(torch.bfloat16)
     for _ in range(3):
         ops.attention_fwd_qkv(qkv, B, NN, H, hd, hd ** -0.5)
+elif kind == "vmaet":         # the tiled VMAE encoder at 1024 tokens, 256 images (MODE 1 once, then MODE 3 + flash attention per block, MODE 2 last)
+    from ldmae_amd.tokenizer import fused_encoder, models_mae
+    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).cuda().eval()
+    x = torch.randn(256, 1024, 192, device="cuda", generator=g)
+    blob = fused_encoder.encoder_blob(m)
+    for _ in range(3):
+        ops.vmae_encoder_fwd_tiled(x, blob, 12, 192, 12, 768, 1e-6)
 elif kind == "vmae":          # the one-kernel VMAE encoder, 256 images (one workgroup per CU)
     from ldmae_amd.tokenizer import fused_encoder, models_mae
     m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).cuda().eval()
