@@ -148,10 +148,14 @@ int ldmae_attention_bwd(int dtype, const void* q, const void* k, const void* v, 
  * relayout passes).  dqkv [B,N,3,H,hd]. */
 int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream);
 /* ldmae_attention_fwd_qkv with a static softmax shift per (batch, head) (see ldmae_attention_fwd_pv_bounded): qk_max2 [B*H][2] f32 on the
- * device = (max_i |q_i|^2, max_j |k_j|^2) over the head's rows as stored; heads whose bound exceeds 50 keep the running maximum.  The
+ * device = (max_i |q_i|^2, max_j |k_j|^2) over the head's rows as stored (first value 0: each query's own norm is used); heads / waves whose
+ * bound exceeds 50 keep the running maximum.  The
  * tiled VMAE encoder's q | k | v kernel produces the maxima as it writes the rows. */
 int ldmae_attention_fwd_qkv_bounded(int dtype, const void* qkv, void* o, float* lse, const float* qk_max2, int B, int H, int N, int hd,
                                     float scale, void* stream);
+/* qk_max2 [B*H][2] = (0, max_j |k_j|^2) from one pass over the k slots of a packed bf16 qkv: a first value of 0 makes the bounded kernel use
+ * each query's own norm.  One extra pass over a third of qkv: pays for long sequences (the 1024-token VMAE decoder), not for short ones. */
+int ldmae_k_norm_max(const void* qkv, float* qk_max2, int B, int N, int H, int hd, void* stream);
 int ldmae_attention_bwd_qkv(int dtype, const void* qkv, const void* o, const void* do_, const float* lse, void* dqkv, float* delta,
                             int B, int H, int N, int hd, float scale, void* stream);
 

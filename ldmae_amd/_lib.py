@@ -52,6 +52,7 @@ SIGNATURES = {
     "ldmae_attention_fwd_qkv": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_attention_bwd_qkv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_attention_fwd_pv": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ldmae_k_norm_max": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_attention_fwd_qkv_bounded": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_attention_fwd_pv_bounded": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ldmae_qk_score_bound": (_i, [_vp, _vp, _i, _f, _vp, _vp]),

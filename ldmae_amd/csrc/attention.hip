@@ -426,9 +426,22 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   // tracked form below, as before.
   // sb_heads: SB is [B*H][2] = (max_i |q_i|^2, max_j |k_j|^2) of each (batch, head) as STORED (unscaled): |q_i . k_j| <= |q_i| |k_j|
   // (the fused VMAE q | k | v kernel leaves these maxima behind for free: csrc/vmae_fused.hip).
+  // A first value of 0 means "no maximum over the queries": every lane then uses the norm of its own (scaled) query (ldmae_k_norm_max).
   float bq = 0.f;
-  if (SB) bq = sb_heads ? sqrtf(SB[2 * bh] * SB[2 * bh + 1]) * c * 1.02f : *SB;
-  const bool stat = SB != nullptr && bq <= 50.f;       // workgroup-uniform
+  if (SB) {
+    if (!sb_heads) bq = *SB;
+    else if (SB[2 * bh] > 0.f) bq = sqrtf(SB[2 * bh] * SB[2 * bh + 1]) * c * 1.02f;
+    else {
+      float qn = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qn += (float)qf[ks][j] * (float)qf[ks][j];
+      qn += __shfl_xor(qn, 32, 64);
+      bq = sqrtf(qn * SB[2 * bh + 1]) * 1.02f + 0.01f;
+    }
+  }
+  const bool stat = SB != nullptr && __builtin_amdgcn_ballot_w64(!(bq <= 50.f)) == 0;       // wave-uniform
   const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int kt) {
     const int so = (kt % ATT_STAGES) * 2 * TB;
@@ -1354,6 +1367,37 @@ extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, floa
   const long hw = (long)H * hd;
   const QkvLayout pk{(long)N * 3 * hw, (long)hd, 3 * hw};
   return attention_fwd_core(dtype, p, p + hw, p + 2 * hw, o, lse, B, H, N, hd, scale, pk, pk, as_stream(stream));
+}
+
+// max_j |k_j|^2 per (batch, head) of a packed token-major qkv [B*N][3][H][hd] (bf16) -> out [B*H][2] = (0, max): the input of
+// ldmae_attention_fwd_qkv_bounded when nothing upstream knows the norms (one pass over the k slots; worth it for long sequences only).
+__global__ __launch_bounds__(256) void k_norm_max_kernel(const bf16* __restrict__ qkv, unsigned* __restrict__ out, int N, int H, int hd) {
+  __shared__ unsigned hmax[64];
+  const int b = blockIdx.y, t0 = blockIdx.x * 64;
+  if (threadIdx.x < 64) hmax[threadIdx.x] = 0u;
+  __syncthreads();
+  const int pairs = min(64, N - t0) * H;
+  for (int p = threadIdx.x; p < pairs; p += 256) {
+    const int tok = t0 + p / H, hh = p % H;
+    const bf16* kr = qkv + (((size_t)b * N + tok) * 3 + 1) * H * hd + (size_t)hh * hd;
+    float ss = 0.f;
+    for (int ch = 0; ch < hd / 8; ++ch) {
+      const bf16x8 v = *(const bf16x8*)(kr + ch * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+    }
+    atomicMax(&hmax[hh], __float_as_uint(ss));           // non-negative floats order like their bits
+  }
+  __syncthreads();
+  if (threadIdx.x < H) atomicMax(out + ((size_t)b * H + threadIdx.x) * 2 + 1, hmax[threadIdx.x]);
+}
+extern "C" int ldmae_k_norm_max(const void* qkv, float* qk_max2, int B, int N, int H, int hd, void* stream) {
+  LDMAE_REQUIRE(qkv && qk_max2 && B > 0 && N > 0, "k_norm_max: null pointer or empty problem");
+  LDMAE_REQUIRE(H >= 1 && H <= 64 && hd % 8 == 0, "k_norm_max: %d heads (1 .. 64) of %d (multiple of 8)", H, hd);
+  hipMemsetAsync(qk_max2, 0, (size_t)B * H * 2 * sizeof(float), as_stream(stream));
+  hipLaunchKernelGGL(k_norm_max_kernel, dim3((N + 63) / 64, B), dim3(256), 0, as_stream(stream), (const bf16*)qkv, (unsigned*)qk_max2, N, H, hd);
+  LDMAE_CHECK_LAUNCH("k_norm_max");
+  return LDMAE_OK;
 }
 
 // ldmae_attention_fwd_qkv with the static softmax shift from per-(batch, head) norm maxima: qk_max2 [B*H][2] f32 on the device =

@@ -285,6 +285,41 @@ def test_attention_fwd_static_shift_from_the_qknorm_bound(ops, hd, H, N):
     assert torch.equal(o_b, o_t) and torch.equal(lse_b, lse_t)
 
 
+@pytest.mark.parametrize("hd,H,N", [(16, 3, 512), (32, 2, 640)])
+def test_attention_fwd_qkv_static_shift_from_the_key_norm_pass(ops, hd, H, N):
+    """attention_fwd_qkv on long sequences of small heads: one pass over the k slots (ldmae_k_norm_max) + each query's own norm bound the
+    scores, the flash kernel then runs without a running maximum.  Same softmax as the tracked form and as the f64 reference; the maxima
+    are the true maxima; huge keys (bound > 50) fall back to the tracked form bit for bit."""
+    import ldmae_amd.ops as opsmod
+    B = 2
+    g = torch.Generator().manual_seed(7)
+    qkv = torch.randn(B * N, 3 * H * hd, generator=g).to(BF16).cuda()
+    scale = hd ** -0.5
+    old = opsmod.BOUNDED_ATTENTION_MIN_SCORES
+    try:
+        opsmod.BOUNDED_ATTENTION_MIN_SCORES = 1 << 62
+        o_t, lse_t = ops.attention_fwd_qkv(qkv, B, N, H, hd, scale)
+        opsmod.BOUNDED_ATTENTION_MIN_SCORES = 0
+        o_s, lse_s = ops.attention_fwd_qkv(qkv, B, N, H, hd, scale)
+        big = (qkv.float() * 40).to(BF16)
+        o_b, lse_b = ops.attention_fwd_qkv(big, B, N, H, hd, scale)
+        opsmod.BOUNDED_ATTENTION_MIN_SCORES = 1 << 62
+        o_bt, lse_bt = ops.attention_fwd_qkv(big, B, N, H, hd, scale)
+    finally:
+        opsmod.BOUNDED_ATTENTION_MIN_SCORES = old
+    q, k, v = (qkv.view(B, N, 3, H, hd)[:, :, i].permute(0, 2, 1, 3).double().cpu() for i in range(3))
+    ro, rl = _attn_ref(q, k, v, scale)
+    assert rel_err(o_s.float().cpu(), ro.float()) < 1e-2 and rel_err(o_t.float().cpu(), ro.float()) < 1e-2
+    assert (lse_s.cpu() - rl.float()).abs().max() < 2e-2 and rel_err(o_s.float().cpu(), o_t.float().cpu()) < 5e-3
+    assert torch.equal(o_b, o_bt) and torch.equal(lse_b, lse_bt)           # bound far above 50: the tracked form
+    kmax = torch.empty(B * H, 2, device="cuda")
+    from ldmae_amd._lib import call
+    from ldmae_amd.ops import ptr, stream
+    call("ldmae_k_norm_max", ptr(qkv), ptr(kmax), B, N, H, hd, stream())
+    want = (k.float() ** 2).sum(-1).amax(-1).reshape(-1)
+    assert torch.equal(kmax[:, 0].cpu(), torch.zeros(B * H)) and rel_err(kmax[:, 1].cpu(), want) < 1e-6
+
+
 def _attn_ref(qq, kk, vv, scale):
     s = (qq @ kk.transpose(-2, -1)) * scale
     o = s.softmax(-1) @ vv
