@@ -39,7 +39,18 @@ def sample_latents(model, sample_fn, n, cfg_scale, cfg_interval_start, device, n
     if cfg_scale > 1.0:
         z = torch.cat([z, z], 0)
         y = torch.cat([y, torch.full((n,), num_classes, device=device)], 0)
-        out = sample_fn(z, model.forward_with_cfg, y=y, cfg_scale=cfg_scale, cfg_interval=True, cfg_interval_start=cfg_interval_start)[-1]
+        def cfg_forward(x, t, y, cfg_scale, cfg_interval=None, cfg_interval_start=None):
+            # Below the interval start forward_with_cfg applies NO guidance (lightningdit.py:436-439): the conditional half gets its own
+            # output, and the unconditional half's output is never used for the samples that are kept -- every step rebuilds the doubled
+            # batch from the first half of the state (:423-424) and only that half is returned (inference.py:288).  So those steps run the
+            # conditional half alone (the model is bitwise independent of the batch: tests/test_gpu_dit.py); 27 % of the 250 steps of the
+            # shipped configuration (interval start 0.10, timestep shift 0.3).  The gate reads t[0] on the host, as the reference's does.
+            if cfg_interval is True and cfg_interval_start and float(t[0]) < cfg_interval_start:
+                half = len(x) // 2
+                out = model.forward(x[:half], t[:half], y[:half])
+                return torch.cat([out, out], dim=0)
+            return model.forward_with_cfg(x, t, y, cfg_scale, cfg_interval, cfg_interval_start)
+        out = sample_fn(z, cfg_forward, y=y, cfg_scale=cfg_scale, cfg_interval=True, cfg_interval_start=cfg_interval_start)[-1]
         out, _ = out.chunk(2, dim=0)
     else:
         out = sample_fn(z, model.forward, y=y)[-1]

@@ -52,6 +52,39 @@ def test_train_driver_checkpoint_resume_and_sampler(tmp_path, monkeypatch):
     assert lat.shape == (4, 16, 8, 8) and torch.isfinite(lat).all()
 
 
+def test_sampler_skips_the_unconditional_half_only_where_it_is_unused(tmp_path):
+    """sample_latents runs the steps below the guidance-interval start on the conditional half alone (forward_with_cfg applies no guidance
+    there and the kept samples never see the unconditional half's output).  The returned latents must equal, bit for bit, what the sampler
+    gives with the reference's forward_with_cfg on the doubled batch at EVERY step, and the shortcut must actually be taken."""
+    import ldmae_amd.train_accum as t
+    from ldmae_amd.inference import build_sampler, sample_latents
+    cfg = tiny_cfg(tmp_path)
+    torch.manual_seed(3)
+    m = t.build_model(cfg).cuda().eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():                         # the zero-initialised adaLN / final layers would make every output equal
+            if "adaLN_modulation" in n or n.startswith("final_layer.linear"):
+                p.copy_(torch.randn_like(p) * 0.05)
+    cfg["sample"].update(num_sampling_steps=12, timestep_shift=0.3)
+    fn = build_sampler(cfg)
+    halves, fulls = [], []
+    orig_fwd, orig_cfg = m.forward, m.forward_with_cfg
+    m.forward = lambda x, tt, y: (halves.append(len(x)), orig_fwd(x, tt, y))[1]
+    m.forward_with_cfg = lambda *a, **k: (fulls.append(len(a[0])), orig_cfg(*a, **k))[1]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    lat, y = sample_latents(m, fn, 4, 4.0, 0.3, torch.device("cuda"), cfg["data"]["num_classes"], generator=g)
+    assert halves.count(4) >= 2 and len(fulls) >= 2 and halves.count(4) + len(fulls) == 11      # 12 grid points = 11 steps: some on 4 samples, the rest on 8
+    # the reference's loop: forward_with_cfg at every step
+    m.forward, m.forward_with_cfg = orig_fwd, orig_cfg
+    g = torch.Generator(device="cuda").manual_seed(5)
+    z = torch.randn(4, m.in_channels, 8, 8, device="cuda", generator=g)
+    y2 = torch.randint(0, cfg["data"]["num_classes"], (4,), device="cuda", generator=g)
+    zz, yy = torch.cat([z, z]), torch.cat([y2, torch.full((4,), cfg["data"]["num_classes"], device="cuda")])
+    with torch.no_grad():
+        ref = fn(zz, m.forward_with_cfg, y=yy, cfg_scale=4.0, cfg_interval=True, cfg_interval_start=0.3)[-1][:4]
+    assert torch.equal(y, y2) and torch.equal(lat, ref)
+
+
 def test_do_sample_end_to_end_writes_pngs(tmp_path, monkeypatch):
     """SURVEY 8(f)1 end to end (reference inference.py:264-299): EMA checkpoint -> shifted-grid Euler with CFG -> latent de-normalisation
     (z * std / multiplier + mean) -> VMAE decode_to_images -> one PNG per sample, indexed i * world + rank + total; the PNG encoding runs
