@@ -426,13 +426,15 @@ class MaskedAutoencoderViT(nn.Module):
             L = pe.num_patches
             keep = int(L * (1 - mask_ratio))
             if (self.fused_encoder and dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.dim() == 4 and
-                    fused_encoder.supported(self, keep, self.pos_embed.shape[-1]) and all(self._chain_ok(blk) for blk in self.blocks)):
+                    fused_encoder.supported(self, keep, self.pos_embed.shape[-1], tiled=True) and all(self._chain_ok(blk) for blk in self.blocks)):
                 if noise is None:
                     noise = torch.rand(x.shape[0], L, device=x.device)             # the draw random_masking makes (:480)
                 ids_keep, mask, ids_restore = ops.random_masking(noise.float().contiguous(), keep)
                 w2d = pe.proj.weight.view(pe.proj.weight.shape[0], -1)
                 xk = ops.patch_embed_kept(x, ids_keep, self.pos_embed[0], w2d, pe.proj.bias, pe.patch_size[0], dtype)
-                return fused_encoder.encoder_forward(self, xk), mask, ids_restore
+                # 256 kept tokens: the whole stack in one launch; 512 / 768 / 1024 (mask_ratio 0.5 / 0.25 / 0): the tiled form
+                run = fused_encoder.encoder_forward if keep == fused_encoder.TOKENS else fused_encoder.encoder_forward_tiled
+                return run(self, xk), mask, ids_restore
             x = self._embed(x, dtype)
             x, mask, ids_restore = self.random_masking(x, mask_ratio, noise)
             x = self._run(self.blocks, x, dtype)

@@ -424,8 +424,13 @@ def test_fused_encoder_kernel_matches_per_layer_path(golden):
                 m.fused_encoder = False
                 layered, _, _ = m.forward_encoder(imgs, 0.75, noise=noise)
                 m.fused_encoder = True
-                other, _, _ = m.forward_encoder(imgs, 0.5, noise=noise)                       # 512 kept tokens: per-layer path
-        assert calls == [(5, 256, 192)] and other.shape[1] == 512
+                other, _, _ = m.forward_encoder(imgs, 0.5, noise=noise)                       # 512 kept tokens: the tiled form of the fused kernels
+                m.fused_encoder = False
+                other_l, _, _ = m.forward_encoder(imgs, 0.5, noise=noise)
+                m.fused_encoder = True
+                odd, _, _ = m.forward_encoder(imgs, 0.7, noise=noise)                         # 307 kept tokens: per-layer path
+        assert calls == [(5, 256, 192)] and other.shape[1] == 512 and odd.shape[1] == 307
+        assert rel_err(other.cpu(), other_l.cpu()) < 2e-2
         assert fused.dtype == torch.float32 and torch.equal(mask_f, mask)
         assert rel_err(fused.cpu(), lat32.cpu()) < 3e-2 and rel_err(layered.cpu(), lat32.cpu()) < 3e-2
         assert rel_err(fused.cpu(), layered.cpu()) < 2e-2
