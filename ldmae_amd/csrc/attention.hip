@@ -1168,6 +1168,111 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
   if (h == 0 && q0 + r < N) LSE[(size_t)bh * N + q0 + r] = (ms + log2f(l)) * 0.6931471805599453f;
 }
 
+// Head dim 16 (the VMAE heads: what `_encode` / `decode_to_images` run in the reference's f32): the 32x32x2 form above pads the P.V product to 32
+// output rows (a third of its MFMA cycles wasted) and stages its tiles synchronously.  Here everything is 16x16x4 f32 MFMAs: S^T blocks
+// [16 keys][16 queries] = K . Q^T (4 MFMAs per block, the 16 dims), and -- the accumulator-as-operand trick of the bf16 kernels in its 16x16
+// form -- element r of a score block's accumulator IS the B operand of step r of O^T[16 dims][16 queries] += V^T . P with contraction slot
+// g = key 4 g + r of the block; the A operand reads V[key][dim] from LDS.  A wave owns 32 queries (two column blocks that share every K / V
+// read), tiles of 64 keys, the next tile's rows in flight in registers under the current tile's arithmetic.  Same softmax arithmetic
+// (exp2f, running maximum per tile) as the general kernel.
+__global__ __launch_bounds__(256) void attn_fwd_f32_hd16_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                                float* __restrict__ O, float* __restrict__ LSE, int H, int N, float c) {
+  constexpr int HD = 16, LD = 20;              // LDS row pitch in floats: 16-B aligned rows; both operand read patterns conflict-free (banks 20 key + g, 80 g + d)
+  __shared__ __attribute__((aligned(16))) float Ks[64 * LD], Vs[64 * LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int qblocks = (N + 127) / 128;
+  const int bh = blockIdx.x / qblocks, q0 = (blockIdx.x % qblocks) * 128 + wave * 32;
+  const float* kb = K + (size_t)bh * N * HD;
+  const float* vb = V + (size_t)bh * N * HD;
+  float qv[2][4];                              // Q[q0 + 16 qb + j][4 s + g] * c: the B operand of the score products
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) qv[qb][s4] = Q[((size_t)bh * N + min(q0 + 16 * qb + j, N - 1)) * HD + 4 * s4 + g] * c;
+  f32x4 oacc[2];
+  float ms[2], l[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) { oacc[qb] = (f32x4){0.f, 0.f, 0.f, 0.f}; ms[qb] = -1e30f; l[qb] = 0.f; }
+  const int nt = (N + 63) / 64;
+  const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) * 4;            // this thread's 16 B of every K and V tile
+  auto fetch = [&](int kt, float4& kr, float4& vr) {
+    const int row = kt * 64 + srow;
+    if (row < N) { kr = *(const float4*)(kb + (size_t)row * HD + sch); vr = *(const float4*)(vb + (size_t)row * HD + sch); }
+    else { kr = make_float4(0.f, 0.f, 0.f, 0.f); vr = kr; }                  // rows past N: zeros, masked below
+  };
+  float4 kr, vr;
+  fetch(0, kr, vr);
+  for (int kt = 0; kt < nt; ++kt) {
+    __syncthreads();                           // every wave is done with the previous tile
+    *(float4*)&Ks[srow * LD + sch] = kr;
+    *(float4*)&Vs[srow * LD + sch] = vr;
+    __syncthreads();
+    if (kt + 1 < nt) fetch(kt + 1, kr, vr);    // lands under this tile's MFMAs
+    f32x4 sc[2][4];                            // [query block][key block]: rows = keys 16 kb + 4 g + r, column = query j
+#pragma unroll
+    for (int kbk = 0; kbk < 4; ++kbk) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) sc[qb][kbk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float a = Ks[(16 * kbk + j) * LD + 4 * s4 + g];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) sc[qb][kbk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qv[qb][s4], sc[qb][kbk], 0, 0, 0);
+      }
+    }
+    if (kt * 64 + 64 > N) {                    // ragged last tile: keys past N drop out of the softmax
+#pragma unroll
+      for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kt * 64 + 16 * kbk + 4 * g + r >= N) { sc[0][kbk][r] = -__builtin_inff(); sc[1][kbk][r] = -__builtin_inff(); }
+    }
+    float alpha[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float mx = sc[qb][0][0];
+#pragma unroll
+      for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[qb][kbk][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float ms_new = fmaxf(ms[qb], mx);
+      alpha[qb] = exp2f(ms[qb] - ms_new);
+      ms[qb] = ms_new;
+      float rs = 0.f;
+#pragma unroll
+      for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float pp = exp2f(sc[qb][kbk][r] - ms_new); sc[qb][kbk][r] = pp; rs += pp; }
+      l[qb] = l[qb] * alpha[qb] + rs;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[qb][r] *= alpha[qb];
+    }
+#pragma unroll
+    for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = Vs[(16 * kbk + 4 * g + r) * LD + j];                  // V^T[dim j][slot g] of step r
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) oacc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sc[qb][kbk][r], oacc[qb], 0, 0, 0);
+      }
+  }
+  const int b = bh / H, hh = bh % H;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float lt = l[qb];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const int q = q0 + 16 * qb + j;
+    if (q < N) {
+      const float inv = 1.f / lt;              // rows of O^T in this lane: dims 4 g .. 4 g + 3 of query q
+      *(float4*)(O + ((size_t)(b * N + q) * H + hh) * HD + 4 * g) = make_float4(oacc[qb][0] * inv, oacc[qb][1] * inv, oacc[qb][2] * inv, oacc[qb][3] * inv);
+      if (g == 0) LSE[(size_t)bh * N + q] = (ms[qb] + log2f(lt)) * 0.6931471805599453f;
+    }
+  }
+}
+
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                                                                 const float* __restrict__ dO, const float* __restrict__ LSE,
@@ -1343,7 +1448,8 @@ static int attention_fwd_core(int dtype, const void* q, const void* k, const voi
 #define L(HD) { const size_t lds = (size_t)(128 + 64 + 64) * (HD + 1) * 4; \
     hipFuncSetAttribute((const void*)attn_fwd_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(attn_fwd_f32_kernel<HD>, dim3(grid), dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, H, N, c); }
-    ATTN_HD_DISPATCH_F32(hd, L);
+    if (hd == 16) hipLaunchKernelGGL(attn_fwd_f32_hd16_kernel, dim3(grid), dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, H, N, c);
+    else ATTN_HD_DISPATCH_F32(hd, L);
 #undef L
   }
   LDMAE_CHECK_LAUNCH("attention_fwd");
