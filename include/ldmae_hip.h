@@ -143,7 +143,7 @@ int ldmae_attention_fwd(int dtype, const void* q, const void* k, const void* v, 
 int ldmae_attention_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
                         void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, void* stream);
 
-/* The same on the PACKED token-major qkv [B,N,3,H,hd] that the qkv Linear writes (bf16 only): the VMAE blocks have no QK-norm / RoPE
+/* The same on the PACKED token-major qkv [B,N,3,H,hd] that the qkv Linear writes (bf16; the forward also f32 at head_dim 16): the VMAE blocks have no QK-norm / RoPE
  * between the Linear and the attention (models_mae.py:133-141), so q / k / v are read, and dq / dk / dv written, in place (no head-major
  * relayout passes).  dqkv [B,N,3,H,hd]. */
 int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream);

@@ -1176,19 +1176,21 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 // read), tiles of 64 keys, the next tile's rows in flight in registers under the current tile's arithmetic.  Same softmax arithmetic
 // (exp2f, running maximum per tile) as the general kernel.
 __global__ __launch_bounds__(256) void attn_fwd_f32_hd16_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                                                                float* __restrict__ O, float* __restrict__ LSE, int H, int N, float c) {
+                                                                float* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L) {
   constexpr int HD = 16, LD = 20;              // LDS row pitch in floats: 16-B aligned rows; both operand read patterns conflict-free (banks 20 key + g, 80 g + d)
   __shared__ __attribute__((aligned(16))) float Ks[64 * LD], Vs[64 * LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   const int qblocks = (N + 127) / 128;
   const int bh = blockIdx.x / qblocks, q0 = (blockIdx.x % qblocks) * 128 + wave * 32;
-  const float* kb = K + (size_t)bh * N * HD;
-  const float* vb = V + (size_t)bh * N * HD;
+  const size_t hb = (size_t)(bh / H) * L.sb + (size_t)(bh % H) * L.sh;      // head-major [B,H,N,16] or the packed token-major qkv (QkvLayout)
+  const long ld = L.ld;
+  const float* kb = K + hb;
+  const float* vb = V + hb;
   float qv[2][4];                              // Q[q0 + 16 qb + j][4 s + g] * c: the B operand of the score products
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) qv[qb][s4] = Q[((size_t)bh * N + min(q0 + 16 * qb + j, N - 1)) * HD + 4 * s4 + g] * c;
+    for (int s4 = 0; s4 < 4; ++s4) qv[qb][s4] = Q[hb + (size_t)min(q0 + 16 * qb + j, N - 1) * ld + 4 * s4 + g] * c;
   f32x4 oacc[2];
   float ms[2], l[2];
 #pragma unroll
@@ -1197,7 +1199,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_hd16_kernel(const float* __r
   const int srow = threadIdx.x >> 2, sch = (threadIdx.x & 3) * 4;            // this thread's 16 B of every K and V tile
   auto fetch = [&](int kt, float4& kr, float4& vr) {
     const int row = kt * 64 + srow;
-    if (row < N) { kr = *(const float4*)(kb + (size_t)row * HD + sch); vr = *(const float4*)(vb + (size_t)row * HD + sch); }
+    if (row < N) { kr = *(const float4*)(kb + (size_t)row * ld + sch); vr = *(const float4*)(vb + (size_t)row * ld + sch); }
     else { kr = make_float4(0.f, 0.f, 0.f, 0.f); vr = kr; }                  // rows past N: zeros, masked below
   };
   float4 kr, vr;
@@ -1444,11 +1446,13 @@ static int attention_fwd_core(int dtype, const void* q, const void* k, const voi
 #undef L
 #undef LR
   } else {
-    LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd && Lv.ld == hd && Lv.sh == (long)N * hd, "attention_fwd(f32): head-major q/k/v only");
+    LDMAE_REQUIRE((hd == 16 && Lq.ld == Lv.ld && Lq.sh == Lv.sh && Lq.sb == Lv.sb) ||
+                  (Lq.ld == hd && Lq.sh == (long)N * hd && Lv.ld == hd && Lv.sh == (long)N * hd),
+                  "attention_fwd(f32): head-major q/k/v only (head_dim 16: also the packed qkv)");
 #define L(HD) { const size_t lds = (size_t)(128 + 64 + 64) * (HD + 1) * 4; \
     hipFuncSetAttribute((const void*)attn_fwd_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(attn_fwd_f32_kernel<HD>, dim3(grid), dim3(256), lds, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, H, N, c); }
-    if (hd == 16) hipLaunchKernelGGL(attn_fwd_f32_hd16_kernel, dim3(grid), dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, H, N, c);
+    if (hd == 16) hipLaunchKernelGGL(attn_fwd_f32_hd16_kernel, dim3(grid), dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, H, N, c, Lq);
     else ATTN_HD_DISPATCH_F32(hd, L);
 #undef L
   }
@@ -1466,12 +1470,17 @@ extern "C" int ldmae_attention_fwd(int dtype, const void* q, const void* k, cons
 
 extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream) {
   LDMAE_REQUIRE(qkv && o && lse, "attention_fwd_qkv: null pointer");
-  LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_fwd_qkv: bf16 only (the f32 path takes head-major q/k/v)");
+  LDMAE_REQUIRE(dtype == LDMAE_BF16 || (dtype == LDMAE_F32 && hd == 16),
+                "attention_fwd_qkv: bf16, or f32 at head_dim 16 (other f32 head dims take head-major q/k/v)");
   if (int e = attn_check("attention_fwd_qkv", dtype, B, H, N, hd)) return e;
   LDMAE_REQUIRE(hd % 8 == 0, "attention_fwd_qkv: head_dim %d must be a multiple of 8", hd);
-  const bf16* p = (const bf16*)qkv;
   const long hw = (long)H * hd;
   const QkvLayout pk{(long)N * 3 * hw, (long)hd, 3 * hw};
+  if (dtype == LDMAE_F32) {
+    const float* pf = (const float*)qkv;
+    return attention_fwd_core(dtype, pf, pf + hw, pf + 2 * hw, o, lse, B, H, N, hd, scale, pk, pk, as_stream(stream));
+  }
+  const bf16* p = (const bf16*)qkv;
   return attention_fwd_core(dtype, p, p + hw, p + 2 * hw, o, lse, B, H, N, hd, scale, pk, pk, as_stream(stream));
 }
 

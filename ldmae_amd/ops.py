@@ -442,13 +442,13 @@ BOUNDED_ATTENTION_MIN_SCORES = int(os.environ.get("LDMAE_BOUNDED_ATTN_MIN", 1 <<
 
 
 def attention_fwd_qkv(qkv, B, N, H, hd, scale):
-    """Attention straight on the packed token-major qkv [B*N, 3*H*hd] (bf16): no head-major relayout.  -> (o [B,N,H*hd], lse).
+    """Attention straight on the packed token-major qkv [B*N, 3*H*hd] (bf16; f32 at head_dim 16): no head-major relayout.  -> (o [B,N,H*hd], lse).
     Long sequences of small heads (the 1024-token VMAE decoder: the kernel is bound by vector issue) first take one pass over the k slots
     for max |k|^2 per (image, head): with each query's own norm it bounds the scores, and the softmax runs with that static shift instead of
     a running maximum (same result; ldmae_k_norm_max + ldmae_attention_fwd_qkv_bounded)."""
     o = torch.empty(B, N, H * hd, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
-    if hd <= 32 and N >= 512 and B * H * N * N >= BOUNDED_ATTENTION_MIN_SCORES:
+    if qkv.dtype == torch.bfloat16 and hd <= 32 and N >= 512 and B * H * N * N >= BOUNDED_ATTENTION_MIN_SCORES:
         kmax = torch.empty(B * H, 2, dtype=torch.float32, device=qkv.device)
         call("ldmae_k_norm_max", ptr(qkv), ptr(kmax), B, N, H, hd, stream())
         call("ldmae_attention_fwd_qkv_bounded", dt(qkv.dtype), ptr(qkv), ptr(o), ptr(lse), ptr(kmax), B, H, N, hd, float(scale), stream())

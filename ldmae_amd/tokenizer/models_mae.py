@@ -99,7 +99,9 @@ class _ViTBlockFn(torch.autograd.Function):
         W2, W2T = _wcopies(f2w, dtype, bwd)
         h1, mu1, rs1 = ops.layernorm_fwd(x2, n1w, n1b, dtype, eps)
         qkv = ops.gemm_nt(h1, Wqkv, qkvb)                                     # activation dtype: bf16 under autocast
-        if dtype == torch.bfloat16:      # flash kernel on the packed qkv as the Linear wrote it (head_dim 16 padded to 32 in LDS)
+        if dtype == torch.bfloat16 or (hd == 16 and not bwd):
+            # flash kernel on the packed qkv as the Linear wrote it (bf16: head_dim 16 padded to 32 in LDS; f32 inference at head_dim 16: the
+            # 16x16x4-MFMA kernel reads the packed rows too -- no head-major relayout.  The f32 BACKWARD kernels take head-major q / k / v.)
             q = k = v = None
             o, lse = ops.attention_fwd_qkv(qkv, B, N, H, hd, hd ** -0.5)
         else:
