@@ -301,6 +301,7 @@ def test_attention_fwd_qkv_static_shift_from_the_key_norm_pass(ops, hd, H, N):
         o_t, lse_t = ops.attention_fwd_qkv(qkv, B, N, H, hd, scale)
         opsmod.BOUNDED_ATTENTION_MIN_SCORES = 0
         o_s, lse_s = ops.attention_fwd_qkv(qkv, B, N, H, hd, scale)
+        o_f = ops.attention_fwd_qkv(qkv.float(), B, N, H, hd, scale)[0] if hd == 16 else None       # f32 packed qkv: never the (bf16) key-norm pass
         big = (qkv.float() * 40).to(BF16)
         o_b, lse_b = ops.attention_fwd_qkv(big, B, N, H, hd, scale)
         opsmod.BOUNDED_ATTENTION_MIN_SCORES = 1 << 62
@@ -312,6 +313,8 @@ def test_attention_fwd_qkv_static_shift_from_the_key_norm_pass(ops, hd, H, N):
     assert rel_err(o_s.float().cpu(), ro.float()) < 1e-2 and rel_err(o_t.float().cpu(), ro.float()) < 1e-2
     assert (lse_s.cpu() - rl.float()).abs().max() < 2e-2 and rel_err(o_s.float().cpu(), o_t.float().cpu()) < 5e-3
     assert torch.equal(o_b, o_bt) and torch.equal(lse_b, lse_bt)           # bound far above 50: the tracked form
+    if o_f is not None:
+        assert rel_err(o_f.cpu(), ro.float()) < 1e-5
     kmax = torch.empty(B * H, 2, device="cuda")
     from ldmae_amd._lib import call
     from ldmae_amd.ops import ptr, stream
