@@ -1173,8 +1173,8 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 // [16 keys][16 queries] = K . Q^T (4 MFMAs per block, the 16 dims), and -- the accumulator-as-operand trick of the bf16 kernels in its 16x16
 // form -- element r of a score block's accumulator IS the B operand of step r of O^T[16 dims][16 queries] += V^T . P with contraction slot
 // g = key 4 g + r of the block; the A operand reads V[key][dim] from LDS.  A wave owns 32 queries (two column blocks that share every K / V
-// read), tiles of 64 keys, the next tile's rows in flight in registers under the current tile's arithmetic.  Same softmax arithmetic
-// (exp2f, running maximum per tile) as the general kernel.
+// read), tiles of 64 keys, the next tile's rows in flight in registers under the current tile's arithmetic.  Running maximum per tile
+// as in the general kernel; the exponentials are the bare v_exp_f32 (arguments <= 0: what it flushes to zero lies below 2^-126 of the row maximum).
 __global__ __launch_bounds__(256) void attn_fwd_f32_hd16_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                                                                 float* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L) {
   constexpr int HD = 16, LD = 20;              // LDS row pitch in floats: 16-B aligned rows; both operand read patterns conflict-free (banks 20 key + g, 80 g + d)
@@ -1240,13 +1240,13 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_hd16_kernel(const float* __r
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float ms_new = fmaxf(ms[qb], mx);
-      alpha[qb] = exp2f(ms[qb] - ms_new);
+      alpha[qb] = EXP2(ms[qb] - ms_new);
       ms[qb] = ms_new;
       float rs = 0.f;
 #pragma unroll
       for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float pp = exp2f(sc[qb][kbk][r] - ms_new); sc[qb][kbk][r] = pp; rs += pp; }
+        for (int r = 0; r < 4; ++r) { const float pp = EXP2(sc[qb][kbk][r] - ms_new); sc[qb][kbk][r] = pp; rs += pp; }
       l[qb] = l[qb] * alpha[qb] + rs;
 #pragma unroll
       for (int r = 0; r < 4; ++r) oacc[qb][r] *= alpha[qb];
