@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 __global__ __launch_bounds__(256) void attn_fwd_f32_hd16_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                                                                 float* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L) {
   constexpr int HD = 16, LD = 20;              // LDS row pitch in floats: 16-B aligned rows; both operand read patterns conflict-free (banks 20 key + g, 80 g + d)
-  __shared__ __attribute__((aligned(16))) float Ks[64 * LD], Vs[64 * LD];
+  __shared__ __attribute__((aligned(16))) float Ks[2][64 * LD], Vs[2][64 * LD];      // double-buffered: one barrier per tile
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
   const int qblocks = (N + 127) / 128;
   const int bh = blockIdx.x / qblocks, q0 = (blockIdx.x % qblocks) * 128 + wave * 32;
@@ -1204,12 +1204,13 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_hd16_kernel(const float* __r
   };
   float4 kr, vr;
   fetch(0, kr, vr);
+  *(float4*)&Ks[0][srow * LD + sch] = kr;
+  *(float4*)&Vs[0][srow * LD + sch] = vr;
+  __syncthreads();
+  if (nt > 1) fetch(1, kr, vr);                // tile kt + 1 waits in registers while tile kt is computed
   for (int kt = 0; kt < nt; ++kt) {
-    __syncthreads();                           // every wave is done with the previous tile
-    *(float4*)&Ks[srow * LD + sch] = kr;
-    *(float4*)&Vs[srow * LD + sch] = vr;
-    __syncthreads();
-    if (kt + 1 < nt) fetch(kt + 1, kr, vr);    // lands under this tile's MFMAs
+    const float* Kt = Ks[kt & 1];
+    const float* Vt = Vs[kt & 1];
     f32x4 sc[2][4];                            // [query block][key block]: rows = keys 16 kb + 4 g + r, column = query j
 #pragma unroll
     for (int kbk = 0; kbk < 4; ++kbk) {
@@ -1217,7 +1218,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_hd16_kernel(const float* __r
       for (int qb = 0; qb < 2; ++qb) sc[qb][kbk] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        const float a = Ks[(16 * kbk + j) * LD + 4 * s4 + g];
+        const float a = Kt[(16 * kbk + j) * LD + 4 * s4 + g];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) sc[qb][kbk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qv[qb][s4], sc[qb][kbk], 0, 0, 0);
       }
@@ -1255,10 +1256,16 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_hd16_kernel(const float* __r
     for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float a = Vs[(16 * kbk + 4 * g + r) * LD + j];                  // V^T[dim j][slot g] of step r
+        const float a = Vt[(16 * kbk + 4 * g + r) * LD + j];                  // V^T[dim j][slot g] of step r
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) oacc[qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sc[qb][kbk][r], oacc[qb], 0, 0, 0);
       }
+    if (kt + 1 < nt) {                         // the other buffer was last read one tile ago, before the previous barrier
+      *(float4*)&Ks[(kt + 1) & 1][srow * LD + sch] = kr;
+      *(float4*)&Vs[(kt + 1) & 1][srow * LD + sch] = vr;
+      __syncthreads();
+      if (kt + 2 < nt) fetch(kt + 2, kr, vr);
+    }
   }
   const int b = bh / H, hh = bh % H;
 #pragma unroll
