@@ -78,35 +78,45 @@ def pack_encoder(blocks, final_norm) -> torch.Tensor:
     return blob
 
 
-def supported(model, tokens: int, dim: int, tiled: bool = False) -> bool:
-    """The fused kernel covers exactly the shipped encoder geometry on a 256-token sequence (mask_ratio 0.75 of 1024 patches); `tiled`:
-    the three-launches-per-block form, any whole number of 256-token tiles (the docking encoder on all 1024 patches)."""
-    b0 = model.blocks[0]
+def _stack(model, which: str):
+    """(blocks, closing LayerNorm) of the encoder ("enc") or the decoder ("dec": the shipped tokenizer's decoder has the encoder's geometry)."""
+    return (model.blocks, model.norm) if which == "enc" else (model.decoder_blocks, model.decoder_norm)
+
+
+def supported(model, tokens: int, dim: int, tiled: bool = False, which: str = "enc") -> bool:
+    """The fused kernel covers exactly the shipped block geometry on a 256-token sequence (mask_ratio 0.75 of 1024 patches); `tiled`:
+    the two-launches-per-block form, any whole number of 256-token tiles (the docking encoder / decoder on all 1024 patches)."""
+    blocks, norm = _stack(model, which)
+    if len(blocks) == 0:
+        return False
+    b0 = blocks[0]
 
     def packable(blk):          # _pack_block reads every bias: a model built with qkv_bias=False (or on another device / type) keeps the per-layer kernels
         ts = (blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.attn.proj.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
               blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias)
         return all(t is not None and t.is_cuda and t.dtype == torch.float32 for t in ts)
-    return ((tokens % TOKENS == 0 and tokens > 0 if tiled else tokens == TOKENS) and dim == DIM and b0.attn.num_heads == HEADS and b0.mlp.fc1.weight.shape[0] == HIDDEN and
-            isinstance(model.norm, torch.nn.LayerNorm) and model.norm.bias is not None and all(packable(blk) for blk in model.blocks) and
-            all(abs(blk.norm1.eps - model.norm.eps) < 1e-12 and abs(blk.norm2.eps - model.norm.eps) < 1e-12 for blk in model.blocks))
+    return ((tokens % TOKENS == 0 and tokens > 0 if tiled else tokens == TOKENS) and dim == DIM and b0.attn.qkv.weight.shape[1] == DIM and
+            b0.attn.num_heads == HEADS and b0.mlp.fc1.weight.shape[0] == HIDDEN and
+            isinstance(norm, torch.nn.LayerNorm) and norm.bias is not None and all(packable(blk) for blk in blocks) and
+            all(abs(blk.norm1.eps - norm.eps) < 1e-12 and abs(blk.norm2.eps - norm.eps) < 1e-12 for blk in blocks))
 
 
 _CACHE: dict = {}
 
 
-def encoder_blob(model) -> torch.Tensor:
-    """Packed weights of `model.blocks` + `model.norm`, rebuilt when any of those parameters changed (version counters, storage, and
-    ops.WEIGHT_EPOCH for writes through the flat optimizer slab)."""
-    ps = [p for blk in model.blocks for p in blk.parameters()] + list(model.norm.parameters())
+def encoder_blob(model, which: str = "enc") -> torch.Tensor:
+    """Packed weights of the stack's blocks + closing LayerNorm, rebuilt when any of those parameters changed (version counters, storage,
+    and ops.WEIGHT_EPOCH for writes through the flat optimizer slab)."""
+    blocks, norm = _stack(model, which)
+    ps = [p for blk in blocks for p in blk.parameters()] + list(norm.parameters())
     stamp = (ops.WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for p in ps)
-    hit = _CACHE.get(id(model))
+    hit = _CACHE.get((id(model), which))
     if hit is not None and hit[0]() is model and hit[1] == stamp:      # the weak reference guards against a recycled id()
         return hit[2]
     for k in [k for k, v in _CACHE.items() if v[0]() is None]:         # models that are gone: drop their 11 MB blobs
         del _CACHE[k]
-    blob = pack_encoder(model.blocks, model.norm)
-    _CACHE[id(model)] = (weakref.ref(model), stamp, blob)
+    blob = pack_encoder(blocks, norm)
+    _CACHE[(id(model), which)] = (weakref.ref(model), stamp, blob)
     return blob
 
 
@@ -115,6 +125,8 @@ def encoder_forward(model, x: torch.Tensor) -> torch.Tensor:
     return ops.vmae_encoder_fwd(x, encoder_blob(model), len(model.blocks), DIM, HEADS, HIDDEN, model.norm.eps)
 
 
-def encoder_forward_tiled(model, x: torch.Tensor) -> torch.Tensor:
-    """x [B, k * 256, 192] f32 (every patch of the image) -> LayerNorm(blocks(x)), three launches per block from the same blob."""
-    return ops.vmae_encoder_fwd_tiled(x, encoder_blob(model), len(model.blocks), DIM, HEADS, HIDDEN, model.norm.eps)
+def encoder_forward_tiled(model, x: torch.Tensor, which: str = "enc") -> torch.Tensor:
+    """x [B, k * 256, 192] f32 (every patch of the image) -> LayerNorm(blocks(x)), two launches per block from the same blob; `which`:
+    the encoder stack or the decoder stack."""
+    blocks, norm = _stack(model, which)
+    return ops.vmae_encoder_fwd_tiled(x, encoder_blob(model, which), len(blocks), DIM, HEADS, HIDDEN, norm.eps)

@@ -523,8 +523,14 @@ class MaskedAutoencoderViT(nn.Module):
             x = z.float().permute(0, 2, 3, 1).reshape(B, -1, z.shape[1]).contiguous()
             x = _LinearFn.apply(x, self.from_latent.weight, self.from_latent.bias)
             x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias) + self.decoder_pos_embed
-            x = self._run(self.decoder_blocks, x, dtype)
-            x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
+            if (self.fused_encoder and dtype == torch.bfloat16 and not torch.is_grad_enabled() and
+                    fused_encoder.supported(self, x.shape[1], x.shape[2], tiled=True, which="dec") and
+                    all(self._chain_ok(blk) for blk in self.decoder_blocks)):
+                # the shipped decoder has the encoder's geometry (192 wide, 12 heads): bf16 inference runs it on the tiled fused kernels too
+                x = fused_encoder.encoder_forward_tiled(self, x.float().contiguous(), which="dec")
+            else:
+                x = self._run(self.decoder_blocks, x, dtype)
+                x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
             x = self.decoder_pred(x) if not isinstance(self.decoder_pred, nn.Linear) else \
                 _LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)
             img = self.unpatchify(x)

@@ -213,8 +213,12 @@ def test_bf16_calls_are_dispatched_to_the_bf16_kernels():
         assert c["nt_bf16"] >= 4 * len(m.blocks) and c["attn_bf16"] == len(m.blocks) and c["attn_f32"] == 0 and c["nt_f32"] <= 2, c
         m.fused_encoder = True
         z = torch.randn(8, 16, 16, 16, device="cuda")
+        c = counted(lambda: m.decode(z))             # the decoder has the encoder's geometry here (as in the shipped tokenizer): tiled fused kernels too
+        assert c["attn_bf16"] == len(m.decoder_blocks) and c["attn_f32"] == 0 and c["nt_f32"] <= 4, c
+        m.fused_encoder = False
         c = counted(lambda: m.decode(z))
         assert c["nt_bf16"] >= 4 * len(m.decoder_blocks) and c["attn_bf16"] == len(m.decoder_blocks) and c["attn_f32"] == 0 and c["nt_f32"] <= 4, c
+        m.fused_encoder = True
     m.set_precision(None)
     with torch.no_grad():
         c = counted(lambda: m._encode(x))                                # no autocast, no precision: the f32 family, and only it
@@ -382,7 +386,7 @@ def test_tiled_encoder_kernels_match_per_layer_path(golden):
     imgs = det_randn("mae_img", (5, 3, 256, 256), 2).clamp(-1, 1).cuda()
     calls = []
     orig = fused_encoder.encoder_forward_tiled
-    fused_encoder.encoder_forward_tiled = lambda model, x: (calls.append(tuple(x.shape)), orig(model, x))[1]
+    fused_encoder.encoder_forward_tiled = lambda model, x, which="enc": (calls.append(tuple(x.shape)), orig(model, x, which))[1]
     try:
         with torch.no_grad():
             lat32 = m._encode(imgs)                                                          # f32: never the fused kernels
@@ -397,9 +401,22 @@ def test_tiled_encoder_kernels_match_per_layer_path(golden):
         assert rel_err(fused.cpu(), lat32.cpu()) < 3e-2 and rel_err(layered.cpu(), lat32.cpu()) < 3e-2
         assert rel_err(fused.cpu(), layered.cpu()) < 2e-2
         assert torch.equal(one[0], fused[3])
+        # the decoder stack of the shipped tokenizer has the same geometry: `decode` (-> decode_to_images) takes the same kernels with its own blob
+        zlat = lat32[:, :16].contiguous()
+        with torch.no_grad():
+            rec32 = m.decode(zlat).sample
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                rec_f = m.decode(zlat).sample
+                m.fused_encoder = False
+                rec_l = m.decode(zlat).sample
+                m.fused_encoder = True
+                rec_1 = m.decode(zlat[3:4]).sample
+        assert calls[-2:] == [(5, 1024, 192), (1, 1024, 192)] and len(calls) == 4
+        assert rel_err(rec_f.cpu(), rec32.cpu()) < 3e-2 and rel_err(rec_l.cpu(), rec32.cpu()) < 3e-2 and rel_err(rec_f.cpu(), rec_l.cpu()) < 2e-2
+        assert torch.equal(rec_1[0], rec_f[3])
         with torch.autocast("cuda", dtype=torch.bfloat16):
             lat_g = m._encode(imgs[:1])
-        assert lat_g.requires_grad and len(calls) == 2
+        assert lat_g.requires_grad and len(calls) == 4
     finally:
         fused_encoder.encoder_forward_tiled = orig
 
