@@ -86,7 +86,7 @@ def _worker(rank, world, port, q):
     torch.cuda.synchronize()
     exposed = red.exposed_comm_ms()
     if rank == 0:
-        q.put((opt.flat.grads.cpu() * scale, exposed))
+        q.put(((opt.flat.grads.cpu() * scale).numpy(), exposed))      # by value: a torch tensor travels as a file descriptor that needs THIS process alive when the parent unpickles it
     dist.barrier()
     try:                                  # the result is out and both ranks are past the barrier: a peer that closed its sockets first
         dist.destroy_process_group()      # ("connection closed by peer" in gloo's teardown) is not a failure of what this test checks
@@ -102,6 +102,7 @@ def test_two_ranks_one_gpu_reduced_grads_equal_concatenated_batch():
     for p in procs:
         p.start()
     got, exposed = q.get(timeout=300)
+    got = torch.from_numpy(got)
     for r, p in enumerate(procs):
         p.join(120)
         assert p.exitcode == 0, f"rank {r} exit code {p.exitcode}"
