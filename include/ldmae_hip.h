@@ -47,6 +47,10 @@ extern "C" {
    data-parallel caller sets it while RCCL's collective kernels share the chip with backward (ldmae_amd/distributed.py); results are
    bitwise equal to the persistent launch */
 #define LDMAE_EPI_TILE_LAUNCH 0x100
+/* kernel form, or'ed into `epi` per call (bf16 GEMMs): keep the HALF-LINE kernel (64-B LDS rows, 16 x 64-B ring pieces: gemm_nt_persist_kernel)
+   for a shape that the whole-line kernel (128-B LDS rows, gemm_nt_lines.hip -- the default wherever operand rows start on 128-B lines and
+   K % 64 == 0) would take.  Same products in the same order: bitwise-equal results; tests and tools/bench_nt.py use it for A/B runs */
+#define LDMAE_EPI_HALF_LINES 0x200
 
 const char* ldmae_last_error(void);
 const char* ldmae_version(void);

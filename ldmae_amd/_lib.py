@@ -99,6 +99,7 @@ DIAG_SIGNATURES = {
     "ldmae_debug_nt_stamps": (None, [_vp]),
 }
 EPI_TILE_LAUNCH = 0x100
+EPI_HALF_LINES = 0x200
 
 _lib = None
 

@@ -703,7 +703,7 @@ extern "C" void ldmae_debug_nt_stamps(void* buf) { g_nt_stamps = buf; }
 static constexpr void* g_nt_stamps = nullptr;
 #endif
 template <typename OutT>
-static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
+static int launch_nt(int dtype, int epi, bool tile_launch, bool half_lines, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e,
                      hipStream_t st) {
   const long pi = (ldmae_prof_is_on() && dtype == LDMAE_BF16) ? ldmae_prof_begin(st, 2.0 * M * N * K) : -1;
   // per call and per device (a process may drive several GPUs; the query is a cached driver attribute, ~100 ns)
@@ -762,6 +762,14 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
     return LDMAE_OK;
   }
 #endif
+  // bf16, whole-line form (gemm_nt_lines.hip; round 5): every shape whose rows start on 128-B lines.  Diagnostic tune key 19 = 1 keeps the
+  // half-line kernel below for A/B runs.
+  if (dtype == LDMAE_BF16 && !half_lines && ldmae_tune_get(19) == 0 && ldmae_tune_get(7) == 0 && ldmae_tune_get(11) == 0 && ldmae_tune_get(14) == 0 &&
+      ldmae_launch_nt_lines(epi, sizeof(OutT) == 2, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, st)) {
+    if (pi >= 0) ldmae_prof_end(pi, st);
+    LDMAE_CHECK_LAUNCH("gemm_nt_lines");
+    return LDMAE_OK;
+  }
   // bf16: the persistent ring kernel (one workgroup per CU).  tune key 5 = start delay of every other workgroup (A/B knob),
   // key 7 = diagnostic per-K-step stamp build.
 #define PERS_ATTR(...) hipFuncSetAttribute((const void*)gemm_nt_persist_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 2048)
@@ -819,8 +827,8 @@ static int launch_nt(int dtype, int epi, bool tile_launch, const void* A, const 
 extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                              int M, int N, int K, const float* bias, float beta, const float* xin, float* xout,
                              const float* gate, int gate_ld, int rows_per_batch, void* stream) {
-  const bool tile_launch = (epi & LDMAE_EPI_TILE_LAUNCH) != 0;
-  epi &= ~LDMAE_EPI_TILE_LAUNCH;
+  const bool tile_launch = (epi & LDMAE_EPI_TILE_LAUNCH) != 0, half_lines = (epi & LDMAE_EPI_HALF_LINES) != 0;
+  epi &= ~(LDMAE_EPI_TILE_LAUNCH | LDMAE_EPI_HALF_LINES);
   LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "gemm_nt: bad dtype %d", dtype);
   LDMAE_REQUIRE(out_dtype == LDMAE_F32 || out_dtype == LDMAE_BF16, "gemm_nt: bad out_dtype %d", out_dtype);
   LDMAE_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
@@ -860,8 +868,8 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
     LDMAE_FAIL(LDMAE_ERR_INVALID, "gemm_nt: unknown epilogue %d", epi);
   }
   ldmae_count(dtype == LDMAE_BF16 ? LDMAE_COUNT_NT_BF16 : LDMAE_COUNT_NT_F32);
-  return out_dtype == LDMAE_BF16 ? launch_nt<bf16>(dtype, epi, tile_launch, A, B, M, N, K, lda, ldb, e, as_stream(stream))
-                                 : launch_nt<float>(dtype, epi, tile_launch, A, B, M, N, K, lda, ldb, e, as_stream(stream));
+  return out_dtype == LDMAE_BF16 ? launch_nt<bf16>(dtype, epi, tile_launch, half_lines, A, B, M, N, K, lda, ldb, e, as_stream(stream))
+                                 : launch_nt<float>(dtype, epi, tile_launch, half_lines, A, B, M, N, K, lda, ldb, e, as_stream(stream));
 }
 
 static int tn_plan(int dtype, int M, int N, int K, int* rows_out) {

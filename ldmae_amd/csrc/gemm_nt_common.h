@@ -21,6 +21,11 @@ struct EpiArgs {
   float beta;           // EPI_BIAS with f32 out: C = acc + bias + beta*C   (beta 0 or 1: gradient accumulation)
 };
 
+// gemm_nt_lines.hip: the whole-line form of the persistent bf16 NT kernel (128-B LDS rows, seamless ring of five half-block slots).  Returns 0
+// when the shape / alignment is outside what it covers; the caller then launches gemm_nt_persist_kernel.
+int ldmae_launch_nt_lines(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const struct EpiArgs& e,
+                          int grid, int ntiles, hipStream_t st);
+
 #ifdef LDMAE_DIAG
 // probe/gemm_nt_defer.hip (diagnostic build): persistent bf16 NT kernel whose fused epilogue (gated residual / SwiGLU) runs inside the NEXT
 // tile's main loop.  Returns 0 when the shape or the arguments are outside what it covers.

@@ -12,7 +12,7 @@ import weakref
 import torch
 
 from . import _lib as L
-from ._lib import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_GATE_RES, EPI_GELU_BWD, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_TILE_LAUNCH, F32, call, dt,
+from ._lib import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_GATE_RES, EPI_GELU_BWD, EPI_HALF_LINES, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_TILE_LAUNCH, F32, call, dt,
                    ptr, stream)
 
 _ws = {}
@@ -86,21 +86,31 @@ def set_gemm_launch_mode(mode: str) -> None:
     _GEMM_MODE = mode
 
 
+_HALF_LINES = 0            # EPI_HALF_LINES while a test / tool asks for the half-line NT kernel (set_gemm_half_lines)
+
+
+def set_gemm_half_lines(on: bool) -> None:
+    """A/B switch of tests and tools: bf16 NT GEMMs keep the half-line kernel (gemm_nt_persist_kernel) where the whole-line kernel
+    (gemm_nt_lines.hip, the default) would run.  Bitwise-equal results; a per-call flag of the C ABI like the launch mode."""
+    global _HALF_LINES
+    _HALF_LINES = EPI_HALF_LINES if on else 0
+
+
 def _launch_flag() -> int:
     global _AUTO_FLAG
     if _GEMM_MODE != "auto":
-        return EPI_TILE_LAUNCH if _GEMM_MODE == "tile" else 0
+        return (EPI_TILE_LAUNCH if _GEMM_MODE == "tile" else 0) | _HALF_LINES
     if _AUTO_FLAG is not None:
-        return _AUTO_FLAG
+        return _AUTO_FLAG | _HALF_LINES
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
-        return 0
+        return _HALF_LINES
     _AUTO_FLAG = EPI_TILE_LAUNCH if dist.get_world_size() > 1 else 0
-    return _AUTO_FLAG
+    return _AUTO_FLAG | _HALF_LINES
 
 
 def gemm_launch_mode() -> str:
-    return "tile" if _launch_flag() else "persistent"
+    return "tile" if (_launch_flag() & EPI_TILE_LAUNCH) else "persistent"
 
 
 def gemm_nt(a, b, bias=None, out_dtype=None, out=None, beta=0.0):
