@@ -1516,7 +1516,8 @@ __global__ __launch_bounds__(256) void k_norm_max_kernel(const bf16* __restrict_
 extern "C" int ldmae_k_norm_max(const void* qkv, float* qk_max2, int B, int N, int H, int hd, void* stream) {
   LDMAE_REQUIRE(qkv && qk_max2 && B > 0 && N > 0, "k_norm_max: null pointer or empty problem");
   LDMAE_REQUIRE(H >= 1 && H <= 64 && hd % 8 == 0, "k_norm_max: %d heads (1 .. 64) of %d (multiple of 8)", H, hd);
-  hipMemsetAsync(qk_max2, 0, (size_t)B * H * 2 * sizeof(float), as_stream(stream));
+  // the atomic-max buffer MUST start at zero (a smaller-than-true maximum makes the static-shift softmax wrong, silently)
+  LDMAE_REQUIRE(hipMemsetAsync(qk_max2, 0, (size_t)B * H * 2 * sizeof(float), as_stream(stream)) == hipSuccess, "k_norm_max: hipMemsetAsync of the norm buffer failed");
   hipLaunchKernelGGL(k_norm_max_kernel, dim3((N + 63) / 64, B), dim3(256), 0, as_stream(stream), (const bf16*)qkv, (unsigned*)qk_max2, N, H, hd);
   LDMAE_CHECK_LAUNCH("k_norm_max");
   return LDMAE_OK;

@@ -547,7 +547,7 @@ extern "C" int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const vo
   float* lse = (float*)(oatt + (size_t)B * tokens * VD);
   const size_t mxs = ((size_t)B * VH * 2 * 4 + 15) / 16 * 16;      // bytes of one block's norm maxima
   char* mx = (char*)(lse + (size_t)B * VH * tokens);
-  hipMemsetAsync(mx, 0, mxs * nblocks, as_stream(stream));
+  LDMAE_REQUIRE(hipMemsetAsync(mx, 0, mxs * nblocks, as_stream(stream)) == hipSuccess, "vmae_encoder_fwd_tiled: hipMemsetAsync of the q / k norm maxima failed");
   const int tpi = tokens / VTOK;
   const unsigned tiles = (unsigned)((long)B * tokens / VTOK);
   hipLaunchKernelGGL(vmae_encoder_kernel<1>, dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), x, (float*)nullptr, (const char*)blob, 0, eps, 0.f, qkv,

@@ -22,6 +22,20 @@ import torch
 import torch.distributed as dist
 
 
+def batched_adaln_pays(adaln_bytes: int, n_blocks: int, world: int, busbw_gbps: float = None, saving_ms_per_block: float = 0.125) -> bool:
+    """Should a data-parallel train step keep BATCHED adaLN (models.lightningdit._AdaLNAllFn)?  Batching saves ~0.125 ms per block
+    (measured on B/1: 1.5 ms for 12 blocks) but finishes the adaLN weight gradients of every block at the very END of backward, so their
+    buckets (`adaln_bytes` of the slab; 170 MB for B/1, 890 MB for XL/1) are all-reduced fully exposed.  Until a multi-rank run measures the
+    exposed time (train_accum logs it), the choice is made by size: batched only while a ring all-reduce of those bytes,
+    2 (w - 1) / w * bytes / bus bandwidth, is below the saving.  LDMAE_XGMI_BUSBW_GBPS sets the bandwidth assumed (default 250 GB/s, the low
+    end of what RCCL reaches on an 8-GPU xGMI node for 100-MB messages); LDMAE_BATCHED_ADALN=0|1 overrides the whole rule."""
+    if world <= 1:
+        return True
+    bw = busbw_gbps if busbw_gbps is not None else float(os.environ.get("LDMAE_XGMI_BUSBW_GBPS", "250"))
+    exposed_ms = 2.0 * (world - 1) / world * adaln_bytes / (bw * 1e9) * 1e3
+    return exposed_ms < saving_ms_per_block * n_blocks
+
+
 class GradBucketReducer:
     def __init__(self, flat, process_group=None, bucket_bytes: int = 64 << 20, overlap: bool = True, force_hooks: bool = False):
         """force_hooks: arm the hooks / side stream / bucket launches for a world of ONE rank too (bench.py --dp-config and the world-1

@@ -45,7 +45,11 @@ def sample_latents(model, sample_fn, n, cfg_scale, cfg_interval_start, device, n
             # batch from the first half of the state (:423-424) and only that half is returned (inference.py:288).  So those steps run the
             # conditional half alone (the model is bitwise independent of the batch: tests/test_gpu_dit.py); 27 % of the 250 steps of the
             # shipped configuration (interval start 0.10, timestep shift 0.3).  The gate reads t[0] on the host, as the reference's does.
-            if cfg_interval is True and cfg_interval_start and float(t[0]) < cfg_interval_start:
+            # Valid ONLY for a fixed-step, per-sample-independent integrator (the shipped Euler / Heun grid): the second half returned here is
+            # the conditional output again, which an adaptive solver's error norm would see.  And only while the half batch takes the same
+            # adaLN path as the doubled one (the batched bf16 adaLN GEMM needs a batch that is a multiple of 8; an n of 4, 12, 20 ... would put
+            # the half on the per-block f32 path and the guided steps on the batched bf16 one: not bit-for-bit the doubled batch any more).
+            if cfg_interval is True and cfg_interval_start and float(t[0]) < cfg_interval_start and ((len(x) // 2) % 8 == 0 or len(x) % 8 != 0):
                 half = len(x) // 2
                 out = model.forward(x[:half], t[:half], y[:half])
                 return torch.cat([out, out], dim=0)

@@ -205,16 +205,22 @@ def gemm_nt_swiglu_bwd(dy, w3t, h12, with_bias=False):
     return (dh12, colsum(dh12)) if with_bias else dh12
 
 
-def gemm_tn(a, b, out=None, beta=0.0, with_bias=False, ws_slot="tn"):
+def gemm_tn(a, b, out=None, beta=0.0, with_bias=False, ws_slot="tn", dbias_out=None):
     """out[N,K] (f32) = beta*out + a[M,N]^T @ b[M,K]   (weight gradient).  with_bias: also return the column sums of `a`
-    (the bias gradient of the same Linear), fused into the same kernel on the bf16 path."""
+    (the bias gradient of the same Linear), fused into the same kernel on the bf16 path.  dbias_out (f32 [N], contiguous): the bias gradient
+    is accumulated THERE under the same beta as `out` (a .grad slab view: no fresh zero-filled buffer, no add afterwards)."""
     M, N = a.shape
     K = b.shape[1]
     if out is None:
         out = torch.empty(N, K, dtype=torch.float32, device=a.device)
         beta = 0.0
-    # the C entry applies ONE beta to C and to dbias: a fresh bias-gradient buffer must be zero when the caller accumulates into `out`
-    dbias = (torch.zeros if beta != 0.0 else torch.empty)(N, dtype=torch.float32, device=a.device) if with_bias else None
+    if dbias_out is not None:
+        if not with_bias or dbias_out.dtype != torch.float32 or dbias_out.numel() != N or not dbias_out.is_contiguous():
+            raise RuntimeError("gemm_tn: dbias_out must be a contiguous f32 [N] buffer and needs with_bias=True")
+        dbias = dbias_out
+    else:
+        # the C entry applies ONE beta to C and to dbias: a fresh bias-gradient buffer must be zero when the caller accumulates into `out`
+        dbias = (torch.zeros if beta != 0.0 else torch.empty)(N, dtype=torch.float32, device=a.device) if with_bias else None
     d = dt(a.dtype)
     nb = max(L.load().ldmae_gemm_tn_workspace_bytes(d, M, N, K), L.load().ldmae_colsum_workspace_bytes(M, N) if with_bias else 0)
     ws = workspace(nb, a.device, ws_slot)

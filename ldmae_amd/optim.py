@@ -118,13 +118,34 @@ class AdamWEMA:
             sd[k] = self.flat.view(self.ema, k, params[k].shape).clone() if k in params else v.clone()
         return sd
 
+    def layout(self):
+        """(name, offset, numel) of every parameter in slab order: m / v / ema are raw slabs, and the order depends on `front_fn` / `group_fn`."""
+        return [(n, int(o), int(k)) for n, (o, k) in self.flat.offsets.items()]
+
     def state_dict(self):
-        return {"step": self.step_count, "m": self.m, "v": self.v, "ema": self.ema,
+        return {"step": self.step_count, "m": self.m, "v": self.v, "ema": self.ema, "layout": self.layout(),
                 "hyper": dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, ema_decay=self.ema_decay)}
 
     def load_state_dict(self, sd):
+        """Restores the moments and the EMA.  The slabs carry their layout: a state saved under ANOTHER slab order (before `adaln_first`, other
+        groups) is re-ordered by name; one saved without a layout record is refused unless its order is known to be this one."""
+        lay = sd.get("layout")
         self.step_count = int(sd["step"])
-        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.ema.copy_(sd["ema"])
+        if lay is None:
+            raise RuntimeError("AdamWEMA.load_state_dict: the saved state has no 'layout' record (written before round 5); the order of its m / v / "
+                               "ema slabs cannot be verified -- restore the model and the by-name EMA instead (train_accum.py does)")
+        if [tuple(x) for x in lay] == self.layout():
+            self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.ema.copy_(sd["ema"])
+            return
+        mine = self.flat.offsets
+        if {n for n, _, _ in lay} != set(mine) or any(mine[n][1] != k for n, _, k in lay):
+            raise RuntimeError("AdamWEMA.load_state_dict: the saved state belongs to a different set of parameters")
+        n_tr = self.flat.n_trainable
+        for n, o, k in lay:                                  # same parameters, other order: copy slab by slab, by name
+            d = mine[n][0]
+            self.ema[d:d + k].copy_(sd["ema"][o:o + k])
+            if d < n_tr:
+                self.m[d:d + k].copy_(sd["m"][o:o + k]); self.v[d:d + k].copy_(sd["v"][o:o + k])
 
     @torch.no_grad()
     def swap_in_ema(self):

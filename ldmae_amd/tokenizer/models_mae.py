@@ -135,9 +135,10 @@ class _ViTBlockFn(torch.autograd.Function):
             dx = dx.clone()                   # the incoming gradient may have other consumers: never modify it (see _DiTBlockFn)
         pl = ctx.plist
 
-        def dw(dy, xin, i):           # weight + bias gradient of Linear i (index of its weight in plist)
-            if pl is not None:
-                return None, ops.gemm_tn(dy, xin, out=pl[i].grad, beta=1.0, with_bias=True)[1]
+        def dw(dy, xin, i):           # weight + bias gradient of Linear i (index of its weight in plist; its bias is plist[i + 1])
+            if pl is not None:        # both straight into their slab views (beta = 1): no zero-filled bias buffer, no add afterwards
+                ops.gemm_tn(dy, xin, out=pl[i].grad, beta=1.0, with_bias=True, dbias_out=pl[i + 1].grad.view(-1))
+                return None, None
             return ops.gemm_tn(dy, xin, with_bias=True)
         # MLP branch
         dy2 = ops.cast(dx, dtype)
@@ -157,7 +158,7 @@ class _ViTBlockFn(torch.autograd.Function):
         dWqkv, dbqkv = dw(dqkv, h1, 2)
         dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT), x2, n1w, mu1, rs1, dx)
         if pl is not None:
-            small = [(0, dn1w), (1, dn1b), (3, dbqkv), (5, dbp), (6, dn2w), (7, dn2b), (9, db1), (11, db2)]
+            small = [(0, dn1w), (1, dn1b), (6, dn2w), (7, dn2b)]          # (the four bias gradients went into the slab with their weights)
             ops.multi_add_([pl[i].grad for i, _ in small], [g_ for _, g_ in small])
             for p_ in pl:              # a data-parallel reducer's post-accumulate hook does not fire for these: tell it (no-op without one)
                 r = getattr(p_, "_ldmae_grad_ready", None)

@@ -27,7 +27,7 @@ if os.path.dirname(_HERE) not in sys.path:
     sys.path.insert(0, os.path.dirname(_HERE))
 
 from ldmae_amd import ops                                 # noqa: E402
-from ldmae_amd.distributed import GradBucketReducer      # noqa: E402
+from ldmae_amd.distributed import GradBucketReducer, batched_adaln_pays      # noqa: E402
 from ldmae_amd.models.lightningdit import LightningDiT_models  # noqa: E402
 from ldmae_amd.optim import AdamWEMA, adaln_first                      # noqa: E402
 from ldmae_amd.transport import create_transport         # noqa: E402
@@ -138,8 +138,14 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
     # are the last to be all-reduced anyway, and every other bucket still starts under backward.  The data-parallel step is then the same
     # program as the single-GPU one (round 3 switched the batched form off for world > 1).
     opt = AdamWEMA(model, lr=o['lr'], betas=(0.9, o['beta2']), weight_decay=0.0, ema_decay=0.9999, front_fn=adaln_first)
-    model.batched_adaln = os.environ.get("LDMAE_BATCHED_ADALN", "1") != "0"
     reducer = GradBucketReducer(opt.flat)
+    # world > 1: those front buckets (170 MB for B/1, 890 MB for XL/1) are all-reduced fully exposed, which can cost more than the ~0.125 ms per
+    # block that batching saves -- chosen by size until a multi-rank run has measured it (distributed.batched_adaln_pays; the exposed time is
+    # logged below); LDMAE_BATCHED_ADALN=0|1 overrides
+    adaln_bytes = sum(p.numel() * 4 for n, p in opt.flat.trainable if adaln_first(n))
+    env = os.environ.get("LDMAE_BATCHED_ADALN")
+    model.batched_adaln = (env != "0") if env is not None else batched_adaln_pays(adaln_bytes, len(model.blocks), reducer.world)
+    reducer.measure_exposed = reducer.world > 1          # two events per step: the first multi-GPU run shows which choice wins
     # world > 1: LDMAE_DP_GEMM_LAUNCH=tile|persistent (default: what bench.py --dp-config measured faster with the reducer's hooks live)
     ops.set_gemm_launch_mode(os.environ.get("LDMAE_DP_GEMM_LAUNCH", reducer.recommended_gemm_launch_mode()) if reducer.world > 1 else "persistent")
     model.direct_param_grads = True       # every .grad is a slab view and backward is a plain loss.backward(): dW goes straight into the slab
@@ -210,7 +216,8 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
                 avg = running / (log_steps * accum)
                 if world > 1:
                     dist.all_reduce(avg, op=dist.ReduceOp.SUM)
-                logger.info(f"(step={train_steps:07d}) Train Loss: {avg.item() / world:.4f}, Train Steps/Sec: {log_steps / (time() - start):.2f}")
+                comm = f", exposed all-reduce {reducer.exposed_comm_ms() / max(log_steps, 1):.2f} ms/step (batched adaLN {'on' if model.batched_adaln else 'off'})" if world > 1 else ""
+                logger.info(f"(step={train_steps:07d}) Train Loss: {avg.item() / world:.4f}, Train Steps/Sec: {log_steps / (time() - start):.2f}{comm}")
                 running.zero_()
                 log_steps, start = 0, time()
             if train_steps % tr_cfg['ckpt_every'] == 0 and train_steps > 0:

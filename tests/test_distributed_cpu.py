@@ -91,3 +91,96 @@ def test_bucketed_allreduce_matches_sum_world2():
         assert p.exitcode == 0, f"rank {r} exit code {p.exitcode}"
     ok, same = q.get(timeout=5)
     assert ok and same
+
+
+# ----------------------------------------------------------------------------- world 8 on the REAL DiT-B/1 gradient slab (pre-flight for the 8-GPU node)
+class _B1Layout:
+    """The parameter names / shapes / trainability of LightningDiT-B/1 (oracle.dit.param_shapes = the reference's state-dict keys) with
+    uninitialised storage: what FlatParams and GradBucketReducer see of the real model, without building it."""
+
+    def __init__(self):
+        from oracle import dit as odit
+        self.shapes = odit.param_shapes(odit.DiTConfig(**odit.DIT_B_1))
+        self.params = [(n, torch.nn.Parameter(torch.empty(s), requires_grad=(n != "pos_embed"))) for n, s in self.shapes.items()]
+
+    def named_parameters(self):
+        return iter(self.params)
+
+
+def _worker8(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ldmae_amd.distributed import GradBucketReducer
+    from ldmae_amd.optim import FlatParams, adaln_first
+    flat = FlatParams(_B1Layout(), front_fn=adaln_first)
+    red = GradBucketReducer(flat)                                    # the driver's default: 64 MiB buckets
+    launched = []
+    launch = red._launch
+    red._launch = lambda bi: (launched.append(bi), launch(bi))[1]
+    names = [n for n, _ in flat.trainable]
+    ada = [n for n in names if adaln_first(n)]
+    rest = [n for n in names if not adaln_first(n)]
+    hooks = {n: p._ldmae_grad_ready for n, p in flat.trainable}
+    params = dict(flat.trainable)
+    # layout facts the 8-GPU run relies on
+    facts = dict(n_buckets=len(red.buckets), slab_mb=flat.n_trainable * 4 / 2 ** 20, n_front=flat.n_front,
+                 ada_buckets=sorted({red.param_bucket[n] for n in ada}), rest_buckets=sorted({red.param_bucket[n] for n in rest}))
+    pattern = (torch.arange(flat.n_trainable, dtype=torch.float32) % 251) - 125            # small integers: every sum below is exact in f32
+
+    def backward_like(scale):
+        """what a micro-step's backward does to the slab: gradients are ADDED, and the hooks fire in the order backward finishes
+        parameters -- last layers first, the blocks' adaLN weights (batched adaLN: two GEMMs at the very end) last of all"""
+        flat.grads.add_(pattern * scale)
+        for n in list(reversed(rest)) + ada:
+            hooks[n](params[n])
+
+    # accumulation of two micro-steps: nothing may be launched on the first (DDP's no_sync), one all-reduce of the local sum on the second
+    flat.grads.zero_()
+    red.sync = False
+    backward_like(float(rank + 1))
+    none_early = not launched and not red._works
+    red.sync = True
+    backward_like(float(2 * (rank + 1)))
+    scale = red.finish()
+    expect = pattern * float(3 * sum(r + 1 for r in range(world)))
+    exact = torch.equal(flat.grads, expect)
+    # end of the slab first, in order, while "backward" runs; the buckets that hold adaLN weights last (in whatever order the batched adaLN
+    # backward hands its gradients over)
+    first_ada = min(red.param_bucket[n] for n in ada)
+    order_ok = launched[:first_ada] == list(range(first_ada)) and sorted(launched[first_ada:]) == list(range(first_ada, len(red.buckets)))
+    # second optimizer step: the counters re-armed
+    launched.clear()
+    flat.grads.zero_()
+    backward_like(1.0)
+    red.finish()
+    again = torch.equal(flat.grads, pattern * float(world)) and sorted(launched) == list(range(len(red.buckets)))
+    if rank == 0:
+        out.put(dict(facts, none_early=none_early, scale=scale, exact=exact, order_ok=order_ok, again=again))
+    dist.barrier()
+    try:
+        dist.destroy_process_group()
+    except Exception as e:                # noqa: BLE001
+        print("destroy_process_group:", e)
+
+
+def test_world8_reducer_on_the_real_b1_slab():
+    """Eight gloo ranks (CPU tensors) run GradBucketReducer on the real DiT-B/1 gradient slab (130 M f32 = 497 MiB, adaLN weights first):
+    bucket count, the adaLN buckets launched LAST, `sync = False` accumulation, result == the exact sum over the ranks, scale = 1/8."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for r, p in enumerate(procs):
+        p.join(600)
+        assert p.exitcode == 0, f"rank {r} exit code {p.exitcode}"
+    res = q.get(timeout=5)
+    assert res["none_early"] and res["exact"] and res["order_ok"] and res["again"], res
+    assert res["scale"] == 1.0 / world
+    assert 495 < res["slab_mb"] < 500 and res["n_buckets"] == 8 and res["n_front"] == 24, res
+    # the blocks' adaLN parameters (24 tensors, 162 MiB) sit at the front: they fill the LAST buckets, and only those
+    assert res["ada_buckets"] == list(range(res["ada_buckets"][0], res["n_buckets"])), res
+    assert max(res["rest_buckets"]) <= res["ada_buckets"][0], res

@@ -151,7 +151,9 @@ def test_full_size_bs256_bf16_properties():
     """BASELINE config 2 (DiT-B/1, bs = 256, bf16 autocast) is too big for the CPU oracle; checked through size-independent properties:
     (1) two identical forward+backward passes give bitwise identical outputs and gradients (fixed-order reductions, no atomics);
     (2) samples are independent: the first 128 rows of the bs-256 forward equal the bs-128 forward on those samples;
-    (3) the mean-loss gradient of the full batch is the mean of the two half-batch gradients."""
+    (3) the mean-loss gradient of the full batch is the mean of the two half-batch gradients;
+    (4) VALUES at the full batch: rows 0 and 255 of the bs-256 bf16 forward against the fp32 CPU oracle run on those two samples alone
+        (the oracle can afford 2 of the 256; 2e-2 = the bf16 tolerance of the real-width test), so config 2 is oracle-checked at its full size."""
     cfg = odit.DiTConfig(**odit.DIT_B_1)
     sd = det_weights(odit.param_shapes(cfg), 5)
     sd.update(odit.fixed_tables(cfg))
@@ -180,6 +182,10 @@ def test_full_size_bs256_bf16_properties():
     assert rel_err(o1[:128].cpu(), oa.cpu()) < 1e-6 and rel_err(o1[128:].cpu(), ob.cpu()) < 1e-6
     worst = max(rel_err(g1[n].cpu(), (0.5 * (ga[n] + gb[n])).cpu()) for n in g1)
     assert worst < 2e-2, worst                                   # bf16 activations: only the reduction order differs
+    pick = torch.tensor([0, 255])
+    ref = odit.dit_forward(sd, x[pick.cuda()].cpu(), t[pick.cuda()].cpu(), y[pick.cuda()].cpu(), cfg, train=False)
+    for r, b in enumerate(pick.tolist()):
+        assert rel_err(o1[b].cpu(), ref[r]) < 2e-2, (b, rel_err(o1[b].cpu(), ref[r]))
 
 
 def test_real_width_b1_forward_and_checkpointing():

@@ -624,3 +624,50 @@ def test_cast_weight_straight_and_transposed(ops, R, C):
         assert torch.equal(a, w.to(dtype)) and torch.equal(at, w.t().contiguous().to(dtype))
         _, only_t = ops.cast_weight(w, dtype, transposed=True, straight=False)
         assert torch.equal(only_t, at)
+
+
+# ----------------------------------------------------------------------------- the reference's real-width kernel goldens, straight into the HIP kernels
+def test_reference_kernel_goldens_through_the_hip_kernels(ops, golden):
+    """tests/golden/kernels.npz holds what the REFERENCE's own modules return at the real B/1 width (make_golden.py: RMSNorm + modulate at
+    768, feat_rope on [1, 2, 1024, 64], SwiGLUFFN 768 -> 2048 -> 768, block 0's Attention at 1024 tokens).  test_oracle_golden.py pins the
+    oracle to them; here the same vectors go DIRECTLY through the HIP kernels (C ABI), f32 at 1e-4 and bf16 at 2e-2."""
+    from weights import det_randn, det_weights
+    from ldmae_amd.models.lightningdit import Attention
+    from ldmae_amd.models.pos_embed import VisionRotaryEmbeddingFast
+    from ldmae_amd.models.swiglu_ffn import SwiGLUFFN
+    g = golden("kernels")
+    # k5: RMSNorm(768) + modulate (rmsnorm.py:51-77, lightningdit.py modulate)
+    x = det_randn("k5_x", (2, 8, 768), 3)
+    w = 1 + 0.1 * det_randn("k5_w", (768,), 3)
+    sh, sc = 0.3 * det_randn("k5_sh", (2, 768), 3), 0.3 * det_randn("k5_sc", (2, 768), 3)
+    for dtype in (F32, BF16):
+        out, _ = ops.rmsnorm_modulate_fwd(dev(x.view(16, 768)), dev(w), dev(sh), dev(sc), 8, dtype)
+        assert rel_err(out.float().cpu().view(2, 8, 768), g["k5_out"]) < TOL[dtype], dtype
+    # k8: 2-D RoPE on [1, 2, 1024, 64] (pos_embed.py:96-133): head / tail rows and, in f32, the reference's own hash if the bits agree
+    rope = VisionRotaryEmbeddingFast(32, pt_seq_len=32).cuda()
+    q8 = det_randn("k8_q", (1, 2, 1024, 64), 3)
+    rq = rope(dev(q8)).cpu()
+    assert rel_err(rq[0, :, :4], g["k8_head"]) < 1e-5 and rel_err(rq[0, :, -4:], g["k8_tail"]) < 1e-5
+    rq16 = rope(dev(q8, BF16)).float().cpu()
+    assert rel_err(rq16[0, :, :4], g["k8_head"]) < TOL[BF16]
+    # k11: SwiGLUFFN (swiglu_ffn.py:15-36) with the golden's weights on 8 rows
+    sdf = det_weights({"w12.weight": (4096, 768), "w12.bias": (4096,), "w3.weight": (768, 2048), "w3.bias": (768,)}, 4)
+    f = SwiGLUFFN(768, 2048).cuda()
+    f.load_state_dict(sdf)
+    x11 = det_randn("k11_x", (8, 768), 3)
+    with torch.no_grad():
+        assert rel_err(f(dev(x11)).cpu(), g["k11_out"]) < TOL[F32]
+        assert rel_err(f(dev(x11, BF16)).float().cpu(), g["k11_out"]) < TOL[BF16]
+    # k9: block 0's Attention (lightningdit.py:32-91: qkv -> QK-RMSNorm -> RoPE -> softmax attention -> proj) on one sample, 1024 tokens
+    sda = det_weights({"qkv.weight": (2304, 768), "qkv.bias": (2304,), "q_norm.weight": (64,), "k_norm.weight": (64,),
+                       "proj.weight": (768, 768), "proj.bias": (768,)}, 6)
+    a = Attention(768, num_heads=12, qkv_bias=True, qk_norm=True, use_rmsnorm=True).cuda()
+    a.load_state_dict(sda)
+    x9 = det_randn("k9_x", (1, 1024, 768), 3) * 0.5
+    with torch.no_grad():
+        ao = a(dev(x9), rope=rope).cpu()
+        assert rel_err(ao[0, :4], g["k9_head"]) < TOL[F32] and rel_err(ao[0, -4:], g["k9_tail"]) < TOL[F32]
+        assert abs(float(ao.double().norm()) - float(g["k9_norm"])) < 1e-4 * float(g["k9_norm"])
+        a.precision = BF16
+        ao16 = a(dev(x9), rope=rope).float().cpu()
+        assert rel_err(ao16[0, :4], g["k9_head"]) < TOL[BF16] and rel_err(ao16[0, -4:], g["k9_tail"]) < TOL[BF16]

@@ -41,6 +41,9 @@ def test_forward_encoder_matches_reference_golden(golden):
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             lat16, mask16, _ = m.forward_encoder(imgs, ratio, noise=noise)
         assert torch.equal(mask16, mask) and rel_err(lat16.cpu(), lat.cpu()) < 3e-2
+        # ... and the bf16 one-kernel encoder DIRECTLY against the reference's own latents (not only through the HIP f32 result)
+        assert rel_err(lat16[:, :4].float().cpu(), g[f"mae{tag}_lat_head"]) < 3e-2
+        assert abs(float(lat16.double().norm()) - float(g[f"mae{tag}_lat_norm"])) < 1e-2 * float(g[f"mae{tag}_lat_norm"])
 
 
 def test_encode_decode_docking_matches_reference_golden(golden):
@@ -60,6 +63,18 @@ def test_encode_decode_docking_matches_reference_golden(golden):
     img8 = m.decode_to_images(mom[:, :16])
     assert img8.dtype == np.uint8 and img8.shape == (2, 256, 256, 3)
     assert (np.abs(img8[:, :4, :4].astype(int) - g["mae_img8_head"].astype(int)) <= 1).all()
+    # the bf16 docking paths (tiled fused encoder, fused decoder stack) DIRECTLY against the reference goldens
+    m.set_precision(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            mom16 = m._encode(imgs)
+            rec16 = m.decode(mom[:, :16]).sample
+    finally:
+        m.set_precision(None)
+    assert rel_err(mom16[:, :, :2, :2].float().cpu(), g["mae_moments_head"]) < 3e-2
+    assert abs(float(mom16.double().norm()) - float(g["mae_moments_norm"])) < 1e-2 * float(g["mae_moments_norm"])
+    assert rel_err(rec16[:, :, :4, :4].float().cpu(), g["mae_rec_head"]) < 3e-2
+    assert abs(float(rec16.double().norm()) - float(g["mae_rec_norm"])) < 1e-2 * float(g["mae_rec_norm"])
 
 
 @pytest.mark.parametrize("ratio", [0.75, 0.8, 0.3])
@@ -226,29 +241,36 @@ def test_bf16_calls_are_dispatched_to_the_bf16_kernels():
 
 
 def test_fused_encoder_is_independent_of_the_batch_at_full_size():
-    """The one-kernel encoder at the bench size: 256 images = one workgroup per CU, every CU busy.  Each image's tokens must equal, bit for
-    bit, what the kernel gives for that image alone / in a small batch (no cross-workgroup state, no dependence on the grid)."""
-    from ldmae_amd.tokenizer import models_mae
-    torch.manual_seed(1)
-    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).cuda().eval()
+    """BASELINE config 4 at its full size.  The one-kernel encoder at the bench size: 256 images = one workgroup per CU, every CU busy.  Each
+    image's tokens must equal, bit for bit, what the kernel gives for that image alone / in a small batch (no cross-workgroup state, no
+    dependence on the grid) -- and images 0 and 255 of the full batch are compared in VALUE with the CPU oracle run on those two images
+    (mask / ids_restore bit-exact, latents at the bf16 tolerance)."""
+    cfg = omae.MAEConfig()
+    sd = full_sd(cfg)
+    m = build({}, sd, 256)
     g = torch.Generator(device="cuda").manual_seed(2)
     x = torch.rand(256, 3, 256, 256, device="cuda", generator=g) * 2 - 1
     noise = torch.rand(256, 1024, device="cuda", generator=g)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        full = m.forward_encoder(x, 0.75, noise=noise)[0]
+        full, mask, ids = m.forward_encoder(x, 0.75, noise=noise)
         assert full.shape == (256, 256, 192) and torch.isfinite(full).all()
         for sl in (slice(0, 1), slice(97, 102), slice(251, 256)):
             part = m.forward_encoder(x[sl], 0.75, noise=noise[sl])[0]
             assert torch.equal(part, full[sl]), sl
+    pick = [0, 255]
+    olat, omask, oids = omae.forward_encoder(sd, x[pick].cpu(), noise[pick].cpu(), 0.75, cfg)
+    np.testing.assert_array_equal(mask[pick].cpu().numpy(), np.asarray(omask))                 # bit-exact
+    np.testing.assert_array_equal(ids[pick].cpu().numpy(), np.asarray(oids))                   # bit-exact
+    assert rel_err(full[pick].float().cpu(), torch.as_tensor(np.asarray(olat))) < 3e-2
 
 
 def test_tiled_encoder_is_independent_of_the_batch_at_full_size():
     """The docking encoder (`_encode`: all 1024 patches) in bf16 at the bench size -- 256 images = 1024 tiles of 256 tokens through the
     q|k|v and proj / MLP kernels of csrc/vmae_fused.hip and the flash kernel between them: an image's latent must equal, bit for bit, what
     the same kernels give for that image alone / in a small batch."""
-    from ldmae_amd.tokenizer import models_mae
-    torch.manual_seed(1)
-    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=False, no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=256).cuda().eval()
+    cfg = omae.MAEConfig()
+    sd = full_sd(cfg)
+    m = build({}, sd, 256)
     g = torch.Generator(device="cuda").manual_seed(2)
     x = torch.rand(256, 3, 256, 256, device="cuda", generator=g) * 2 - 1
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
@@ -256,6 +278,9 @@ def test_tiled_encoder_is_independent_of_the_batch_at_full_size():
         assert full.shape[0] == 256 and torch.isfinite(full).all()
         for sl in (slice(0, 1), slice(97, 102), slice(251, 256)):
             assert torch.equal(m._encode(x[sl]), full[sl]), sl
+    # values at the full batch: the posterior moments of images 0 and 255 against the CPU oracle on those two images
+    omom = omae.encode_moments(sd, x[[0, 255]].cpu(), cfg)
+    assert rel_err(full[[0, 255]].float().cpu(), torch.as_tensor(np.asarray(omom))) < 3e-2
 
 
 def test_vmae_direct_param_grads_equal_autograd_accumulation():
