@@ -68,33 +68,73 @@ def train_step(model, opt, reducer, transport, x, y):
     return loss
 
 
-def kernel_source_sha():
+def kernel_source_sha(files=("gemm.hip", "gemm_nt_lines.hip", "gemm_nt_common.h", "common.h")):
     """sha256[:16] of the dominant kernel's sources: a committed PMC figure is only quoted for the kernel it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gemm.hip", "gemm_nt_common.h", "common.h"):
+    for f in files:
         with open(os.path.join(ROOT, "ldmae_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC run (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate passes over this same bench, FETCH_SIZE doubled per the gfx950 note).  PMC needs rocprofv3 around the
-    process, so it cannot be measured inside this run; the committed figure is quoted ONLY while the kernel sources still hash to the
-    value recorded with it -- otherwise traffic is null.  Returns (bytes or None, note)."""
+def committed_pmc():
+    """The newest committed PMC run of this bench (tools/pmc_bench.sh -> profiles/rNN_pmc_bench.json).  PMC needs rocprofv3 around the
+    process, so the counters cannot be read inside this run; the committed figures are quoted ONLY while the kernel sources still hash to the
+    values recorded with them.  Returns (dict or None, relative path)."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench.json")), reverse=True):
         try:
             with open(f) as fh:
-                d = json.load(fh)
-            rel = os.path.relpath(f, ROOT)
-            if d.get("kernel_source_sha") != kernel_source_sha():
-                return None, f"{rel} was measured on other kernel sources (sha {d.get('kernel_source_sha')}); not quoted"
-            return round(d["gemm_nt"]["hbm_bytes_per_launch"]), rel + " (committed rocprofv3 --pmc run of this bench on these kernel sources)"
+                return json.load(fh), os.path.relpath(f, ROOT)
         except Exception:
             continue
     return None, None
+
+
+def measured_traffic():
+    """Counters of the dominant kernel (bf16 NT GEMM) from the committed PMC run: HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate
+    passes, the gfx950 correction of MI355X_MICROARCH.md), matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (256 CUs x 4 SIMDs x
+    GRBM_GUI_ACTIVE / 8)) and the clock the chip held.  Null when the kernel sources have changed since.  Returns (dict, note)."""
+    d, rel = committed_pmc()
+    none = {"traffic": None, "mfma_busy": None, "clock_ghz": None}
+    if d is None:
+        return none, None
+    if d.get("kernel_source_sha") != kernel_source_sha():
+        return none, f"{rel} was measured on other kernel sources (sha {d.get('kernel_source_sha')}); not quoted"
+    g = d["gemm_nt"]
+    return ({"traffic": round(g["hbm_bytes_per_launch"]), "mfma_busy": round(g["mfma_busy"], 4) if "mfma_busy" in g else None,
+             "clock_ghz": round(g["clock_ghz"], 3) if "clock_ghz" in g else None},
+            rel + " (committed rocprofv3 --pmc run of this bench on these kernel sources)")
+
+
+# the dominant HBM-bound kernel of the step: rmsnorm_mod_bwd_kernel<GATE> (RMSNorm + modulate backward with the gated-residual backward of the
+# branch below it, elementwise.hip).  Algorithmic bytes per launch at bs = 256 (M = 262144 rows of D = 768; DESIGN section 5): reads dout (bf16),
+# x (f32), the running dx (f32), y (bf16); writes dx (f32), the branch gradient (bf16): 2 + 4 + 4 + 2 + 4 + 2 = 18 B per element.
+ROWWISE_BYTES_PER_ELEMENT = 18
+
+
+def hbm_block(batch, tokens=1024, width=768):
+    """`hbm` block of the JSON line: achieved HBM rate of the dominant HBM-bound kernel = algorithmic bytes per launch / its average duration in
+    the committed rocprofv3 run (and the PMC-measured bytes beside it), against the 8 TB/s peak.  Null figures when elementwise.hip changed."""
+    d, rel = committed_pmc()
+    algo = batch * tokens * width * ROWWISE_BYTES_PER_ELEMENT
+    blk = {"bound": "hbm", "kernel": "rmsnorm_mod_bwd_kernel<GATE> (RMSNorm + modulate backward + gated-residual backward, 24 launches per step)",
+           "algorithmic_bytes_per_launch": algo, "peak": 8000.0, "unit": "GB/s", "achieved": None, "frac": None, "traffic": None, "source": None}
+    if d is None or "rmsnorm_mod_bwd" not in d:
+        return blk
+    if d.get("rowwise_source_sha") != kernel_source_sha(("elementwise.hip", "common.h")):
+        blk["source"] = f"{rel} was measured on other kernel sources; not quoted"
+        return blk
+    r = d["rmsnorm_mod_bwd"]
+    us = r.get("avg_duration_us_in_FETCH_SIZE_pass") or r.get("avg_duration_us_in_WRITE_SIZE_pass")
+    if us and batch == 256:
+        blk["achieved"] = round(algo / (us * 1e-6) / 1e9, 1)
+        blk["frac"] = round(blk["achieved"] / 8000.0, 4)
+        blk["avg_launch_us"] = round(us, 1)
+    blk["traffic"] = round(r["hbm_bytes_per_launch"]) if "hbm_bytes_per_launch" in r else None
+    blk["source"] = rel + " (rocprofv3 --pmc + --kernel-trace over this bench: duration and FETCH_SIZE x2 + WRITE_SIZE per launch)"
+    return blk
 
 
 def usable_cores():
@@ -312,10 +352,12 @@ def gemm_roofline(lib, fn, steps=2):
     ms, fl, nl = C.c_double(), C.c_double(), C.c_long()
     lib.ldmae_prof_collect(C.byref(ms), C.byref(fl), C.byref(nl))
     tf = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
-    traffic, src = measured_traffic()
-    return {"bound": "mfma", "kernel": "gemm_nt_persist_kernel (bf16 NT GEMM: every Linear fwd + dX)",
+    pmc, src = measured_traffic()
+    return {"bound": "mfma", "kernel": "gemm_nt_lines_kernel (bf16 NT GEMM, whole-line ring: every Linear fwd + dX; gemm_nt_persist_kernel for shapes off 128-B lines)",
             "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic": pmc["traffic"], "traffic_unit": "HBM bytes per launch (PMC: FETCH_SIZE x2 + WRITE_SIZE)",
+            "mfma_busy": pmc["mfma_busy"], "clock_ghz": pmc["clock_ghz"],
+            "counters_unit": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (256 CUs x 4 SIMDs x kernel cycles); clock_ghz = GRBM_GUI_ACTIVE / 8 / duration (profiled pass)",
             "traffic_source": src,
             "launches": int(nl.value), "avg_launch_ms": round(ms.value / max(1, nl.value), 4),
             "avg_launch_gflop": round(fl.value / max(1, nl.value) / 1e9, 2),
@@ -410,6 +452,7 @@ def bench_dit(args, world, rank, device, lib, backend):
                    "parallelism": f"dp{world}", "loss": round(final_loss, 5)},
         "step_mfma_frac": round(FLOPS_PER_IMAGE * ips / world / (PEAK_BF16_TFLOPS * 1e12), 4),
         "roofline": roof,
+        "hbm": hbm_block(args.batch),
         "h2d_inclusive": {"ms_per_step": round(el_h / hsteps * 1e3, 3), "images_per_s": round(args.batch * world * hsteps / el_h, 2), "steps": hsteps,
                           "note": "same step with a fresh pinned-host batch copied H2D (non_blocking) every step, SURVEY 8(d); rank 0 clock"},
         "power": ps.summary(),
@@ -548,11 +591,16 @@ def bench_vmae_paths(device, batch=256):
             fn()
         torch.cuda.synchronize()
         return round((time.perf_counter() - t0) / iters * 1e3, 2)
-    for tag, prec in (("f32", None), ("bf16", torch.bfloat16)):
+    tf32_prev = torch.backends.cuda.matmul.allow_tf32
+    # f32: exact-f32 MFMA kernels (torch's default, allow_tf32 = False: the parity path); f32_tf32: the same f32 calls with the switch the
+    # reference's drivers set (inference.py:79, extract_features.py:2-3) -> the TF32-class fp16 family; bf16: set_precision
+    for tag, prec, tf32 in (("f32", None, False), ("f32_tf32", None, True), ("bf16", torch.bfloat16, False)):
         m.set_precision(prec)
+        torch.backends.cuda.matmul.allow_tf32 = tf32
         with torch.no_grad():
             out[f"encode_all_tokens_ms_{tag}"] = ms(lambda: m._encode(x))
         out[f"decode_to_images_ms_{tag}"] = ms(lambda: m.decode_to_images(z))
+    torch.backends.cuda.matmul.allow_tf32 = tf32_prev
     del m
     free_gpu_memory()
     torch.manual_seed(0)
@@ -569,7 +617,9 @@ def bench_vmae_paths(device, batch=256):
         stats = vp.train_one_epoch(pm, loader, opt, 0, a, log=lambda s_: None, scaler=scaler)
     out["pretrain_step_ms_bf16"] = ms(step, iters=4)
     out["pretrain_loss"] = round(float(stats["loss"]), 5)
-    out["note"] = "wall time per call with a device synchronise at both ends; f32 = what the reference's drivers run these calls in"
+    out["note"] = ("wall time per call with a device synchronise at both ends; the reference's drivers run these calls in f32 WITH "
+                   "torch.backends.cuda.matmul.allow_tf32 = True: f32_tf32 is that configuration (fp16 operands = TF32's mantissa, f32 accumulation), "
+                   "f32 the exact-f32 parity path (flag off)")
     return out
 
 

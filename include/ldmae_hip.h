@@ -32,6 +32,12 @@ extern "C" {
 
 #define LDMAE_F32 0
 #define LDMAE_BF16 1
+/* fp16 activations: the TF32-CLASS forward path (round 5).  What the reference's drivers ask for with torch.backends.cuda.matmul.allow_tf32 = True
+ * (inference.py:79, extract_features.py:2-3) is 10-bit-mantissa products with f32 accumulation; gfx950 has no TF32 MFMA, but fp16 has exactly
+ * that mantissa at the bf16 rate, and the operands it is used for are O(1) (conversion saturates at +-65504).  Forward-only entry points:
+ * ldmae_cast / ldmae_cast_weight (dst), ldmae_layernorm_fwd (out), ldmae_gemm_nt (dtype; epilogues BIAS / GATE_RES / BIAS_POS / BIAS_GELU; out
+ * fp16 or f32; shapes of the whole-line kernel: K % 64 == 0, rows on 128-B lines), ldmae_attention_fwd_qkv (head_dim 16). */
+#define LDMAE_F16 2
 
 /* GEMM epilogues */
 #define LDMAE_EPI_BIAS 0       /* C = acc + bias (+ beta*C)                                   */
@@ -273,13 +279,15 @@ int ldmae_prof_collect(double* total_ms, double* total_flops, long* launches);  
 /* Launch counts by kernel family since the last reset, always on (one relaxed atomic add per entry-point call): which ARITHMETIC TYPE a
  * model's calls were dispatched to -- a bf16 forward that silently runs the f32 kernels (round 3: the VMAE decoder under autocast, 250 of
  * 304 ms) shows up as f32 counts.  counts[0..5] = NT GEMM bf16 / f32, TN GEMM bf16 / f32, attention (fwd or bwd entry) bf16 / f32;
- * n = how many to copy (<= 6).  reset != 0 zeroes them after the copy. */
+ * counts[6..7] = NT GEMM / attention forward in fp16 (the TF32-class path).  n = how many to copy (<= 8).  reset != 0 zeroes them after the copy. */
 #define LDMAE_COUNT_NT_BF16 0
 #define LDMAE_COUNT_NT_F32 1
 #define LDMAE_COUNT_TN_BF16 2
 #define LDMAE_COUNT_TN_F32 3
 #define LDMAE_COUNT_ATTN_BF16 4
 #define LDMAE_COUNT_ATTN_F32 5
+#define LDMAE_COUNT_NT_F16 6      /* round 5: the TF32-class (fp16) forward family */
+#define LDMAE_COUNT_ATTN_F16 7
 int ldmae_launch_counts(long* counts, int n, int reset);
 
 #ifdef __cplusplus

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libldmae_hip.so")
 LIB_PATH = os.environ.get("LDMAE_HIP_LIB", LIB_PATH)      # A/B builds of the same library (tools/); unset = the in-tree build
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 EPI_BIAS, EPI_GATE_RES, EPI_BIAS_POS, EPI_BIAS_GELU, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_GELU_BWD = 0, 1, 2, 3, 4, 5, 6
 
 _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
@@ -162,14 +162,16 @@ def dt(dtype) -> int:
         return F32
     if dtype == torch.bfloat16:
         return BF16
-    raise RuntimeError(f"unsupported activation dtype {dtype} (float32 or bfloat16)")
+    if dtype == torch.float16:          # the TF32-class forward path (LDMAE_F16: forward-only entry points)
+        return F16
+    raise RuntimeError(f"unsupported activation dtype {dtype} (float32, bfloat16, or float16 on the forward-only TF32-class path)")
 
 
-COUNT_NAMES = ("nt_bf16", "nt_f32", "tn_bf16", "tn_f32", "attn_bf16", "attn_f32")
+COUNT_NAMES = ("nt_bf16", "nt_f32", "tn_bf16", "tn_f32", "attn_bf16", "attn_f32", "nt_f16", "attn_f16")
 
 
 def launch_counts(reset: bool = False) -> dict:
     """Launch counts by kernel family since the last reset (ldmae_launch_counts): which arithmetic type the calls were dispatched to."""
-    arr = (C.c_long * 6)()
-    call("ldmae_launch_counts", arr, 6, 1 if reset else 0)
+    arr = (C.c_long * 8)()
+    call("ldmae_launch_counts", arr, 8, 1 if reset else 0)
     return dict(zip(COUNT_NAMES, [int(v) for v in arr]))

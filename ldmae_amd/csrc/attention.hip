@@ -43,10 +43,11 @@ __device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
 // 1.0 (bf16) in the first of eight columns: as the first PADDED chunk of a V row it makes column HD of the V image a column of ones, and
 // the P.V product then delivers the softmax row sums in accumulator row HD of the (padded) output -- for free, on the matrix pipe
 __device__ __attribute__((aligned(16))) unsigned g_one16[4] = {0x00003F80u, 0u, 0u, 0u};
+__device__ __attribute__((aligned(16))) unsigned g_one16h[4] = {0x00003C00u, 0u, 0u, 0u};     // the same column of ones in fp16
 constexpr int hd_pad(int hd) { return (hd + 31) / 32 * 32; }
 
 // stage a [ROWS][HD] bf16 tile (global row stride ld elements) into the [ROWS][HDP] LDS image with global_load_lds; 256 threads
-template <int HD, int ROWS, bool ONES = false>      // ONES: the first padded chunk of every row comes from g_one16 (the forward kernel's V tile)
+template <int HD, int ROWS, bool ONES = false, bool F16 = false>      // ONES: the first padded chunk of every row comes from g_one16 (the forward kernel's V tile)
 __device__ __forceinline__ void stage_tile(const bf16* __restrict__ g, long ld, int row_limit, char* lds, int wave, int lane) {
   constexpr int HDP = hd_pad(HD), PIECES = ROWS * HDP * 2 / 1024;
   static_assert(PIECES % 4 == 0 || PIECES == 2 || PIECES == 1, "tile too small");
@@ -58,7 +59,7 @@ __device__ __forceinline__ void stage_tile(const bf16* __restrict__ g, long ld, 
       tile_inv<HDP>(pi * 1024 + lane * 16, row, ch);
       row = min(row, row_limit);
       const void* src = (HD == HDP || ch * 8 < HD) ? (const void*)(g + (long)row * ld + ch * 8)
-                                                    : ((ONES && ch * 8 == HD) ? (const void*)g_one16 : (const void*)g_zero16);
+                                                    : ((ONES && ch * 8 == HD) ? (const void*)(F16 ? g_one16h : g_one16) : (const void*)g_zero16);
       glds16(src, lds + pi * 1024);
     }
   }
@@ -86,14 +87,14 @@ template <int HD, int ROWS> struct TileMap {
     }
   }
   // the padded chunks of one LDS tile image (call once per image, then lgkmcnt(0) + a barrier before the first read)
-  template <bool ONES = false> __device__ __forceinline__ void prefill(char* lds, int wave, int lane) const {
+  template <bool ONES = false, bool F16 = false> __device__ __forceinline__ void prefill(char* lds, int wave, int lane) const {
     if constexpr (HD != HDP) {
 #pragma unroll
       for (int i = 0; i < NPW; ++i)
         if (wave * NPW + i < PIECES && !((real >> i) & 1u)) {
           int row, ch;
           tile_inv<HDP>((wave * NPW + i) * 1024 + lane * 16, row, ch);
-          *(uint4*)(lds + (wave * NPW + i) * 1024 + lane * 16) = make_uint4((ONES && ch * 8 == HD) ? 0x00003F80u : 0u, 0u, 0u, 0u);
+          *(uint4*)(lds + (wave * NPW + i) * 1024 + lane * 16) = make_uint4((ONES && ch * 8 == HD) ? (F16 ? 0x00003C00u : 0x00003F80u) : 0u, 0u, 0u, 0u);
         }
     }
   }
@@ -114,6 +115,18 @@ __device__ __forceinline__ bf16x8 frag_scale(const bf16x8& a, float c) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] * c);
   return o;
+}
+// the fp16 forms (the forward kernel's TF32-class instantiation: fragments keep the bf16x8 REGISTER type, the bits are fp16)
+__device__ __forceinline__ bf16x8 frag_scale_h(const bf16x8& a, float c) {
+  const f16x8 x = __builtin_bit_cast(f16x8, a);
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = from_f<f16>((float)x[j] * c);
+  return __builtin_bit_cast(bf16x8, o);
+}
+template <bool F16> __device__ __forceinline__ f32x16 mfma_att(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x16 splat16(float v) {
   f32x16 o;
@@ -150,6 +163,12 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
   for (int j = 0; j < 8; ++j) f[j] = (bf16)x[8 * s + j];
   return f;
 }
+__device__ __forceinline__ bf16x8 acc_frag_h(const f32x16& x, int s) {       // p in [0, 1]: no saturation needed
+  f16x8 f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (f16)x[8 * s + j];
+  return __builtin_bit_cast(bf16x8, f);
+}
 __device__ __forceinline__ int acc_row(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
 // Sequence lengths that are not a multiple of 64 (VMAE: int(L * (1 - mask_ratio)) kept tokens for any ratio, models_mae.py:472-497): the
@@ -181,7 +200,7 @@ constexpr float RESCALE_THR = 6.0f;
 // column d*32 + 8*(t/4) + 4h + t%4).  Per-lane stores would put 8 B into 32 different rows per instruction (the store tail of a
 // workgroup then costs ~9k cycles, MI355X_MICROARCH 'attention epilogue store tail'); instead the tile goes through a wave-private
 // LDS image (144-B row pitch) and leaves as whole 128-B rows, 16 B per lane, 8 rows per instruction.  `mul` is per lane (= per row).
-template <int HD>
+template <int HD, typename T = bf16>
 __device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[hd_pad(HD) / 32], float mul, char* lds_wave, bf16* gbase, long gstride, int lane,
                                              int nrows = 32) {      // nrows: rows of the wave's 32 that exist (ragged last block when N % 32 != 0)
   constexpr int PITCH = hd_pad(HD) * 2 + 16, CPR = HD / 8;    // bytes per LDS row; 16-B chunks per (true) row
@@ -190,10 +209,10 @@ __device__ __forceinline__ void store_rows_t(const f32x16 (&acc)[hd_pad(HD) / 32
   for (int d = 0; d < hd_pad(HD) / 32; ++d)
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
-      bf16x4 w;
+      typename Pack<T>::v4 w;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = (bf16)(acc[d][4 * t4 + j] * mul);
-      *(bf16x4*)(lds_wave + r * PITCH + (d * 32 + 8 * t4 + 4 * h) * 2) = w;
+      for (int j = 0; j < 4; ++j) w[j] = from_f<T>(acc[d][4 * t4 + j] * mul);
+      *(typename Pack<T>::v4*)(lds_wave + r * PITCH + (d * 32 + 8 * t4 + 4 * h) * 2) = w;
     }
 #pragma unroll
   for (int it = 0; it < (32 * CPR + 63) / 64; ++it) {
@@ -376,7 +395,8 @@ struct QkvLayout { long sb, sh, ld; };
 // (i) q carries scale*log2(e) (rounded once more to bf16 in registers) and every score chain starts from the accumulator block
 // nm = -(running max): the MFMA result is already the exponent, p = exp2(s) is ONE instruction per score; (ii) the running max only
 // moves in the (rare, wave-uniform) rescale branch, which shifts the tile's scores and refreshes nm; (iii) K / V tile addresses are scalar.
-template <int HD, bool RAGGED = false>      // RAGGED: N % 64 != 0 (its own instantiation: the masking costs the hot shapes no registers)
+// F16: the operands are fp16 (same bytes per element; v_mfma_f32_32x32x16_f16): the TF32-class forward path of the VMAE docking calls
+template <int HD, bool RAGGED = false, bool F16 = false>      // RAGGED: N % 64 != 0 (its own instantiation: the masking costs the hot shapes no registers)
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                             bf16* __restrict__ O, float* __restrict__ LSE, int H, int N, float c, QkvLayout L, QkvLayout Lv,
                                                             const float* __restrict__ SB, int sb_heads) {
@@ -395,7 +415,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   const long ld = L.ld, ldv = Lv.ld;
   bf16x8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_scale(gfrag<HD>(qp + (size_t)min(q0 + r, N - 1) * ld, ks * 16 + 8 * h), c);
+  for (int ks = 0; ks < KS; ++ks) {
+    const bf16x8 qraw = gfrag<HD>(qp + (size_t)min(q0 + r, N - 1) * ld, ks * 16 + 8 * h);
+    qf[ks] = F16 ? frag_scale_h(qraw, c) : frag_scale(qraw, c);
+  }
   f32x16 oacc[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d) oacc[d] = splat16(0.f);
@@ -414,7 +437,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
 #pragma unroll
     for (int st = 0; st < ATT_STAGES; ++st) {
       mk.prefill(smem + st * 2 * TB, wave, lane);
-      mv.template prefill<true>(smem + st * 2 * TB + TB, wave, lane);
+      mv.template prefill<true, F16>(smem + st * 2 * TB + TB, wave, lane);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): in LDS before this wave reaches the first tile barrier
   }
@@ -428,7 +451,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   // (the fused VMAE q | k | v kernel leaves these maxima behind for free: csrc/vmae_fused.hip).
   // A first value of 0 means "no maximum over the queries": every lane then uses the norm of its own (scaled) query (ldmae_k_norm_max).
   float bq = 0.f;
-  if (SB) {
+  if (SB && !F16) {                         // (the fp16 instantiation keeps the tracked form: its callers pass no bound)
     if (!sb_heads) bq = *SB;
     else if (SB[2 * bh] > 0.f) bq = sqrtf(SB[2 * bh] * SB[2 * bh + 1]) * c * 1.02f;
     else {
@@ -441,13 +464,13 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
       bq = sqrtf(qn * SB[2 * bh + 1]) * 1.02f + 0.01f;
     }
   }
-  const bool stat = SB != nullptr && __builtin_amdgcn_ballot_w64(!(bq <= 50.f)) == 0;       // wave-uniform
+  const bool stat = SB != nullptr && !F16 && __builtin_amdgcn_ballot_w64(!(bq <= 50.f)) == 0;       // wave-uniform
   const unsigned lds0 = lds_addr_of(smem);
   auto stage = [&](int kt) {
     const int so = (kt % ATT_STAGES) * 2 * TB;
     if (ragged && kt == nt - 1) {          // same number of LDS-DMA instructions per wave as the hoisted form: the vmcnt counts hold
       stage_tile<HD, 64>(kp + (size_t)kt * 64 * ld, ld, N - 1 - kt * 64, smem + so, wave, lane);
-      stage_tile<HD, 64, LSUM>(vp + (size_t)kt * 64 * ldv, ldv, N - 1 - kt * 64, smem + so + TB, wave, lane);
+      stage_tile<HD, 64, LSUM, F16>(vp + (size_t)kt * 64 * ldv, ldv, N - 1 - kt * 64, smem + so + TB, wave, lane);
       return;
     }
     mk.issue(kp + (size_t)kt * 64 * ld, ld, smem + so, lds0 + so, wave, lane);
@@ -484,7 +507,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
-        s[kb] = MFMA_BF16(BATCH ? kfr[ks][kb] : frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], ks == 0 ? nm : s[kb]);
+        s[kb] = mfma_att<F16>(BATCH ? kfr[ks][kb] : frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], ks == 0 ? nm : s[kb]);
     bf16x8 vfr[2][2][DB];                              // V^T fragments: in flight under the softmax arithmetic
     if constexpr (BATCH) {
 #pragma unroll
@@ -529,10 +552,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = acc_frag(s[kb], s2);
+        const bf16x8 pf = F16 ? acc_frag_h(s[kb], s2) : acc_frag(s[kb], s2);
 #pragma unroll
         for (int d = 0; d < DB; ++d)
-          oacc[d] = MFMA_BF16(BATCH ? vfr[kb][s2][d] : frag_tr<HDP>(Vt, kb * 32 + 16 * s2, d * 32, lane), pf, oacc[d]);
+          oacc[d] = mfma_att<F16>(BATCH ? vfr[kb][s2][d] : frag_tr<HDP>(Vt, kb * 32 + 16 * s2, d * 32, lane), pf, oacc[d]);
       }
   };
   if (stat) {                               // the shift is the bound: no maximum to track
@@ -556,7 +579,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16* __restri
   if (!active) return;
   const float inv = 1.f / l;
   const int b = bh / H, hh = bh % H;
-  store_rows_t<HD>(oacc, inv, smem + wave * 32 * (HDP * 2 + 16), O + ((size_t)(b * N + q0) * H + hh) * HD, (long)H * HD, lane, N - q0);
+  if constexpr (F16) store_rows_t<HD, f16>(oacc, inv, smem + wave * 32 * (HDP * 2 + 16), O + ((size_t)(b * N + q0) * H + hh) * HD, (long)H * HD, lane, N - q0);
+  else store_rows_t<HD>(oacc, inv, smem + wave * 32 * (HDP * 2 + 16), O + ((size_t)(b * N + q0) * H + hh) * HD, (long)H * HD, lane, N - q0);
   if (h == 0 && q0 + r < N) LSE[(size_t)bh * N + q0 + r] = (ms + log2f(l)) * 0.6931471805599453f;
 }
 
@@ -1435,8 +1459,8 @@ static int attn_lds(int hd, int extra) {
 }
 
 static int attn_check(const char* who, int dtype, int B, int H, int N, int hd) {
-  ldmae_count(dtype == LDMAE_BF16 ? LDMAE_COUNT_ATTN_BF16 : LDMAE_COUNT_ATTN_F32);
-  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "%s: bad dtype %d", who, dtype);
+  ldmae_count(dtype == LDMAE_F16 ? LDMAE_COUNT_ATTN_F16 : (dtype == LDMAE_BF16 ? LDMAE_COUNT_ATTN_BF16 : LDMAE_COUNT_ATTN_F32));
+  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16 || dtype == LDMAE_F16, "%s: bad dtype %d", who, dtype);
   LDMAE_REQUIRE(B > 0 && H > 0 && N > 0 && hd > 0, "%s: empty problem", who);
   return LDMAE_OK;      // any N: the last 64-row tile of a sweep may be ragged (mask_rows_past)
 }
@@ -1445,7 +1469,14 @@ static int attention_fwd_core(int dtype, const void* q, const void* k, const voi
                               float scale, QkvLayout Lq, QkvLayout Lv, hipStream_t st, const float* score_bound = nullptr, int sb_heads = 0) {
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
   const float c = scale * 1.4426950408889634f;
-  if (dtype == LDMAE_BF16) {
+  if (dtype == LDMAE_F16) {
+    // the TF32-class forward (fp16 operands): head_dim 16, the VMAE heads
+    LDMAE_REQUIRE(hd == 16 && score_bound == nullptr, "attention_fwd(fp16): head_dim 16 only (the VMAE heads), no static bound");
+#define LRH(R) { hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<16, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(16, 0)); \
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<16, R, true>), dim3(grid), dim3(256), attn_lds(16, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq, Lv, (const float*)nullptr, 0); }
+    if (N % 64 == 0) LRH(false) else LRH(true)
+#undef LRH
+  } else if (dtype == LDMAE_BF16) {
 #define LR(HD, R) { hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<HD, R>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
     hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, R>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, lse, H, N, c, Lq, Lv, score_bound, sb_heads); }
 #define L(HD) if (N % 64 == 0) LR(HD, false) else LR(HD, true)
@@ -1477,8 +1508,8 @@ extern "C" int ldmae_attention_fwd(int dtype, const void* q, const void* k, cons
 
 extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream) {
   LDMAE_REQUIRE(qkv && o && lse, "attention_fwd_qkv: null pointer");
-  LDMAE_REQUIRE(dtype == LDMAE_BF16 || (dtype == LDMAE_F32 && hd == 16),
-                "attention_fwd_qkv: bf16, or f32 at head_dim 16 (other f32 head dims take head-major q/k/v)");
+  LDMAE_REQUIRE(dtype == LDMAE_BF16 || ((dtype == LDMAE_F32 || dtype == LDMAE_F16) && hd == 16),
+                "attention_fwd_qkv: bf16, or f32 / fp16 at head_dim 16 (other f32 head dims take head-major q/k/v)");
   if (int e = attn_check("attention_fwd_qkv", dtype, B, H, N, hd)) return e;
   LDMAE_REQUIRE(hd % 8 == 0, "attention_fwd_qkv: head_dim %d must be a multiple of 8", hd);
   const long hw = (long)H * hd;

@@ -10,6 +10,12 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// fp16 activations (round 5): the TF32-CLASS forward path.  fp16 has TF32's 10-bit mantissa; the operands of the GEMMs / attention products it is
+// used for (LayerNorm outputs, q / k / v, softmax probabilities, GELU outputs) are O(1), so the 5-bit exponent is enough -- and the conversion
+// SATURATES at +-65504 instead of producing infinities.  v_mfma_f32_*_f16 runs at the bf16 rate with f32 accumulation.
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -55,6 +61,12 @@ template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32, RNE, NaN-safe
+template <> __device__ __forceinline__ float to_f<f16>(f16 v) { return (float)v; }
+template <> __device__ __forceinline__ f16 from_f<f16>(float v) { return (f16)(v == v ? __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) : v); }   // saturating, NaN kept
+// 8- / 4-element register vectors of a 2-byte activation type
+template <typename T> struct Pack;
+template <> struct Pack<bf16> { typedef bf16x8 v8; typedef bf16x4 v4; };
+template <> struct Pack<f16> { typedef f16x8 v8; typedef f16x4 v4; };
 
 // 8-element vector load/store as floats (16 B for bf16, 2 x 16 B for f32); pointers 16-B aligned
 // Exact-erf GELU (timm Mlp act, models_mae.py:172).  f32 activations: libm's erff.  bf16 activations: erf by Abramowitz-Stegun 7.1.26
@@ -68,6 +80,7 @@ __device__ __forceinline__ float erf_as(float x) {
 }
 template <typename T> __device__ __forceinline__ float erf_act(float x) { return erff(x); }
 template <> __device__ __forceinline__ float erf_act<bf16>(float x) { return erf_as(x); }
+template <> __device__ __forceinline__ float erf_act<f16>(float x) { return erf_as(x); }      // 1.5e-7 against fp16's 5e-4 rounding
 template <typename T> __device__ __forceinline__ float gelu_act(float y) { return 0.5f * y * (1.f + erf_act<T>(y * 0.70710678118654752f)); }
 
 template <typename T> struct Vec8;
@@ -92,6 +105,20 @@ template <> struct Vec8<bf16> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
     *(bf16x8*)p = a;
+  }
+};
+
+template <> struct Vec8<f16> {
+  static __device__ __forceinline__ void load(const f16* p, float (&v)[8]) {
+    f16x8 a = *(const f16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+  }
+  static __device__ __forceinline__ void store(f16* p, const float (&v)[8]) {
+    f16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = from_f<f16>(v[i]);
+    *(f16x8*)p = a;
   }
 };
 

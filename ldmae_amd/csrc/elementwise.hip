@@ -963,6 +963,8 @@ extern "C" int ldmae_cast(int src_dtype, int dst_dtype, const void* src, void* d
   const unsigned grid = ew_grid(n / 8 + 1);
   if (src_dtype == LDMAE_F32 && dst_dtype == LDMAE_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, st, (const float*)src, (bf16*)dst, n);
   else if (src_dtype == LDMAE_BF16 && dst_dtype == LDMAE_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, st, (const bf16*)src, (float*)dst, n);
+  else if (src_dtype == LDMAE_F32 && dst_dtype == LDMAE_F16) hipLaunchKernelGGL((cast_kernel<float, f16>), dim3(grid), dim3(256), 0, st, (const float*)src, (f16*)dst, n);
+  else if (src_dtype == LDMAE_F16 && dst_dtype == LDMAE_F32) hipLaunchKernelGGL((cast_kernel<f16, float>), dim3(grid), dim3(256), 0, st, (const f16*)src, (float*)dst, n);
   else if (src_dtype == LDMAE_F32 && dst_dtype == LDMAE_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n);
   else LDMAE_FAIL(LDMAE_ERR_INVALID, "cast: unsupported %d -> %d", src_dtype, dst_dtype);
   LDMAE_CHECK_LAUNCH("cast");
@@ -1194,7 +1196,7 @@ __global__ __launch_bounds__(256) void cast_weight64_kernel(const float* __restr
     if (dst) {
       T* d = dst + (size_t)(r0 + r) * C + c0 + lc;
       if constexpr (sizeof(T) == 4) *(float4*)d = v;
-      else { bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w; *(bf16x4*)d = o; }
+      else { typename Pack<T>::v4 o; o[0] = from_f<T>(v.x); o[1] = from_f<T>(v.y); o[2] = from_f<T>(v.z); o[3] = from_f<T>(v.w); *(typename Pack<T>::v4*)d = o; }
     }
     tile[r][lc] = v.x; tile[r][lc + 1] = v.y; tile[r][lc + 2] = v.z; tile[r][lc + 3] = v.w;
   }
@@ -1206,7 +1208,7 @@ __global__ __launch_bounds__(256) void cast_weight64_kernel(const float* __restr
   for (int k = 0; k < 16; k += 4) {
     const float a0 = tile[rq + k][c], a1 = tile[rq + k + 1][c], a2 = tile[rq + k + 2][c], a3 = tile[rq + k + 3][c];
     if constexpr (sizeof(T) == 4) *(float4*)(d + k) = make_float4(a0, a1, a2, a3);
-    else { bf16x4 o; o[0] = (bf16)a0; o[1] = (bf16)a1; o[2] = (bf16)a2; o[3] = (bf16)a3; *(bf16x4*)(d + k) = o; }
+    else { typename Pack<T>::v4 o; o[0] = from_f<T>(a0); o[1] = from_f<T>(a1); o[2] = from_f<T>(a2); o[3] = from_f<T>(a3); *(typename Pack<T>::v4*)(d + k) = o; }
   }
 }
 extern "C" int ldmae_cast_weight(int dst_dtype, const float* src, void* dst, void* dstT, int R, int C, void* stream) {
@@ -1214,13 +1216,15 @@ extern "C" int ldmae_cast_weight(int dst_dtype, const float* src, void* dst, voi
   const bool al = ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0 && ((uintptr_t)dstT & 15) == 0;
   if (R % 64 == 0 && C % 64 == 0 && al) {
     dim3 grid(C / 64, R / 64);
-    if (dst_dtype == LDMAE_BF16) hipLaunchKernelGGL(cast_weight64_kernel<bf16>, grid, dim3(256), 0, as_stream(stream), src, (bf16*)dst, (bf16*)dstT, R, C);
+    if (dst_dtype == LDMAE_F16) hipLaunchKernelGGL(cast_weight64_kernel<f16>, grid, dim3(256), 0, as_stream(stream), src, (f16*)dst, (f16*)dstT, R, C);
+    else if (dst_dtype == LDMAE_BF16) hipLaunchKernelGGL(cast_weight64_kernel<bf16>, grid, dim3(256), 0, as_stream(stream), src, (bf16*)dst, (bf16*)dstT, R, C);
     else hipLaunchKernelGGL(cast_weight64_kernel<float>, grid, dim3(256), 0, as_stream(stream), src, (float*)dst, (float*)dstT, R, C);
     LDMAE_CHECK_LAUNCH("cast_weight");
     return LDMAE_OK;
   }
   dim3 grid(cdiv(C, 32), cdiv(R, 32));
-  if (dst_dtype == LDMAE_BF16) hipLaunchKernelGGL(cast_weight_kernel<bf16>, grid, dim3(256), 0, as_stream(stream), src, (bf16*)dst, (bf16*)dstT, R, C);
+  if (dst_dtype == LDMAE_F16) hipLaunchKernelGGL(cast_weight_kernel<f16>, grid, dim3(256), 0, as_stream(stream), src, (f16*)dst, (f16*)dstT, R, C);
+  else if (dst_dtype == LDMAE_BF16) hipLaunchKernelGGL(cast_weight_kernel<bf16>, grid, dim3(256), 0, as_stream(stream), src, (bf16*)dst, (bf16*)dstT, R, C);
   else hipLaunchKernelGGL(cast_weight_kernel<float>, grid, dim3(256), 0, as_stream(stream), src, (float*)dst, (float*)dstT, R, C);
   LDMAE_CHECK_LAUNCH("cast_weight");
   return LDMAE_OK;

@@ -829,11 +829,12 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
                              const float* gate, int gate_ld, int rows_per_batch, void* stream) {
   const bool tile_launch = (epi & LDMAE_EPI_TILE_LAUNCH) != 0, half_lines = (epi & LDMAE_EPI_HALF_LINES) != 0;
   epi &= ~(LDMAE_EPI_TILE_LAUNCH | LDMAE_EPI_HALF_LINES);
-  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "gemm_nt: bad dtype %d", dtype);
-  LDMAE_REQUIRE(out_dtype == LDMAE_F32 || out_dtype == LDMAE_BF16, "gemm_nt: bad out_dtype %d", out_dtype);
+  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16 || dtype == LDMAE_F16, "gemm_nt: bad dtype %d", dtype);
+  LDMAE_REQUIRE(out_dtype == LDMAE_F32 || out_dtype == LDMAE_BF16 || (out_dtype == LDMAE_F16 && dtype == LDMAE_F16), "gemm_nt: bad out_dtype %d", out_dtype);
+  LDMAE_REQUIRE(dtype != LDMAE_F16 || out_dtype != LDMAE_BF16, "gemm_nt: fp16 operands give fp16 or f32 outputs");
   LDMAE_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   LDMAE_REQUIRE(A && B, "gemm_nt: null operand");
-  const int kq = dtype == LDMAE_BF16 ? 64 : F_BK, al = dtype == LDMAE_BF16 ? 8 : 4;
+  const int kq = dtype != LDMAE_F32 ? 64 : F_BK, al = dtype != LDMAE_F32 ? 8 : 4;
   LDMAE_REQUIRE(K % kq == 0, "gemm_nt: K=%d must be a multiple of %d", K, kq);
   LDMAE_REQUIRE(lda % al == 0 && ldb % al == 0 && lda >= K && ldb >= K, "gemm_nt: lda=%d ldb=%d need 16-B aligned rows >= K", lda, ldb);
   LDMAE_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_nt: operands must be 16-B aligned");
@@ -866,6 +867,25 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
     e.xout = xout;   /* optional: [ceil(M/128)][2*Hs] f32 partial column sums of dh12 (bias gradient of w12) */
   } else {
     LDMAE_FAIL(LDMAE_ERR_INVALID, "gemm_nt: unknown epilogue %d", epi);
+  }
+  if (dtype == LDMAE_F16) {
+    // the TF32-class forward family: whole-line kernel only (every Linear of the VMAE / DiT blocks qualifies), one tile per workgroup or persistent
+    LDMAE_REQUIRE(epi == LDMAE_EPI_BIAS || epi == LDMAE_EPI_GATE_RES || epi == LDMAE_EPI_BIAS_POS || epi == LDMAE_EPI_BIAS_GELU,
+                  "gemm_nt(fp16): forward epilogues only (bias, gated residual, pos, gelu), got %d", epi);
+    LDMAE_REQUIRE(beta == 0.f, "gemm_nt(fp16): beta must be 0");
+    ldmae_count(LDMAE_COUNT_NT_F16);
+    int ncu = 0, dev = 0;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    ncu = ncu >= 8 ? ncu / 8 * 8 : 8;
+    const int ntiles = cdiv(M, 256) * cdiv(N, 256);
+    const bool pers = !tile_launch && cdiv(M, 256) >= 8;
+    const int pgrid = (pers && ntiles != ncu) ? ncu : ntiles;
+    LDMAE_REQUIRE(ldmae_launch_nt_lines_f16(epi, out_dtype == LDMAE_F16, A, B, M, N, K, lda, ldb, e, pgrid, ntiles, as_stream(stream)),
+                  "gemm_nt(fp16): shape outside the whole-line kernel (M=%d N=%d multiples of 8, K=%d lda=%d ldb=%d multiples of 64, 128-B aligned operands)",
+                  M, N, K, lda, ldb);
+    LDMAE_CHECK_LAUNCH("gemm_nt_lines_f16");
+    return LDMAE_OK;
   }
   ldmae_count(dtype == LDMAE_BF16 ? LDMAE_COUNT_NT_BF16 : LDMAE_COUNT_NT_F32);
   return out_dtype == LDMAE_BF16 ? launch_nt<bf16>(dtype, epi, tile_launch, half_lines, A, B, M, N, K, lda, ldb, e, as_stream(stream))

@@ -25,6 +25,10 @@ struct EpiArgs {
 // when the shape / alignment is outside what it covers; the caller then launches gemm_nt_persist_kernel.
 int ldmae_launch_nt_lines(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const struct EpiArgs& e,
                           int grid, int ntiles, hipStream_t st);
+// the same kernel on fp16 operands (v_mfma_f32_16x16x32_f16; the TF32-class forward path): epilogues BIAS / GATE_RES / BIAS_POS / BIAS_GELU,
+// output fp16 (out_f16) or f32.  Returns 0 for anything else.
+int ldmae_launch_nt_lines_f16(int epi, int out_f16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const struct EpiArgs& e,
+                              int grid, int ntiles, hipStream_t st);
 
 #ifdef LDMAE_DIAG
 // probe/gemm_nt_defer.hip (diagnostic build): persistent bf16 NT kernel whose fused epilogue (gated residual / SwiGLU) runs inside the NEXT
@@ -107,7 +111,7 @@ template <int EPI, typename OutT> struct Epi4 {
   static __device__ __forceinline__ void put(void* base, size_t off, float4 v) {
     OutT* p = (OutT*)base + off;
     if constexpr (sizeof(OutT) == 4) *(float4*)p = v;
-    else { bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w; *(bf16x4*)p = o; }
+    else { typename Pack<OutT>::v4 o; o[0] = from_f<OutT>(v.x); o[1] = from_f<OutT>(v.y); o[2] = from_f<OutT>(v.z); o[3] = from_f<OutT>(v.w); *(typename Pack<OutT>::v4*)p = o; }
   }
   // value destined for C (and C2 for GELU) without storing them; side outputs (xout) are stored here
   __device__ __forceinline__ void compute(int m, float4 a, float4& c, float4& c2) const {
@@ -338,9 +342,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
   auto put8 = [&](void* base, size_t oc, float4 a, float4 b) {
     if constexpr (sizeof(OutT) == 4) { *(float4*)((float*)base + oc) = a; *(float4*)((float*)base + oc + 4) = b; }
     else {
-      bf16x8 o;
-      o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w; o[4] = (bf16)b.x; o[5] = (bf16)b.y; o[6] = (bf16)b.z; o[7] = (bf16)b.w;
-      __builtin_nontemporal_store(o, (bf16x8*)((bf16*)base + oc));      // streamed output: keeps the B tiles in L2 (+0.5..2 %)
+      typename Pack<OutT>::v8 o;
+      o[0] = from_f<OutT>(a.x); o[1] = from_f<OutT>(a.y); o[2] = from_f<OutT>(a.z); o[3] = from_f<OutT>(a.w);
+      o[4] = from_f<OutT>(b.x); o[5] = from_f<OutT>(b.y); o[6] = from_f<OutT>(b.z); o[7] = from_f<OutT>(b.w);
+      __builtin_nontemporal_store(o, (typename Pack<OutT>::v8*)((OutT*)base + oc));      // streamed output: keeps the B tiles in L2 (+0.5..2 %)
     }
   };
 #pragma unroll

@@ -29,7 +29,8 @@
 // closing barrier above its 32 MFMAs (csrc/probe/ingest_probe.hip, mode 7 before the pin: 1700 cycles per K-step instead of 1150)
 #define LINES_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int EPI, typename OutT>
+// InT: bf16, or f16 (same bytes, v_mfma_f32_16x16x32_f16: the TF32-class forward path; A / B stay typed as 2-byte elements)
+template <int EPI, typename OutT, typename InT = bf16>
 __global__ __launch_bounds__(512) void gemm_nt_lines_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int lda,
                                                             int ldb, EpiArgs e, int ntiles) {
   constexpr int BM = 256, BN = 256, WN = 4, TM = 128, TNn = 64, MI = 8, NI = 4, SLOT = 256 * 128;
@@ -137,7 +138,11 @@ __global__ __launch_bounds__(512) void gemm_nt_lines_kernel(const bf16* __restri
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int jj = 0; jj < NI; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[jj], acc[i][jj], 0, 0, 0);
+          for (int jj = 0; jj < NI; ++jj) {
+            if constexpr (sizeof(InT) == 2 && !__is_same(InT, bf16))
+              acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, bfr[jj]), acc[i][jj], 0, 0, 0);
+            else acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[jj], acc[i][jj], 0, 0, 0);
+          }
         if (!grpB && h == 1 && j + 1 < nb) {
           if (issued) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -182,11 +187,43 @@ static int launch_lines(int epi, const void* A, const void* B, int M, int N, int
 #undef LINES_GO
 }
 
+static bool lines_shape_ok(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb) {
+  if (M < 8 || N < 8 || M % 8 != 0 || N % 8 != 0 || K % 64 != 0 || lda % 64 != 0 || ldb % 64 != 0) return false;
+  if (((uintptr_t)A & 127) != 0 || ((uintptr_t)B & 127) != 0) return false;
+  return !(epi == LDMAE_EPI_SWIGLU && N % 256 != 0);
+}
+
+template <typename OutT>
+static int launch_lines_f16(int epi, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid, int ntiles,
+                            hipStream_t st) {
+  constexpr int lds = 5 * 256 * 128;
+#define LINES_GO(E)                                                                                                                    \
+  {                                                                                                                                     \
+    hipFuncSetAttribute((const void*)gemm_nt_lines_kernel<E, OutT, f16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);              \
+    hipLaunchKernelGGL((gemm_nt_lines_kernel<E, OutT, f16>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, \
+                       e, ntiles);                                                                                                     \
+    return 1;                                                                                                                           \
+  }
+  switch (epi) {
+    case LDMAE_EPI_BIAS: LINES_GO(LDMAE_EPI_BIAS);
+    case LDMAE_EPI_GATE_RES: LINES_GO(LDMAE_EPI_GATE_RES);
+    case LDMAE_EPI_BIAS_POS: LINES_GO(LDMAE_EPI_BIAS_POS);
+    case LDMAE_EPI_BIAS_GELU: LINES_GO(LDMAE_EPI_BIAS_GELU);
+    default: return 0;
+  }
+#undef LINES_GO
+}
+
+int ldmae_launch_nt_lines_f16(int epi, int out_f16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
+                              int ntiles, hipStream_t st) {
+  if (!lines_shape_ok(epi, A, B, M, N, K, lda, ldb)) return 0;
+  return out_f16 ? launch_lines_f16<f16>(epi, A, B, M, N, K, lda, ldb, e, grid, ntiles, st)
+                 : launch_lines_f16<float>(epi, A, B, M, N, K, lda, ldb, e, grid, ntiles, st);
+}
+
 int ldmae_launch_nt_lines(int epi, int out_bf16, const void* A, const void* B, int M, int N, int K, int lda, int ldb, const EpiArgs& e, int grid,
                           int ntiles, hipStream_t st) {
-  if (M < 8 || N < 8 || M % 8 != 0 || N % 8 != 0 || K % 64 != 0 || lda % 64 != 0 || ldb % 64 != 0) return 0;
-  if (((uintptr_t)A & 127) != 0 || ((uintptr_t)B & 127) != 0) return 0;
-  if (epi == LDMAE_EPI_SWIGLU && N % 256 != 0) return 0;
+  if (!lines_shape_ok(epi, A, B, M, N, K, lda, ldb)) return 0;
   // the lane offsets are 32-bit: 8 rows of the operand must stay below 4 GiB (they do by many orders of magnitude)
   return out_bf16 ? launch_lines<bf16>(epi, A, B, M, N, K, lda, ldb, e, grid, ntiles, st)
                   : launch_lines<float>(epi, A, B, M, N, K, lda, ldb, e, grid, ntiles, st);

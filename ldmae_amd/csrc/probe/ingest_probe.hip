@@ -45,6 +45,7 @@ template <int N> __device__ __forceinline__ void vmwait_on2(f32x4& a, f32x4& b) 
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 constexpr int BM = 256, BN = 256, STAGE_BYTES = (BM + BN) * 64;
 
+__device__ int g_bstream = 0;             // mode 7: 1 = the B rows are STREAMED too, shared like the A rows (the TN GEMM's situation); 2 = streamed, unshared
 __device__ int g_wrap_rb = 1 << 30;       // E2: A row-blocks wrap at this count (small = the A stream is L2-resident)
 struct Walk {   // tile ownership of gemm_nt_persist_kernel (persistent form)
   int t, tend, tstride, tiles_n;
@@ -565,7 +566,12 @@ __global__ __launch_bounds__(512) void wl5_kernel(const bf16* __restrict__ A, co
   int tA = w.t, jA = 0, tB = w.t, jB = 0;
   unsigned sA = 0, sB = 1;                              // slot of the next A / B half-block (stream position mod 5)
   auto rowA = [&](int t) { return (const char*)(A + (size_t)(((t / w.tiles_n) % wrap_rb) * BM + 8 * wave) * lda); };
-  auto rowB = [&](int t) { return (const char*)(B + (size_t)((t % w.tiles_n) * BN + 8 * wave) * ldb); };
+  const int bstream = g_bstream;
+  auto rowB = [&](int t) {
+    if (bstream == 1) return (const char*)(A + (size_t)M * 2048 + (size_t)(((t / w.tiles_n) % wrap_rb) * BM + 8 * wave) * ldb);       // second half of the A allocation
+    if (bstream == 2) return (const char*)(A + (size_t)M * 2048 + (size_t)((t % (M / BM)) * BM + 8 * wave) * ldb);
+    return (const char*)(B + (size_t)((t % w.tiles_n) * BN + 8 * wave) * ldb);
+  };
   const char* pA = rowA(tA);                            // wave-uniform: first row of this wave's pieces, advanced 128 B per block
   const char* pB = rowB(tB);
   const size_t step64 = (size_t)64 * lda * 2;           // 64 rows further: the wave's next piece
@@ -648,6 +654,7 @@ int main(int argc, char** argv) {
   const int grid_override = argc > 2 ? atoi(argv[2]) : 0;          // E1: fewer workgroups (64 = 8 CUs per XCD)
   const int wrap_rb = argc > 3 ? atoi(argv[3]) : (1 << 30);          // E2: A row-blocks wrap (32 = 4 per XCD: L2-resident A)
   const int skip_shape = argc > 4 ? atoi(argv[4]) : 0;
+  const int bstream = argc > 5 ? atoi(argv[5]) : 0;                  // mode 7 only: B streamed from the second half of the A allocation (1 shared like A, 2 unshared): shapes with K > 2048 are SKIPPED then
   int ncu = 0; HIPCK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
   const int ncu_real = ncu;
   if (argc > 2 && atoi(argv[2]) > 0) ncu = atoi(argv[2]);
@@ -660,6 +667,7 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, A, amax, 1u);
   hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, B, bmax, 77u);
   HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_wrap_rb), &wrap_rb, sizeof(int)));
+  HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_bstream), &bstream, sizeof(int)));
   HIPCK(hipDeviceSynchronize());
   struct Row { const char* name; KernelFn fn; int dma_frac16; };
   std::vector<Row> rows = {
@@ -692,6 +700,7 @@ int main(int argc, char** argv) {
   std::vector<unsigned long long> hs(ncu * 2);
   printf("ingest probe: %d workgroups on %d CUs, A row-blocks wrap at %d, M = %d, one 512-thread workgroup per CU, 32 KiB of operands per K-step (256 x 256 x 32)\n", ncu, ncu_real, wrap_rb, M);
   for (const Shape& sh : shapes) {
+    if (bstream && sh.K > 2048) continue;                           // the streamed B rows would leave the allocation
     const int ntiles = (M / BM) * (sh.N / BN), nk = sh.K / 32;
     const double ksteps_per_cu = (double)ntiles * nk / ncu;
     printf("\nN = %d, K = %d: %d tiles, %d K-steps per tile, %.0f K-steps per CU\n", sh.N, sh.K, ntiles, nk, ksteps_per_cu);

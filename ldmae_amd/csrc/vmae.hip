@@ -151,6 +151,7 @@ template <> __device__ __forceinline__ void ld4<bf16>(const bf16* p, float (&v)[
 template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
 template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 template <> __device__ __forceinline__ void st4<bf16>(bf16* p, const float (&v)[4]) { bf16x4 a; for (int j = 0; j < 4; ++j) a[j] = (bf16)v[j]; *(bf16x4*)p = a; }
+template <> __device__ __forceinline__ void st4<f16>(f16* p, const float (&v)[4]) { f16x4 a; for (int j = 0; j < 4; ++j) a[j] = from_f<f16>(v[j]); *(f16x4*)p = a; }
 
 template <typename OutT, int NV>     // NV = ceil(D / 64): 16-B chunks per lane
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
@@ -288,7 +289,8 @@ extern "C" int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w
                                    int M, int D, float eps, void* stream) {
   LDMAE_REQUIRE(x && w && b && out && M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_fwd: bad arguments (D=%d: multiple of 4, <= 1024)", D);
   const unsigned grid = cdiv(M, 16) < 4096 ? cdiv(M, 16) : 4096;
-#define LN_F(NV) { if (out_dtype == LDMAE_BF16) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, NV>), dim3(grid), dim3(256), 0, as_stream(stream), x, w, b, (bf16*)out, mean, rstd, M, D, eps); \
+#define LN_F(NV) { if (out_dtype == LDMAE_F16) hipLaunchKernelGGL((layernorm_fwd_kernel<f16, NV>), dim3(grid), dim3(256), 0, as_stream(stream), x, w, b, (f16*)out, mean, rstd, M, D, eps); \
+                   else if (out_dtype == LDMAE_BF16) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, NV>), dim3(grid), dim3(256), 0, as_stream(stream), x, w, b, (bf16*)out, mean, rstd, M, D, eps); \
                    else hipLaunchKernelGGL((layernorm_fwd_kernel<float, NV>), dim3(grid), dim3(256), 0, as_stream(stream), x, w, b, (float*)out, mean, rstd, M, D, eps); }
   LN_NV_DISPATCH(D, LN_F);
 #undef LN_F

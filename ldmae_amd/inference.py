@@ -15,6 +15,7 @@ for p in (_HERE, os.path.dirname(_HERE)):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+from ldmae_amd.models.lightningdit import _act_dtype        # noqa: E402
 from ldmae_amd.tokenizer import models_mae                  # noqa: E402
 from ldmae_amd.train_accum import build_model               # noqa: E402
 from ldmae_amd.transport import Sampler, create_transport   # noqa: E402
@@ -49,7 +50,8 @@ def sample_latents(model, sample_fn, n, cfg_scale, cfg_interval_start, device, n
             # the conditional output again, which an adaptive solver's error norm would see.  And only while the half batch takes the same
             # adaLN path as the doubled one (the batched bf16 adaLN GEMM needs a batch that is a multiple of 8; an n of 4, 12, 20 ... would put
             # the half on the per-block f32 path and the guided steps on the batched bf16 one: not bit-for-bit the doubled batch any more).
-            if cfg_interval is True and cfg_interval_start and float(t[0]) < cfg_interval_start and ((len(x) // 2) % 8 == 0 or len(x) % 8 != 0):
+            same_path = _act_dtype(getattr(model, "precision", None)) != torch.bfloat16 or (len(x) // 2) % 8 == 0 or len(x) % 8 != 0
+            if cfg_interval is True and cfg_interval_start and float(t[0]) < cfg_interval_start and same_path:
                 half = len(x) // 2
                 out = model.forward(x[:half], t[:half], y[:half])
                 return torch.cat([out, out], dim=0)

@@ -83,6 +83,25 @@ def test_sampler_skips_the_unconditional_half_only_where_it_is_unused(tmp_path):
     with torch.no_grad():
         ref = fn(zz, m.forward_with_cfg, y=yy, cfg_scale=4.0, cfg_interval=True, cfg_interval_start=0.3)[-1][:4]
     assert torch.equal(y, y2) and torch.equal(lat, ref)
+    # bf16 autocast: the batched adaLN GEMM needs a batch that is a multiple of 8.  n = 4: the half batch (4) would take the per-block f32
+    # adaLN path and the doubled batch (8) the batched bf16 one -> the shortcut must NOT be taken; n = 8: both batched -> taken.  Either way
+    # the latents equal the reference's loop bit for bit.
+    for n, taken in ((4, False), (8, True)):
+        halves.clear(); fulls.clear()
+        m.forward = lambda x, tt, y: (halves.append(len(x)), orig_fwd(x, tt, y))[1]
+        m.forward_with_cfg = lambda *a, **k: (fulls.append(len(a[0])), orig_cfg(*a, **k))[1]
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            g = torch.Generator(device="cuda").manual_seed(5)
+            lat, y = sample_latents(m, fn, n, 4.0, 0.3, torch.device("cuda"), cfg["data"]["num_classes"], generator=g)
+            assert (halves.count(n) >= 2) == taken and halves.count(n) + len(fulls) == 11, (n, halves, fulls)
+            m.forward, m.forward_with_cfg = orig_fwd, orig_cfg
+            g = torch.Generator(device="cuda").manual_seed(5)
+            z = torch.randn(n, m.in_channels, 8, 8, device="cuda", generator=g)
+            y2 = torch.randint(0, cfg["data"]["num_classes"], (n,), device="cuda", generator=g)
+            zz, yy = torch.cat([z, z]), torch.cat([y2, torch.full((n,), cfg["data"]["num_classes"], device="cuda")])
+            with torch.no_grad():
+                ref = fn(zz, m.forward_with_cfg, y=yy, cfg_scale=4.0, cfg_interval=True, cfg_interval_start=0.3)[-1][:n]
+        assert torch.equal(y, y2) and torch.equal(lat, ref), n
 
 
 def test_do_sample_end_to_end_writes_pngs(tmp_path, monkeypatch):

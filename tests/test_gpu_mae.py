@@ -511,3 +511,50 @@ def test_patch_embed_of_kept_tokens_equals_embed_then_gather():
             ref = ops.gather_rows(full.contiguous(), ids_keep)
             got = ops.patch_embed_kept(imgs, ids_keep, m.pos_embed[0], w2d, pe.proj.bias, 8, dtype)
         assert got.shape == ref.shape == (3, 256, 192) and torch.equal(got, ref), dtype
+
+
+def test_tf32_class_docking_path_matches_reference_golden(golden):
+    """The reference's drivers set torch.backends.cuda.matmul.allow_tf32 = True before they call `_encode` / `decode` in f32 (inference.py:79,
+    extract_features.py:2-3).  With that flag on, f32 forward-only calls run the TF32-CLASS kernels (fp16 operands = TF32's 10-bit mantissa, f32
+    accumulation: LDMAE_F16 family of the C ABI): within 1e-3 of the reference's own f32 results (TF32's error class; emulated TF32 gives 5.6e-4
+    on the oracle), counted as the f16 family.  With the flag off (torch's default) the same calls stay on the exact-f32 kernels at 1e-4."""
+    from ldmae_amd import _lib
+    g = golden("mae")
+    cfg = omae.MAEConfig()
+    m = build({}, full_sd(cfg), 256)
+    imgs = det_randn("mae_img", (2, 3, 256, 256), 2).clamp(-1, 1).cuda()
+    noise = torch.from_numpy(g["mae_noise"]).cuda()
+    prev = torch.backends.cuda.matmul.allow_tf32
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = True
+        _lib.launch_counts(reset=True)
+        with torch.no_grad():
+            mom = m._encode(imgs)
+            c_enc = _lib.launch_counts(reset=True)
+            rec = m.decode(mom[:, :16]).sample
+            c_dec = _lib.launch_counts(reset=True)
+            lat, mask, ids = m.forward_encoder(imgs, 0.75, noise=noise)
+        nb, nd = len(m.blocks), len(m.decoder_blocks)
+        assert c_enc["nt_f16"] == 4 * nb and c_enc["attn_f16"] == nb and c_enc["attn_f32"] == 0 and c_enc["nt_bf16"] == 0, c_enc
+        assert c_dec["nt_f16"] == 4 * nd and c_dec["attn_f16"] == nd and c_dec["attn_f32"] == 0 and c_dec["nt_bf16"] == 0, c_dec
+        assert rel_err(mom[:, :, :2, :2].cpu(), g["mae_moments_head"]) < 1e-3
+        assert abs(float(mom.double().norm()) - float(g["mae_moments_norm"])) < 1e-3 * float(g["mae_moments_norm"])
+        assert rel_err(rec[:, :, :4, :4].cpu(), g["mae_rec_head"]) < 1e-3
+        assert abs(float(rec.double().norm()) - float(g["mae_rec_norm"])) < 1e-3 * float(g["mae_rec_norm"])
+        np.testing.assert_array_equal(mask.cpu().numpy(), g["mae75_mask"])                   # masks / indices stay bit-exact
+        np.testing.assert_array_equal(ids.cpu().numpy(), g["mae75_ids_restore"])
+        assert rel_err(lat[:, :4].cpu(), g["mae75_lat_head"]) < 1e-3
+        # a training call is NOT switched (the fp16 family is forward-only): gradients on -> exact f32
+        _lib.launch_counts(reset=True)
+        m.forward_encoder(imgs, 0.75, noise=noise)[0].sum().backward()
+        c = _lib.launch_counts(reset=True)
+        assert c["nt_f16"] == 0 and c["attn_f16"] == 0 and c["nt_f32"] > 0, c
+        torch.backends.cuda.matmul.allow_tf32 = False
+        with torch.no_grad():
+            mom32 = m._encode(imgs)
+        c = _lib.launch_counts(reset=True)
+        assert c["nt_f16"] == 0 and c["attn_f16"] == 0 and c["attn_f32"] == nb, c
+        assert rel_err(mom32[:, :, :2, :2].cpu(), g["mae_moments_head"]) < 1e-4
+        assert 1e-6 < rel_err(mom.cpu(), mom32.cpu()) < 1e-3                                  # the two paths really differ, by TF32's margin
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
