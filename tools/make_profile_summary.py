@@ -8,10 +8,10 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = list(csv.DictReader(open(src)))
 shutil.copy(src, os.path.join(root, "profiles", f"{tag}_kernel_stats.csv"))
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
-grp = {"bf16 NT GEMMs (gemm_nt_persist_kernel)": 0.0, "bf16 TN GEMM (gemm_tn_ring_kernel)": 0.0, "attention": 0.0, "row-wise HBM-bound kernels": 0.0, "other": 0.0}
+grp = {"bf16 NT GEMMs (gemm_nt_lines_kernel + gemm_nt_persist_kernel)": 0.0, "bf16 TN GEMM (gemm_tn_ring_kernel)": 0.0, "attention": 0.0, "row-wise HBM-bound kernels": 0.0, "other": 0.0}
 for r in rows:
     n, ms = r["Name"], float(r["TotalDurationNs"]) / steps / 1e6
-    if "gemm_nt_persist" in n: grp["bf16 NT GEMMs (gemm_nt_persist_kernel)"] += ms
+    if "gemm_nt_persist" in n or "gemm_nt_lines" in n: grp["bf16 NT GEMMs (gemm_nt_lines_kernel + gemm_nt_persist_kernel)"] += ms
     elif "gemm_tn_ring" in n: grp["bf16 TN GEMM (gemm_tn_ring_kernel)"] += ms
     elif "attn_" in n: grp["attention"] += ms
     elif any(k in n for k in ("rmsnorm_mod", "gate_bwd", "qknorm_rope", "swiglu_", "layernorm")): grp["row-wise HBM-bound kernels"] += ms
