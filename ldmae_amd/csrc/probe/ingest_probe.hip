@@ -45,6 +45,8 @@ template <int N> __device__ __forceinline__ void vmwait_on2(f32x4& a, f32x4& b) 
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 constexpr int BM = 256, BN = 256, STAGE_BYTES = (BM + BN) * 64;
 
+__device__ char* g_xbuf = nullptr;         // mode 7 + epilogue-like traffic: streamed reads from here ...
+__device__ char* g_ybuf = nullptr;         // ... and streamed writes to here, EL / ES KiB per wave and K-step, issued inside the K loop
 __device__ int g_bstream = 0;             // mode 7: 1 = the B rows are STREAMED too, shared like the A rows (the TN GEMM's situation); 2 = streamed, unshared
 __device__ int g_wrap_rb = 1 << 30;       // E2: A row-blocks wrap at this count (small = the A stream is L2-resident)
 struct Walk {   // tile ownership of gemm_nt_persist_kernel (persistent form)
@@ -534,7 +536,9 @@ template <int FLAGS, int SPLIT> static KernelFn winst() {
 // is A0 B0 A1 | B1 A2 | B2 A3 | ... (slot = position in the stream mod 5) and runs on ACROSS tiles: during block j (K-steps 2j, 2j+1) every
 // wave issues its 4 pieces of B(j+1) in the first K-step and of A(j+2) in the second -- 4 pieces per wave and K-step, the L2-resident B rows
 // one block ahead, the streamed A rows two.  One counted wait per block (vmcnt(4): the A pieces just issued stay in flight).
-template <int FLAGS>
+// EL / ES: what a DEFERRED fused epilogue would add to the K loop -- per wave and K-step EL streamed 1-KiB loads (8 rows x 128 B of an f32 / bf16
+// activation tensor) and ES streamed 1-KiB stores, issued behind the ring pieces in the load phase; the counted waits skip over them
+template <int FLAGS, int EL = 0, int ES = 0>
 __global__ __launch_bounds__(512) void wl5_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, int M, int N, int K, int ntiles,
                                                   float* __restrict__ out, unsigned long long* __restrict__ stamps) {
   constexpr bool MF = FLAGS & 1, FR = FLAGS & 2;
@@ -595,6 +599,22 @@ __global__ __launch_bounds__(512) void wl5_kernel(const bf16* __restrict__ A, co
     if (++jB == nb) { jB = 0; tB += w.tstride; if (tB < w.tend) pB = rowB(tB); }
     return true;
   };
+  // epilogue-like traffic: every wave streams through its own part of the X (read) and Y (write) buffers, 1 KiB per instruction
+  auto uni = [](const char* p) {      // wave-uniform 64-bit pointer in scalar registers
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    return (const char*)(uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v));
+  };
+  const char* xp = uni(g_xbuf + ((size_t)blockIdx.x * 8 + wave) * (size_t)(3 << 20));
+  const char* yp = uni(g_ybuf + ((size_t)blockIdx.x * 8 + wave) * (size_t)(3 << 20));
+  const unsigned xlane = (unsigned)lane * 16u;
+  f32x4 xr[EL > 0 ? EL : 1];
+  auto extras = [&]() {
+#pragma unroll
+    for (int e = 0; e < EL; ++e) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xr[e]) : "v"(xlane), "s"(xp) : "memory"); xp += 1024; }
+#pragma unroll
+    for (int e = 0; e < ES; ++e) { asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(xlane), "v"(xr[EL > 0 ? e % EL : 0]), "s"(yp) : "memory"); yp += 1024; }
+  };
+  if constexpr (EL == 0 && ES > 0) xr[0] = (f32x4){1.f, 2.f, 3.f, 4.f};
   issueA(); issueB(); issueA();                         // A0 B0 A1
   unsigned ga = 0, gb = 1;                              // slots of the block being multiplied
   vmwait<4>();                                          // A0, B0 landed (A1 may stay in flight)
@@ -615,8 +635,9 @@ __global__ __launch_bounds__(512) void wl5_kernel(const bf16* __restrict__ A, co
         for (int i = 0; i < MI; ++i) af[i] = FR ? *(const bf16x8*)(sa + ao + i * 2048) : rz;
         bool issued = false;
         if (h == 0) issueB(); else issued = issueA();
+        extras();
         __builtin_amdgcn_s_setprio(0);
-        if (grpB && h == 1) { if (issued) vmwait<4>(); else vmwait<0>(); }
+        if (grpB && h == 1) { if (issued) vmwait<4 + EL + ES>(); else vmwait<0>(); }
         BAR();
         if constexpr (MF) {
 #pragma unroll
@@ -627,14 +648,15 @@ __global__ __launch_bounds__(512) void wl5_kernel(const bf16* __restrict__ A, co
 #pragma unroll
           for (int i = 0; i < MI; ++i) acc[i][0][0] += (float)af[i][0] + (float)bfr[i & 3][1];
         }
-        if (!grpB && h == 1) { if (issued) vmwait<4>(); else vmwait<0>(); }
+        if (!grpB && h == 1) { if (issued) vmwait<4 + EL + ES>(); else vmwait<0>(); }
         BAR();
       }
     }
     w.t += w.tstride;
   }
   if (!grpB) BAR();
-  float s = 0.f;
+  vmwait<0>();
+  float s = EL > 0 ? xr[0][0] * 1e-30f : 0.f;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -643,8 +665,8 @@ __global__ __launch_bounds__(512) void wl5_kernel(const bf16* __restrict__ A, co
   __syncthreads();
   if (tid == 0) { stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - c0; stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
-template <int FLAGS> static KernelFn w5inst() {
-  KernelFn f = wl5_kernel<FLAGS>;
+template <int FLAGS, int EL = 0, int ES = 0> static KernelFn w5inst() {
+  KernelFn f = wl5_kernel<FLAGS, EL, ES>;
   HIPCK(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 256 * 128));
   return f;
 }
@@ -666,6 +688,13 @@ int main(int argc, char** argv) {
   HIPCK(hipMalloc(&stamps, ncu * 16));
   hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, A, amax, 1u);
   hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, B, bmax, 77u);
+  {   // X / Y buffers of the epilogue-like traffic rows: 3 MiB per wave x 2048 waves = 6 GiB each would be too much: a wave's K-steps move at
+      // most (K-steps per CU) x 2 KiB = 1536 x 2 KiB = 3 MiB
+    char *xb, *yb;
+    HIPCK(hipMalloc(&xb, (size_t)2048 * (3 << 20) + (1 << 20))); HIPCK(hipMalloc(&yb, (size_t)2048 * (3 << 20) + (1 << 20)));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (bf16*)xb, (size_t)2048 * (3 << 20) / 2, 5u);
+    HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_xbuf), &xb, sizeof(char*))); HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_ybuf), &yb, sizeof(char*)));
+  }
   HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_wrap_rb), &wrap_rb, sizeof(int)));
   HIPCK(hipMemcpyToSymbol(HIP_SYMBOL(g_bstream), &bstream, sizeof(int)));
   HIPCK(hipDeviceSynchronize());
@@ -695,6 +724,11 @@ int main(int argc, char** argv) {
       {"7 whole lines, seamless 5-slot half-block ring", w5inst<3>(), 1},
       {"7   .. MFMAs off                             ", w5inst<2>(), 1},
       {"7   .. MFMAs and fragment reads off (ingest) ", w5inst<0>(), 1},
+      {"7 + 2 KiB loads, 1 KiB stores / wave / K-step ", w5inst<3, 2, 1>(), 1},
+      {"7 + 2 KiB loads, 2 KiB stores / wave / K-step ", w5inst<3, 2, 2>(), 1},
+      {"7 + 1 KiB loads, 1 KiB stores / wave / K-step ", w5inst<3, 1, 1>(), 1},
+      {"7 + 0 KiB loads, 2 KiB stores / wave / K-step ", w5inst<3, 0, 2>(), 1},
+      {"7 + 2 KiB loads, 1 KiB stores, MFMAs off      ", w5inst<2, 2, 1>(), 1},
   };
   hipEvent_t e0, e1; HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
   std::vector<unsigned long long> hs(ncu * 2);
