@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""VMAE pre-training step driver on the HIP kernels -- counterpart of the reference's VMAE/engine_pretrain.py:21-110 and the optimizer /
-schedule set-up of VMAE/main_pretrain.py:236-300 (minimal slice: no ImageFolder I/O, no LPIPS, no TensorBoard).
+"""VMAE pre-training driver on the HIP kernels -- counterpart of the reference's VMAE/main_pretrain.py:74-300 + VMAE/engine_pretrain.py:21-110
+(SURVEY 8f rank 4): image-folder input (main_pretrain.py:111-192), DistributedSampler + data-parallel gradient exchange (:204-215, 254-256),
+checkpoint save / resume with the position-embedding resize (VMAE/util/misc.py:468-531).  No LPIPS (`ldmae_mode`), no TensorBoard.
 
+    python ldmae_amd/vmae_pretrain.py --data_path /data/imagenet --output_dir out --batch_size 64          # <data_path>/train/<class>/*.JPEG
+    python ldmae_amd/vmae_pretrain.py --data_path /data/my_pngs --output_dir out                          # any tree of images
+    python -m torch.distributed.run --nproc-per-node 8 ldmae_amd/vmae_pretrain.py --data_path ...          # one rank per GPU over RCCL
     python ldmae_amd/vmae_pretrain.py --synthetic --epochs 1 --steps-per-epoch 10 --batch_size 64
 
 What is kept: forward_vanilla loss (masked / visible MSE + KL), per-iteration half-cycle cosine LR with linear warm-up
@@ -9,11 +13,12 @@ What is kept: forward_vanilla loss (masked / visible MSE + KL), per-iteration ha
 1-D parameters, main_pretrain.py:258-259), gradient accumulation, and the GradScaler PROTOCOL of the reference's
 ``NativeScalerWithGradNormCount`` (VMAE/util/misc.py:406-435: scale the loss, unscale, SKIP the optimizer step when a gradient is
 inf / nan and halve the scale, double it after 2000 clean steps) -- ``LossScaler`` below, with 1/scale folded into the fused AdamW
-kernel's grad_scale.  What differs on purpose: the activation type is bf16 where the reference's ``torch.amp.autocast('cuda')`` gives
-fp16 (engine_pretrain.py:51-57).  bf16 keeps f32's exponent range, so the scaler never has an overflow to back off from in practice
-(it is kept for the skip-on-non-finite semantics and so that checkpoints carry the same ``amp_scaler`` state); it has 8 significant
-bits against fp16's 11, which is what the bf16-vs-f32 tolerance in tests/test_gpu_mae.py (loss within 2e-2 relative) prices.  The
-kernels have no fp16 path.  Also: the fused AdamW kernel on a grouped contiguous slab instead of torch.optim.AdamW.
+kernel's grad_scale.  What differs on purpose: the TRAINING activation type is bf16 where the reference's ``torch.amp.autocast('cuda')``
+gives fp16 (engine_pretrain.py:51-57).  bf16 keeps f32's exponent range, so the scaler never has an overflow to back off from in practice
+(it is kept for the skip-on-non-finite semantics and so that checkpoints carry the same ``scaler`` state); it has 8 significant
+bits against fp16's 11, which is what the bf16-vs-f32 tolerance in tests/test_gpu_mae.py (loss within 2e-2 relative) prices.  (The
+fp16 kernel family added in round 5, LDMAE_F16, is forward-only: the TF32-class docking calls.)  Also: the fused AdamW kernel on a
+grouped contiguous slab instead of torch.optim.AdamW; the host reads the loss where the reference prints it, not on every micro-step.
 """
 import argparse
 import math
@@ -27,6 +32,7 @@ for p in (_HERE, os.path.dirname(_HERE)):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+from ldmae_amd.distributed import GradBucketReducer        # noqa: E402
 from ldmae_amd.optim import AdamWEMA, FlatParams           # noqa: E402
 from ldmae_amd.tokenizer import models_mae                # noqa: E402
 
@@ -65,7 +71,8 @@ class LossScaler:
         self.growth_factor, self.backoff_factor, self.growth_interval, self.enabled = growth_factor, backoff_factor, growth_interval, enabled
         self._good, self.skipped = 0, 0
 
-    def step(self, opt):
+    def step(self, opt, grad_scale=1.0):
+        """grad_scale: what the gradient slab still has to be multiplied by besides 1 / scale (1 / world after a summing all-reduce)."""
         g = opt.flat.grads
         norm = torch.linalg.vector_norm(g)                       # inf / nan anywhere in the slab makes the norm non-finite
         if self.enabled and not bool(torch.isfinite(norm)):
@@ -73,13 +80,13 @@ class LossScaler:
             self._good = 0
             self.scale *= self.backoff_factor
             return None
-        opt.step(grad_scale=1.0 / self.scale)
+        opt.step(grad_scale=grad_scale / self.scale)
         if self.enabled:
             self._good += 1
             if self._good >= self.growth_interval:
                 self.scale *= self.growth_factor
                 self._good = 0
-        return float(norm) / self.scale
+        return float(norm) * grad_scale / self.scale
 
     def state_dict(self):
         return {"scale": self.scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
@@ -89,33 +96,53 @@ class LossScaler:
         self.scale, self._good = float(sd["scale"]), int(sd.get("_growth_tracker", 0))
 
 
-def train_one_epoch(model, loader, opt, epoch, args, log=print, scaler=None):
+def train_one_epoch(model, loader, opt, epoch, args, log=print, scaler=None, reducer=None):
     """engine_pretrain.py:21-110 without the metric logger.  `scaler`: a LossScaler (the reference's loss_scaler argument); None = plain
-    steps."""
+    steps.  `reducer`: a GradBucketReducer over opt.flat (data parallel: the slab accumulates the local micro-steps and is all-reduced once,
+    on the last one; parameters that got no gradient -- DDP(find_unused_parameters=True), main_pretrain.py:255 -- keep their zeros and their
+    buckets are launched by finish()).
+    The host reads the loss only where the reference PRINTS it (every print_freq iterations) and at the end of the epoch -- the reference's
+    per-iteration `loss.item()` (engine_pretrain.py:59-63) stalls the launch queue on every micro-step; a non-finite loss still stops the
+    run, at the next check."""
     model.train(True)
     opt.zero_grad()
     n = len(loader)
-    stats = None
+    stats, bad = None, torch.zeros((), dtype=torch.bool, device="cuda")
+    world = reducer.world if reducer is not None else 1
+
+    def read(st):
+        if bool(bad):
+            raise RuntimeError("Loss is not finite, stopping training")
+        return {k: (float(v) if torch.is_tensor(v) else v) for k, v in st.items()}
     for it, (samples, _) in enumerate(loader):
         if it % args.accum_iter == 0:
             opt.lr = cosine_lr(it / n + epoch, args.lr, args.min_lr, args.warmup_epochs, args.epochs, args.fixed_lr)
         samples = samples.cuda(non_blocking=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.precision == "bf16"):
             loss, _, _, vis_loss, mask_loss, kl_loss = model(samples, mask_ratio=args.mask_ratio, visible_loss_ratio=args.visible_loss_ratio)
-        if not math.isfinite(float(loss)):
-            raise RuntimeError(f"Loss is {float(loss)}, stopping training")
+        bad |= ~torch.isfinite(loss.detach())
+        last = (it + 1) % args.accum_iter == 0
+        if reducer is not None:
+            reducer.sync = last
         (loss * (scaler.scale if scaler is not None else 1.0) / args.accum_iter).backward()
-        if (it + 1) % args.accum_iter == 0:
+        if last:
+            gscale = reducer.finish() if reducer is not None else 1.0          # 1 / world: the mean over the ranks, as DDP
             if scaler is not None:
-                scaler.step(opt)
+                scaler.step(opt, gscale)
             else:
-                opt.step()
+                opt.step(grad_scale=gscale)
             opt.zero_grad()
-        stats = dict(loss=float(loss), vis_loss=float(vis_loss), mask_loss=float(mask_loss), kl_loss=float(kl_loss) if kl_loss is not None else 0.0,
-                     lr=opt.lr)
+        stats = dict(loss=loss.detach(), vis_loss=vis_loss.detach(), mask_loss=mask_loss.detach(),
+                     kl_loss=kl_loss.detach() if kl_loss is not None else 0.0, lr=opt.lr)
         if it % args.print_freq == 0:
-            log(f"Epoch: [{epoch}] [{it}/{n}] " + "  ".join(f"{k}: {v:.6f}" for k, v in stats.items()))
-    return stats
+            log(f"Epoch: [{epoch}] [{it}/{n}] " + "  ".join(f"{k}: {v:.6f}" for k, v in read(stats).items()))
+    out = read(stats) if stats is not None else None
+    if out is not None and world > 1:                          # the reference logs the mean over the ranks (misc.all_reduce_mean)
+        import torch.distributed as dist
+        t = torch.tensor([out["loss"]], device="cuda")
+        dist.all_reduce(t)
+        out["loss"] = float(t) / world
+    return out
 
 
 class _SyntheticImages(torch.utils.data.Dataset):
@@ -130,11 +157,150 @@ class _SyntheticImages(torch.utils.data.Dataset):
         return torch.rand(3, self.size, self.size, generator=g) * 2 - 1, 0
 
 
-def main():
+# ----------------------------------------------------------------------------- image input (main_pretrain.py:111-192), PIL only
+def _to_normalised_tensor(img):
+    """ToTensor() + Normalize(mean 0.5, std 0.5) (main_pretrain.py:155)."""
+    import numpy as np
+    x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).to(torch.float32).div_(255.0)
+    return x.sub_(0.5).div_(0.5)
+
+
+class RandomResizedCropFlip:
+    """RandomResizedCrop(size, scale=(0.75, 1.0), ratio=(3/4, 4/3), bicubic) + RandomHorizontalFlip + ToTensor + Normalize: the 'imagenet'
+    / 'laion' transform of main_pretrain.py:161-175, by torchvision's published algorithm (ten draws of (area fraction, log-uniform aspect
+    ratio), the first crop that fits; otherwise the central crop clamped to the ratio range) on torch's RNG."""
+
+    def __init__(self, size, scale=(0.75, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
+        self.size, self.scale, self.ratio = int(size), scale, ratio
+
+    def _box(self, w, h):
+        area = w * h
+        lr = (math.log(self.ratio[0]), math.log(self.ratio[1]))
+        for _ in range(10):
+            ta = area * float(torch.empty(1).uniform_(self.scale[0], self.scale[1]))
+            ar = math.exp(float(torch.empty(1).uniform_(lr[0], lr[1])))
+            cw, ch = int(round(math.sqrt(ta * ar))), int(round(math.sqrt(ta / ar)))
+            if 0 < cw <= w and 0 < ch <= h:
+                return int(torch.randint(0, h - ch + 1, (1,))), int(torch.randint(0, w - cw + 1, (1,))), ch, cw
+        r = w / h
+        if r < self.ratio[0]:
+            cw, ch = w, int(round(w / self.ratio[0]))
+        elif r > self.ratio[1]:
+            ch, cw = h, int(round(h * self.ratio[1]))
+        else:
+            cw, ch = w, h
+        return (h - ch) // 2, (w - cw) // 2, ch, cw
+
+    def __call__(self, img):
+        from PIL import Image
+        top, left, ch, cw = self._box(*img.size)
+        img = img.crop((left, top, left + cw, top + ch)).resize((self.size, self.size), Image.BICUBIC)
+        if torch.rand(1) < 0.5:
+            img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        return _to_normalised_tensor(img)
+
+
+class ResizeSquare:
+    """Resize((S, S)) + ToTensor + Normalize: the custom-folder transform (main_pretrain.py:186-190)."""
+
+    def __init__(self, size):
+        self.size = int(size)
+
+    def __call__(self, img):
+        from PIL import Image
+        return _to_normalised_tensor(img.resize((self.size, self.size), Image.BILINEAR))
+
+
+class FlatImageTree(torch.utils.data.Dataset):
+    """CustomImageDataset (main_pretrain.py:117-150): every image under `root` (recursive, sorted), a random label in [0, 1000)."""
+
+    def __init__(self, root, transform):
+        from ldmae_amd.datasets.image_folder import IMG_EXTENSIONS
+        self.paths = sorted(os.path.join(d, f) for d, _, fs in os.walk(root, followlinks=True) for f in fs if f.lower().endswith(IMG_EXTENSIONS))
+        if not self.paths:
+            raise FileNotFoundError(f"no image files under {root}")
+        self.transform = transform
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        with open(self.paths[i], "rb") as f:
+            img = Image.open(f).convert("RGB")
+        return self.transform(img), int(torch.randint(0, 1000, (1,)))
+
+
+def get_dataset(args):
+    """main_pretrain.py:111-192: 'imagenet' in the path -> ImageFolder(<path>/train) with the random-resized-crop transform; 'laion' -> the same
+    transform over the image tree (the reference's HuggingFace 'imagefolder' loader falls back to exactly that); anything else -> the
+    tree resized to a square."""
+    if args.synthetic:
+        return _SyntheticImages(args.batch_size * args.steps_per_epoch * max(1, int(os.environ.get("WORLD_SIZE", 1))), args.input_size)
+    if "imagenet" in args.data_path:
+        from ldmae_amd.datasets.image_folder import ImageFolder
+        return ImageFolder(os.path.join(args.data_path, "train"), transform=RandomResizedCropFlip(args.input_size))
+    if "laion" in args.data_path:
+        return FlatImageTree(args.data_path, RandomResizedCropFlip(args.input_size))
+    return FlatImageTree(args.data_path, ResizeSquare(args.input_size))
+
+
+# ----------------------------------------------------------------------------- checkpoints (VMAE/util/misc.py:468-531)
+def resize_pos_embed(pos_embed, new_size):
+    """[1, H*H, D] -> [1, new*new, D], bilinear, align_corners=False (misc.py:488-499)."""
+    _, hw, d = pos_embed.shape
+    h = int(hw ** 0.5)
+    assert h * h == hw
+    x = torch.nn.functional.interpolate(pos_embed.reshape(1, h, h, d).permute(0, 3, 1, 2), size=(new_size, new_size), mode="bilinear", align_corners=False)
+    return x.permute(0, 2, 3, 1).reshape(1, -1, d)
+
+
+def save_model(args, epoch, model, opt, scaler, rank=0):
+    """checkpoint-<epoch>.pth = {model, optimizer, epoch, scaler, args} (misc.py:468-484), written by rank 0."""
+    if rank != 0:
+        return None
+    os.makedirs(args.output_dir, exist_ok=True)
+    path = os.path.join(args.output_dir, f"checkpoint-{epoch}.pth")
+    torch.save({"model": model.state_dict(), "optimizer": opt.state_dict(), "epoch": epoch,
+                "scaler": scaler.state_dict() if scaler is not None else None, "args": vars(args)}, path)
+    return path
+
+
+def load_model(args, model, opt, scaler, log=print):
+    """--resume (misc.py:501-531): state dict with strict=False, both position embeddings resized when the grid differs, optimizer / epoch /
+    scaler restored when present.  Returns the epoch to start from."""
+    if not args.resume:
+        return args.start_epoch
+    ck = torch.load(args.resume, map_location="cpu", weights_only=False)
+    sd = ck["model"]
+    if sd["pos_embed"].shape[1] != model.pos_embed.shape[1]:
+        new = int(model.pos_embed.shape[1] ** 0.5)
+        log(f"latent resolution is {new} x {new}, reshape pos embedding ({tuple(sd['pos_embed'].shape)} -> {new * new} positions)")
+        sd["pos_embed"] = resize_pos_embed(sd["pos_embed"], new)
+        sd["decoder_pos_embed"] = resize_pos_embed(sd["decoder_pos_embed"], new)
+        resized = True
+    else:
+        resized = False
+    log(str(model.load_state_dict(sd, strict=False)))
+    from ldmae_amd import ops
+    ops.invalidate_weight_cache()
+    log(f"Resume checkpoint {args.resume}")
+    start = args.start_epoch
+    if "optimizer" in ck and "epoch" in ck:
+        if not resized:                     # (a resized grid changes the slab: the moments of the old layout do not apply)
+            opt.load_state_dict(ck["optimizer"])
+        start = int(ck["epoch"]) + 1
+        if scaler is not None and ck.get("scaler") is not None:
+            scaler.load_state_dict(ck["scaler"])
+        log("With optim & sched!")
+    return start
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="mae_for_ldmae_f8d16_prev")
     ap.add_argument("--input_size", type=int, default=256)
-    ap.add_argument("--batch_size", type=int, default=64)
+    ap.add_argument("--batch_size", type=int, default=64, help="per GPU")
     ap.add_argument("--epochs", type=int, default=400)
     ap.add_argument("--accum_iter", type=int, default=1)
     ap.add_argument("--mask_ratio", type=float, default=0.75)
@@ -150,19 +316,67 @@ def main():
     ap.add_argument("--print_freq", type=int, default=20)
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--steps-per-epoch", type=int, default=100)
-    args = ap.parse_args()
-    if not args.synthetic:
-        raise NotImplementedError("image-folder input is host I/O outside the kernel path: use --synthetic (SURVEY 8f rank 4)")
+    ap.add_argument("--data_path", default="", help="'imagenet' in the path: <path>/train/<class>/<image>; otherwise any tree of images")
+    ap.add_argument("--output_dir", default="./output_dir")
+    ap.add_argument("--save_epochs", type=int, default=10)
+    ap.add_argument("--resume", default="")
+    ap.add_argument("--start_epoch", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--num_workers", type=int, default=8)
+    ap.add_argument("--no_pin_mem", action="store_false", dest="pin_mem")
+    args = ap.parse_args(argv)
+    if not args.synthetic and not args.data_path:
+        ap.error("--data_path (an image folder) or --synthetic")
+    import torch.distributed as dist
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    # LDMAE_DIST_BACKEND=gloo + LDMAE_DEVICE=0: several ranks share ONE GPU (rehearsal of the multi-rank launch on a 1-GPU box), as train_accum.py
+    backend = os.environ.get("LDMAE_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("LDMAE_DEVICE", local))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(local)
+    log = print if rank == 0 else (lambda *a, **k: None)
+    torch.manual_seed(args.seed + rank)                                       # main_pretrain.py:99-101: seed + rank
+    eff = args.batch_size * args.accum_iter * world
     if args.lr is None:
-        args.lr = args.blr * args.batch_size * args.accum_iter / 256          # main_pretrain.py:249-252
+        args.lr = args.blr * eff / 256                                        # main_pretrain.py:236-239
+    log(f"actual lr: {args.lr:.2e}  accumulate grad iterations: {args.accum_iter}  effective batch size: {eff}")
+    dataset = get_dataset(args)
+    sampler = torch.utils.data.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True)    # :204-207
+    nw = 0 if args.synthetic else args.num_workers
+    loader = torch.utils.data.DataLoader(dataset, sampler=sampler, batch_size=args.batch_size, num_workers=nw, pin_memory=args.pin_mem,
+                                         drop_last=True, multiprocessing_context="forkserver" if nw > 0 else None)
+    torch.manual_seed(args.seed)                                              # every rank builds the same initial weights
     model = getattr(models_mae, args.model)(ldmae_mode=False, no_cls=True, kl_loss_weight=args.kl_loss_weight, smooth_output=True,
                                             img_size=args.input_size).cuda()
+    torch.manual_seed(args.seed + rank)
     opt = build_optimizer(model, args.lr, args.weight_decay)
-    loader = torch.utils.data.DataLoader(_SyntheticImages(args.batch_size * args.steps_per_epoch, args.input_size), batch_size=args.batch_size,
-                                         drop_last=True)
-    scaler = LossScaler(enabled=args.precision == "bf16")          # main_pretrain.py:268: loss_scaler = NativeScaler()
-    for epoch in range(args.epochs):
-        print("Averaged stats:", train_one_epoch(model, loader, opt, epoch, args, scaler=scaler), "skipped steps:", scaler.skipped)
+    scaler = LossScaler(enabled=args.precision == "bf16")                     # main_pretrain.py:260: loss_scaler = NativeScaler()
+    start = load_model(args, model, opt, scaler, log)
+    reducer = GradBucketReducer(opt.flat) if world > 1 else None
+    if reducer is not None:
+        from ldmae_amd import ops
+        ops.set_gemm_launch_mode(os.environ.get("LDMAE_DP_GEMM_LAUNCH", reducer.recommended_gemm_launch_mode()))
+        reducer.broadcast_params(0)
+    log(f"number of params (M): {sum(p.numel() for p in model.parameters() if p.requires_grad) / 1e6:.2f}; {len(dataset)} images; "
+        f"{len(loader)} iterations per epoch and rank")
+    for epoch in range(start, args.epochs):
+        sampler.set_epoch(epoch)
+        stats = train_one_epoch(model, loader, opt, epoch, args, log=log, scaler=scaler, reducer=reducer)
+        log("Averaged stats:", stats, "skipped steps:", scaler.skipped)
+        if args.output_dir and (epoch % args.save_epochs == 0 or epoch + 1 == args.epochs):
+            p_ = save_model(args, epoch, model, opt, scaler, rank)
+            if p_:
+                log(f"Saved checkpoint to {p_}")
+            if world > 1:
+                dist.barrier()
+    if world > 1:
+        dist.destroy_process_group()
+    return model, opt
 
 
 if __name__ == "__main__":

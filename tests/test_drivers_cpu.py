@@ -169,3 +169,55 @@ def test_mae_arch_registry_has_every_reference_constructor():
                 m = f()
             if m is not None:
                 assert (m.pos_embed.shape[-1], len(m.blocks), m.decoder_pos_embed.shape[-1], m.pos_embed.shape[1]) == geo[n]
+
+
+# ----------------------------------------------------------------------------- VMAE pre-training driver: host side (main_pretrain.py:111-192, misc.py:488-531)
+def _png_tree(root, n=6, size=(48, 40)):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(n):
+        d = root / ("a" if i % 2 else "b")
+        d.mkdir(parents=True, exist_ok=True)
+        p = d / f"img_{i}.png"
+        Image.fromarray(rng.integers(0, 256, size=(size[1], size[0], 3), dtype=np.uint8)).save(p)
+        paths.append(str(p))
+    return sorted(paths)
+
+
+def test_vmae_pretrain_image_input(tmp_path):
+    """The three dataset branches of main_pretrain.py:111-192 on PIL alone: 'imagenet' in the path -> ImageFolder(<path>/train) with the
+    random-resized-crop + flip transform; any other tree -> every image, resized to a square, a random label."""
+    import argparse
+    from ldmae_amd import vmae_pretrain as vp
+    tree = tmp_path / "pics"
+    paths = _png_tree(tree)
+    ds = vp.get_dataset(argparse.Namespace(synthetic=False, data_path=str(tree), input_size=32))
+    assert isinstance(ds, vp.FlatImageTree) and ds.paths == paths and len(ds) == 6
+    x, y = ds[0]
+    assert x.shape == (3, 32, 32) and x.dtype == torch.float32 and -1.0 <= float(x.min()) and float(x.max()) <= 1.0 and 0 <= y < 1000
+    from PIL import Image
+    ref = torch.from_numpy(np.asarray(Image.open(paths[0]).convert("RGB").resize((32, 32), Image.BILINEAR)).copy()).permute(2, 0, 1).float() / 255
+    assert torch.equal(x, (ref - 0.5) / 0.5)
+    inet = tmp_path / "imagenet_x"
+    _png_tree(inet / "train")
+    ds2 = vp.get_dataset(argparse.Namespace(synthetic=False, data_path=str(inet), input_size=32))
+    assert type(ds2).__name__ == "ImageFolder" and ds2.classes == ["a", "b"] and len(ds2) == 6
+    torch.manual_seed(0)
+    crops = [ds2[i][0] for i in range(6)]
+    assert all(c.shape == (3, 32, 32) and torch.isfinite(c).all() for c in crops)
+    # the crop box: area fraction in [0.75, 1], aspect ratio in [3/4, 4/3], inside the image
+    t = vp.RandomResizedCropFlip(32)
+    for _ in range(50):
+        top, left, ch, cw = t._box(48, 40)
+        assert 0 <= top and 0 <= left and top + ch <= 40 and left + cw <= 48
+        assert 0.74 <= ch * cw / (48 * 40) <= 1.0 + 1e-9 and 0.74 <= cw / ch <= 1.35
+
+
+def test_vmae_pretrain_pos_embed_resize():
+    from ldmae_amd import vmae_pretrain as vp
+    pe = torch.randn(1, 16 * 16, 24)
+    out = vp.resize_pos_embed(pe, 32)
+    ref = torch.nn.functional.interpolate(pe.reshape(1, 16, 16, 24).permute(0, 3, 1, 2), size=(32, 32), mode="bilinear", align_corners=False)
+    assert out.shape == (1, 1024, 24) and torch.equal(out, ref.permute(0, 2, 3, 1).reshape(1, -1, 24))
+    assert torch.equal(vp.resize_pos_embed(pe, 16), pe)

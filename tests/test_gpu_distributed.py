@@ -252,3 +252,40 @@ def test_extract_features_two_ranks_share_the_dataset(tmp_path):
         assert lat.shape == (5, 32, 8, 8) and labels.tolist() == [ds[i][1] for i in range(rank, 10, 2)]      # rank-strided, in order
     from ldmae_amd.datasets.img_latent_dataset import ImgLatentDataset
     assert len(ImgLatentDataset(str(out), latent_norm=True, sample=True)) == 10
+
+
+def test_vmae_pretrain_two_ranks_on_a_folder_of_pngs(tmp_path):
+    """VMAE pre-training as main_pretrain.py drives it (reference :204-215, 254-256): 2 ranks (gloo, both on cuda:0) over a folder of PNGs --
+    DistributedSampler, gradient slab all-reduced by GradBucketReducer (unused parameters keep their zero gradient), fused AdamW, a
+    checkpoint per `save_epochs`; then ONE process resumes that checkpoint at twice the resolution (position embeddings resized,
+    util/misc.py:488-531) and trains on."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    pics = tmp_path / "pics"
+    for i in range(16):
+        d = pics / f"d{i % 3}"
+        d.mkdir(parents=True, exist_ok=True)
+        Image.fromarray(rng.integers(0, 256, size=(72, 80, 3), dtype=np.uint8)).save(d / f"{i}.png")
+    out = tmp_path / "out"
+    env = dict(os.environ, LDMAE_DIST_BACKEND="gloo", LDMAE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("LDMAE_TUNE", None)
+    script = os.path.join(ROOT, "ldmae_amd", "vmae_pretrain.py")
+    common = ["--data_path", str(pics), "--output_dir", str(out), "--batch_size", "4", "--num_workers", "0", "--warmup_epochs", "1",
+              "--print_freq", "1", "--save_epochs", "1"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script, "--input_size", "64", "--epochs", "2"] + common
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "effective batch size: 8" in r.stdout and "16 images; 2 iterations per epoch and rank" in r.stdout, r.stdout[-1500:]
+    ck = torch.load(out / "checkpoint-1.pth", map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 1 and ck["model"]["pos_embed"].shape[1] == 64 and all(torch.isfinite(v).all() for v in ck["model"].values())
+    assert ck["optimizer"]["step"] == 4 and ck["optimizer"]["layout"] and ck["scaler"]["scale"] > 0
+    losses = [float(l.split("loss: ")[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("Epoch: [")]
+    assert len(losses) == 4 and all(np.isfinite(losses)) and losses[-1] < losses[0]
+    # resume on one rank at 128 px: 64 -> 256 positions
+    r2 = subprocess.run([sys.executable, script, "--input_size", "128", "--epochs", "3", "--resume", str(out / "checkpoint-1.pth")] + common,
+                        env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-3000:]
+    assert "reshape pos embedding" in r2.stdout and "Epoch: [2]" in r2.stdout and "Epoch: [1]" not in r2.stdout
+    ck2 = torch.load(out / "checkpoint-2.pth", map_location="cpu", weights_only=False)
+    assert ck2["model"]["pos_embed"].shape[1] == 256 and ck2["epoch"] == 2
