@@ -50,8 +50,13 @@ def build(device, per_gpu_batch, force_hooks=False):
     # the adaLN weights FIRST in the slab: the batched adaLN backward finishes them at the very end of backward, and the reducer's buckets are
     # cut from the end of the slab backwards -- so N > 1 runs the same program as N = 1 (ldmae_amd/train_accum.py does the same)
     opt = AdamWEMA(model, lr=2e-4, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9999, front_fn=adaln_first)
-    model.batched_adaln = os.environ.get("LDMAE_BATCHED_ADALN", "1") != "0"
     reducer = GradBucketReducer(opt.flat, force_hooks=force_hooks)
+    # batched adaLN under data parallelism: by size until a multi-rank run has measured the exposed tail (distributed.batched_adaln_pays;
+    # B/1: 170 MB -> on, XL/1: 890 MB -> off); LDMAE_BATCHED_ADALN=0|1 overrides -- as ldmae_amd/train_accum.py
+    from ldmae_amd.distributed import batched_adaln_pays
+    env = os.environ.get("LDMAE_BATCHED_ADALN")
+    adaln_bytes = sum(p.numel() * 4 for n, p in opt.flat.trainable if adaln_first(n))
+    model.batched_adaln = (env != "0") if env is not None else batched_adaln_pays(adaln_bytes, len(model.blocks), reducer.world)
     model.direct_param_grads = os.environ.get("LDMAE_DIRECT_GRADS", "1") != "0"       # every .grad is a slab view and backward is a plain loss.backward(): dW goes straight into the slab
     reducer.broadcast_params(0)
     opt.ema.copy_(opt.flat.params)
@@ -509,6 +514,14 @@ def bench_dit(args, world, rank, device, lib, backend):
         return train_step(model, opt, reducer, transport, xh[i].to(device, non_blocking=True), yh[i].to(device, non_blocking=True))
     el_h, _ = timed_loop(step_h2d, hsteps, 1, world)
     reducer.exposed_comm_ms()
+    timeline = None
+    if world > 1 and reducer.overlap:
+        # one more step with per-bucket events: when backward released each bucket, how long its all-reduce took, how much ran past backward
+        reducer.measure_timeline = True
+        step()
+        torch.cuda.synchronize()
+        timeline = reducer.bucket_timeline()
+        reducer.measure_timeline = False
     roof = gemm_roofline(lib, step)
     if rank != 0:
         return None
@@ -531,7 +544,9 @@ def bench_dit(args, world, rank, device, lib, backend):
         out["comm"] = {"backend": "rccl" if backend == "nccl" else backend, "rccl_ranks": world if backend == "nccl" else 0,
                        "grad_bytes_per_step": int(opt.flat.n_trainable) * 4, "buckets": len(reducer.buckets),
                        "exposed_comm_ms_per_step_rank0": round(exposed, 3),
-                       "gemm_launch_mode": "one tile per workgroup" if ops.gemm_launch_mode() == "tile" else "persistent"}
+                       "gemm_launch_mode": "one tile per workgroup" if ops.gemm_launch_mode() == "tile" else "persistent",
+                       "batched_adaln": bool(model._use_batched_adaln()) if hasattr(model, "_use_batched_adaln") else None,
+                       "bucket_timeline_rank0": timeline}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     return out
@@ -814,11 +829,24 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            # the RCCL run is refused rather than degraded: every rank needs its own GPU (a rehearsal on fewer GPUs asks for it explicitly:
+            # LDMAE_BENCH_BACKEND=gloo LDMAE_BENCH_DEVICE=0), and the group that comes up must really be the nccl (= RCCL) backend
+            if torch.cuda.device_count() < world or local >= torch.cuda.device_count():
+                sys.exit(f"[bench] --gpus {world} over RCCL needs {world} visible GPUs (found {torch.cuda.device_count()}); "
+                         "a rehearsal on one GPU is LDMAE_BENCH_BACKEND=gloo LDMAE_BENCH_DEVICE=0 and is labelled as such")
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            if dist.get_backend() != "nccl":
+                sys.exit(f"[bench] asked for the nccl (RCCL) backend, the process group came up as {dist.get_backend()!r}: refusing a silent fallback")
         else:
             dist.init_process_group(backend)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if world > 1:
+        # one collective through the backend before anything is timed: the ranks that answer are the ranks the line may claim
+        probe = torch.ones(1, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
+        if int(probe.item()) != world:
+            sys.exit(f"[bench] all-reduce of ones over {world} ranks returned {probe.item()}")
 
     from ldmae_amd import _lib
     lib = _lib.load()

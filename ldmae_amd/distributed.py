@@ -70,6 +70,8 @@ class GradBucketReducer:
         self._hooks = []
         self._exposed = []
         self.measure_exposed = False      # bench.py sets it: two timing events per step, drained by exposed_comm_ms(); off in training
+        self.measure_timeline = False     # bench.py, one step: per-bucket launch / completion events -> bucket_timeline()
+        self._tl, self._tl_done = [], None
         # DDP.no_sync() equivalent: with gradient accumulation the slab holds the LOCAL sum of the micro-step gradients and is
         # all-reduced once, on the last micro-step (`sync = True` before that backward).  All-reducing the accumulating slab on
         # every micro-step would re-sum earlier micro-steps across ranks (world * g1 + g2).
@@ -100,11 +102,19 @@ class GradBucketReducer:
         lo, hi, _ = self.buckets[bi]
         buf = self.flat.grads[lo:hi]
         if self.overlap:
-            ev = torch.cuda.Event()
+            tl = self.measure_timeline
+            ev = torch.cuda.Event(enable_timing=tl)
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
+                if tl:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
                 self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if tl:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(self.stream)
+                    self._tl.append((bi, (hi - lo) * 4, ev, e0, e1))
         else:
             self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -115,6 +125,9 @@ class GradBucketReducer:
             for bi, pend in enumerate(self._pending):
                 if pend > 0:
                     self._launch(bi)
+            if self.is_cuda and self.measure_timeline and self.overlap:
+                self._tl_done = torch.cuda.Event(enable_timing=True)      # "backward has finished" on the compute stream
+                self._tl_done.record(torch.cuda.current_stream())
             ev0 = ev1 = None
             if self.is_cuda and self.measure_exposed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -140,6 +153,22 @@ class GradBucketReducer:
             tot += e0.elapsed_time(e1)
         self._exposed = []
         return tot
+
+    def bucket_timeline(self):
+        """Per bucket of the steps since `measure_timeline` was set (synchronises): when backward released it (ms before the end of backward),
+        how long its all-reduce took on the side stream, and how much of that ran past the end of backward (= exposed).  What the first
+        multi-GPU run needs to see to size buckets and to judge the late adaLN buckets."""
+        out = []
+        if self._tl_done is None:
+            return out
+        self._tl_done.synchronize()
+        for bi, nbytes, ready, e0, e1 in self._tl:
+            e1.synchronize()
+            out.append({"bucket": bi, "mbytes": round(nbytes / 2 ** 20, 1), "released_ms_before_backward_end": round(ready.elapsed_time(self._tl_done), 3),
+                        "start_delay_ms": round(ready.elapsed_time(e0), 3), "allreduce_ms": round(e0.elapsed_time(e1), 3),
+                        "past_backward_end_ms": round(max(0.0, self._tl_done.elapsed_time(e1)), 3)})
+        self._tl, self._tl_done = [], None
+        return out
 
     def broadcast_params(self, src: int = 0):
         """DDP-constructor equivalent: replicate rank `src` parameters (and nothing else) to every rank."""

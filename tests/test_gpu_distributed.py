@@ -223,6 +223,20 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
     assert line["comm"]["backend"] == "gloo" and line["comm"]["buckets"] >= 1 and line["comm"]["gemm_launch_mode"] == "one tile per workgroup"
     assert line["value"] > 0 and line["roofline"]["achieved"] > 0 and "cpu_baseline" not in line
+    # per-bucket timeline of one step (when backward released the bucket, how long its all-reduce took, how much ran past backward)
+    tl = line["comm"]["bucket_timeline_rank0"]
+    assert len(tl) == line["comm"]["buckets"] and all(b["allreduce_ms"] >= 0 and b["released_ms_before_backward_end"] >= -1e-3 for b in tl), tl
+    assert line["comm"]["rccl_ranks"] == 0            # a gloo rehearsal is never labelled as an RCCL run
+
+
+def test_bench_refuses_an_rccl_run_without_one_gpu_per_rank():
+    """`--gpus 2` with the default (nccl = RCCL) backend on a box with fewer GPUs than ranks must fail loudly, not fall back to anything."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LDMAE_BENCH_BACKEND", "LDMAE_BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8", "--no-power"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "needs 2 visible GPUs" in (r.stdout + r.stderr), (r.stdout + r.stderr)[-1500:]
 
 
 def test_extract_features_two_ranks_share_the_dataset(tmp_path):
