@@ -36,7 +36,9 @@ extern "C" {
  * (inference.py:79, extract_features.py:2-3) is 10-bit-mantissa products with f32 accumulation; gfx950 has no TF32 MFMA, but fp16 has exactly
  * that mantissa at the bf16 rate, and the operands it is used for are O(1) (conversion saturates at +-65504).  Forward-only entry points:
  * ldmae_cast / ldmae_cast_weight (dst), ldmae_layernorm_fwd (out), ldmae_gemm_nt (dtype; epilogues BIAS / GATE_RES / BIAS_POS / BIAS_GELU; out
- * fp16 or f32; shapes of the whole-line kernel: K % 64 == 0, rows on 128-B lines), ldmae_attention_fwd_qkv (head_dim 16). */
+ * fp16 or f32; shapes of the whole-line kernel: K % 64 == 0, rows on 128-B lines), ldmae_attention_fwd_qkv (head_dim 16).  For VMAE pre-training
+ * under fp16 autocast (engine_pretrain.py:51-57) also the backward: ldmae_gemm_nt(EPI_BIAS / EPI_GELU_BWD | LDMAE_EPI_F16_INF), ldmae_gemm_tn,
+ * ldmae_attention_bwd_qkv (head_dim 16), ldmae_layernorm_bwd, ldmae_colsum, ldmae_gelu_fwd/bwd. */
 #define LDMAE_F16 2
 
 /* GEMM epilogues */
@@ -57,6 +59,10 @@ extern "C" {
    for a shape that the whole-line kernel (128-B LDS rows, gemm_nt_lines.hip -- the default wherever operand rows start on 128-B lines and
    K % 64 == 0) would take.  Same products in the same order: bitwise-equal results; tests and tools/bench_nt.py use it for A/B runs */
 #define LDMAE_EPI_HALF_LINES 0x200
+/* fp16 outputs (dtype LDMAE_F16), or'ed into `epi` per call: values beyond +-65504 become INFINITIES, as under torch's fp16 autocast -- what a
+   gradient GEMM under a loss scaler wants (the scaler sees the non-finite gradient and skips the step).  Without the flag fp16 outputs SATURATE
+   at +-65504 (the forward / TF32-class calls) */
+#define LDMAE_EPI_F16_INF 0x400
 
 const char* ldmae_last_error(void);
 const char* ldmae_version(void);
@@ -279,7 +285,7 @@ int ldmae_prof_collect(double* total_ms, double* total_flops, long* launches);  
 /* Launch counts by kernel family since the last reset, always on (one relaxed atomic add per entry-point call): which ARITHMETIC TYPE a
  * model's calls were dispatched to -- a bf16 forward that silently runs the f32 kernels (round 3: the VMAE decoder under autocast, 250 of
  * 304 ms) shows up as f32 counts.  counts[0..5] = NT GEMM bf16 / f32, TN GEMM bf16 / f32, attention (fwd or bwd entry) bf16 / f32;
- * counts[6..7] = NT GEMM / attention forward in fp16 (the TF32-class path).  n = how many to copy (<= 8).  reset != 0 zeroes them after the copy. */
+ * counts[6..8] = NT GEMM / attention / TN GEMM in fp16 (the TF32-class forward path; VMAE pre-training under fp16 autocast).  n = how many to copy (<= 9).  reset != 0 zeroes them after the copy. */
 #define LDMAE_COUNT_NT_BF16 0
 #define LDMAE_COUNT_NT_F32 1
 #define LDMAE_COUNT_TN_BF16 2
@@ -288,6 +294,7 @@ int ldmae_prof_collect(double* total_ms, double* total_flops, long* launches);  
 #define LDMAE_COUNT_ATTN_F32 5
 #define LDMAE_COUNT_NT_F16 6      /* round 5: the TF32-class (fp16) forward family */
 #define LDMAE_COUNT_ATTN_F16 7
+#define LDMAE_COUNT_TN_F16 8
 int ldmae_launch_counts(long* counts, int n, int reset);
 
 #ifdef __cplusplus

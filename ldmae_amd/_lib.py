@@ -100,6 +100,7 @@ DIAG_SIGNATURES = {
 }
 EPI_TILE_LAUNCH = 0x100
 EPI_HALF_LINES = 0x200
+EPI_F16_INF = 0x400
 
 _lib = None
 
@@ -167,11 +168,11 @@ def dt(dtype) -> int:
     raise RuntimeError(f"unsupported activation dtype {dtype} (float32, bfloat16, or float16 on the forward-only TF32-class path)")
 
 
-COUNT_NAMES = ("nt_bf16", "nt_f32", "tn_bf16", "tn_f32", "attn_bf16", "attn_f32", "nt_f16", "attn_f16")
+COUNT_NAMES = ("nt_bf16", "nt_f32", "tn_bf16", "tn_f32", "attn_bf16", "attn_f32", "nt_f16", "attn_f16", "tn_f16")
 
 
 def launch_counts(reset: bool = False) -> dict:
     """Launch counts by kernel family since the last reset (ldmae_launch_counts): which arithmetic type the calls were dispatched to."""
-    arr = (C.c_long * 8)()
-    call("ldmae_launch_counts", arr, 8, 1 if reset else 0)
+    arr = (C.c_long * 9)()
+    call("ldmae_launch_counts", arr, 9, 1 if reset else 0)
     return dict(zip(COUNT_NAMES, [int(v) for v in arr]))

@@ -128,6 +128,24 @@ template <bool F16> __device__ __forceinline__ f32x16 mfma_att(const bf16x8& a, 
   if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+template <bool F16> __device__ __forceinline__ bf16x8 frag_scale_t(const bf16x8& a, float c) {
+  if constexpr (F16) return frag_scale_h(a, c); else return frag_scale(a, c);
+}
+template <bool F16> struct ActT { typedef bf16 t; };
+template <> struct ActT<true> { typedef f16 t; };
+// dot product of two 8-element register fragments in f32
+template <bool F16> __device__ __forceinline__ float frag_dot(const bf16x8& a, const bf16x8& b) {
+  float d = 0.f;
+  if constexpr (F16) {
+    const f16x8 x = __builtin_bit_cast(f16x8, a), y = __builtin_bit_cast(f16x8, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d += (float)x[j] * (float)y[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d += (float)a[j] * (float)b[j];
+  }
+  return d;
+}
 __device__ __forceinline__ f32x16 splat16(float v) {
   f32x16 o;
 #pragma unroll
@@ -168,6 +186,9 @@ __device__ __forceinline__ bf16x8 acc_frag_h(const f32x16& x, int s) {       // 
 #pragma unroll
   for (int j = 0; j < 8; ++j) f[j] = (f16)x[8 * s + j];
   return __builtin_bit_cast(bf16x8, f);
+}
+template <bool F16> __device__ __forceinline__ bf16x8 acc_frag_t(const f32x16& x, int s) {
+  if constexpr (F16) return acc_frag_h(x, s); else return acc_frag(x, s);
 }
 __device__ __forceinline__ int acc_row(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
@@ -611,7 +632,7 @@ __global__ void attn_delta_kernel(const T* __restrict__ O, const T* __restrict__
 // ROWC = [2][B*H*N] f32 written by the dQ kernel (which runs first): slot 0 = -delta, slot 1 = -lse * log2(e).  They are the INITIAL
 // ACCUMULATORS of the dP and S chains (a query row = an accumulator element here, so they come from the LDS copy of the tile's 64 values
 // by ds_read_b128), k carries scale*log2(e): p = exp2(S) and dS = p * dP are one instruction per element each.
-template <int HD, bool QKN = false, bool RAGGED = false>
+template <int HD, bool QKN = false, bool RAGGED = false, bool F16 = false>      // F16: fp16 operands / outputs (VMAE pre-training under fp16 autocast), QKN = false only
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                  const bf16* __restrict__ dO, const float* __restrict__ ROWC, long rc_stride,
                                                                  bf16* __restrict__ dK, bf16* __restrict__ dV,
@@ -634,7 +655,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
   bf16x8 kf[KS], vf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    kf[ks] = frag_scale(gfrag<HD>(K + hb + (size_t)min(k0 + r, N - 1) * ld, ks * 16 + 8 * h), c);
+    kf[ks] = frag_scale_t<F16>(gfrag<HD>(K + hb + (size_t)min(k0 + r, N - 1) * ld, ks * 16 + 8 * h), c);
     vf[ks] = gfrag<HD>(V + hbv + (size_t)min(k0 + r, N - 1) * Lv.ld, ks * 16 + 8 * h);
   }
   f32x16 dkacc[DB], dvacc[DB];
@@ -694,8 +715,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s = MFMA_BF16(frag_row<HDP>(Qt, qb * 32, ks, lane), kf[ks], s);
-        dp = MFMA_BF16(frag_row<HDP>(dOt, qb * 32, ks, lane), vf[ks], dp);
+        s = mfma_att<F16>(frag_row<HDP>(Qt, qb * 32, ks, lane), kf[ks], s);
+        dp = mfma_att<F16>(frag_row<HDP>(dOt, qb * 32, ks, lane), vf[ks], dp);
       }
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
@@ -705,11 +726,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = acc_frag(s, s2), dsf = acc_frag(dp, s2);
+        const bf16x8 pf = acc_frag_t<F16>(s, s2), dsf = acc_frag_t<F16>(dp, s2);
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
-          dvacc[d] = MFMA_BF16(frag_tr<HDP>(dOt, qb * 32 + 16 * s2, d * 32, lane), pf, dvacc[d]);
-          dkacc[d] = MFMA_BF16(frag_tr<HDP>(Qt, qb * 32 + 16 * s2, d * 32, lane), dsf, dkacc[d]);
+          dvacc[d] = mfma_att<F16>(frag_tr<HDP>(dOt, qb * 32 + 16 * s2, d * 32, lane), pf, dvacc[d]);
+          dkacc[d] = mfma_att<F16>(frag_tr<HDP>(Qt, qb * 32 + 16 * s2, d * 32, lane), dsf, dkacc[d]);
         }
       }
     }
@@ -739,13 +760,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
     __syncthreads();                                   // ring -> store scratch
     if (!active) return;
     char* sw = smem + wave * 32 * (HDP * 2 + 16);
-    store_rows_t<HD>(dkacc, scale, sw, dK + hb + (size_t)k0 * ld, ld, lane, N - k0);
-    store_rows_t<HD>(dvacc, 1.f, sw, dV + hbv + (size_t)k0 * Lv.ld, Lv.ld, lane, N - k0);       // same wave, same scratch: LDS ops stay in order
+    store_rows_t<HD, typename ActT<F16>::t>(dkacc, scale, sw, dK + hb + (size_t)k0 * ld, ld, lane, N - k0);
+    store_rows_t<HD, typename ActT<F16>::t>(dvacc, 1.f, sw, dV + hbv + (size_t)k0 * Lv.ld, Lv.ld, lane, N - k0);       // same wave, same scratch: LDS ops stay in order
   }
 }
 
 // ================================================================================================ backward dQ, bf16
-template <int HD, bool QKN = false, bool RAGGED = false>
+template <int HD, bool QKN = false, bool RAGGED = false, bool F16 = false>      // F16: fp16 operands / outputs (VMAE pre-training under fp16 autocast), QKN = false only
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                const bf16* __restrict__ O, const bf16* __restrict__ dO,
                                                                const float* __restrict__ LSE, float* __restrict__ ROWC, long rc_stride,
@@ -773,12 +794,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   float dpart = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    qf[ks] = frag_scale(gfrag<HD>(Q + hb + (size_t)qrow * ld, ks * 16 + 8 * h), c);
+    qf[ks] = frag_scale_t<F16>(gfrag<HD>(Q + hb + (size_t)qrow * ld, ks * 16 + 8 * h), c);
     const size_t oo = (((size_t)b * N + qrow) * H + hh) * HD;
     dof[ks] = gfrag<HD>(dO + oo, ks * 16 + 8 * h);
     const bf16x8 of = gfrag<HD>(O + oo, ks * 16 + 8 * h);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dpart += (float)dof[ks][j] * (float)of[j];
+    dpart += frag_dot<F16>(dof[ks], of);
   }
   const float dl = dpart + __shfl_xor(dpart, 32);
   const float lse2 = LSE[(size_t)bh * N + qrow] * 1.4426950408889634f;
@@ -833,8 +853,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
       f32x16 s, dp;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s = MFMA_BF16(frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], ks == 0 ? nl : s);
-        dp = MFMA_BF16(frag_row<HDP>(Vt, kb * 32, ks, lane), dof[ks], ks == 0 ? nd : dp);
+        s = mfma_att<F16>(frag_row<HDP>(Kt, kb * 32, ks, lane), qf[ks], ks == 0 ? nl : s);
+        dp = mfma_att<F16>(frag_row<HDP>(Vt, kb * 32, ks, lane), dof[ks], ks == 0 ? nd : dp);
       }
       if (ragged && kt == nt - 1) mask_rows_past(s, kt * 64 + kb * 32, h, N);       // keys past N: p = 0, dS = 0
       bf16x8 ktr[2][DB];
@@ -849,9 +869,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
       for (int t = 0; t < 16; ++t) dp[t] *= EXP2(s[t]);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 dsf = acc_frag(dp, s2);
+        const bf16x8 dsf = acc_frag_t<F16>(dp, s2);
 #pragma unroll
-        for (int d = 0; d < DB; ++d) dqacc[d] = MFMA_BF16(BTR ? ktr[s2][d] : frag_tr<HDP>(Kt, kb * 32 + 16 * s2, d * 32, lane), dsf, dqacc[d]);
+        for (int d = 0; d < DB; ++d) dqacc[d] = mfma_att<F16>(BTR ? ktr[s2][d] : frag_tr<HDP>(Kt, kb * 32 + 16 * s2, d * 32, lane), dsf, dqacc[d]);
       }
     }
   };
@@ -873,7 +893,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
   } else {
     __syncthreads();                                   // ring -> store scratch
     if (!active) return;
-    store_rows_t<HD>(dqacc, scale, smem + wave * 32 * (HDP * 2 + 16), dQ + hb + (size_t)q0 * ld, ld, lane, N - q0);
+    store_rows_t<HD, typename ActT<F16>::t>(dqacc, scale, smem + wave * 32 * (HDP * 2 + 16), dQ + hb + (size_t)q0 * ld, ld, lane, N - q0);
   }
 }
 
@@ -1575,7 +1595,17 @@ static int attention_bwd_core(int dtype, const void* q, const void* k, const voi
   // delta = [2][B*H*NP] f32 workspace, NP = N rounded up to 64 (bf16: -delta | -lse*log2e, rows padded to whole tiles; f32: slot 0 = delta, unpadded)
   const long items = (long)B * N * H, rcs = (long)B * H * ((N + 63) / 64 * 64);
   const unsigned dgrid = (unsigned)((items * 8 + 255) / 256 < 8192 ? (items * 8 + 255) / 256 : 8192);
-  if (dtype == LDMAE_BF16) {
+  if (dtype == LDMAE_F16) {
+    // fp16 operands / gradients (VMAE pre-training under fp16 autocast; head_dim 16): the bf16 kernels with the f16 MFMAs and conversions
+    LDMAE_REQUIRE(hd == 16, "attention_bwd(fp16): head_dim 16 only (the VMAE heads)");
+#define LRH(R) { \
+    hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<16, false, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(16, 0)); \
+    hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<16, false, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(16, 1024)); \
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<16, false, R, true>), dim3(grid), dim3(256), attn_lds(16, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, rcs, (bf16*)dq, H, N, scale, Lq, Lv, QkNormBwd{}); \
+    hipLaunchKernelGGL((attn_bwd_dkdv_bf16_kernel<16, false, R, true>), dim3(grid), dim3(256), attn_lds(16, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, delta, rcs, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv, QkNormBwd{}); }
+    if (N % 64 == 0) LRH(false) else LRH(true)
+#undef LRH
+  } else if (dtype == LDMAE_BF16) {
     // dQ first: it forms delta = rowsum(dO * O) from its own fragments and publishes it for the dK/dV kernel
 #define LR(HD, R) { \
     hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD, false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
@@ -1613,7 +1643,7 @@ extern "C" int ldmae_attention_bwd(int dtype, const void* q, const void* k, cons
 extern "C" int ldmae_attention_bwd_qkv(int dtype, const void* qkv, const void* o, const void* do_, const float* lse, void* dqkv, float* delta,
                                        int B, int H, int N, int hd, float scale, void* stream) {
   LDMAE_REQUIRE(qkv && o && do_ && lse && dqkv && delta, "attention_bwd_qkv: null pointer");
-  LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_bwd_qkv: bf16 only");
+  LDMAE_REQUIRE(dtype == LDMAE_BF16 || (dtype == LDMAE_F16 && hd == 16), "attention_bwd_qkv: bf16, or fp16 at head_dim 16");
   if (int e = attn_check("attention_bwd_qkv", dtype, B, H, N, hd)) return e;
   LDMAE_REQUIRE(hd % 8 == 0, "attention_bwd_qkv: head_dim %d must be a multiple of 8", hd);
   const bf16* p = (const bf16*)qkv;

@@ -10,9 +10,10 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-// fp16 activations (round 5): the TF32-CLASS forward path.  fp16 has TF32's 10-bit mantissa; the operands of the GEMMs / attention products it is
-// used for (LayerNorm outputs, q / k / v, softmax probabilities, GELU outputs) are O(1), so the 5-bit exponent is enough -- and the conversion
-// SATURATES at +-65504 instead of producing infinities.  v_mfma_f32_*_f16 runs at the bf16 rate with f32 accumulation.
+// fp16 activations (round 5): the TF32-CLASS forward path and VMAE pre-training under fp16 autocast.  fp16 has TF32's 10-bit mantissa; the operands of
+// the GEMMs / attention products it is used for (LayerNorm outputs, q / k / v, softmax probabilities, GELU outputs) are O(1), so the 5-bit exponent is
+// enough; the FORWARD GEMM epilogues saturate at +-65504 instead of producing infinities (EpiArgs::f16_max), gradient outputs overflow to infinity as
+// under torch's fp16 autocast (the loss scaler skips the step).  v_mfma_f32_*_f16 runs at the bf16 rate with f32 accumulation.
 typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
@@ -62,7 +63,10 @@ template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32, RNE, NaN-safe
 template <> __device__ __forceinline__ float to_f<f16>(f16 v) { return (float)v; }
-template <> __device__ __forceinline__ f16 from_f<f16>(float v) { return (f16)(v == v ? __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f) : v); }   // saturating, NaN kept
+template <> __device__ __forceinline__ f16 from_f<f16>(float v) { return (f16)v; }   // IEEE: beyond +-65504 -> infinity (what a loss scaler watches for)
+// forward outputs of the fp16 GEMM epilogues SATURATE instead (mx = 65504; mx = infinity: no-op, the gradient GEMMs); NaN kept
+__device__ __forceinline__ float sat_f16(float v, float mx) { return v == v ? __builtin_amdgcn_fmed3f(v, -mx, mx) : v; }
+__device__ __forceinline__ float4 sat_f16(float4 v, float mx) { return make_float4(sat_f16(v.x, mx), sat_f16(v.y, mx), sat_f16(v.z, mx), sat_f16(v.w, mx)); }
 // 8- / 4-element register vectors of a 2-byte activation type
 template <typename T> struct Pack;
 template <> struct Pack<bf16> { typedef bf16x8 v8; typedef bf16x4 v4; };

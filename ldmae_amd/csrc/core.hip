@@ -69,10 +69,10 @@ extern "C" int ldmae_prof_collect(double* total_ms, double* total_flops, long* l
 
 // ---------------------------------------------------------------- launch counts by kernel family (include/ldmae_hip.h)
 #include <atomic>
-static std::atomic<long> g_counts[8];
+static std::atomic<long> g_counts[9];
 void ldmae_count(int family) { g_counts[family].fetch_add(1, std::memory_order_relaxed); }
 extern "C" int ldmae_launch_counts(long* counts, int n, int reset) {
-  LDMAE_REQUIRE(counts && n >= 0 && n <= 8, "launch_counts: counts null or n outside 0..8");
+  LDMAE_REQUIRE(counts && n >= 0 && n <= 9, "launch_counts: counts null or n outside 0..9");
   for (int i = 0; i < n; ++i) counts[i] = g_counts[i].load(std::memory_order_relaxed);
   if (reset)
     for (auto& c : g_counts) c.store(0, std::memory_order_relaxed);

@@ -11,6 +11,10 @@ template <> __device__ __forceinline__ float4 load4<bf16>(const bf16* p) {
   bf16x4 v = __builtin_nontemporal_load((const bf16x4*)p);
   return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
+template <> __device__ __forceinline__ float4 load4<f16>(const f16* p) {
+  const f16x4 a = *(const f16x4*)p;
+  return make_float4((float)a[0], (float)a[1], (float)a[2], (float)a[3]);
+}
 template <typename T> __device__ __forceinline__ void store4(T* p, float4 v);
 template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) { f32x4 o = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(o, (f32x4*)p); }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, float4 v) {
@@ -938,7 +942,8 @@ extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, flo
   LDMAE_REQUIRE(X && out && workspace && M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0, "colsum: bad arguments (N=%d ldx=%d multiples of 4)", N, ldx);
   hipStream_t st = as_stream(stream);
   const int rows = colsum_rows(M, N), G = cdiv(M, rows);
-  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(cdiv(N, 1024), G), dim3(256), 0, st, (const bf16*)X, ldx, M, N, rows, workspace);
+  if (dtype == LDMAE_F16) hipLaunchKernelGGL(colsum_kernel<f16>, dim3(cdiv(N, 1024), G), dim3(256), 0, st, (const f16*)X, ldx, M, N, rows, workspace);
+  else if (dtype == LDMAE_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(cdiv(N, 1024), G), dim3(256), 0, st, (const bf16*)X, ldx, M, N, rows, workspace);
   else hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(N, 1024), G), dim3(256), 0, st, (const float*)X, ldx, M, N, rows, workspace);
   group_reduce(workspace, N, 1, N, G, out, N, beta, st);
   LDMAE_CHECK_LAUNCH("colsum");

@@ -13,6 +13,12 @@
 
 #include "gemm_nt_common.h"
 
+// bf16 or fp16 operand bits in the same bf16x8 registers (F16: VMAE pre-training under fp16 autocast, the LDMAE_F16 family)
+template <bool F16> __device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 NT GEMM kernel: persistent, one 512-thread workgroup per CU walks the 256x256 output tiles t = b, b + grid, ...
 // Main loop: the two M wave groups (which share the SIMDs pairwise) run half a K-step apart -- while one group issues its
@@ -290,6 +296,7 @@ __device__ __forceinline__ int tn_sw(int r) { return ((r & 3) << 2) | ((r >> 2) 
 // 16 zero bytes -- the LDS-DMA source address is per lane -- so they add nothing to the products
 __device__ __attribute__((aligned(16))) unsigned g_tn_zero16[4] = {0u, 0u, 0u, 0u};
 
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B,
                                                            float* __restrict__ P, int M, int N, int K, int lda, int ldb,
                                                            int rows_per_split) {
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restric
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const bf16* __restric
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tnr_sw(int r) { return ((r & 3) << 1) | (((r >> 3) & 1) << 3); }
 
-template <int STAGES, int WNn = 2, bool STAG = false>
+template <int STAGES, int WNn = 2, bool STAG = false, bool F16 = false>
 __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, float* __restrict__ P,
                                                            float* __restrict__ Pb, int M, int N, int K, int lda, int ldb,
                                                            int rows_per_split) {
@@ -447,8 +454,11 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
     return u.v;
   };
   bf16x8 ones;
+  if constexpr (F16) { f16x8 o; for (int j = 0; j < 8; ++j) o[j] = (f16)1.0f; ones = __builtin_bit_cast(bf16x8, o); }
+  else {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+  }
 
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
@@ -480,10 +490,10 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
       if (want_bias) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+        for (int i = 0; i < MI; ++i) accb[i] = mfma16<F16>(af[i], ones, accb[i]);
       }
       if (!grpB) wait_next(st);
       __builtin_amdgcn_s_barrier();
@@ -509,10 +519,10 @@ __global__ __launch_bounds__(WNn * 4 * 64) void gemm_tn_ring_kernel(const bf16* 
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NI; ++j) acc[i][j] = mfma16<F16>(af[i], bfr[j], acc[i][j]);
     if (want_bias) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+      for (int i = 0; i < MI; ++i) accb[i] = mfma16<F16>(af[i], ones, accb[i]);
     }
     __builtin_amdgcn_s_setprio(0);
   }
@@ -827,8 +837,8 @@ static int launch_nt(int dtype, int epi, bool tile_launch, bool half_lines, cons
 extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                              int M, int N, int K, const float* bias, float beta, const float* xin, float* xout,
                              const float* gate, int gate_ld, int rows_per_batch, void* stream) {
-  const bool tile_launch = (epi & LDMAE_EPI_TILE_LAUNCH) != 0, half_lines = (epi & LDMAE_EPI_HALF_LINES) != 0;
-  epi &= ~(LDMAE_EPI_TILE_LAUNCH | LDMAE_EPI_HALF_LINES);
+  const bool tile_launch = (epi & LDMAE_EPI_TILE_LAUNCH) != 0, half_lines = (epi & LDMAE_EPI_HALF_LINES) != 0, f16_inf = (epi & LDMAE_EPI_F16_INF) != 0;
+  epi &= ~(LDMAE_EPI_TILE_LAUNCH | LDMAE_EPI_HALF_LINES | LDMAE_EPI_F16_INF);
   LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16 || dtype == LDMAE_F16, "gemm_nt: bad dtype %d", dtype);
   LDMAE_REQUIRE(out_dtype == LDMAE_F32 || out_dtype == LDMAE_BF16 || (out_dtype == LDMAE_F16 && dtype == LDMAE_F16), "gemm_nt: bad out_dtype %d", out_dtype);
   LDMAE_REQUIRE(dtype != LDMAE_F16 || out_dtype != LDMAE_BF16, "gemm_nt: fp16 operands give fp16 or f32 outputs");
@@ -840,6 +850,7 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
   LDMAE_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_nt: operands must be 16-B aligned");
   EpiArgs e{};
   e.C = C; e.bias = bias; e.ldc = ldc; e.beta = beta;
+  e.f16_max = f16_inf ? __builtin_inff() : 65504.f;
   if (epi == LDMAE_EPI_BIAS) {
     LDMAE_REQUIRE(C && ldc >= N, "gemm_nt: C null or ldc < N");
     LDMAE_REQUIRE(beta == 0.f || beta == 1.f, "gemm_nt: beta must be 0 or 1");
@@ -870,8 +881,8 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
   }
   if (dtype == LDMAE_F16) {
     // the TF32-class forward family: whole-line kernel only (every Linear of the VMAE / DiT blocks qualifies), one tile per workgroup or persistent
-    LDMAE_REQUIRE(epi == LDMAE_EPI_BIAS || epi == LDMAE_EPI_GATE_RES || epi == LDMAE_EPI_BIAS_POS || epi == LDMAE_EPI_BIAS_GELU,
-                  "gemm_nt(fp16): forward epilogues only (bias, gated residual, pos, gelu), got %d", epi);
+    LDMAE_REQUIRE(epi == LDMAE_EPI_BIAS || epi == LDMAE_EPI_GATE_RES || epi == LDMAE_EPI_BIAS_POS || epi == LDMAE_EPI_BIAS_GELU || epi == LDMAE_EPI_GELU_BWD,
+                  "gemm_nt(fp16): bias, gated residual, pos, gelu, gelu-bwd epilogues (the VMAE blocks), got %d", epi);
     LDMAE_REQUIRE(beta == 0.f, "gemm_nt(fp16): beta must be 0");
     ldmae_count(LDMAE_COUNT_NT_F16);
     int ncu = 0, dev = 0;
@@ -910,16 +921,18 @@ static int tn_plan(int dtype, int M, int N, int K, int* rows_out) {
   return (M + rows - 1) / rows;
 }
 
-extern "C" int ldmae_gemm_tn_splits(int dtype, int M, int N, int K) { return tn_plan(dtype, M, N, K, nullptr); }
+extern "C" int ldmae_gemm_tn_splits(int dtype, int M, int N, int K) { return tn_plan(dtype == LDMAE_F16 ? LDMAE_BF16 : dtype, M, N, K, nullptr); }
 
 extern "C" long ldmae_gemm_tn_workspace_bytes(int dtype, int M, int N, int K) {
-  return (long)tn_plan(dtype, M, N, K, nullptr) * ((long)N * K + N) * 4;
+  return (long)tn_plan(dtype == LDMAE_F16 ? LDMAE_BF16 : dtype, M, N, K, nullptr) * ((long)N * K + N) * 4;
 }
 
 extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, float* C, float* dbias, int M, int N, int K,
                              float beta, float* workspace, long workspace_bytes, void* stream) {
-  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "gemm_tn: bad dtype %d", dtype);
+  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16 || dtype == LDMAE_F16, "gemm_tn: bad dtype %d", dtype);
   LDMAE_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C, "gemm_tn: empty problem or null pointer");
+  const bool half = dtype == LDMAE_F16;
+  if (half) dtype = LDMAE_BF16;                 // same tiling, plan and workspace as bf16; only the MFMA differs
   LDMAE_REQUIRE(beta == 0.f || beta == 1.f, "gemm_tn: beta must be 0 or 1");
   const int al = dtype == LDMAE_BF16 ? 8 : 4;
   LDMAE_REQUIRE(N % al == 0 && K % al == 0 && lda % al == 0 && ldb % al == 0, "gemm_tn: N=%d K=%d lda=%d ldb=%d must be multiples of %d", N, K, lda, ldb, al);
@@ -928,7 +941,7 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   const int splits = tn_plan(dtype, M, N, K, &rows);
   const bool ring = dtype == LDMAE_BF16 && ldmae_tune_get(1) == 0 && M % 32 == 0;
   hipStream_t st = as_stream(stream);
-  ldmae_count(dtype == LDMAE_BF16 ? LDMAE_COUNT_TN_BF16 : LDMAE_COUNT_TN_F32);
+  ldmae_count(half ? LDMAE_COUNT_TN_F16 : (dtype == LDMAE_BF16 ? LDMAE_COUNT_TN_BF16 : LDMAE_COUNT_TN_F32));
   LDMAE_REQUIRE(workspace && workspace_bytes >= (long)splits * ((long)N * K + N) * 4, "gemm_tn: workspace too small (%ld < %ld)",
                 workspace_bytes, (long)splits * ((long)N * K + N) * 4);
   // one split and nothing to accumulate into: the GEMM writes C (and the bias gradient) itself -- no partial slab, no reduce pass
@@ -949,11 +962,15 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
       hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 4, false>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
     else if (ldmae_tune_get(4) == 4)
       hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 4, true>), dim3(grid), dim3(1024), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
-    else
+    else if (half) {
+      hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<4, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 2, true, true>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
+    } else
       hipLaunchKernelGGL((gemm_tn_ring_kernel<4, 2, true>), dim3(grid), dim3(512), lds, st, (const bf16*)A, (const bf16*)B, P, dbias ? Pb : nullptr, M, N, K, lda, ldb, rows);
   } else if (dtype == LDMAE_BF16) {
     const unsigned grid = cdiv(N, TN_BN) * cdiv(K, TN_BK) * splits;
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(grid), dim3(256), 4 * TN_TILE_BYTES, st, (const bf16*)A, (const bf16*)B, P, M, N, K, lda, ldb, rows);
+    if (half) hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, dim3(grid), dim3(256), 4 * TN_TILE_BYTES, st, (const bf16*)A, (const bf16*)B, P, M, N, K, lda, ldb, rows);
+    else hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, dim3(grid), dim3(256), 4 * TN_TILE_BYTES, st, (const bf16*)A, (const bf16*)B, P, M, N, K, lda, ldb, rows);
   } else {
     const unsigned grid = cdiv(N, FT_BN) * cdiv(K, FT_BK) * splits;
     hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(grid), dim3(256), 0, st, (const float*)A, (const float*)B, P, M, N, K, lda, ldb, rows);
@@ -966,7 +983,7 @@ extern "C" int ldmae_gemm_tn(int dtype, const void* A, int lda, const void* B, i
   }
   if (dbias && !ring) {   // non-ring paths: separate column-sum pass (elementwise.hip), re-using the workspace
     LDMAE_REQUIRE(workspace_bytes >= ldmae_colsum_workspace_bytes(M, N), "gemm_tn: workspace too small for the bias-gradient pass");
-    return ldmae_colsum(dtype, A, lda, M, N, dbias, beta, workspace, stream);
+    return ldmae_colsum(half ? LDMAE_F16 : dtype, A, lda, M, N, dbias, beta, workspace, stream);
   }
   return LDMAE_OK;
 }

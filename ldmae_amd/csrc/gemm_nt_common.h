@@ -19,6 +19,7 @@ struct EpiArgs {
   int rows_per_batch;
   int ldc;              // row stride of C in elements
   float beta;           // EPI_BIAS with f32 out: C = acc + bias + beta*C   (beta 0 or 1: gradient accumulation)
+  float f16_max;        // fp16 outputs: clamp to +-f16_max before the conversion (65504: forward GEMMs saturate; infinity: gradient GEMMs overflow to inf)
 };
 
 // gemm_nt_lines.hip: the whole-line form of the persistent bf16 NT kernel (128-B LDS rows, seamless ring of five half-block slots).  Returns 0
@@ -108,10 +109,12 @@ template <int EPI, typename OutT> struct Epi4 {
     gate = make_float4(1.f, 1.f, 1.f, 1.f);
     if (EPI == LDMAE_EPI_GATE_RES && e.gate) gate = *(const float4*)(e.gate + (size_t)(m_first / e.rows_per_batch) * e.gate_ld + n);
   }
-  static __device__ __forceinline__ void put(void* base, size_t off, float4 v) {
+  __device__ __forceinline__ void put(void* base, size_t off, float4 v) const {
+    const float e_f16_max = e.f16_max;
     OutT* p = (OutT*)base + off;
     if constexpr (sizeof(OutT) == 4) *(float4*)p = v;
-    else { typename Pack<OutT>::v4 o; o[0] = from_f<OutT>(v.x); o[1] = from_f<OutT>(v.y); o[2] = from_f<OutT>(v.z); o[3] = from_f<OutT>(v.w); *(typename Pack<OutT>::v4*)p = o; }
+    else { if constexpr (__is_same(OutT, f16)) v = sat_f16(v, e_f16_max);
+      typename Pack<OutT>::v4 o; o[0] = from_f<OutT>(v.x); o[1] = from_f<OutT>(v.y); o[2] = from_f<OutT>(v.z); o[3] = from_f<OutT>(v.w); *(typename Pack<OutT>::v4*)p = o; }
   }
   // value destined for C (and C2 for GELU) without storing them; side outputs (xout) are stored here
   __device__ __forceinline__ void compute(int m, float4 a, float4& c, float4& c2) const {
@@ -342,6 +345,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
   auto put8 = [&](void* base, size_t oc, float4 a, float4 b) {
     if constexpr (sizeof(OutT) == 4) { *(float4*)((float*)base + oc) = a; *(float4*)((float*)base + oc + 4) = b; }
     else {
+      if constexpr (__is_same(OutT, f16)) { a = sat_f16(a, e.f16_max); b = sat_f16(b, e.f16_max); }
       typename Pack<OutT>::v8 o;
       o[0] = from_f<OutT>(a.x); o[1] = from_f<OutT>(a.y); o[2] = from_f<OutT>(a.z); o[3] = from_f<OutT>(a.w);
       o[4] = from_f<OutT>(b.x); o[5] = from_f<OutT>(b.y); o[6] = from_f<OutT>(b.z); o[7] = from_f<OutT>(b.w);

@@ -209,6 +209,7 @@ static int launch_lines_f16(int epi, const void* A, const void* B, int M, int N,
     case LDMAE_EPI_GATE_RES: LINES_GO(LDMAE_EPI_GATE_RES);
     case LDMAE_EPI_BIAS_POS: LINES_GO(LDMAE_EPI_BIAS_POS);
     case LDMAE_EPI_BIAS_GELU: LINES_GO(LDMAE_EPI_BIAS_GELU);
+    case LDMAE_EPI_GELU_BWD: if constexpr (sizeof(OutT) == 2) LINES_GO(LDMAE_EPI_GELU_BWD) else return 0;
     default: return 0;
   }
 #undef LINES_GO

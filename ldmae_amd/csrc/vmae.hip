@@ -148,6 +148,7 @@ extern "C" int ldmae_scatter_rows(const float* dout, const long long* ids, float
 template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&v)[4]);
 template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&v)[4]) { const float4 a = *(const float4*)p; v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
 template <> __device__ __forceinline__ void ld4<bf16>(const bf16* p, float (&v)[4]) { const bf16x4 a = *(const bf16x4*)p; for (int j = 0; j < 4; ++j) v[j] = (float)a[j]; }
+template <> __device__ __forceinline__ void ld4<f16>(const f16* p, float (&v)[4]) { const f16x4 a = *(const f16x4*)p; for (int j = 0; j < 4; ++j) v[j] = (float)a[j]; }
 template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
 template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 template <> __device__ __forceinline__ void st4<bf16>(bf16* p, const float (&v)[4]) { bf16x4 a; for (int j = 0; j < 4; ++j) a[j] = (bf16)v[j]; *(bf16x4*)p = a; }
@@ -305,7 +306,9 @@ extern "C" int ldmae_layernorm_bwd(int dtype, const void* dout, const float* x, 
   hipStream_t st = as_stream(stream);
   const int G = cdiv(M, LN_ROWS);
   const size_t lds = (size_t)32 * D * 4;
-#define LN_B(NV) { if (dtype == LDMAE_BF16) { hipFuncSetAttribute((const void*)layernorm_bwd_kernel<bf16, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define LN_B(NV) { if (dtype == LDMAE_F16) { hipFuncSetAttribute((const void*)layernorm_bwd_kernel<f16, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                     hipLaunchKernelGGL((layernorm_bwd_kernel<f16, NV>), dim3(G), dim3(256), lds, st, (const f16*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS); } \
+                   else if (dtype == LDMAE_BF16) { hipFuncSetAttribute((const void*)layernorm_bwd_kernel<bf16, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                      hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NV>), dim3(G), dim3(256), lds, st, (const bf16*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS); } \
                    else { hipFuncSetAttribute((const void*)layernorm_bwd_kernel<float, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                      hipLaunchKernelGGL((layernorm_bwd_kernel<float, NV>), dim3(G), dim3(256), lds, st, (const float*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS); } }
@@ -335,14 +338,16 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ dout, const T* __restrict_
 static unsigned gelu_grid(long n) { long g = (n + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 extern "C" int ldmae_gelu_fwd(int dtype, const void* x, void* out, long n, void* stream) {
   LDMAE_REQUIRE(x && out && n > 0, "gelu_fwd: bad arguments");
-  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const bf16*)x, (bf16*)out, n);
+  if (dtype == LDMAE_F16) hipLaunchKernelGGL(gelu_fwd_kernel<f16>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const f16*)x, (f16*)out, n);
+  else if (dtype == LDMAE_BF16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const bf16*)x, (bf16*)out, n);
   else hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)out, n);
   LDMAE_CHECK_LAUNCH("gelu_fwd");
   return LDMAE_OK;
 }
 extern "C" int ldmae_gelu_bwd(int dtype, const void* dout, const void* x, void* dx, long n, void* stream) {
   LDMAE_REQUIRE(dout && x && dx && n > 0, "gelu_bwd: bad arguments");
-  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const bf16*)dout, (const bf16*)x, (bf16*)dx, n);
+  if (dtype == LDMAE_F16) hipLaunchKernelGGL(gelu_bwd_kernel<f16>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const f16*)dout, (const f16*)x, (f16*)dx, n);
+  else if (dtype == LDMAE_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const bf16*)dout, (const bf16*)x, (bf16*)dx, n);
   else hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const float*)dout, (const float*)x, (float*)dx, n);
   LDMAE_CHECK_LAUNCH("gelu_bwd");
   return LDMAE_OK;

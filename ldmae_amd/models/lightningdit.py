@@ -32,13 +32,17 @@ from .rmsnorm import RMSNorm
 from .swiglu_ffn import SwiGLUFFN
 
 
-def _act_dtype(override=None):
+def _act_dtype(override=None, allow_f16=False):
+    """Activation type of a call: the module's `precision` override, else torch's autocast state.  allow_f16: fp16 autocast is accepted (the VMAE
+    blocks have an fp16 kernel family -- VMAE/engine_pretrain.py:51-57 trains under it; the LightningDiT kernels are bf16 / f32 only)."""
     if override is not None:
         return override
     if torch.is_autocast_enabled("cuda"):
         d = torch.get_autocast_dtype("cuda")
+        if d == torch.float16 and allow_f16:
+            return torch.float16
         if d != torch.bfloat16:
-            raise RuntimeError(f"ldmae_amd: autocast dtype {d} unsupported (bfloat16 or no autocast)")
+            raise RuntimeError(f"ldmae_amd: autocast dtype {d} unsupported here (bfloat16 or no autocast; float16 on the VMAE tokenizer only)")
         return torch.bfloat16
     return torch.float32
 

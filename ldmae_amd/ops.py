@@ -12,7 +12,7 @@ import weakref
 import torch
 
 from . import _lib as L
-from ._lib import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_GATE_RES, EPI_GELU_BWD, EPI_HALF_LINES, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_TILE_LAUNCH, F32, call, dt,
+from ._lib import (BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_POS, EPI_F16_INF, EPI_GATE_RES, EPI_GELU_BWD, EPI_HALF_LINES, EPI_SWIGLU, EPI_SWIGLU_BWD, EPI_TILE_LAUNCH, F32, call, dt,
                    ptr, stream)
 
 _ws = {}
@@ -113,14 +113,20 @@ def gemm_launch_mode() -> str:
     return "tile" if (_launch_flag() & EPI_TILE_LAUNCH) else "persistent"
 
 
-def gemm_nt(a, b, bias=None, out_dtype=None, out=None, beta=0.0):
+def _grad_flag(dtype, grad) -> int:
+    """fp16 GRADIENT outputs overflow to infinity (torch's fp16 autocast semantics: the loss scaler then skips the step); forward fp16 outputs
+    saturate at +-65504.  A per-call flag of the C ABI (LDMAE_EPI_F16_INF)."""
+    return EPI_F16_INF if (grad and dtype == torch.float16) else 0
+
+
+def gemm_nt(a, b, bias=None, out_dtype=None, out=None, beta=0.0, grad=False):
     """out[M,N] = a[M,K] @ b[N,K]^T + bias (+ beta*out)."""
     M, K = a.shape
     N = b.shape[0]
     out_dtype = out_dtype or a.dtype
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
-    call("ldmae_gemm_nt", dt(a.dtype), dt(out.dtype), EPI_BIAS | _launch_flag(), ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
+    call("ldmae_gemm_nt", dt(a.dtype), dt(out.dtype), EPI_BIAS | _launch_flag() | _grad_flag(out.dtype, grad), ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0),
          M, N, K, ptr(bias), float(beta), None, None, None, 0, 0, stream())
     return out
 
@@ -167,7 +173,7 @@ def gemm_nt_gelu_bwd(dy, w2t, pre):
     M, K = dy.shape
     N = w2t.shape[0]
     out = torch.empty(M, N, dtype=dy.dtype, device=dy.device)
-    call("ldmae_gemm_nt", dt(dy.dtype), dt(dy.dtype), EPI_GELU_BWD | _launch_flag(), ptr(dy), dy.stride(0), ptr(w2t), w2t.stride(0), ptr(out), N,
+    call("ldmae_gemm_nt", dt(dy.dtype), dt(dy.dtype), EPI_GELU_BWD | _launch_flag() | _grad_flag(dy.dtype, True), ptr(dy), dy.stride(0), ptr(w2t), w2t.stride(0), ptr(out), N,
          M, N, K, None, 0.0, ptr(pre), None, None, 0, 0, stream())
     return out
 

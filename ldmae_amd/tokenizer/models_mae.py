@@ -86,7 +86,7 @@ class _ViTBlockFn(torch.autograd.Function):
     """Block.forward (:176-187): x += proj(attn(LN1(x))); x += fc2(gelu(fc1(LN2(x))))."""
 
     @staticmethod
-    def forward(ctx, x, H, eps, dtype, inplace, fwd_only, direct, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
+    def forward(ctx, x, H, eps, dtype, inplace, fwd_only, direct, yres_f32, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b):
         B, N, D = x.shape
         M, hd = B * N, D // H
         x2 = x.contiguous().view(M, D)
@@ -99,8 +99,8 @@ class _ViTBlockFn(torch.autograd.Function):
         W2, W2T = _wcopies(f2w, dtype, bwd)
         h1, mu1, rs1 = ops.layernorm_fwd(x2, n1w, n1b, dtype, eps)
         qkv = ops.gemm_nt(h1, Wqkv, qkvb)                                     # activation dtype: bf16 under autocast
-        if dtype == torch.float16 and (bwd or hd != 16):
-            raise RuntimeError("ldmae_amd: the fp16 (TF32-class) activation type is forward-only, head_dim 16")
+        if dtype == torch.float16 and hd != 16:
+            raise RuntimeError("ldmae_amd: the fp16 kernel family covers head_dim 16 (the shipped VMAE heads)")
         if dtype in (torch.bfloat16, torch.float16) or (hd == 16 and not bwd):
             # flash kernel on the packed qkv as the Linear wrote it (bf16: head_dim 16 padded to 32 in LDS; f32 inference at head_dim 16: the
             # 16x16x4-MFMA kernel reads the packed rows too -- no head-major relayout.  The f32 BACKWARD kernels take head-major q / k / v.)
@@ -111,9 +111,9 @@ class _ViTBlockFn(torch.autograd.Function):
             o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)                    # [B,N,D]
             qkv = None
         oa = o.view(M, D)
-        # fp16 = the TF32-class forward (inputs of every product rounded to a 10-bit mantissa, f32 accumulation): like a TF32 Linear, the branch
-        # output joins the residual stream UNROUNDED
-        ydt = torch.float32 if dtype == torch.float16 else None
+        # yres_f32 (the TF32-class docking calls: fp16 operands = inputs rounded to a 10-bit mantissa, f32 accumulation): like a TF32 Linear, the
+        # branch output joins the residual stream UNROUNDED.  Under fp16 / bf16 AUTOCAST the Linear's output is the activation type, rounded.
+        ydt = torch.float32 if yres_f32 else None
         xmid, _ = ops.gemm_nt_gate_res(oa, Wp, pb, x2, None, N, save_y=False, y_dtype=ydt)
         h2, mu2, rs2 = ops.layernorm_fwd(xmid, n2w, n2b, dtype, eps)
         act, pre = ops.gemm_nt_gelu(h2, W1, f1b, save_pre=bwd)
@@ -150,18 +150,18 @@ class _ViTBlockFn(torch.autograd.Function):
         dW2, db2 = dw(dy2, act, 10)
         dpre = ops.gemm_nt_gelu_bwd(dy2, W2T, pre)                 # fc2's input gradient with the GELU backward in the GEMM epilogue
         dW1, db1 = dw(dpre, h2, 8)
-        dn2w, dn2b = ops.layernorm_bwd(ops.gemm_nt(dpre, W1T), xmid, n2w, mu2, rs2, dx)
+        dn2w, dn2b = ops.layernorm_bwd(ops.gemm_nt(dpre, W1T, grad=True), xmid, n2w, mu2, rs2, dx)
         # attention branch
         dy1 = ops.cast(dx, dtype)
         dWp, dbp = dw(dy1, oa, 4)
-        do = ops.gemm_nt(dy1, WpT)
+        do = ops.gemm_nt(dy1, WpT, grad=True)
         if qkv is not None:
             dqkv = ops.attention_bwd_qkv(qkv, o, do, lse, B, N, H, hd, hd ** -0.5)
         else:
             dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
             dqkv = ops.heads_merge(dq, dk, dv, B, N, H, hd)
         dWqkv, dbqkv = dw(dqkv, h1, 2)
-        dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT), x2, n1w, mu1, rs1, dx)
+        dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT, grad=True), x2, n1w, mu1, rs1, dx)
         if pl is not None:
             small = [(0, dn1w), (1, dn1b), (6, dn2w), (7, dn2b)]          # (the four bias gradients went into the slab with their weights)
             ops.multi_add_([pl[i].grad for i, _ in small], [g_ for _, g_ in small])
@@ -170,7 +170,7 @@ class _ViTBlockFn(torch.autograd.Function):
                 if r is not None:
                     r(p_)
             dn1w = dn1b = dbqkv = dbp = dn2w = dn2b = db1 = db2 = None
-        return (dx.view(B, N, D), None, None, None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
+        return (dx.view(B, N, D), None, None, None, None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -281,10 +281,12 @@ class Block(nn.Module):
         switched autocast off around the stack passes what it read before doing so); None: the block's own `precision` setting / autocast.
         `last_dtype` records what the call ran in (tests)."""
         a, m = self.attn, self.mlp
-        dtype = dtype if dtype is not None else _act_dtype(self.precision)
+        dtype = dtype if dtype is not None else _act_dtype(self.precision, allow_f16=True)
         self.last_dtype = dtype
+        # fp16 WITHOUT autocast = the TF32-class docking call (MaskedAutoencoderViT._docking_dtype): unrounded branch outputs
+        yres_f32 = dtype == torch.float16 and not torch.is_autocast_enabled("cuda") and self.precision is None
         return _ViTBlockFn.apply(x.float(), a.num_heads, self.norm1.eps, dtype, _inplace_grad,
-                                 not torch.is_grad_enabled(), bool(getattr(self, "direct_param_grads", False)), self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                                 not torch.is_grad_enabled(), bool(getattr(self, "direct_param_grads", False)), yres_f32, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                  self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
 
 
@@ -420,7 +422,7 @@ class MaskedAutoencoderViT(nn.Module):
         residual stream, LayerNorm and softmax statistics stay f32, as under TF32.  End to end (12 blocks) 5.6e-4 relative against exact f32 --
         the same as emulated TF32 (tests/test_gpu_mae.py).  With the flag off (torch's default) f32 calls stay on the exact-f32 MFMA kernels,
         the 1e-4 parity path.  LDMAE_TF32=0 keeps them there regardless."""
-        dtype = _act_dtype(self.precision)
+        dtype = _act_dtype(self.precision, allow_f16=True)
         if dtype != torch.float32 or torch.is_grad_enabled() or not torch.backends.cuda.matmul.allow_tf32 or os.environ.get("LDMAE_TF32", "1") == "0":
             return dtype
         ok = all(b.norm1.weight.numel() // b.attn.num_heads == 16 and b.norm1.weight.numel() % 64 == 0 and b.mlp.fc1.weight.shape[0] % 64 == 0 for b in blocks)
@@ -467,7 +469,7 @@ class MaskedAutoencoderViT(nn.Module):
         """:525-554 (no cls token).  `dtype`: activation type of the decoder blocks; a caller that has switched autocast off around this call
         (forward) passes the type it read BEFORE doing so -- the blocks would otherwise see "no autocast" and run their f32 kernels (the
         1024-token decoder of the pre-training step did: 250 of its 304 ms)."""
-        dtype = dtype if dtype is not None else _act_dtype(self.precision)
+        dtype = dtype if dtype is not None else _act_dtype(self.precision, allow_f16=True)
         x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias)
         mask_tokens = self.mask_token.repeat(x.shape[0], ids_restore.shape[1] - x.shape[1], 1)
         x_ = torch.cat([x, mask_tokens], dim=1)
@@ -496,7 +498,7 @@ class MaskedAutoencoderViT(nn.Module):
         posterior-sample noise instead of the device RNG draws the reference makes at the same two places."""
         if self.ldmae_mode:
             raise NotImplementedError("ldmae_amd: ldmae_mode (decoder fine-tuning with LPIPS) is out of scope")
-        dtype = _act_dtype(self.precision)           # read before autocast is switched off below
+        dtype = _act_dtype(self.precision, allow_f16=True)           # read before autocast is switched off below
         latent, mask, ids_restore = self.forward_encoder(imgs, mask_ratio, noise=_noise)
         with torch.autocast(device_type="cuda", enabled=False):
             latent = _LinearFn.apply(latent, self.to_latent.weight, self.to_latent.bias)

@@ -13,11 +13,10 @@ What is kept: forward_vanilla loss (masked / visible MSE + KL), per-iteration ha
 1-D parameters, main_pretrain.py:258-259), gradient accumulation, and the GradScaler PROTOCOL of the reference's
 ``NativeScalerWithGradNormCount`` (VMAE/util/misc.py:406-435: scale the loss, unscale, SKIP the optimizer step when a gradient is
 inf / nan and halve the scale, double it after 2000 clean steps) -- ``LossScaler`` below, with 1/scale folded into the fused AdamW
-kernel's grad_scale.  What differs on purpose: the TRAINING activation type is bf16 where the reference's ``torch.amp.autocast('cuda')``
-gives fp16 (engine_pretrain.py:51-57).  bf16 keeps f32's exponent range, so the scaler never has an overflow to back off from in practice
-(it is kept for the skip-on-non-finite semantics and so that checkpoints carry the same ``scaler`` state); it has 8 significant
-bits against fp16's 11, which is what the bf16-vs-f32 tolerance in tests/test_gpu_mae.py (loss within 2e-2 relative) prices.  (The
-fp16 kernel family added in round 5, LDMAE_F16, is forward-only: the TF32-class docking calls.)  Also: the fused AdamW kernel on a
+kernel's grad_scale.  Activation type: ``--precision fp16`` is the reference's ``torch.amp.autocast('cuda')`` (engine_pretrain.py:51-57) on the
+fp16 kernel family (LDMAE_F16, round 5: forward and backward of the blocks; gradient GEMM outputs overflow to infinity, which the scaler
+answers by skipping the step and halving the scale); the default stays bf16 (f32's exponent range: the scaler never has an overflow to back
+off from; 8 significant bits against fp16's 11 -- tests/test_gpu_mae.py prices both against f32 over 50 steps).  Also: the fused AdamW kernel on a
 grouped contiguous slab instead of torch.optim.AdamW; the host reads the loss where the reference prints it, not on every micro-step.
 """
 import argparse
@@ -118,7 +117,7 @@ def train_one_epoch(model, loader, opt, epoch, args, log=print, scaler=None, red
         if it % args.accum_iter == 0:
             opt.lr = cosine_lr(it / n + epoch, args.lr, args.min_lr, args.warmup_epochs, args.epochs, args.fixed_lr)
         samples = samples.cuda(non_blocking=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.precision == "bf16"):
+        with torch.autocast("cuda", dtype=torch.float16 if args.precision == "fp16" else torch.bfloat16, enabled=args.precision in ("bf16", "fp16")):
             loss, _, _, vis_loss, mask_loss, kl_loss = model(samples, mask_ratio=args.mask_ratio, visible_loss_ratio=args.visible_loss_ratio)
         bad |= ~torch.isfinite(loss.detach())
         last = (it + 1) % args.accum_iter == 0
@@ -312,7 +311,8 @@ def main(argv=None):
     ap.add_argument("--min_lr", type=float, default=0.)
     ap.add_argument("--warmup_epochs", type=int, default=40)
     ap.add_argument("--fixed_lr", action="store_true")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="fp16 = the reference's torch.amp.autocast('cuda') (engine_pretrain.py:51-57): the loss scaler then really protects against overflow")
     ap.add_argument("--print_freq", type=int, default=20)
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--steps-per-epoch", type=int, default=100)
@@ -355,7 +355,7 @@ def main(argv=None):
                                             img_size=args.input_size).cuda()
     torch.manual_seed(args.seed + rank)
     opt = build_optimizer(model, args.lr, args.weight_decay)
-    scaler = LossScaler(enabled=args.precision == "bf16")                     # main_pretrain.py:260: loss_scaler = NativeScaler()
+    scaler = LossScaler(enabled=args.precision in ("bf16", "fp16"))           # main_pretrain.py:260: loss_scaler = NativeScaler()
     start = load_model(args, model, opt, scaler, log)
     reducer = GradBucketReducer(opt.flat) if world > 1 else None
     if reducer is not None:

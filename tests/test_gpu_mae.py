@@ -161,6 +161,20 @@ def test_pretraining_step_loss_and_all_grads_vs_oracle():
     assert abs(float(loss16) - float(ol)) < 2e-2 * abs(float(ol))
     g, r = params["decoder_pred.conv_smoother.weight"].grad.cpu(), leaves["decoder_pred.conv_smoother.weight"].grad
     assert rel_err(g, r) < 5e-2
+    # ... and under fp16 autocast (what the reference's engine_pretrain.py:51-57 trains in): the fp16 kernel family, forward and backward --
+    # three more mantissa bits than bf16: every gradient within 1e-2 of the f32 oracle (loss scale 1: nothing overflows at this size)
+    from ldmae_amd import _lib
+    m.zero_grad(set_to_none=True)
+    _lib.launch_counts(reset=True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        lossh = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())[0]
+    lossh.backward()
+    c = _lib.launch_counts(reset=True)
+    assert c["nt_f16"] > 0 and c["tn_f16"] > 0 and c["attn_f16"] == 2 * (len(m.blocks) + len(m.decoder_blocks)) and c["attn_bf16"] == 0 and c["nt_bf16"] == 0, c
+    assert abs(float(lossh) - float(ol)) < 3e-3 * abs(float(ol))
+    worst16 = max(rel_err(params[k].grad.cpu(), leaves[k].grad) for k in keys)
+    print("fp16 worst grad rel err", worst16)
+    assert worst16 < 1e-2, worst16
 
 
 def test_vmae_pretrain_driver_steps():
@@ -321,7 +335,7 @@ def test_vmae_pretrain_bf16_tracks_f32_over_50_steps():
     from ldmae_amd import vmae_pretrain as vp
     from ldmae_amd.tokenizer import models_mae
     curves = {}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "fp16"):
         torch.manual_seed(0)
         m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192, decoder_depth=2,
                                             decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
@@ -331,13 +345,18 @@ def test_vmae_pretrain_bf16_tracks_f32_over_50_steps():
                                   visible_loss_ratio=0.5, print_freq=1)
         g = torch.Generator().manual_seed(5)
         loader = [(torch.rand(8, 3, 128, 128, generator=g) * 2 - 1, 0) for _ in range(50)]
-        scaler = vp.LossScaler(enabled=prec == "bf16")
+        scaler = vp.LossScaler(enabled=prec != "fp32")
         losses = []
         torch.manual_seed(123)                       # the device RNG behind the masking noise and the posterior sample
         vp.train_one_epoch(m, loader, opt, 0, args, log=lambda s: losses.append(float(s.split("loss: ")[1].split()[0])), scaler=scaler)
-        assert len(losses) == 50 and opt.step_count == 50 and scaler.skipped == 0
+        assert len(losses) == 50 and opt.step_count + scaler.skipped == 50
+        assert scaler.skipped == 0 or prec == "fp16", (prec, scaler.skipped)      # only fp16 has a range to overflow
+        print(prec, "skipped steps", scaler.skipped, "final loss scale", scaler.scale)
         curves[prec] = np.array(losses)
-    f, b = curves["fp32"], curves["bf16"]
+    f, b, h = curves["fp32"], curves["bf16"], curves["fp16"]
+    relh = np.abs(h - f) / f
+    print("fp16 vs f32 pre-training loss: worst step", relh.max(), "last ten", abs(h[-10:].mean() - f[-10:].mean()) / f[-10:].mean())
+    assert relh.max() < 2e-2 and abs(h[-10:].mean() - f[-10:].mean()) / f[-10:].mean() < 1e-2
     rel = np.abs(b - f) / f
     print("bf16 vs f32 pre-training loss: worst step", rel.max(), "last ten", abs(b[-10:].mean() - f[-10:].mean()) / f[-10:].mean(), "f32 first/last", f[0], f[-1])
     assert f[-10:].mean() < 0.8 * f[:5].mean()                                  # it trains
@@ -558,3 +577,26 @@ def test_tf32_class_docking_path_matches_reference_golden(golden):
         assert 1e-6 < rel_err(mom.cpu(), mom32.cpu()) < 1e-3                                  # the two paths really differ, by TF32's margin
     finally:
         torch.backends.cuda.matmul.allow_tf32 = prev
+
+
+def test_fp16_pretraining_loss_scaler_backs_off_on_overflow():
+    """fp16 autocast has a range to overflow: with an absurd initial loss scale the gradient GEMMs / attention backward produce INFINITIES
+    (LDMAE_EPI_F16_INF: gradient outputs are not saturated), the scaler sees the non-finite slab, skips the step and halves the scale
+    (VMAE/util/misc.py:413-430 via torch.amp.GradScaler) until steps go through; parameters stay finite and the loss falls."""
+    import argparse
+    from ldmae_amd import vmae_pretrain as vp
+    from ldmae_amd.tokenizer import models_mae
+    torch.manual_seed(0)
+    m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192, decoder_depth=2,
+                                        decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
+                                        kl_loss_weight=1e-6, smooth_output=True).cuda()
+    opt = vp.build_optimizer(m, 1e-3, 0.05)
+    args = argparse.Namespace(accum_iter=1, lr=1e-3, min_lr=0.0, warmup_epochs=0, epochs=100, fixed_lr=True, precision="fp16", mask_ratio=0.75,
+                              visible_loss_ratio=0.5, print_freq=1)
+    x = torch.rand(8, 3, 128, 128, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    scaler = vp.LossScaler(init_scale=2.0 ** 36, enabled=True)
+    losses = []
+    vp.train_one_epoch(m, [(x, 0)] * 40, opt, 0, args, log=lambda s: losses.append(float(s.split("loss: ")[1].split()[0])), scaler=scaler)
+    print("skipped", scaler.skipped, "scale", scaler.scale, "steps", opt.step_count, "loss", losses[0], losses[-1])
+    assert scaler.skipped >= 5 and scaler.scale == 2.0 ** 36 * 0.5 ** scaler.skipped and opt.step_count == 40 - scaler.skipped and opt.step_count >= 10
+    assert all(torch.isfinite(p).all() for p in m.parameters()) and np.isfinite(losses).all() and losses[-1] < losses[0]
