@@ -702,6 +702,9 @@ def bench_vmae_paths(device, batch=256):
         stats = vp.train_one_epoch(pm, loader, opt, 0, a, log=lambda s_: None, scaler=scaler)
     out["pretrain_step_ms_bf16"] = ms(step, iters=4)
     out["pretrain_loss"] = round(float(stats["loss"]), 5)
+    a.precision = "fp16"                          # the reference's own autocast type (engine_pretrain.py:51-57): the fp16 kernel family
+    out["pretrain_step_ms_fp16"] = ms(step, iters=4)
+    out["pretrain_loss_fp16"] = round(float(stats["loss"]), 5)
     out["note"] = ("wall time per call with a device synchronise at both ends; the reference's drivers run these calls in f32 WITH "
                    "torch.backends.cuda.matmul.allow_tf32 = True: f32_tf32 is that configuration (fp16 operands = TF32's mantissa, f32 accumulation), "
                    "f32 the exact-f32 parity path (flag off)")

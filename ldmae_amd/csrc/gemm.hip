@@ -650,7 +650,7 @@ __device__ __forceinline__ void splitk_reduce_threads(const float* __restrict__ 
     *(float4*)(out + i) = s;
   }
 }
-// the same sum for MANY splits of a SMALL output (VMAE weight gradients: 192 x 192 outputs from up to 128 row splits): one wave per 4
+// the same sum for MANY splits of a SMALL output (VMAE weight gradients: 192 x 192 outputs from up to 256 row splits): one wave per 4
 // adjacent outputs, lane l sums splits l, l + 64, ... and a butterfly folds the lane sums -- fixed order, so still deterministic; the
 // per-thread loop above left 36 workgroups walking 100 partial slabs one after the other (24 us, 197 times per VMAE step)
 __device__ __forceinline__ void splitk_reduce_waves(const float* __restrict__ P, float* __restrict__ out, long n, int splits, float beta, unsigned bid) {
@@ -914,7 +914,7 @@ static int tn_plan(int dtype, int M, int N, int K, int* rows_out) {
   long maxs = M / (64 * 8) > 0 ? M / (64 * 8) : 1;           // at least 8 steps of 64 rows per split
   long s = want < maxs ? want : maxs;
   if (s < 1) s = 1;
-  if (s > 128) s = 128;
+  if (s > 256) s = 256;          // one-tile outputs (VMAE: 192 x 192) take a split per CU (128 left half the chip idle)
   int rows = (int)(((long)M + s - 1) / s);
   rows = (rows + 63) / 64 * 64;
   if (rows_out) *rows_out = rows;
