@@ -671,3 +671,47 @@ def test_reference_kernel_goldens_through_the_hip_kernels(ops, golden):
         a.precision = BF16
         ao16 = a(dev(x9), rope=rope).float().cpu()
         assert rel_err(ao16[0, :4], g["k9_head"]) < TOL[BF16] and rel_err(ao16[0, -4:], g["k9_tail"]) < TOL[BF16]
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 41 + 104, 2304 + 64, 192), (8, 768, 64), (264, 264, 128), (16384, 768, 768), (2048 + 8, 1152, 1152)])
+def test_whole_line_nt_kernel_is_bitwise_equal_to_the_half_line_kernel(ops, M, N, K):
+    """gemm_nt_lines_kernel (128-B LDS rows, seamless five-slot ring; the default for these shapes) against gemm_nt_persist_kernel (per-call flag
+    LDMAE_EPI_HALF_LINES): the same products in the same order -> the same bits, for every fused epilogue, ragged row and column tiles
+    (M, N multiples of 8 only), one / two / many 64-deep blocks per tile, persistent and one-tile-per-workgroup launches."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rb = lambda *s: torch.randn(*s, device="cuda", generator=g).to(BF16)
+    rf = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    a, w, bias = rb(M, K), rb(N, K) * K ** -0.5, rf(N)
+    T = 8 if M % 8 == 0 and M >= 8 else 1
+    xin, gate, pos = rf(M, N), rf(M // T, N), rf(T, N)
+    cases = {
+        "bias": lambda: ops.gemm_nt(a, w, bias),
+        "bias_f32out": lambda: ops.gemm_nt(a, w, bias, out_dtype=F32),
+        "gate_res": lambda: ops.gemm_nt_gate_res(a, w, bias, xin, gate, T),
+        "gelu": lambda: ops.gemm_nt_gelu(a, w, bias, save_pre=True),
+        "pos": lambda: ops.gemm_nt_pos(a, w, bias, pos, T),
+    }
+    pre = rb(M, N)
+    cases["gelu_bwd"] = lambda: ops.gemm_nt_gelu_bwd(a, w, pre)
+    if N % 512 == 0 or N == 768:
+        pass
+    if N % 256 == 0 and N >= 512:
+        cases["swiglu"] = lambda: ops.gemm_nt_swiglu(a, w, bias)
+    h12 = rb(M, 2 * N)
+    cases["swiglu_bwd"] = lambda: ops.gemm_nt_swiglu_bwd(a, w, h12, with_bias=True)
+    flat = lambda o: [t for t in (o if isinstance(o, (tuple, list)) else (o,)) if torch.is_tensor(t)]
+    try:
+        for mode in ("persistent", "tile"):
+            ops.set_gemm_launch_mode(mode)
+            for name, fn in cases.items():
+                ops.set_gemm_half_lines(True)
+                ref = [t.clone() for t in flat(fn())]
+                ops.set_gemm_half_lines(False)
+                got = flat(fn())
+                assert len(ref) == len(got) and all(torch.equal(x.view(torch.uint8), y.view(torch.uint8)) for x, y in zip(ref, got)), (name, mode)
+        # and against the arithmetic, once
+        ops.set_gemm_half_lines(False)
+        assert rel_err(ops.gemm_nt(a, w, bias).float().cpu(), (a.float() @ w.float().T + bias).cpu()) < TOL[BF16]
+    finally:
+        ops.set_gemm_half_lines(False)
+        ops.set_gemm_launch_mode("persistent")
