@@ -750,7 +750,8 @@ def bench_do_sample(args, device, batches=1):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 lat, _ = inf.sample_latents(model, sample_fn, n, s["cfg_scale"], s.get("cfg_interval_start", 0), device, cfg["data"]["num_classes"], generator=gen)
             ev[1].record()
-            imgs = vae.decode_to_images(lat * std / mult + mean)
+            with models_mae.reference_tf32():                # inference.py:79: the reference decodes in f32 with allow_tf32 on -> the TF32-class family
+                imgs = vae.decode_to_images(lat * std / mult + mean)
             ev[2].record()
             writer.put(imgs, [f"{out_dir}/{it * n + i:06d}.png" for i in range(len(imgs))])
             torch.cuda.synchronize()

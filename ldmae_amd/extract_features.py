@@ -92,7 +92,9 @@ def extract(tokenizer, loaders, output_dir, rank=0, batch_size=64, sample=True, 
         if rank == 0 and (run_images % 100 == 0 or batch_idx % 8 == 7):      # the reference's rule (:147) never fires at batch sizes like 64 / 256
             log(f"{datetime.now()} processing {run_images} of {total} images")
         for which, (x, y) in enumerate(pair):
-            with torch.no_grad():
+            # extract_features.py:2-3 of the reference set allow_tf32 at import: the tokenizer's f32 `_encode` runs TF32-class (fp16 operands =
+            # TF32's mantissa, f32 accumulation; 5.6e-4 against exact f32); LDMAE_TF32=0 keeps the exact-f32 kernels
+            with torch.no_grad(), models_mae.reference_tf32():
                 x = x.cuda(non_blocking=True)
                 z = tokenizer._encode(x) if sample else tokenizer.encode(x).latent_dist.mode()
                 z = z.float().contiguous()

@@ -128,7 +128,10 @@ def do_sample(cfg, ckpt_path, out_dir, num_samples=None, precision="bf16"):
         for it in range(total // (n * world)):
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=precision == "bf16"):
                 lat, _ = sample_latents(model, sample_fn, n, s['cfg_scale'], s.get('cfg_interval_start', 0), device, cfg['data']['num_classes'])
-            imgs = vae.decode_to_images(lat * std / mult + mean)                     # uint8 NHWC on the host (inference.py:290-292)
+            # inference.py:79 of the reference sets allow_tf32: the f32 decode runs TF32-class (fp16 operands = TF32's mantissa, f32
+            # accumulation: the LDMAE_F16 kernel family); LDMAE_TF32=0 keeps the exact-f32 kernels
+            with models_mae.reference_tf32():
+                imgs = vae.decode_to_images(lat * std / mult + mean)                 # uint8 NHWC on the host (inference.py:290-292)
             writer.put(imgs, [f"{out_dir}/{i * world + rank + done:06d}.png" for i in range(len(imgs))])   # index rule: inference.py:294
             done += n * world
     finally:

@@ -81,6 +81,22 @@ class ImageTransform:
         return x.sub_(0.5).div_(0.5)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def reference_tf32():
+    """`torch.backends.cuda.matmul.allow_tf32 = True` for the duration of a driver's tokenizer calls, restored afterwards.  The reference's
+    drivers set the flag for the whole process (inference.py:79, extract_features.py:2-3); the drivers here are also called in-process (tests,
+    bench.py), so they scope it.  With it on, f32 forward-only calls of the tokenizer run TF32-class (MaskedAutoencoderViT._docking_dtype)."""
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = True
+    try:
+        yield
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+
+
 # ----------------------------------------------------------------------------- autograd Functions
 class _ViTBlockFn(torch.autograd.Function):
     """Block.forward (:176-187): x += proj(attn(LN1(x))); x += fc2(gelu(fc1(LN2(x))))."""

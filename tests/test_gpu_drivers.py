@@ -191,7 +191,7 @@ def test_extract_features_writes_reference_shards(tmp_path):
     vae = vae.cuda().eval()
     ds = ImageFolder(str(root / "train"), transform=vae.img_transform(p_hflip=0.0, img_size=64))
     x = torch.stack([ds[i][0] for i in range(n_img)]).cuda()
-    with torch.no_grad():
+    with torch.no_grad(), models_mae.reference_tf32():          # the writer encodes under the reference's allow_tf32 switch (extract_features.py:2-3)
         want, want_flip = vae._encode(x).float().cpu(), vae._encode(x.flip(-1)).float().cpu()
     assert torch.allclose(lat, want, atol=1e-5, rtol=1e-5) and torch.allclose(flip, want_flip, atol=1e-5, rtol=1e-5)
     assert not torch.allclose(lat, flip, atol=1e-3)
