@@ -64,6 +64,11 @@ template <typename OutT> __device__ __forceinline__ float gelu_bwd_val(float acc
   return act_round<OutT>(acc) * (cdf + v * pdf);
 }
 
+// scalar-path output conversion: fp16 outputs clamp to +-e.f16_max first (forward: 65504 = saturate; gradient GEMMs: infinity = plain cast)
+template <typename OutT> __device__ __forceinline__ OutT cvt_out(const EpiArgs& e, float v) {
+  if constexpr (__is_same(OutT, f16)) return from_f<OutT>(sat_f16(v, e.f16_max));
+  else return from_f<OutT>(v);
+}
 template <int EPI, typename OutT>
 __device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M, int N, float acc) {
   if (m >= M || n >= N) return;
@@ -71,18 +76,18 @@ __device__ __forceinline__ void epi_store(const EpiArgs& e, int m, int n, int M,
   if (EPI == LDMAE_EPI_BIAS) {
     OutT* C = (OutT*)e.C;
     if (e.beta != 0.f) y += e.beta * to_f<OutT>(C[(size_t)m * e.ldc + n]);
-    C[(size_t)m * e.ldc + n] = from_f<OutT>(y);
+    C[(size_t)m * e.ldc + n] = cvt_out<OutT>(e, y);
   } else if (EPI == LDMAE_EPI_BIAS_POS) {
     y += e.xin[(size_t)(m % e.rows_per_batch) * N + n];
-    ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
+    ((OutT*)e.C)[(size_t)m * e.ldc + n] = cvt_out<OutT>(e, y);
   } else if (EPI == LDMAE_EPI_BIAS_GELU) {
-    if (e.C2) ((OutT*)e.C2)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
-    ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(gelu_act<OutT>(y));
+    if (e.C2) ((OutT*)e.C2)[(size_t)m * e.ldc + n] = cvt_out<OutT>(e, y);
+    ((OutT*)e.C)[(size_t)m * e.ldc + n] = cvt_out<OutT>(e, gelu_act<OutT>(y));
   } else if (EPI == LDMAE_EPI_GELU_BWD) {
     const size_t o = (size_t)m * e.ldc + n;
-    ((OutT*)e.C)[o] = from_f<OutT>(gelu_bwd_val<OutT>(y, to_f<OutT>(((const OutT*)e.xin)[o])));
+    ((OutT*)e.C)[o] = cvt_out<OutT>(e, gelu_bwd_val<OutT>(y, to_f<OutT>(((const OutT*)e.xin)[o])));
   } else {  // LDMAE_EPI_GATE_RES
-    if (e.C) ((OutT*)e.C)[(size_t)m * e.ldc + n] = from_f<OutT>(y);
+    if (e.C) ((OutT*)e.C)[(size_t)m * e.ldc + n] = cvt_out<OutT>(e, y);
     const size_t o = (size_t)m * N + n;
     const float gt = e.gate ? e.gate[(size_t)(m / e.rows_per_batch) * e.gate_ld + n] : 1.f;
     e.xout[o] = fmaf(gt, act_round<OutT>(y), e.xin[o]);

@@ -693,8 +693,6 @@ def test_whole_line_nt_kernel_is_bitwise_equal_to_the_half_line_kernel(ops, M, N
     }
     pre = rb(M, N)
     cases["gelu_bwd"] = lambda: ops.gemm_nt_gelu_bwd(a, w, pre)
-    if N % 512 == 0 or N == 768:
-        pass
     if N % 256 == 0 and N >= 512:
         cases["swiglu"] = lambda: ops.gemm_nt_swiglu(a, w, bias)
     h12 = rb(M, 2 * N)
@@ -715,3 +713,86 @@ def test_whole_line_nt_kernel_is_bitwise_equal_to_the_half_line_kernel(ops, M, N
     finally:
         ops.set_gemm_half_lines(False)
         ops.set_gemm_launch_mode("persistent")
+
+
+# ----------------------------------------------------------------------------- the fp16 kernel family (LDMAE_F16), kernel by kernel
+F16 = torch.float16
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 576, 192), (4104, 768, 768), (264, 192, 64)])
+def test_f16_gemm_nt_epilogues(ops, M, N, K):
+    """fp16 operands (v_mfma_f32_16x16x32_f16, f32 accumulation) against f64 products of the same fp16-rounded data: bias (fp16 and f32 out),
+    exact-erf GELU with its pre-activation copy, gated residual adding the UNROUNDED product (the TF32-class form) and the rounded one (autocast),
+    the GELU-backward gradient GEMM.  Forward outputs saturate at 65504, gradient outputs overflow to infinity (LDMAE_EPI_F16_INF)."""
+    a, w, bias = dev(rnd(M, K, seed=1), F16), dev(rnd(N, K, seed=2, scale=K ** -0.5), F16), dev(rnd(N, seed=3))
+    ref = a.double().cpu() @ w.double().cpu().T + bias.double().cpu()
+    out = ops.gemm_nt(a, w, bias)
+    assert out.dtype == F16 and rel_err(out.float().cpu(), ref) < 1e-3
+    assert rel_err(ops.gemm_nt(a, w, bias, out_dtype=F32).cpu(), ref) < 2e-5
+    act, pre = ops.gemm_nt_gelu(a, w, bias, save_pre=True)
+    assert rel_err(pre.float().cpu(), ref) < 1e-3 and rel_err(act.float().cpu(), torch.nn.functional.gelu(ref)) < 1e-3
+    T = 8
+    xin, gate = dev(rnd(M, N, seed=4)), dev(rnd(M // T, N, seed=5))
+    xo, _ = ops.gemm_nt_gate_res(a, w, bias, xin, gate, T, save_y=False, y_dtype=F32)
+    assert rel_err(xo.cpu(), xin.double().cpu() + gate.double().cpu().repeat_interleave(T, 0) * ref) < 2e-5
+    xo16, y16 = ops.gemm_nt_gate_res(a, w, bias, xin, gate, T, save_y=True)
+    assert y16.dtype == F16 and torch.equal(y16, out)
+    assert rel_err(xo16.cpu(), torch.addcmul(xin, gate.repeat_interleave(T, 0), y16.float()).cpu()) < 1e-6
+    dy = dev(rnd(M, K, seed=6), F16)
+    got = ops.gemm_nt_gelu_bwd(dy, w, pre)                       # [M, N] = (dy @ w^T) * gelu'(pre)
+    v = pre.double().cpu()
+    dgelu = 0.5 * (1 + torch.erf(v / 2 ** 0.5)) + v * torch.exp(-0.5 * v * v) / (2 * torch.pi) ** 0.5
+    assert rel_err(got.float().cpu(), (dy.double().cpu() @ w.double().cpu().T).half().double() * dgelu) < 2e-3
+    # overflow: forward saturates, a gradient GEMM gives infinity
+    ab, wb = (a.float().abs() * 1e3).to(F16), (w.float().abs() * 40).to(F16)      # finite operands, products far beyond 65504
+    assert torch.isfinite(ab).all() and torch.isfinite(wb).all()
+    big = ops.gemm_nt(ab, wb, None)
+    assert torch.isfinite(big).all() and float(big.float().abs().max()) == 65504.0
+    bigg = ops.gemm_nt(ab, wb, None, grad=True)
+    assert torch.isinf(bigg).any() and not torch.isnan(bigg).any()
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 192, 768), (8192, 576, 192), (51 * 8, 192, 192), (16384, 768, 192)])
+def test_f16_gemm_tn(ops, M, N, K):
+    a, b = dev(rnd(M, N, seed=1), F16), dev(rnd(M, K, seed=2), F16)
+    ref = a.double().cpu().T @ b.double().cpu()
+    out, db = ops.gemm_tn(a, b, with_bias=True)
+    assert out.dtype == F32 and rel_err(out.cpu(), ref) < 1e-5 and rel_err(db.cpu(), a.double().cpu().sum(0)) < 1e-5
+    out2 = ops.gemm_tn(a, b, out=out.clone(), beta=1.0)
+    assert rel_err(out2.cpu(), 2 * ref) < 1e-5 and torch.equal(ops.gemm_tn(a, b), out)
+
+
+@pytest.mark.parametrize("H,N", [(12, 256), (3, 200), (12, 1024)])
+def test_f16_attention_fwd_bwd_head_dim_16(ops, H, N):
+    """The head-dim-16 flash kernels on fp16 operands (packed qkv, ragged N too) against f64 softmax attention of the same fp16-rounded data:
+    fp16's 11-bit mantissa gives 8x the accuracy of the bf16 instantiation."""
+    B, hd = 2, 16
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B * N, 3 * H * hd, generator=g).to(F16).cuda()
+    do = torch.randn(B, N, H * hd, generator=g).to(F16).cuda()
+    scale = hd ** -0.5
+    o, lse = ops.attention_fwd_qkv(qkv, B, N, H, hd, scale)
+    q, k, v = (qkv.view(B, N, 3, H, hd)[:, :, i].permute(0, 2, 1, 3).double().cpu().requires_grad_(True) for i in range(3))
+    s = (q @ k.transpose(-1, -2)) * scale
+    ro = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, H * hd)
+    assert o.dtype == F16 and rel_err(o.float().cpu(), ro.detach()) < 2e-3
+    assert (lse.cpu() - torch.logsumexp(s, -1).detach().float()).abs().max() < 5e-3
+    (ro * do.double().cpu()).sum().backward()
+    dqkv = ops.attention_bwd_qkv(qkv, o, do, lse, B, N, H, hd, scale).view(B, N, 3, H, hd)
+    for i, t in enumerate((q, k, v)):
+        assert rel_err(dqkv[:, :, i].permute(0, 2, 1, 3).float().cpu(), t.grad) < 4e-3, i
+    o16, _ = ops.attention_fwd_qkv(qkv.to(BF16), B, N, H, hd, scale)
+    assert rel_err(o.float().cpu(), ro.detach()) < 0.5 * rel_err(o16.float().cpu(), ro.detach())      # really the fp16 instantiation
+
+
+def test_f16_layernorm_cast_colsum(ops):
+    x = dev(rnd(4096, 192, seed=1) * 3 + 0.5)
+    w, b = dev(1 + 0.1 * rnd(192, seed=2)), dev(0.1 * rnd(192, seed=3))
+    y, mu, rs = ops.layernorm_fwd(x, w, b, F16)
+    ref = torch.nn.functional.layer_norm(x.double().cpu(), (192,), w.double().cpu(), b.double().cpu(), 1e-6)
+    assert y.dtype == F16 and rel_err(y.float().cpu(), ref) < 5e-4
+    assert torch.equal(ops.cast(x, F16), x.half()) and torch.equal(ops.cast(x.half(), F32), x.half().float())
+    wt, wtt = ops.cast_weight(dev(rnd(192, 576, seed=4)), F16)
+    assert torch.equal(wt, dev(rnd(192, 576, seed=4)).half()) and torch.equal(wtt, wt.t().contiguous())
+    assert torch.isinf(ops.cast(x * 1e6, F16)).any()                          # plain casts overflow to infinity (gradients under a loss scaler)
+    assert rel_err(ops.colsum(y).cpu(), y.double().cpu().sum(0)) < 1e-5
