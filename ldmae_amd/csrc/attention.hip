@@ -898,6 +898,202 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
 }
 
 #ifdef LDMAE_DIAG
+// ================================================================================================ backward in one kernel, head_dim 16
+// DIAGNOSTIC BUILD ONLY (tune key 21 = 1; ablations: tune key 22; A/B: tools/bench_attn16.py, profiles/r05_attn16_onepass.txt).  Built to
+// test whether the VMAE heads' backward (two kernels, each bound by vector issue + LDS, the exponential paid twice) runs faster as one
+// kernel -- and it does NOT: 1.31 ms against 0.70 + 0.54 ms at 256 x 12 heads x 1024 tokens.  Per (batch, head) the kernel below needs a
+// whole workgroup (the dQ sum across key blocks must stay on chip to avoid the float atomics that sank the head-dim-64 one-pass kernel),
+// which pins the CU at 2 waves per SIMD with 222 registers: with nothing else resident, every LDS round trip and MFMA result of the
+// score -> exp2 -> dV / dK -> dS image -> dQ chain is exposed (removing the exponentials or the accumulator-initialising LDS reads changes
+// nothing: ablations 4, 8; the stripped S / dP / dV / dK loop alone takes 1.13 ms where the 3-waves-per-SIMD dK/dV kernel does all of it in 0.70).
+// The VMAE heads (models_mae.py:103-147: 12 heads of 16 over 256 .. 1024 tokens).  At head_dim 16 a score costs two MFMA k-steps and SIX
+// vector-instruction slots (exp2 = 4, the dS multiply, two packed conversions): the two-kernel backward above is bound by vector issue and
+// pays the exponential twice (profiles/r05_vmae_pretrain: dK/dV 0.70 + dQ 0.54 ms per 256 x 12 x 1024^2 scores against 0.56 ms of
+// exponentials + multiplies for ONE pass).  Here a whole (batch, head) belongs to one 512-thread workgroup, which is what makes one pass
+// possible without atomics: the dQ rows of a 64-query tile are the sum over the eight waves' key blocks, formed in LDS in a fixed order.
+//   * wave w owns KSETS x 32 keys per SWEEP (key on the lane, dK^T / dV^T stationary in registers as in the dK/dV kernel); a sweep walks
+//     all N queries in 64-row tiles through the 3-deep LDS-DMA ring (waves 0-3 fetch the Q image, 4-7 the dO image: one piece each);
+//     N = 256 KSETS keys per sweep; longer sequences take N / (256 KSETS) sweeps over the queries, the partial dQ waiting in LDS (f32);
+//   * S, dP, p = exp2(S), dS = p dP, dV^T += dO^T p, dK^T += Q^T dS exactly as in the dK/dV kernel; then the dS block [32 keys][32
+//     queries] goes through a wave-private 2-KiB LDS image (written as the accumulator holds it, read back transposed by
+//     ds_read_b64_tr_b16) and dQ^T[d, q] += K^T[d, keys] . dS^T[keys, q] with the K^T fragments stationary;
+//   * per tile the eight partial dQ^T blocks [64 q][16 d] f32 meet in LDS, one barrier, and thread (q, d pair) adds them in wave order:
+//     bitwise reproducible.  -delta and -lse log2(e) of all N rows are formed once per workgroup from O, dO and LSE (no separate pass).
+template <int KSETS, bool F16>
+__global__ __launch_bounds__(512) void attn_bwd_fused16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
+                                                               const bf16* __restrict__ O, const bf16* __restrict__ dO, const float* __restrict__ LSE,
+                                                               bf16* __restrict__ dQ, bf16* __restrict__ dK, bf16* __restrict__ dV,
+                                                               int H, int N, float scale, QkvLayout L, QkvLayout Lv, int dbg) {
+  constexpr int HD = 16, HDP = 32, TB = 64 * HDP * 2, STG = 2 * TB;          // one ring stage = Q image | dO image
+  typedef typename ActT<F16>::t T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [3 stages][Q | dO]  |  -lse2[N] -delta[N]  |  dS images [8 waves][2 KiB]  |  partial dQ [8 waves][64 q][16 d] f32  |  dQ sums [N][16] f32
+  char* const ring = smem;
+  float* const nl = (float*)(smem + ATT_STAGES * STG);
+  float* const nd = nl + N;
+  char* const dsimg = (char*)(nd + N);
+  float* const slab = (float*)(dsimg + 8 * 2048);
+  float* const dqsum = slab + 8 * 64 * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const float c = scale * 1.4426950408889634f;
+  const unsigned bh = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = bh / H, hh = bh % H;
+  const size_t hb = (size_t)b * L.sb + (size_t)hh * L.sh, hbv = (size_t)b * Lv.sb + (size_t)hh * Lv.sh;
+  const long ld = L.ld, dold = (long)H * HD;
+  const bf16* qp = Q + hb;
+  const bf16* dop = dO + ((size_t)b * N * H + hh) * HD;
+  const int nt = N / 64, sweeps = N / (256 * KSETS), total = nt * sweeps;
+
+  // ---- ring: wave w < 4 fetches piece w of the Q image, wave w >= 4 piece w - 4 of the dO image
+  const bool isq = wave < 4;
+  TileMap<HD, 64> tm;
+  tm.init(isq ? ld : dold, wave & 3, lane);
+#pragma unroll
+  for (int st = 0; st < ATT_STAGES; ++st) tm.prefill(ring + st * STG + (isq ? 0 : TB), wave & 3, lane);
+  const unsigned lds0 = lds_addr_of(smem);
+  const bf16* const gsrc = isq ? qp : dop;
+  const long gstep = (isq ? ld : dold) * 64;
+  auto stage = [&](int j) {                 // j = running tile number over all sweeps
+    const int qt = j % nt;
+    tm.issue(gsrc + (size_t)qt * gstep, 0, nullptr, lds0 + (j % ATT_STAGES) * STG + (isq ? 0 : TB), wave & 3, lane);
+  };
+  stage(0);
+  if (total > 1) stage(1);
+
+  // ---- -lse log2(e) and -delta = -sum_d dO O of every query row of the head
+  for (int n = tid; n < N; n += 512) {
+    const size_t oo = (((size_t)b * N + n) * H + hh) * HD;
+    float d = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) d += frag_dot<F16>(*(const bf16x8*)(dO + oo + 8 * ch), *(const bf16x8*)(O + oo + 8 * ch));
+    nl[n] = -LSE[(size_t)bh * N + n] * 1.4426950408889634f;
+    nd[n] = -d;
+  }
+
+  f32x16 dkacc[KSETS], dvacc[KSETS];
+  bf16x8 kf[KSETS], vf[KSETS], ktr[KSETS][2];
+  char* const myimg = dsimg + wave * 2048;
+  float* const myslab = slab + wave * 64 * 16;
+  int j = 0;
+#pragma unroll 1
+  for (int sw = 0; sw < sweeps; ++sw) {
+    // ---- this sweep's keys: operand fragments from global memory; K^T fragments through the (idle) slab as a dual-use image
+    const int kbase = sw * 256 * KSETS + wave * 32;                            // + 256 s for set s
+    __syncthreads();                                                           // previous sweep's reduce has read the slabs
+#pragma unroll
+    for (int s = 0; s < KSETS; ++s) {
+      const bf16x8 kraw = *(const bf16x8*)(K + hb + (size_t)(kbase + 256 * s + r) * ld + 8 * h);
+      vf[s] = *(const bf16x8*)(V + hbv + (size_t)(kbase + 256 * s + r) * Lv.ld + 8 * h);
+      kf[s] = frag_scale_t<F16>(kraw, c);
+      char* img = (char*)myslab + s * 2048;
+      bf16x8 z;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) z[i] = (bf16)0.f;
+      *(bf16x8*)(img + tile_off<HDP>(r, h)) = kraw;
+      *(bf16x8*)(img + tile_off<HDP>(r, 2 + h)) = z;
+      dkacc[s] = splat16(0.f); dvacc[s] = splat16(0.f);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) through the builtin: the fragments (and the ring stages in flight) have landed: no compiler-counted wait in the tile loop
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the image writes
+#pragma unroll
+    for (int s = 0; s < KSETS; ++s)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) ktr[s][k2] = frag_tr<HDP>((const char*)myslab + s * 2048, 16 * k2, 0, lane);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const bool first = sw == 0, last = sw == sweeps - 1;
+#pragma unroll 1
+    for (int qt = 0; qt < nt; ++qt, ++j) {
+      // stage j has landed: behind it in the (in-order) vector-memory queue are stage j + 1 and, in the last sweep, the dQ stores of the two tiles before
+      if (j + 1 < total) { if (last && qt >= 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else if (last && qt == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();          // (also: the previous tile's reduce has read the slabs; sweep 0, tile 0: nl / nd and the prefill are visible)
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + 2 < total) stage(j + 2);
+      const char* Qt = ring + (j % ATT_STAGES) * STG;
+      const char* dOt = Qt + TB;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x16 dq = splat16(0.f);
+        const bf16x8 qrow = frag_row<HDP>(Qt, qb * 32, 0, lane), dorow = frag_row<HDP>(dOt, qb * 32, 0, lane);
+        bf16x8 qtr[2], dotr[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) { qtr[s2] = frag_tr<HDP>(Qt, qb * 32 + 16 * s2, 0, lane); dotr[s2] = frag_tr<HDP>(dOt, qb * 32 + 16 * s2, 0, lane); }
+#pragma unroll
+        for (int s = 0; s < KSETS; ++s) {
+          f32x16 sc, dp;
+          if (dbg & 8) { sc = splat16(-10.f); dp = splat16(0.5f); } else
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {          // accumulator element 4g + j <-> query row qb*32 + 8g + 4h + j
+            const f32x4 a = *(const f32x4*)(nl + qt * 64 + qb * 32 + 8 * g + 4 * h), e = *(const f32x4*)(nd + qt * 64 + qb * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sc[4 * g + i] = a[i]; dp[4 * g + i] = e[i]; }
+          }
+          sc = mfma_att<F16>(qrow, kf[s], sc);
+          dp = mfma_att<F16>(dorow, vf[s], dp);
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const float p = (dbg & 4) ? sc[t] * 0.01f : EXP2(sc[t]);
+            sc[t] = p;
+            dp[t] *= p;
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pf = acc_frag_t<F16>(sc, s2), dsf = acc_frag_t<F16>(dp, s2);
+            dvacc[s] = mfma_att<F16>(dotr[s2], pf, dvacc[s]);
+            dkacc[s] = mfma_att<F16>(qtr[s2], dsf, dkacc[s]);
+            if (dbg & 2) continue;
+            // dS^T image: row = key (this lane's), columns = queries; elements 8 s2 + 4 gg + i are queries 8 (2 s2 + gg) + 4h + i
+            union { bf16x8 v; bf16x4 q[2]; } u;
+            u.v = dsf;
+            *(bf16x4*)(myimg + tile_off<HDP>(r, 2 * s2) + 8 * h) = u.q[0];
+            *(bf16x4*)(myimg + tile_off<HDP>(r, 2 * s2 + 1) + 8 * h) = u.q[1];
+          }
+          // (no wait: the LDS operations of one wave execute in order, the transposed reads see the image just written)
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2) if (!(dbg & 2)) dq = mfma_att<F16>(ktr[s][k2], frag_tr<HDP>(myimg, 16 * k2, 0, lane), dq);
+        }
+        // rows of dq = d (elements 0..7 are d = 4h + i and 8 + 4h + i), lane column = query qb*32 + r
+        float* dst = myslab + (qb * 32 + r) * 16 + 4 * h;
+        if (dbg & 1) continue;
+        *(f32x4*)dst = f32x4{dq[0], dq[1], dq[2], dq[3]};
+        *(f32x4*)(dst + 8) = f32x4{dq[4], dq[5], dq[6], dq[7]};
+      }
+      if (dbg & 1) continue;
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        const int q = tid >> 3, d2 = (tid & 7) * 2;
+        float2 a = *(const float2*)(slab + q * 16 + d2);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { const float2 e = *(const float2*)(slab + (w * 64 + q) * 16 + d2); a.x += e.x; a.y += e.y; }
+        float2* acc = (float2*)(dqsum + (size_t)(qt * 64 + q) * 16 + d2);
+        if (!first) { const float2 e = *acc; a.x += e.x; a.y += e.y; }
+        if (!last) *acc = a;
+        else {
+          typedef T T2 __attribute__((ext_vector_type(2)));
+          T2 o2;
+          o2[0] = from_f<T>(a.x * scale); o2[1] = from_f<T>(a.y * scale);
+          *(T2*)(dQ + hb + (size_t)(qt * 64 + q) * ld + d2) = o2;
+        }
+      }
+    }
+    // ---- this sweep's dK / dV rows (the slabs double as the store images once every wave is through its reduce)
+    __syncthreads();
+    char* sw_img = (char*)myslab;
+#pragma unroll
+    for (int s = 0; s < KSETS; ++s) {
+      store_rows_t<HD, T>(*(const f32x16(*)[1])&dkacc[s], scale, sw_img, dK + hb + (size_t)(kbase + 256 * s) * ld, ld, lane);
+      store_rows_t<HD, T>(*(const f32x16(*)[1])&dvacc[s], 1.f, sw_img, dV + hbv + (size_t)(kbase + 256 * s) * Lv.ld, Lv.ld, lane);
+    }
+  }
+}
+
+#endif
+
+#ifdef LDMAE_DIAG
 // ================================================================================================ backward in ONE pass, bf16
 // DIAGNOSTIC BUILD ONLY (tune key 17 = 1; A/B and ablations: tools/bench_attn.py --fused, profiles/r04_attn_onepass_ab.txt).  Built to
 // settle the question the two-kernel backward leaves open -- it executes 7 products for the 5 the backward has -- and it LOSES on this
@@ -1595,6 +1791,21 @@ static int attention_bwd_core(int dtype, const void* q, const void* k, const voi
   // delta = [2][B*H*NP] f32 workspace, NP = N rounded up to 64 (bf16: -delta | -lse*log2e, rows padded to whole tiles; f32: slot 0 = delta, unpadded)
   const long items = (long)B * N * H, rcs = (long)B * H * ((N + 63) / 64 * 64);
   const unsigned dgrid = (unsigned)((items * 8 + 255) / 256 < 8192 ? (items * 8 + 255) / 256 : 8192);
+#ifdef LDMAE_DIAG
+  if (hd == 16 && (dtype == LDMAE_BF16 || dtype == LDMAE_F16) && ldmae_tune_get(21) == 1 && N % 256 == 0 && N <= 1024) {
+    // diagnostic A/B: the VMAE heads on whole 256-token blocks in one kernel, one workgroup per (batch, head) (attn_bwd_fused16_kernel); `delta` stays unused
+    const int ksets = N % 512 == 0 ? 2 : 1, sweeps = N / (256 * ksets);
+    const int dbg = ldmae_tune_get(22);      // ablations (timing only): 1 = no dQ slabs / reduce, 2 = no dS image and dQ product, 4 = no exponential, 8 = no accumulator-initialising LDS reads
+    const int lds = ATT_STAGES * 2 * 64 * 32 * 2 + 8 * N + 8 * 2048 + 8 * 64 * 16 * 4 + (sweeps > 1 ? 64 * N : 0);
+#define LF(KS, F) { hipFuncSetAttribute((const void*)attn_bwd_fused16_kernel<KS, F>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    hipLaunchKernelGGL((attn_bwd_fused16_kernel<KS, F>), dim3((unsigned)B * H), dim3(512), lds, st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, (bf16*)dq, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv, dbg); }
+    if (dtype == LDMAE_F16) { if (ksets == 2) LF(2, true) else LF(1, true) }
+    else { if (ksets == 2) LF(2, false) else LF(1, false) }
+#undef LF
+    LDMAE_CHECK_LAUNCH("attention_bwd(fused, head_dim 16)");
+    return LDMAE_OK;
+  }
+#endif
   if (dtype == LDMAE_F16) {
     // fp16 operands / gradients (VMAE pre-training under fp16 autocast; head_dim 16): the bf16 kernels with the f16 MFMAs and conversions
     LDMAE_REQUIRE(hd == 16, "attention_bwd(fp16): head_dim 16 only (the VMAE heads)");
