@@ -268,6 +268,10 @@ int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w, const flo
 long ldmae_layernorm_bwd_workspace_bytes(int M, int D);
 int ldmae_layernorm_bwd(int dtype, const void* dout, const float* x, const float* w, const float* mean, const float* rstd,
                         float* dx_accum, float* dw, float* db, float beta_w, int M, int D, float* workspace, void* stream);
+/* the same with a second output: dx_cast [M,D] (bf16 / fp16 = dtype; NULL: none) = dx_accum AFTER the update, rounded -- the operand of the
+ * next Linear's backward in a ViT block (saves the separate cast pass over the f32 residual gradient: 0.2 GB read per block at 256 images) */
+int ldmae_layernorm_bwd_cast(int dtype, const void* dout, const float* x, const float* w, const float* mean, const float* rstd,
+                             float* dx_accum, void* dx_cast, float* dw, float* db, float beta_w, int M, int D, float* workspace, void* stream);
 /* exact-erf GELU (timm Mlp act, models_mae.py:172) */
 int ldmae_gelu_fwd(int dtype, const void* x, void* out, long n, void* stream);
 int ldmae_gelu_bwd(int dtype, const void* dout, const void* x, void* dx, long n, void* stream);

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
-                                                            float* __restrict__ P, int M, int D, int rows_per_wg) {
+                                                            T* __restrict__ dxc, float* __restrict__ P, int M, int D, int rows_per_wg) {
   extern __shared__ float red[];   // [16 row groups][2][D]
   const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
   float wv[NV][4], aw[NV][4], ab[NV][4];
@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) dxo[i][j] += rs * (g[i][j] * wv[i][j] - s1 - xh[i][j] * s2);
         st4<float>(dxr + c, dxo[i]);
+        if (dxc) st4<T>(dxc + (size_t)m * D + c, dxo[i]);      // the sum, rounded to the activation type: the operand of the next Linear's backward
       }
     }
   }
@@ -299,24 +300,29 @@ extern "C" int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w
   return LDMAE_OK;
 }
 extern "C" long ldmae_layernorm_bwd_workspace_bytes(int M, int D) { return (long)cdiv(M, LN_ROWS) * 2 * D * 4; }
-extern "C" int ldmae_layernorm_bwd(int dtype, const void* dout, const float* x, const float* w, const float* mean, const float* rstd,
-                                   float* dx_accum, float* dw, float* db, float beta_w, int M, int D, float* workspace, void* stream) {
+extern "C" int ldmae_layernorm_bwd_cast(int dtype, const void* dout, const float* x, const float* w, const float* mean, const float* rstd,
+                                        float* dx_accum, void* dx_cast, float* dw, float* db, float beta_w, int M, int D, float* workspace, void* stream) {
   LDMAE_REQUIRE(dout && x && w && mean && rstd && dx_accum && dw && db && workspace && M > 0 && D > 0 && D % 4 == 0 && D <= 1024,
                 "layernorm_bwd: bad arguments (D=%d: multiple of 4, <= 1024)", D);
+  LDMAE_REQUIRE(!dx_cast || dtype != LDMAE_F32, "layernorm_bwd: dx_cast is a copy in the (16-bit) type of dout");
   hipStream_t st = as_stream(stream);
   const int G = cdiv(M, LN_ROWS);
   const size_t lds = (size_t)32 * D * 4;
 #define LN_B(NV) { if (dtype == LDMAE_F16) { hipFuncSetAttribute((const void*)layernorm_bwd_kernel<f16, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                     hipLaunchKernelGGL((layernorm_bwd_kernel<f16, NV>), dim3(G), dim3(256), lds, st, (const f16*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS); } \
+                     hipLaunchKernelGGL((layernorm_bwd_kernel<f16, NV>), dim3(G), dim3(256), lds, st, (const f16*)dout, x, w, mean, rstd, dx_accum, (f16*)dx_cast, workspace, M, D, LN_ROWS); } \
                    else if (dtype == LDMAE_BF16) { hipFuncSetAttribute((const void*)layernorm_bwd_kernel<bf16, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                     hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NV>), dim3(G), dim3(256), lds, st, (const bf16*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS); } \
+                     hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NV>), dim3(G), dim3(256), lds, st, (const bf16*)dout, x, w, mean, rstd, dx_accum, (bf16*)dx_cast, workspace, M, D, LN_ROWS); } \
                    else { hipFuncSetAttribute((const void*)layernorm_bwd_kernel<float, NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                     hipLaunchKernelGGL((layernorm_bwd_kernel<float, NV>), dim3(G), dim3(256), lds, st, (const float*)dout, x, w, mean, rstd, dx_accum, workspace, M, D, LN_ROWS); } }
+                     hipLaunchKernelGGL((layernorm_bwd_kernel<float, NV>), dim3(G), dim3(256), lds, st, (const float*)dout, x, w, mean, rstd, dx_accum, (float*)nullptr, workspace, M, D, LN_ROWS); } }
   LN_NV_DISPATCH(D, LN_B);
 #undef LN_B
   hipLaunchKernelGGL(ln_reduce_kernel, dim3(cdiv(2 * D / 4, 4)), dim3(256), 0, st, workspace, G, D, dw, db, beta_w);
   LDMAE_CHECK_LAUNCH("layernorm_bwd");
   return LDMAE_OK;
+}
+extern "C" int ldmae_layernorm_bwd(int dtype, const void* dout, const float* x, const float* w, const float* mean, const float* rstd,
+                                   float* dx_accum, float* dw, float* db, float beta_w, int M, int D, float* workspace, void* stream) {
+  return ldmae_layernorm_bwd_cast(dtype, dout, x, w, mean, rstd, dx_accum, nullptr, dw, db, beta_w, M, D, workspace, stream);
 }
 
 // ------------------------------------------------------------------ exact GELU
@@ -370,9 +376,57 @@ __global__ void conv3x3_kernel(const float* __restrict__ x, const float* __restr
       }
   out[i] = s;
 }
+// The shipped shape (3 channels, row length a multiple of 4): a thread owns four consecutive pixels of a row for ALL three output channels:
+// per input plane and tap row one float4 + the two neighbours (the one-thread-per-output kernel above re-read every input 27 times with
+// 64-bit index arithmetic per tap: 0.81 ms per 256 images of 256^2 against ~0.1 ms of HBM time).  The 81 taps are compile-time indices of
+// a uniform pointer: scalar loads.  TR: the input-gradient form, dx[ci] = sum_co corr(dout[co], w[co][ci] flipped) -- the same loop with
+// the tap index transposed and mirrored.
+template <bool TR>
+__global__ __launch_bounds__(256) void conv3x3_rgb_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ out, int B, int Hh, int Ww) {
+  const int W4 = Ww >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)B * Hh * W4) return;
+  const int x0 = (int)(t % W4) * 4, yy = (int)((t / W4) % Hh);
+  const long n = t / ((long)W4 * Hh);
+  float acc[3][4];
+#pragma unroll
+  for (int co = 0; co < 3; ++co)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[co][p] = (!TR && b) ? b[co] : 0.f;
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci) {
+    const float* plane = x + ((size_t)n * 3 + ci) * Hh * Ww;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int y2 = yy + dy;
+      if (y2 < 0 || y2 >= Hh) continue;
+      const float* row = plane + (size_t)y2 * Ww + x0;
+      const float4 m = *(const float4*)row;
+      const float v[6] = {x0 > 0 ? row[-1] : 0.f, m.x, m.y, m.z, m.w, x0 + 4 < Ww ? row[4] : 0.f};
+#pragma unroll
+      for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const float wt = TR ? w[((ci * 3 + co) * 3 + (1 - dy)) * 3 + (1 - dx)] : w[((co * 3 + ci) * 3 + (dy + 1)) * 3 + (dx + 1)];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[co][p] += v[p + 1 + dx] * wt;
+        }
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < 3; ++co)
+    *(float4*)(out + (((size_t)n * 3 + co) * Hh + yy) * Ww + x0) = make_float4(acc[co][0], acc[co][1], acc[co][2], acc[co][3]);
+}
+static bool conv_rgb_shape(const float* a, const float* b_, int C, int W) { return C == 3 && W % 4 == 0 && (((uintptr_t)a | (uintptr_t)b_) & 15) == 0; }
+
 extern "C" int ldmae_conv3x3(const float* x, const float* w, const float* b, float* out, int B, int C, int H, int W, void* stream) {
   LDMAE_REQUIRE(x && w && out && B > 0 && C > 0 && H > 0 && W > 0, "conv3x3: bad arguments");
   const long n = (long)B * C * H * W;
+  if (conv_rgb_shape(x, out, C, W)) {
+    const long nt = (long)B * H * (W / 4);
+    hipLaunchKernelGGL(conv3x3_rgb_kernel<false>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, as_stream(stream), x, w, b, out, B, H, W);
+  } else
   hipLaunchKernelGGL(conv3x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, w, b, out, B, C, H, W);
   LDMAE_CHECK_LAUNCH("conv3x3");
   return LDMAE_OK;
@@ -436,12 +490,17 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_dw_kernel(const float* __rest
   __syncthreads();
   if (threadIdx.x < NA) P[(size_t)blockIdx.x * NA + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void conv3x3_bwd_reduce_kernel(const float* __restrict__ P, int G, int NA, int NW, float* __restrict__ dw, float* __restrict__ db) {
-  const int a = threadIdx.x;
-  if (a >= NA) return;
+// one workgroup per tap / bias gradient: 256 threads stride over the G partials, fixed-order tree (a single 128-thread block walking all
+// 1024 partials serially took as long as the pass that produced them)
+__global__ __launch_bounds__(256) void conv3x3_bwd_reduce_kernel(const float* __restrict__ P, int G, int NA, int NW, float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[4];
+  const int a = blockIdx.x;
   float s = 0.f;
-  for (int g = 0; g < G; ++g) s += P[(size_t)g * NA + a];
-  if (a < NW) dw[a] = s; else db[a - NW] = s;
+  for (int g = threadIdx.x; g < G; g += 256) s += P[(size_t)g * NA + a];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { const float v = (red[0] + red[1]) + (red[2] + red[3]); if (a < NW) dw[a] = v; else db[a - NW] = v; }
 }
 constexpr int CONV_BWD_G = 1024;
 extern "C" long ldmae_conv3x3_bwd_workspace_bytes(int C) { return (long)CONV_BWD_G * (C * C * 9 + C) * 4; }
@@ -451,10 +510,13 @@ extern "C" int ldmae_conv3x3_bwd(const float* dout, const float* x, const float*
   LDMAE_REQUIRE(C == 3, "conv3x3_bwd: C=%d unsupported (the RGB smoothing conv has 3 channels)", C);
   hipStream_t st = as_stream(stream);
   const long n = (long)B * C * H * W, npix = (long)B * H * W;
-  if (dx) hipLaunchKernelGGL(conv3x3_bwd_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, w, dx, B, C, H, W);
+  if (dx && conv_rgb_shape(dout, dx, C, W)) {
+    const long nt = (long)B * H * (W / 4);
+    hipLaunchKernelGGL(conv3x3_rgb_kernel<true>, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, dout, w, (const float*)nullptr, dx, B, H, W);
+  } else if (dx) hipLaunchKernelGGL(conv3x3_bwd_dx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, w, dx, B, C, H, W);
   const int G = (int)((npix + 255) / 256 < CONV_BWD_G ? (npix + 255) / 256 : CONV_BWD_G);
   hipLaunchKernelGGL(conv3x3_bwd_dw_kernel<3>, dim3(G), dim3(256), 0, st, dout, x, workspace, B, H, W);
-  hipLaunchKernelGGL(conv3x3_bwd_reduce_kernel, dim3(1), dim3(128), 0, st, workspace, G, C * C * 9 + C, C * C * 9, dw, db);
+  hipLaunchKernelGGL(conv3x3_bwd_reduce_kernel, dim3(C * C * 9 + C), dim3(256), 0, st, workspace, G, C * C * 9 + C, C * C * 9, dw, db);
   LDMAE_CHECK_LAUNCH("conv3x3_bwd");
   return LDMAE_OK;
 }

@@ -725,14 +725,16 @@ def layernorm_fwd(x, w, b, out_dtype, eps=1e-6):
     return out, mean, rstd
 
 
-def layernorm_bwd(dout, x, w, mean, rstd, dx_accum):
+def layernorm_bwd(dout, x, w, mean, rstd, dx_accum, cast=False):
+    """dx_accum += dLN/dx; -> (dw, db), with cast=True (16-bit dout) also the updated dx_accum rounded to dout's type."""
     M, D = x.shape
     dw = torch.empty(D, dtype=torch.float32, device=x.device)
     db = torch.empty_like(dw)
     ws = workspace(L.load().ldmae_layernorm_bwd_workspace_bytes(M, D), x.device)
-    call("ldmae_layernorm_bwd", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(mean), ptr(rstd), ptr(dx_accum), ptr(dw), ptr(db), 0.0,
+    dxc = torch.empty(M, D, dtype=dout.dtype, device=x.device) if cast else None
+    call("ldmae_layernorm_bwd_cast", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(mean), ptr(rstd), ptr(dx_accum), ptr(dxc), ptr(dw), ptr(db), 0.0,
          M, D, ptr(ws), stream())
-    return dw, db
+    return (dw, db, dxc) if cast else (dw, db)
 
 
 def gelu_bwd(dout, pre):

@@ -161,14 +161,21 @@ class _ViTBlockFn(torch.autograd.Function):
                 ops.gemm_tn(dy, xin, out=pl[i].grad, beta=1.0, with_bias=True, dbias_out=pl[i + 1].grad.view(-1))
                 return None, None
             return ops.gemm_tn(dy, xin, with_bias=True)
-        # MLP branch
-        dy2 = ops.cast(dx, dtype)
+        half = dtype != torch.float32
+        # MLP branch.  The residual gradient rounded to the activation type is the operand of both Linear backwards of a branch: the LayerNorm
+        # backward that last updated dx writes that copy beside it (ops.layernorm_bwd(cast=True)); across blocks it rides on the returned tensor
+        # (`_ldmae_cast`: the next block's backward finds it only if autograd hands over that very tensor, unmodified) -- else one cast pass.
+        stash = getattr(gout, "_ldmae_cast", None) if half else None
+        dy2 = stash[0] if stash is not None and stash[1] == gout._version and stash[0].dtype == dtype and dx.data_ptr() == stash[2] else ops.cast(dx, dtype)
         dW2, db2 = dw(dy2, act, 10)
         dpre = ops.gemm_nt_gelu_bwd(dy2, W2T, pre)                 # fc2's input gradient with the GELU backward in the GEMM epilogue
         dW1, db1 = dw(dpre, h2, 8)
-        dn2w, dn2b = ops.layernorm_bwd(ops.gemm_nt(dpre, W1T, grad=True), xmid, n2w, mu2, rs2, dx)
         # attention branch
-        dy1 = ops.cast(dx, dtype)
+        if half:
+            dn2w, dn2b, dy1 = ops.layernorm_bwd(ops.gemm_nt(dpre, W1T, grad=True), xmid, n2w, mu2, rs2, dx, cast=True)
+        else:
+            dn2w, dn2b = ops.layernorm_bwd(ops.gemm_nt(dpre, W1T, grad=True), xmid, n2w, mu2, rs2, dx)
+            dy1 = dx
         dWp, dbp = dw(dy1, oa, 4)
         do = ops.gemm_nt(dy1, WpT, grad=True)
         if qkv is not None:
@@ -177,7 +184,11 @@ class _ViTBlockFn(torch.autograd.Function):
             dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
             dqkv = ops.heads_merge(dq, dk, dv, B, N, H, hd)
         dWqkv, dbqkv = dw(dqkv, h1, 2)
-        dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT, grad=True), x2, n1w, mu1, rs1, dx)
+        if half and ctx.inplace:
+            dn1w, dn1b, dxc = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT, grad=True), x2, n1w, mu1, rs1, dx, cast=True)
+        else:
+            dn1w, dn1b = ops.layernorm_bwd(ops.gemm_nt(dqkv, WqkvT, grad=True), x2, n1w, mu1, rs1, dx)
+            dxc = None
         if pl is not None:
             small = [(0, dn1w), (1, dn1b), (6, dn2w), (7, dn2b)]          # (the four bias gradients went into the slab with their weights)
             ops.multi_add_([pl[i].grad for i, _ in small], [g_ for _, g_ in small])
@@ -186,7 +197,10 @@ class _ViTBlockFn(torch.autograd.Function):
                 if r is not None:
                     r(p_)
             dn1w = dn1b = dbqkv = dbp = dn2w = dn2b = db1 = db2 = None
-        return (dx.view(B, N, D), None, None, None, None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
+        gx = dx.view(B, N, D)
+        if dxc is not None:
+            gx._ldmae_cast = (dxc, gx._version, dx.data_ptr())
+        return (gx, None, None, None, None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
 
 
 class _LayerNormFn(torch.autograd.Function):

@@ -532,9 +532,32 @@ def test_layernorm_gelu(ops, dtype):
     dx = torch.zeros(M, D, device="cuda")
     dw, db = ops.layernorm_bwd(dev(g, dtype), dev(x.detach()), dev(w.detach()), mean, rstd, dx)
     assert rel_err(dx.cpu(), x.grad) < 1e-4 and rel_err(dw.cpu(), w.grad) < 1e-4 and rel_err(db.cpu(), b.grad) < 1e-4
+    if dtype != F32:       # the second output of the block backward: the UPDATED residual gradient rounded to the activation type, bit for bit a cast
+        acc = dev(rnd(M, D, seed=6))
+        ref_acc = acc.clone()
+        ops.layernorm_bwd(dev(g, dtype), dev(x.detach()), dev(w.detach()), mean, rstd, ref_acc)
+        dw2, db2, dxc = ops.layernorm_bwd(dev(g, dtype), dev(x.detach()), dev(w.detach()), mean, rstd, acc, cast=True)
+        assert torch.equal(acc, ref_acc) and torch.equal(dxc, ops.cast(acc, dtype)) and torch.equal(dw2, dw) and torch.equal(db2, db)
     pre = q(rnd(M, D, seed=5), dtype).requires_grad_(True)
     torch.nn.functional.gelu(pre).backward(g)
     assert rel_err(ops.gelu_bwd(dev(g, dtype), dev(pre.detach(), dtype)).float().cpu(), pre.grad) < (1e-5 if dtype == F32 else 1e-2)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 64, 64), (2, 3, 17, 20), (2, 3, 9, 10)])
+def test_conv3x3_rgb_and_its_backward(ops, shape):
+    """The RGB smoothing convolution (models_mae.py:254,275) and its backward: the four-pixels-per-thread kernels (row length % 4 == 0) and the
+    generic ones (the last shape) against torch's conv2d in f64."""
+    B, C, Hh, Ww = shape
+    x = rnd(*shape, seed=1).double().requires_grad_(True)
+    w = (0.3 * rnd(C, C, 3, 3, seed=2)).double().requires_grad_(True)
+    b = (0.1 * rnd(C, seed=3)).double().requires_grad_(True)
+    g = rnd(*shape, seed=4).double()
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+    ref.backward(g)
+    out = ops.conv3x3(dev(x.detach().float()), dev(w.detach().float()), dev(b.detach().float()))
+    assert rel_err(out.cpu(), ref.detach()) < 1e-6
+    dx, dw, db = ops.conv3x3_bwd(dev(g.float()), dev(x.detach().float()), dev(w.detach().float()))
+    assert rel_err(dx.cpu(), x.grad) < 1e-6 and rel_err(dw.cpu(), w.grad) < 1e-5 and rel_err(db.cpu(), b.grad) < 1e-5
 
 
 def test_errors_are_loud(ops):
