@@ -262,6 +262,10 @@ int ldmae_vmae_encoder_fwd(const float* x, float* out, const void* blob, int B, 
 long ldmae_vmae_encoder_fwd_tiled_workspace_bytes(int B, int tokens);
 int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const void* blob, void* workspace, int B, int tokens, int dim, int heads,
                                  int hidden, int nblocks, float eps, void* stream);
+/* the TF32-class form of the same call (fp16 operands = TF32's mantissa; the blob packed in fp16, same layout and size): what f32 docking calls
+ * run while torch.backends.cuda.matmul.allow_tf32 is set (inference.py:79, extract_features.py:2-3) */
+int ldmae_vmae_encoder_fwd_tiled_f16(const float* x, float* out, const void* blob, void* workspace, int B, int tokens, int dim, int heads,
+                                     int hidden, int nblocks, float eps, void* stream);
 /* LayerNorm with affine (models_mae.py:163,171,369; eps 1e-6).  mean/rstd [M] saved. */
 int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w, const float* b, void* out, float* mean, float* rstd,
                         int M, int D, float eps, void* stream);

@@ -80,6 +80,7 @@ SIGNATURES = {
     "ldmae_vmae_encoder_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ldmae_vmae_encoder_fwd_tiled_workspace_bytes": (_l, [_i, _i]),
     "ldmae_vmae_encoder_fwd_tiled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "ldmae_vmae_encoder_fwd_tiled_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ldmae_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ldmae_layernorm_bwd_workspace_bytes": (_l, [_i, _i]),
     "ldmae_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),

@@ -25,7 +25,21 @@
 
 #include <type_traits>
 
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// F16 (the TF32-class docking calls, MODE 1 / 2 / 3 only): fp16 operands = TF32's 10-bit mantissa; fragments keep the bf16x8 REGISTER type, the
+// bits are fp16 (the blob is packed in fp16, ldmae_amd/tokenizer/fused_encoder.py); conversions saturate at +-65504 like the forward GEMMs
+#define MFMA(a, b, c) vf_mfma<F16>(a, b, c)
+template <bool F16> __device__ __forceinline__ f32x16 vf_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ bf16 vf_cv(float v) {            // f32 -> the operand type (as bits in a bf16 register slot)
+  if constexpr (F16) return __builtin_bit_cast(bf16, from_f<f16>(sat_f16(v, 65504.f)));
+  else return (bf16)v;
+}
+template <bool F16> __device__ __forceinline__ float vf_rnd(float v) {          // v as the operand type stores it
+  if constexpr (F16) return (float)from_f<f16>(sat_f16(v, 65504.f));
+  else return (float)(bf16)v;
+}
 
 #ifndef VF_TL
 #define VF_TL 0
@@ -41,10 +55,10 @@ constexpr int STEPS = 36;                                          // per block:
 constexpr int KVB = 32768;                                         // K [2 heads][8 key blocks][1 KiB] | V^T [8 key blocks][2 k-steps][1 KiB]
 constexpr int LDS_BYTES = NSLOT * SLOTB + KVB;                     // 139,264 B
 
-__device__ __forceinline__ bf16x8 cvt8(const f32x16& x, int s, float mul = 1.f) {
+template <bool F16 = false> __device__ __forceinline__ bf16x8 cvt8(const f32x16& x, int s, float mul = 1.f) {
   bf16x8 f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) f[j] = (bf16)(x[8 * s + j] * mul);
+  for (int j = 0; j < 8; ++j) f[j] = vf_cv<F16>(x[8 * s + j] * mul);
   return f;
 }
 __device__ __forceinline__ f32x16 zero16() {
@@ -74,7 +88,7 @@ constexpr int LDS_BYTES_QKV = NSLOT * SLOTB + VTOK * STG_PITCH;    // 143,360 B
 
 // MODE 0: x, out: [B, 256, 192] f32, nblk = number of blocks.  MODE 1 / 2 / 3: x, out [tiles * 256, 192] f32, nblk = INDEX of the block.
 // blob: 36 slots of SLOTB bytes per block (ldmae_amd/tokenizer/fused_encoder.py packs it; layout in the header).
-template <int MODE>
+template <int MODE, bool F16 = false>
 __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restrict__ x, float* __restrict__ out, const char* __restrict__ blob,
                                                            int nblk, float eps, float qscale, bf16* __restrict__ qkv, const bf16* __restrict__ oatt, int last,
                                                            unsigned* __restrict__ qkmax, int tpi) {
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
   };
   auto to_frags = [&](int d, int g, float4 y) {      // element 4g + j of block d -> fragment 2d + (g >> 1), slot 4 (g & 1) + j
     const int f = 2 * d + (g >> 1), o = 4 * (g & 1);
-    xf[f][o] = (bf16)y.x; xf[f][o + 1] = (bf16)y.y; xf[f][o + 2] = (bf16)y.z; xf[f][o + 3] = (bf16)y.w;
+    xf[f][o] = vf_cv<F16>(y.x); xf[f][o + 1] = vf_cv<F16>(y.y); xf[f][o + 2] = vf_cv<F16>(y.z); xf[f][o + 3] = vf_cv<F16>(y.w);
   };
   auto add_rowvec = [&](const float* v) {             // xacc += v[feature] (proj / fc2 bias)
 #pragma unroll
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
       for (int gq = 0; gq < 4; ++gq) {
         bf16x4 w;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = (bf16)a[4 * gq + j];
+        for (int j = 0; j < 4; ++j) w[j] = vf_cv<F16>(a[4 * gq + j]);
         *(bf16x4*)(stg + (wave * 32 + r) * STG_PITCH + byteoff + (8 * gq + 4 * h) * 2) = w;
       }
     };
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
           float qs = 0.f, ks = 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float a = (float)(bf16)qT[8 * e + j], b = (float)(bf16)kT[8 * e + j];
+            const float a = vf_rnd<F16>(qT[8 * e + j]), b = vf_rnd<F16>(kT[8 * e + j]);
             qs += a * a; ks += b * b;
           }
           qs += __shfl_xor(qs, 32, 64); ks += __shfl_xor(ks, 32, 64);
@@ -336,12 +350,12 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
         add_rows32(qT, vec + 384);
         // a lane's elements 8e .. 8e+7 are head e's 8 head-dim values of its half: exactly the 16-B operand fragment of S^T = K . Q^T
         // (both operands in the same implicit order of the head dim, which a dot product does not care about)
-        qf[0] = cvt8(qT, 0, qscale); qf[1] = cvt8(qT, 1, qscale);
+        qf[0] = cvt8<F16>(qT, 0, qscale); qf[1] = cvt8<F16>(qT, 1, qscale);
         f32x16 kT = mm12(zero16(), p1, std::false_type{});
         add_rows32(kT, vec + 416);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const bf16x8 kf = cvt8(kT, e);
+          const bf16x8 kf = cvt8<F16>(kT, e);
           *(bf16x8*)(kv + (e * 8 + wave) * FRAG + lane * 16) = kf;
           // |k|^2 of this lane's token (as stored), maximum over the wave's 32 tokens -> the slot's spare vector floats (readable through
           // the next step): with |q| it bounds every score of the head, and the softmax below needs no maximum pass (see `bq`)
@@ -367,8 +381,8 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
 #pragma unroll
         for (int tt = 0; tt < 16; ++tt) v[tt] += bv;
         // V^T image: [key block = wave][k-step s][lane = (h, column d)]: elements 8s .. 8s+7 are tokens in the accumulator k-order
-        *(bf16x8*)(kv + 16384 + (wave * 2 + 0) * FRAG + lane * 16) = cvt8(v, 0);
-        *(bf16x8*)(kv + 16384 + (wave * 2 + 1) * FRAG + lane * 16) = cvt8(v, 1);
+        *(bf16x8*)(kv + 16384 + (wave * 2 + 0) * FRAG + lane * 16) = cvt8<F16>(v, 0);
+        *(bf16x8*)(kv + 16384 + (wave * 2 + 1) * FRAG + lane * 16) = cvt8<F16>(v, 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // K (written in step A) and V^T of all 256 tokens are in LDS
         bf16x8 of[2];                                        // o^T of the two heads as proj operand fragments
@@ -407,12 +421,12 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
             for (int tt = 0; tt < 16; ++tt) { sc[tt] = __builtin_amdgcn_exp2f(sc[tt]); l += sc[tt]; }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
-              o = MFMA(*(const bf16x8*)(kv + 16384 + (kb * 2 + s2) * FRAG + lane * 16), cvt8(sc, s2), o);
+              o = MFMA(*(const bf16x8*)(kv + 16384 + (kb * 2 + s2) * FRAG + lane * 16), cvt8<F16>(sc, s2), o);
             __builtin_amdgcn_sched_barrier(0);
           }
           l += __shfl_xor(l, 32, 64);
           // rows 16e .. 16e+15 of o^T (elements 8e .. 8e+7) belong to head e; the other half multiplied the other head's V: dropped
-          of[e] = cvt8(o, e, 1.f / l);
+          of[e] = cvt8<F16>(o, e, 1.f / l);
         }
         // proj: x^T += Wp[:, 32hp .. 32hp+31] . o_pair^T   (panel 1: 6 feature blocks x 2 k-steps; k-step e = head e of the pair)
         mm_out(p1, of[0], of[1]);
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
         }
         TLS(2);
         add_rows32(hT, vec + 384);
-        const bf16x8 h0 = cvt8(hprev, 0), h1 = cvt8(hprev, 1);
+        const bf16x8 h0 = cvt8<F16>(hprev, 0), h1 = cvt8<F16>(hprev, 1);
         TLS(3);
         if (c > 0) mm_out(p1prev, h0, h1);
         TLS(4);
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(512) void vmae_encoder_kernel(const float* __restri
       if (VF_DBG != 4) {                         // drain: GELU and fc2 of the last chunk, + fc2 bias
 #pragma unroll
         for (int q = 0; q < 4; ++q) { gelu4(hprev, q); __builtin_amdgcn_sched_barrier(0); }
-        mm_out(p1prev, cvt8(hprev, 0), cvt8(hprev, 1));
+        mm_out(p1prev, cvt8<F16>(hprev, 0), cvt8<F16>(hprev, 1));
         add_rowvec(vec);
       }
     }
@@ -529,8 +543,10 @@ extern "C" int ldmae_attention_fwd_qkv_bounded(int dtype, const void* qkv, void*
 extern "C" long ldmae_vmae_encoder_fwd_tiled_workspace_bytes(int B, int tokens) {
   return (long)B * tokens * (3 * VD + VD) * 2 + (long)B * VH * tokens * 4 + ((long)B * VH * 2 * 4 + 15) / 16 * 16 * 64;      // (up to 64 blocks)
 }
-extern "C" int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const void* blob, void* workspace, int B, int tokens, int dim, int heads,
-                                            int hidden, int nblocks, float eps, void* stream) {
+extern "C" int ldmae_attention_fwd_qkv(int dtype, const void* qkv, void* o, float* lse, int B, int H, int N, int hd, float scale, void* stream);
+template <bool F16>
+static int encoder_fwd_tiled(const float* x, float* out, const void* blob, void* workspace, int B, int tokens, int dim, int heads,
+                             int hidden, int nblocks, float eps, void* stream) {
   LDMAE_REQUIRE(x && out && blob && workspace && B > 0, "vmae_encoder_fwd_tiled: null pointer or empty batch");
   LDMAE_REQUIRE(tokens > 0 && tokens % VTOK == 0 && dim == VD && heads == VH && hidden == VHID,
                 "vmae_encoder_fwd_tiled: built for whole %d-token tiles of width %d, %d heads, hidden %d (got %d, %d, %d, %d): use the per-layer entry points",
@@ -539,9 +555,9 @@ extern "C" int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const vo
   LDMAE_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)blob & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
                 "vmae_encoder_fwd_tiled: pointers must be 16-B aligned");
   LDMAE_REQUIRE((long)B * tokens / VTOK < (1L << 31), "vmae_encoder_fwd_tiled: too many tiles");
-  hipFuncSetAttribute((const void*)vmae_encoder_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_QKV);
-  hipFuncSetAttribute((const void*)vmae_encoder_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  hipFuncSetAttribute((const void*)vmae_encoder_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_QKV);
+  hipFuncSetAttribute((const void*)vmae_encoder_kernel<1, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_QKV);
+  hipFuncSetAttribute((const void*)vmae_encoder_kernel<2, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipFuncSetAttribute((const void*)vmae_encoder_kernel<3, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_QKV);
   bf16* qkv = (bf16*)workspace;
   bf16* oatt = qkv + (size_t)B * tokens * 3 * VD;
   float* lse = (float*)(oatt + (size_t)B * tokens * VD);
@@ -550,20 +566,33 @@ extern "C" int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const vo
   LDMAE_REQUIRE(hipMemsetAsync(mx, 0, mxs * nblocks, as_stream(stream)) == hipSuccess, "vmae_encoder_fwd_tiled: hipMemsetAsync of the q / k norm maxima failed");
   const int tpi = tokens / VTOK;
   const unsigned tiles = (unsigned)((long)B * tokens / VTOK);
-  hipLaunchKernelGGL(vmae_encoder_kernel<1>, dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), x, (float*)nullptr, (const char*)blob, 0, eps, 0.f, qkv,
+  hipLaunchKernelGGL((vmae_encoder_kernel<1, F16>), dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), x, (float*)nullptr, (const char*)blob, 0, eps, 0.f, qkv,
                      (const bf16*)nullptr, 0, (unsigned*)mx, tpi);
   LDMAE_CHECK_LAUNCH("vmae_encoder_fwd_tiled(qkv)");
   for (int blk = 0; blk < nblocks; ++blk) {
     const float* xin = blk == 0 ? x : out;                    // the residual stream lives in `out` from the first block on (a tile rewrites only its own rows)
-    if (int e = ldmae_attention_fwd_qkv_bounded(LDMAE_BF16, qkv, oatt, lse, (const float*)(mx + mxs * blk), B, VH, tokens, VD / VH, 0.25f, stream))
-      return e;                                                 // scale = head_dim^-0.5 (models_mae.py:123)
+    // scale = head_dim^-0.5 (models_mae.py:123).  bf16: the static softmax shift from the norm maxima the q | k | v kernel left behind.  fp16
+    // keeps the running maximum: with a static shift the probabilities of a row whose scores sit far below the bound leave fp16's range.
+    if (int e = F16 ? ldmae_attention_fwd_qkv(LDMAE_F16, qkv, oatt, lse, B, VH, tokens, VD / VH, 0.25f, stream)
+                    : ldmae_attention_fwd_qkv_bounded(LDMAE_BF16, qkv, oatt, lse, (const float*)(mx + mxs * blk), B, VH, tokens, VD / VH, 0.25f, stream))
+      return e;
     if (blk + 1 < nblocks)      // proj / MLP of this block, then q | k | v of the next one (the attention has consumed this block's)
-      hipLaunchKernelGGL(vmae_encoder_kernel<3>, dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), xin, out, (const char*)blob, blk, eps, 0.f, qkv,
+      hipLaunchKernelGGL((vmae_encoder_kernel<3, F16>), dim3(tiles), dim3(512), LDS_BYTES_QKV, as_stream(stream), xin, out, (const char*)blob, blk, eps, 0.f, qkv,
                          (const bf16*)oatt, 0, (unsigned*)(mx + mxs * (blk + 1)), tpi);
     else
-      hipLaunchKernelGGL(vmae_encoder_kernel<2>, dim3(tiles), dim3(512), LDS_BYTES, as_stream(stream), xin, out, (const char*)blob, blk, eps, 0.f, (bf16*)nullptr,
+      hipLaunchKernelGGL((vmae_encoder_kernel<2, F16>), dim3(tiles), dim3(512), LDS_BYTES, as_stream(stream), xin, out, (const char*)blob, blk, eps, 0.f, (bf16*)nullptr,
                          (const bf16*)oatt, 1, (unsigned*)nullptr, tpi);
     LDMAE_CHECK_LAUNCH("vmae_encoder_fwd_tiled(post)");
   }
   return LDMAE_OK;
+}
+extern "C" int ldmae_vmae_encoder_fwd_tiled(const float* x, float* out, const void* blob, void* workspace, int B, int tokens, int dim, int heads,
+                                            int hidden, int nblocks, float eps, void* stream) {
+  return encoder_fwd_tiled<false>(x, out, blob, workspace, B, tokens, dim, heads, hidden, nblocks, eps, stream);
+}
+// The TF32-class form (f32 docking calls under torch.backends.cuda.matmul.allow_tf32): the same kernels on fp16 operands -- the blob packed in fp16
+// (same layout, same size), qkv / attention output in fp16, f32 residual stream, statistics and accumulation.
+extern "C" int ldmae_vmae_encoder_fwd_tiled_f16(const float* x, float* out, const void* blob, void* workspace, int B, int tokens, int dim, int heads,
+                                                int hidden, int nblocks, float eps, void* stream) {
+  return encoder_fwd_tiled<true>(x, out, blob, workspace, B, tokens, dim, heads, hidden, nblocks, eps, stream);
 }

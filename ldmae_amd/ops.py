@@ -669,9 +669,10 @@ def vmae_encoder_fwd(x, blob, nblocks, dim, heads, hidden, eps=1e-6):
     return out
 
 
-def vmae_encoder_fwd_tiled(x, blob, nblocks, dim, heads, hidden, eps=1e-6):
+def vmae_encoder_fwd_tiled(x, blob, nblocks, dim, heads, hidden, eps=1e-6, f16=False):
     """The same stack on sequences of several whole 256-token tiles per image (the docking encoder on all 1024 patches): three launches per
-    block -- q|k|v of a tile, flash attention on the packed qkv, proj + MLP of a tile -- from the same weight blob."""
+    block -- q|k|v of a tile, flash attention on the packed qkv, proj + MLP of a tile -- from the same weight blob.  f16: the TF32-class form
+    (the blob packed in fp16)."""
     B, T, D = x.shape
     x = _c(x.float())
     need = L.load().ldmae_vmae_encoder_blob_bytes(nblocks)
@@ -679,7 +680,8 @@ def vmae_encoder_fwd_tiled(x, blob, nblocks, dim, heads, hidden, eps=1e-6):
         raise RuntimeError(f"vmae_encoder_fwd_tiled: weight blob has {blob.numel() * blob.element_size()} bytes, the kernels expect {need}")
     out = torch.empty_like(x)
     ws = workspace(L.load().ldmae_vmae_encoder_fwd_tiled_workspace_bytes(B, T), x.device)
-    call("ldmae_vmae_encoder_fwd_tiled", ptr(x), ptr(out), ptr(blob), ptr(ws), B, T, D, heads, hidden, nblocks, float(eps), stream())
+    call("ldmae_vmae_encoder_fwd_tiled_f16" if f16 else "ldmae_vmae_encoder_fwd_tiled", ptr(x), ptr(out), ptr(blob), ptr(ws), B, T, D, heads, hidden,
+         nblocks, float(eps), stream())
     return out
 
 

@@ -21,10 +21,13 @@ PERM16 = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
 TOKENS, DIM, HEADS, HIDDEN, STEPS = 256, 192, 12, 768, 36
 
 
+_PACK_DTYPE = torch.bfloat16        # set by pack_encoder for the duration of one packing
+
+
 def _frags(w: torch.Tensor) -> torch.Tensor:
-    """[R, K] (R % 32 == 0, K % 16 == 0) -> [R/32, K/16, 512] bf16 operand fragments."""
+    """[R, K] (R % 32 == 0, K % 16 == 0) -> [R/32, K/16, 512] operand fragments (bf16, or fp16 for the TF32-class blob)."""
     R, K = w.shape
-    f = w.to(torch.bfloat16).reshape(R // 32, 32, K // 16, 16)[..., PERM16]
+    f = (w.clamp(-65504.0, 65504.0) if _PACK_DTYPE == torch.float16 else w).to(_PACK_DTYPE).reshape(R // 32, 32, K // 16, 16)[..., PERM16]
     return f.reshape(R // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(R // 32, K // 16, 512).contiguous()
 
 
@@ -68,11 +71,16 @@ def _pack_block(blk, final_norm=None):
     return steps
 
 
-def pack_encoder(blocks, final_norm) -> torch.Tensor:
+def pack_encoder(blocks, final_norm, dtype=torch.bfloat16) -> torch.Tensor:
+    global _PACK_DTYPE
     parts = []
-    for i, blk in enumerate(blocks):
-        for p0, p1, v in _pack_block(blk, final_norm if i == len(blocks) - 1 else None):
-            parts += [p0.reshape(-1).view(torch.uint8), p1.reshape(-1).view(torch.uint8), v.view(torch.uint8)]
+    _PACK_DTYPE = dtype
+    try:
+        for i, blk in enumerate(blocks):
+            for p0, p1, v in _pack_block(blk, final_norm if i == len(blocks) - 1 else None):
+                parts += [p0.reshape(-1).view(torch.uint8), p1.reshape(-1).view(torch.uint8), v.view(torch.uint8)]
+    finally:
+        _PACK_DTYPE = torch.bfloat16
     blob = torch.cat(parts)
     assert blob.numel() == len(blocks) * STEPS * (2 * 12 * 1024 + 2048)
     return blob
@@ -104,19 +112,19 @@ def supported(model, tokens: int, dim: int, tiled: bool = False, which: str = "e
 _CACHE: dict = {}
 
 
-def encoder_blob(model, which: str = "enc") -> torch.Tensor:
+def encoder_blob(model, which: str = "enc", dtype=torch.bfloat16) -> torch.Tensor:
     """Packed weights of the stack's blocks + closing LayerNorm, rebuilt when any of those parameters changed (version counters, storage,
     and ops.WEIGHT_EPOCH for writes through the flat optimizer slab)."""
     blocks, norm = _stack(model, which)
     ps = [p for blk in blocks for p in blk.parameters()] + list(norm.parameters())
     stamp = (ops.WEIGHT_EPOCH,) + tuple((p.data_ptr(), p._version) for p in ps)
-    hit = _CACHE.get((id(model), which))
+    hit = _CACHE.get((id(model), which, dtype))
     if hit is not None and hit[0]() is model and hit[1] == stamp:      # the weak reference guards against a recycled id()
         return hit[2]
     for k in [k for k, v in _CACHE.items() if v[0]() is None]:         # models that are gone: drop their 11 MB blobs
         del _CACHE[k]
-    blob = pack_encoder(blocks, norm)
-    _CACHE[(id(model), which)] = (weakref.ref(model), stamp, blob)
+    blob = pack_encoder(blocks, norm, dtype)
+    _CACHE[(id(model), which, dtype)] = (weakref.ref(model), stamp, blob)
     return blob
 
 
@@ -125,8 +133,8 @@ def encoder_forward(model, x: torch.Tensor) -> torch.Tensor:
     return ops.vmae_encoder_fwd(x, encoder_blob(model), len(model.blocks), DIM, HEADS, HIDDEN, model.norm.eps)
 
 
-def encoder_forward_tiled(model, x: torch.Tensor, which: str = "enc") -> torch.Tensor:
+def encoder_forward_tiled(model, x: torch.Tensor, which: str = "enc", dtype=torch.bfloat16) -> torch.Tensor:
     """x [B, k * 256, 192] f32 (every patch of the image) -> LayerNorm(blocks(x)), two launches per block from the same blob; `which`:
-    the encoder stack or the decoder stack."""
+    the encoder stack or the decoder stack; `dtype`: bf16, or fp16 = the TF32-class form (its own blob)."""
     blocks, norm = _stack(model, which)
-    return ops.vmae_encoder_fwd_tiled(x, encoder_blob(model, which), len(blocks), DIM, HEADS, HIDDEN, norm.eps)
+    return ops.vmae_encoder_fwd_tiled(x, encoder_blob(model, which, dtype), len(blocks), DIM, HEADS, HIDDEN, norm.eps, f16=dtype == torch.float16)

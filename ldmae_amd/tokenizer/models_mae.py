@@ -479,16 +479,18 @@ class MaskedAutoencoderViT(nn.Module):
             pe = self.patch_embed
             L = pe.num_patches
             keep = int(L * (1 - mask_ratio))
-            if (self.fused_encoder and dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.dim() == 4 and
+            if (self.fused_encoder and dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled() and x.dim() == 4 and
                     fused_encoder.supported(self, keep, self.pos_embed.shape[-1], tiled=True) and all(self._chain_ok(blk) for blk in self.blocks)):
                 if noise is None:
                     noise = torch.rand(x.shape[0], L, device=x.device)             # the draw random_masking makes (:480)
                 ids_keep, mask, ids_restore = ops.random_masking(noise.float().contiguous(), keep)
                 w2d = pe.proj.weight.view(pe.proj.weight.shape[0], -1)
-                xk = ops.patch_embed_kept(x, ids_keep, self.pos_embed[0], w2d, pe.proj.bias, pe.patch_size[0], dtype)
-                # 256 kept tokens: the whole stack in one launch; 512 / 768 / 1024 (mask_ratio 0.5 / 0.25 / 0): the tiled form
-                run = fused_encoder.encoder_forward if keep == fused_encoder.TOKENS else fused_encoder.encoder_forward_tiled
-                return run(self, xk), mask, ids_restore
+                xk = ops.patch_embed_kept(x, ids_keep, self.pos_embed[0], w2d, pe.proj.bias, pe.patch_size[0], dtype if dtype != torch.float16 else torch.float32)
+                # 256 kept tokens in bf16: the whole stack in one launch; 512 / 768 / 1024 (mask_ratio 0.5 / 0.25 / 0) and the TF32-class (fp16)
+                # calls: the tiled form
+                if keep == fused_encoder.TOKENS and dtype == torch.bfloat16:
+                    return fused_encoder.encoder_forward(self, xk), mask, ids_restore
+                return fused_encoder.encoder_forward_tiled(self, xk, dtype=dtype), mask, ids_restore
             x = self._embed(x, dtype)
             x, mask, ids_restore = self.random_masking(x, mask_ratio, noise)
             x = self._run(self.blocks, x, dtype)
@@ -551,11 +553,11 @@ class MaskedAutoencoderViT(nn.Module):
         dtype = self._docking_dtype(self.blocks)
         with torch.autocast(device_type="cuda", enabled=False):
             x = self._embed(x, dtype)
-            if (self.fused_encoder and dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.dim() == 3 and
+            if (self.fused_encoder and dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled() and x.dim() == 3 and
                     fused_encoder.supported(self, x.shape[1], x.shape[2], tiled=True) and all(self._chain_ok(blk) for blk in self.blocks)):
-                # bf16 inference on the shipped geometry: per block three launches instead of seven, the residual stream of a 256-token tile
-                # in registers through proj / LayerNorm / MLP (csrc/vmae_fused.hip, MODE 1 / 2), the closing LayerNorm in the last of them
-                x = fused_encoder.encoder_forward_tiled(self, x.float())
+                # bf16 / TF32-class inference on the shipped geometry: per block three launches instead of seven, the residual stream of a 256-token
+                # tile in registers through proj / LayerNorm / MLP (csrc/vmae_fused.hip, MODE 1 / 2), the closing LayerNorm in the last of them
+                x = fused_encoder.encoder_forward_tiled(self, x.float(), dtype=dtype)
             else:
                 x = self._run(self.blocks, x, dtype)
                 x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
@@ -575,11 +577,11 @@ class MaskedAutoencoderViT(nn.Module):
             x = z.float().permute(0, 2, 3, 1).reshape(B, -1, z.shape[1]).contiguous()
             x = _LinearFn.apply(x, self.from_latent.weight, self.from_latent.bias)
             x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias) + self.decoder_pos_embed
-            if (self.fused_encoder and dtype == torch.bfloat16 and not torch.is_grad_enabled() and
+            if (self.fused_encoder and dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled() and
                     fused_encoder.supported(self, x.shape[1], x.shape[2], tiled=True, which="dec") and
                     all(self._chain_ok(blk) for blk in self.decoder_blocks)):
-                # the shipped decoder has the encoder's geometry (192 wide, 12 heads): bf16 inference runs it on the tiled fused kernels too
-                x = fused_encoder.encoder_forward_tiled(self, x.float().contiguous(), which="dec")
+                # the shipped decoder has the encoder's geometry (192 wide, 12 heads): bf16 / TF32-class inference runs it on the tiled fused kernels too
+                x = fused_encoder.encoder_forward_tiled(self, x.float().contiguous(), which="dec", dtype=dtype)
             else:
                 x = self._run(self.decoder_blocks, x, dtype)
                 x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)

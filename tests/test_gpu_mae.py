@@ -430,7 +430,7 @@ def test_tiled_encoder_kernels_match_per_layer_path(golden):
     imgs = det_randn("mae_img", (5, 3, 256, 256), 2).clamp(-1, 1).cuda()
     calls = []
     orig = fused_encoder.encoder_forward_tiled
-    fused_encoder.encoder_forward_tiled = lambda model, x, which="enc": (calls.append(tuple(x.shape)), orig(model, x, which))[1]
+    fused_encoder.encoder_forward_tiled = lambda model, x, which="enc", **kw: (calls.append(tuple(x.shape)), orig(model, x, which, **kw))[1]
     try:
         with torch.no_grad():
             lat32 = m._encode(imgs)                                                          # f32: never the fused kernels
@@ -554,8 +554,22 @@ def test_tf32_class_docking_path_matches_reference_golden(golden):
             c_dec = _lib.launch_counts(reset=True)
             lat, mask, ids = m.forward_encoder(imgs, 0.75, noise=noise)
         nb, nd = len(m.blocks), len(m.decoder_blocks)
+        # default: the tiled fused kernels on fp16 operands (csrc/vmae_fused.hip, F16) around the fp16 flash kernel -- no per-layer GEMM launches
+        assert c_enc["nt_f16"] == 0 and c_enc["attn_f16"] == nb and c_enc["attn_f32"] == 0 and c_enc["nt_bf16"] == 0 and c_enc["attn_bf16"] == 0, c_enc
+        assert c_dec["nt_f16"] == 0 and c_dec["attn_f16"] == nd and c_dec["attn_f32"] == 0 and c_dec["nt_bf16"] == 0 and c_dec["attn_bf16"] == 0, c_dec
+        # the per-layer fp16 kernels (model.fused_encoder = False; geometries the fused kernels do not cover): same error class, own launch family
+        m.fused_encoder = False
+        _lib.launch_counts(reset=True)
+        with torch.no_grad():
+            mom_pl = m._encode(imgs)
+            c_enc = _lib.launch_counts(reset=True)
+            rec_pl = m.decode(mom_pl[:, :16]).sample
+            c_dec = _lib.launch_counts(reset=True)
+        m.fused_encoder = True
         assert c_enc["nt_f16"] == 4 * nb and c_enc["attn_f16"] == nb and c_enc["attn_f32"] == 0 and c_enc["nt_bf16"] == 0, c_enc
         assert c_dec["nt_f16"] == 4 * nd and c_dec["attn_f16"] == nd and c_dec["attn_f32"] == 0 and c_dec["nt_bf16"] == 0, c_dec
+        assert rel_err(mom_pl[:, :, :2, :2].cpu(), g["mae_moments_head"]) < 1e-3 and rel_err(rec_pl[:, :, :4, :4].cpu(), g["mae_rec_head"]) < 1e-3
+        assert rel_err(mom.cpu(), mom_pl.cpu()) < 1e-3 and rel_err(rec.cpu(), rec_pl.cpu()) < 1.5e-3
         assert rel_err(mom[:, :, :2, :2].cpu(), g["mae_moments_head"]) < 1e-3
         assert abs(float(mom.double().norm()) - float(g["mae_moments_norm"])) < 1e-3 * float(g["mae_moments_norm"])
         assert rel_err(rec[:, :, :4, :4].cpu(), g["mae_rec_head"]) < 1e-3
