@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the whole-line NT GEMM (gemm_nt_lines_kernel, the default) against the half-line kernel it replaced
+(LDMAE_EPI_HALF_LINES): bitwise-equal outputs for every fused epilogue and both launch modes on random shapes (M, N multiples of 8, K of 64),
+plus the arithmetic against an f32 matmul.  The fixed-shape version is tests/test_gpu_kernels.py; this is the wide net.
+    python tools/fuzz_lines.py [shapes=40] [seed=0]"""
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ldmae_amd import ops  # noqa: E402
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rb = lambda *s: torch.randn(*s, device="cuda", generator=g).to(BF16)      # noqa: E731
+    rf = lambda *s: torch.randn(*s, device="cuda", generator=g)               # noqa: E731
+    flat = lambda o: [t for t in (o if isinstance(o, (tuple, list)) else (o,)) if torch.is_tensor(t)]      # noqa: E731
+    bad = 0
+    for i in range(n):
+        M = 8 * rnd.choice([1, 2, 3, 31, 32, 33, 64, 100, 257, 512, 1000, 2049, 4096, rnd.randint(1, 6000)])
+        N = 8 * rnd.choice([1, 2, 24, 31, 32, 33, 64, 72, 96, 144, 288, 512, rnd.randint(1, 600)])
+        K = 64 * rnd.choice([1, 1, 2, 2, 3, 4, 5, 12, 18, 32, 36, 64, rnd.randint(1, 48)])
+        a, w, bias = rb(M, K), rb(N, K) * K ** -0.5, rf(N)
+        T = 8
+        xin, gate, pos, pre, h12 = rf(M, N), rf(M // T, N), rf(T, N), rb(M, N), rb(M, 2 * N)
+        cases = {
+            "bias": lambda: ops.gemm_nt(a, w, bias), "bias_f32out": lambda: ops.gemm_nt(a, w, bias, out_dtype=F32),
+            "gate_res": lambda: ops.gemm_nt_gate_res(a, w, bias, xin, gate, T), "gelu": lambda: ops.gemm_nt_gelu(a, w, bias, save_pre=True),
+            "pos": lambda: ops.gemm_nt_pos(a, w, bias, pos, T), "gelu_bwd": lambda: ops.gemm_nt_gelu_bwd(a, w, pre),
+            "swiglu_bwd": lambda: ops.gemm_nt_swiglu_bwd(a, w, h12, with_bias=True),
+        }
+        if N % 256 == 0 and N >= 512:
+            cases["swiglu"] = lambda: ops.gemm_nt_swiglu(a, w, bias)
+        fails = []
+        try:
+            for mode in ("persistent", "tile"):
+                ops.set_gemm_launch_mode(mode)
+                for name, fn in cases.items():
+                    ops.set_gemm_half_lines(True)
+                    ref = [t.clone() for t in flat(fn())]
+                    ops.set_gemm_half_lines(False)
+                    got = flat(fn())
+                    if not (len(ref) == len(got) and all(torch.equal(x.view(torch.uint8), y.view(torch.uint8)) for x, y in zip(ref, got))):
+                        fails.append((name, mode))
+            ops.set_gemm_half_lines(False)
+            want = a.float() @ w.float().T + bias
+            err = float((ops.gemm_nt(a, w, bias).float() - want).norm() / want.norm())
+        finally:
+            ops.set_gemm_half_lines(False)
+            ops.set_gemm_launch_mode("persistent")
+        ok = not fails and err < 1e-2
+        bad += not ok
+        print(f"{i:3d}  M {M:6d} N {N:5d} K {K:5d}  {'ok' if ok else 'FAIL ' + str(fails)}  rel err vs f32 {err:.2e}", flush=True)
+    print(f"{n - bad} / {n} shapes bitwise equal on all epilogues and launch modes")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
