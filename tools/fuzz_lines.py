@@ -15,7 +15,34 @@ from ldmae_amd import ops  # noqa: E402
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+def main_f16(n, rnd):
+    """fp16 instantiation (no half-line twin): every forward epilogue against f32 torch arithmetic on the same fp16 operands."""
+    F16 = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(6)
+    bad = 0
+    rel = lambda x, y: float((x.float() - y).norm() / y.norm())      # noqa: E731
+    for i in range(n):
+        M = 8 * rnd.choice([1, 2, 31, 33, 64, 257, 513, 2049, rnd.randint(1, 4000)])
+        N = 8 * rnd.choice([1, 3, 24, 32, 33, 72, 96, 288, rnd.randint(1, 400)])
+        K = 64 * rnd.choice([1, 2, 3, 4, 12, 18, rnd.randint(1, 40)])
+        a = torch.randn(M, K, device="cuda", generator=g).to(F16)
+        w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(F16)
+        bias, xin = torch.randn(N, device="cuda", generator=g), torch.randn(M, N, device="cuda", generator=g)
+        y = a.float() @ w.float().T + bias
+        errs = {"bias": rel(ops.gemm_nt(a, w, bias), y), "bias_f32out": rel(ops.gemm_nt(a, w, bias, out_dtype=F32), y),
+                "gate_res": rel(ops.gemm_nt_gate_res(a, w, bias, xin, None, M, save_y=False, y_dtype=F32)[0], xin + y),
+                "gelu": rel(ops.gemm_nt_gelu(a, w, bias, save_pre=False)[0], torch.nn.functional.gelu(y))}
+        ok = all(e < 1.5e-3 for e in errs.values())
+        bad += not ok
+        print(f"{i:3d}  M {M:6d} N {N:5d} K {K:5d}  {'ok' if ok else 'FAIL'}  " + "  ".join(f"{k} {v:.1e}" for k, v in errs.items()), flush=True)
+    print(f"{n - bad} / {n} fp16 shapes within 1.5e-3 of the f32 arithmetic on every epilogue")
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if "--f16" in sys.argv:
+        sys.argv.remove("--f16")
+        return main_f16(int(sys.argv[1]) if len(sys.argv) > 1 else 40, random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     g = torch.Generator(device="cuda").manual_seed(5)
