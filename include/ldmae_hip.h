@@ -286,6 +286,15 @@ long ldmae_conv3x3_bwd_workspace_bytes(int C);
 int ldmae_conv3x3_bwd(const float* dout, const float* x, const float* w, float* dx, float* dw, float* db, int B, int C, int H, int W,
                       float* workspace, void* stream);
 
+/* The masked / visible reconstruction loss of forward_loss (models_mae.py:733-754) in IMAGE space: pred_img = the smoothing conv's output
+ * [B,C,H,W] f32, imgs the input images, mask [B, (H/p)*(W/p)] f32 (1 = masked).  fwd: partials [ldmae_mae_loss_groups(B*C*H*W)][2] =
+ * per-workgroup (sum over masked patches' pixels of d^2, the same over visible ones); the caller adds the rows and divides by p*p*C * patch
+ * count.  bwd: dpred_img = 2 d (coef[0] mask + coef[1] (1 - mask)), coef on the device.  norm_pix_loss targets stay in torch. */
+long ldmae_mae_loss_groups(long elements);
+int ldmae_mae_loss_fwd(const float* pred_img, const float* imgs, const float* mask, float* partials, int B, int C, int H, int W, int p, void* stream);
+int ldmae_mae_loss_bwd(const float* pred_img, const float* imgs, const float* mask, const float* coef, float* dpred_img, int B, int C, int H, int W,
+                       int p, void* stream);
+
 /* ---- optional per-kernel timing hook used by bench.py for the roofline line ------------------- */
 /* When enabled, ldmae_gemm_nt brackets each launch with HIP events on the launch stream. */
 int ldmae_prof_enable(int on);

@@ -84,6 +84,9 @@ SIGNATURES = {
     "ldmae_layernorm_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "ldmae_layernorm_bwd_workspace_bytes": (_l, [_i, _i]),
     "ldmae_layernorm_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
+    "ldmae_mae_loss_groups": (_l, [_l]),
+    "ldmae_mae_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ldmae_mae_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ldmae_layernorm_bwd_cast": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
     "ldmae_gelu_fwd": (_i, [_i, _vp, _vp, _l, _vp]),
     "ldmae_gelu_bwd": (_i, [_i, _vp, _vp, _vp, _l, _vp]),

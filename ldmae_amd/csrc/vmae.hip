@@ -432,6 +432,68 @@ extern "C" int ldmae_conv3x3(const float* x, const float* w, const float* b, flo
   return LDMAE_OK;
 }
 
+// ------------------------------------------------------------------ masked / visible reconstruction loss in IMAGE space (models_mae.py:733-754)
+// forward_loss patchifies the target, takes the per-patch mean of (pred - target)^2 and averages it over the masked and over the visible
+// patches.  Every patch has the same number of elements, so both numbers are weighted sums over PIXELS: sum_m = sum mask[patch(pixel)] d^2,
+// sum_v = sum (1 - mask) d^2, with d taken between the smoothing conv's output image and the input image -- no patchify of either, no
+// [B, L, p*p*3] temporaries (the torch formulation was ~20 elementwise / reduce / permute launches per step with its backward).
+// fwd: per-workgroup partial sums [G][2] (fixed order; the caller adds the G rows); bwd: dpred_img = 2 d (cm mask + cv (1 - mask)) with the two
+// coefficients read from the device (upstream gradient / (elements per patch * patch count): no host round trip).
+__global__ __launch_bounds__(256) void mae_loss_fwd_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ mask,
+                                                           float* __restrict__ P, long n4, int C, int Hh, int Ww, int p) {
+  __shared__ float red[4][2];
+  const int W4 = Ww >> 2, gw = Ww / p;
+  float am = 0.f, av = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const int x0 = (int)(i % W4) * 4, yy = (int)((i / W4) % Hh);
+    const long b = i / ((long)W4 * Hh * C);
+    const float m = mask[b * (long)(Hh / p) * gw + (yy / p) * gw + x0 / p];           // (p % 4 == 0: the four pixels share a patch)
+    const float4 a = *(const float4*)(x + i * 4), c = *(const float4*)(t + i * 4);
+    const float d0 = a.x - c.x, d1 = a.y - c.y, d2 = a.z - c.z, d3 = a.w - c.w;
+    const float ss = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    am += m * ss; av += (1.f - m) * ss;
+  }
+  am = wave_sum(am); av = wave_sum(av);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = am; red[threadIdx.x >> 6][1] = av; }
+  __syncthreads();
+  if (threadIdx.x < 2) P[(size_t)blockIdx.x * 2 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void mae_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ t, const float* __restrict__ mask,
+                                                           const float* __restrict__ coef, float* __restrict__ dx, long n4, int C, int Hh, int Ww, int p) {
+  const int W4 = Ww >> 2, gw = Ww / p;
+  const float cm = coef[0], cv = coef[1];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const int x0 = (int)(i % W4) * 4, yy = (int)((i / W4) % Hh);
+    const long b = i / ((long)W4 * Hh * C);
+    const float m = mask[b * (long)(Hh / p) * gw + (yy / p) * gw + x0 / p];
+    const float k = 2.f * (cm * m + cv * (1.f - m));
+    const float4 a = *(const float4*)(x + i * 4), c = *(const float4*)(t + i * 4);
+    *(float4*)(dx + i * 4) = make_float4(k * (a.x - c.x), k * (a.y - c.y), k * (a.z - c.z), k * (a.w - c.w));
+  }
+}
+static unsigned mae_loss_grid(long n4) { const long g = (n4 + 255) / 256; return (unsigned)(g < 2048 ? (g > 0 ? g : 1) : 2048); }
+extern "C" long ldmae_mae_loss_groups(long elements) { return (long)mae_loss_grid(elements / 4); }
+extern "C" int ldmae_mae_loss_fwd(const float* pred_img, const float* imgs, const float* mask, float* partials, int B, int C, int H, int W, int p,
+                                  void* stream) {
+  LDMAE_REQUIRE(pred_img && imgs && mask && partials && B > 0 && C > 0 && H > 0 && W > 0, "mae_loss_fwd: bad arguments");
+  LDMAE_REQUIRE(p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0 && (((uintptr_t)pred_img | (uintptr_t)imgs) & 15) == 0,
+                "mae_loss_fwd: patch size %d must be a multiple of 4 that divides the image (%d x %d), images 16-B aligned", p, H, W);
+  const long n4 = (long)B * C * H * W / 4;
+  hipLaunchKernelGGL(mae_loss_fwd_kernel, dim3(mae_loss_grid(n4)), dim3(256), 0, as_stream(stream), pred_img, imgs, mask, partials, n4, C, H, W, p);
+  LDMAE_CHECK_LAUNCH("mae_loss_fwd");
+  return LDMAE_OK;
+}
+extern "C" int ldmae_mae_loss_bwd(const float* pred_img, const float* imgs, const float* mask, const float* coef, float* dpred_img, int B, int C, int H,
+                                  int W, int p, void* stream) {
+  LDMAE_REQUIRE(pred_img && imgs && mask && coef && dpred_img && B > 0 && C > 0 && H > 0 && W > 0, "mae_loss_bwd: bad arguments");
+  LDMAE_REQUIRE(p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0 && (((uintptr_t)pred_img | (uintptr_t)imgs | (uintptr_t)dpred_img) & 15) == 0,
+                "mae_loss_bwd: patch size %d must be a multiple of 4 that divides the image (%d x %d), images 16-B aligned", p, H, W);
+  const long n4 = (long)B * C * H * W / 4;
+  hipLaunchKernelGGL(mae_loss_bwd_kernel, dim3(mae_loss_grid(n4)), dim3(256), 0, as_stream(stream), pred_img, imgs, mask, coef, dpred_img, n4, C, H, W, p);
+  LDMAE_CHECK_LAUNCH("mae_loss_bwd");
+  return LDMAE_OK;
+}
+
 // ------------------------------------------------------------------ backward of the 3x3 RGB smoothing conv (VMAE pre-training, engine_pretrain.py:51-76:
 // the decoder's conv_smoother is trained with everything else).  C = 3: dx is the correlation of dout with the transposed taps,
 // dw / db are 84 whole-tensor sums -> per-workgroup partials [G][C*C*9 + C] (registers -> wave shuffles -> LDS), summed in fixed order.

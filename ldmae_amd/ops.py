@@ -718,6 +718,22 @@ def conv3x3_bwd(dout, x, w, need_dx=True):
     return dx, dw, db
 
 
+def mae_loss_fwd(pred_img, imgs, mask, p):
+    """-> [2] f32 on the device: (sum over masked patches' pixels of (pred - img)^2, the same over visible patches)."""
+    B, C, Hh, Ww = imgs.shape
+    G = L.load().ldmae_mae_loss_groups(imgs.numel())
+    part = torch.empty(G, 2, dtype=torch.float32, device=imgs.device)
+    call("ldmae_mae_loss_fwd", ptr(_c(pred_img)), ptr(_c(imgs)), ptr(_c(mask)), ptr(part), B, C, Hh, Ww, int(p), stream())
+    return part.sum(0)
+
+
+def mae_loss_bwd(pred_img, imgs, mask, coef, p):
+    B, C, Hh, Ww = imgs.shape
+    d = torch.empty_like(pred_img)
+    call("ldmae_mae_loss_bwd", ptr(_c(pred_img)), ptr(_c(imgs)), ptr(_c(mask)), ptr(_c(coef)), ptr(d), B, C, Hh, Ww, int(p), stream())
+    return d
+
+
 def layernorm_fwd(x, w, b, out_dtype, eps=1e-6):
     M, D = x.shape
     out = torch.empty(M, D, dtype=out_dtype, device=x.device)

@@ -254,6 +254,29 @@ class _Conv3x3Fn(torch.autograd.Function):
         return dx, dw, db
 
 
+class _MaeLossFn(torch.autograd.Function):
+    """forward_loss (:733-754) without norm_pix_loss, in IMAGE space: (mask_loss, visible_loss) from the smoothing conv's output image, the input
+    images and the patch mask -- all patches have p*p*C elements, so the two means over patches are weighted sums over pixels (csrc/vmae.hip:
+    mae_loss_fwd / bwd); patch counts and the two backward coefficients stay on the device."""
+
+    @staticmethod
+    def forward(ctx, pred_img, imgs, mask, p):
+        sums = ops.mae_loss_fwd(pred_img, imgs, mask, p)
+        cm = mask.sum()
+        cnt = torch.stack([cm, mask.numel() - cm]) * float(p * p * imgs.shape[1])
+        out = sums / cnt
+        ctx.save_for_backward(pred_img, imgs, mask, cnt)
+        ctx.p = p
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, gm, gv):
+        pred_img, imgs, mask, cnt = ctx.saved_tensors
+        z = torch.zeros((), device=cnt.device)
+        coef = torch.stack([gm if gm is not None else z, gv if gv is not None else z]).float() / cnt
+        return ops.mae_loss_bwd(pred_img, imgs, mask, coef, ctx.p), None, None, None
+
+
 class _GatherFn(torch.autograd.Function):
     """torch.gather(x, 1, ids_keep) on token rows (:486)."""
 
@@ -332,14 +355,15 @@ class conv_decoder_pred(nn.Module):
         self.linear_pred = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans, bias=True)
         self.conv_smoother = nn.Conv2d(in_chans, in_chans, 3, 1, 1)
 
-    def forward(self, x):
+    def forward(self, x, return_image=False):
         h = w = int(x.shape[1] ** .5)
         x = _LinearFn.apply(x, self.linear_pred.weight, self.linear_pred.bias)
         x = x.reshape(x.shape[0], h, w, self.p, self.p, 3)
         x = torch.einsum('nhwpqc->nchpwq', x).reshape(x.shape[0], 3, h * self.p, w * self.p)
-        x = _Conv3x3Fn.apply(x, self.conv_smoother.weight, self.conv_smoother.bias)
-        x = x.reshape(x.shape[0], 3, h, self.p, w, self.p)
-        return torch.einsum('nchpwq->nhwpqc', x).reshape(x.shape[0], h * w, self.p * self.p * 3)
+        img = _Conv3x3Fn.apply(x, self.conv_smoother.weight, self.conv_smoother.bias)
+        x = img.reshape(img.shape[0], 3, h, self.p, w, self.p)
+        pred = torch.einsum('nchpwq->nhwpqc', x).reshape(x.shape[0], h * w, self.p * self.p * 3)
+        return (pred, img) if return_image else pred            # img: what the pre-training loss reads (MaskedAutoencoderViT.forward)
 
 
 class MaskedAutoencoderViT(nn.Module):
@@ -497,7 +521,7 @@ class MaskedAutoencoderViT(nn.Module):
             x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x, mask, ids_restore
 
-    def forward_decoder(self, x, ids_restore, dtype=None):
+    def forward_decoder(self, x, ids_restore, dtype=None, return_image=False):
         """:525-554 (no cls token).  `dtype`: activation type of the decoder blocks; a caller that has switched autocast off around this call
         (forward) passes the type it read BEFORE doing so -- the blocks would otherwise see "no autocast" and run their f32 kernels (the
         1024-token decoder of the pre-training step did: 250 of its 304 ms)."""
@@ -509,6 +533,8 @@ class MaskedAutoencoderViT(nn.Module):
         x = x + self.decoder_pos_embed
         x = self._run(self.decoder_blocks, x, dtype)
         x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
+        if return_image:                     # (pred, smoothed image): only with the conv_decoder_pred head
+            return self.decoder_pred(x, return_image=True)
         return self.decoder_pred(x) if not isinstance(self.decoder_pred, nn.Linear) else \
             _LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)
 
@@ -542,8 +568,15 @@ class MaskedAutoencoderViT(nn.Module):
                 kl_loss = torch.sum(kl) / kl.shape[0] / N
                 latent = (posterior.sample() if _eps is None else posterior.mean + posterior.std * _eps).permute(0, 2, 1)
             latent = _LinearFn.apply(latent.contiguous(), self.from_latent.weight, self.from_latent.bias)
-            pred = self.forward_decoder(latent, ids_restore, dtype)
-            loss, vis_loss, mask_loss = self.forward_loss(imgs, pred, mask, visible_loss_ratio)
+            pe = self.patch_embed.patch_size[0]
+            if isinstance(self.decoder_pred, conv_decoder_pred) and not self.norm_pix_loss and pe % 4 == 0 and imgs.shape[1] == 3:
+                # the loss straight from the smoothing conv's output image (no patchify of target or prediction, one kernel each way)
+                pred, pimg = self.forward_decoder(latent, ids_restore, dtype, return_image=True)
+                mask_loss, vis_loss = _MaeLossFn.apply(pimg, imgs.float().contiguous(), mask, pe)
+                loss = (1 - visible_loss_ratio) * mask_loss + visible_loss_ratio * vis_loss
+            else:
+                pred = self.forward_decoder(latent, ids_restore, dtype)
+                loss, vis_loss, mask_loss = self.forward_loss(imgs, pred, mask, visible_loss_ratio)
             if kl_loss is not None:
                 loss = loss + self.kl_loss_weight * kl_loss
         return loss, pred, mask, vis_loss, mask_loss, kl_loss

@@ -560,6 +560,25 @@ def test_conv3x3_rgb_and_its_backward(ops, shape):
     assert rel_err(dx.cpu(), x.grad) < 1e-6 and rel_err(dw.cpu(), w.grad) < 1e-5 and rel_err(db.cpu(), b.grad) < 1e-5
 
 
+def test_mae_loss_in_image_space(ops):
+    """forward_loss (models_mae.py:733-754: patchify the target, per-patch mean of the squared error, means over masked / visible patches) against the
+    image-space kernels: values and the gradient with respect to the predicted image, f64 reference."""
+    B, p, g = 3, 8, 5
+    img = rnd(B, 3, g * p, g * p, seed=1).double()
+    pred = rnd(B, 3, g * p, g * p, seed=2).double().requires_grad_(True)
+    mask = (rnd(B, g * g, seed=3) > 0.3).double()
+    patch = lambda x: torch.einsum('nchpwq->nhwpqc', x.reshape(B, 3, g, p, g, p)).reshape(B, g * g, p * p * 3)      # noqa: E731
+    loss = ((patch(pred) - patch(img)) ** 2).mean(-1)
+    ml, vl = (loss * mask).sum() / mask.sum(), (loss * (1 - mask)).sum() / (1 - mask).sum()
+    (0.7 * ml + 0.3 * vl).backward()
+    sums = ops.mae_loss_fwd(dev(pred.detach().float()), dev(img.float()), dev(mask.float()), p).cpu().double()
+    P = p * p * 3
+    assert abs(float(sums[0] / (mask.sum() * P)) - float(ml)) < 1e-6 * float(ml) and abs(float(sums[1] / ((1 - mask).sum() * P)) - float(vl)) < 1e-6 * float(vl)
+    coef = torch.tensor([0.7 / float(mask.sum() * P), 0.3 / float((1 - mask).sum() * P)], device="cuda")
+    d = ops.mae_loss_bwd(dev(pred.detach().float()), dev(img.float()), dev(mask.float()), coef, p)
+    assert rel_err(d.cpu(), pred.grad) < 1e-6
+
+
 def test_errors_are_loud(ops):
     a = torch.zeros(128, 100, device="cuda", dtype=BF16)
     with pytest.raises(RuntimeError, match="multiple of 64"):
