@@ -1829,6 +1829,8 @@ static int attention_bwd_core(int dtype, const void* q, const void* k, const voi
 #undef LR
   } else {
     LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd && Lv.ld == hd && Lv.sh == (long)N * hd, "attention_bwd(f32): head-major q/k/v only");
+    LDMAE_REQUIRE((size_t)(128 + 128 + 64 + 64) * (hd + 1) * 4 + 512 <= 160 * 1024,
+                  "attention_bwd(f32): head_dim %d needs more than the 160 KiB of LDS (f32 backward: head dims up to 72; bf16 covers 128)", hd);
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(dgrid), dim3(256), 0, st, (const float*)o, (const float*)do_, delta, B, H, N, hd);
 #define L(HD) { const size_t l1 = (size_t)(128 + 128 + 64 + 64) * (HD + 1) * 4 + 512; \
     hipFuncSetAttribute((const void*)attn_bwd_dkdv_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \

@@ -393,11 +393,29 @@ def rope(t, cos, sin, transposed=False):
     return out
 
 
+_ATTN_HDS = (16, 32, 64, 72, 128)            # head dims the attention kernels are instantiated for (csrc/attention.hip: ATTN_HD_DISPATCH)
+
+
+def _attn_pad(hd: int) -> int:
+    for h in _ATTN_HDS:
+        if h >= hd:
+            return h
+    raise RuntimeError(f"ldmae_amd attention: head_dim {hd} is above the largest instantiated kernel (128)")
+
+
 def attention_fwd(q, k, v, scale):
     """softmax(q k^T * scale) v.  q, k, v: [B,H,N,hd]; returns (o [B,N,H*hd], lse [B,H,N] f32).
     bf16 head dims that are not a multiple of 32 (LightningDiT-XL: 72, VMAE: 16) are zero-padded to the next multiple of 32
     INSIDE the kernels (LDS images and register fragments); HBM tensors keep the true head dim."""
     B, H, N, hd = q.shape
+    if hd not in _ATTN_HDS:
+        # Head dims outside the instantiated set (16, 32, 64, 72, 128) -- e.g. 24 (mae_for_ldmae_f8d16_prev_large), 80 (mae_vit_huge), 8: zero
+        # columns add nothing to q . k and produce zero output columns, so the next larger kernel on zero-padded copies is exact (`scale` is
+        # the caller's, from the true head dim).  Costs the copies; the shipped archs never come here.
+        P = _attn_pad(hd)
+        pad = lambda t: torch.nn.functional.pad(t, (0, P - hd))      # noqa: E731
+        o, lse = attention_fwd(pad(q), pad(k), pad(v), scale)
+        return o.view(B, N, H, P)[..., :hd].reshape(B, N, H * hd), lse
     o = torch.empty(B, N, H * hd, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
     call("ldmae_attention_fwd", dt(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, H, N, hd, float(scale), stream())
@@ -406,6 +424,11 @@ def attention_fwd(q, k, v, scale):
 
 def attention_bwd(q, k, v, o, do, lse, scale):
     B, H, N, hd = q.shape
+    if hd not in _ATTN_HDS:                                   # head dims the kernels are not instantiated for: zero-padded (see attention_fwd)
+        P = _attn_pad(hd)
+        pad, padt = (lambda t: torch.nn.functional.pad(t, (0, P - hd))), (lambda t: torch.nn.functional.pad(t.reshape(B, N, H, hd), (0, P - hd)).reshape(B, N, H * P))
+        dq, dk, dv = attention_bwd(pad(q), pad(k), pad(v), padt(o), padt(_c(do)), lse, scale)
+        return dq[..., :hd].contiguous(), dk[..., :hd].contiguous(), dv[..., :hd].contiguous()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     delta = torch.empty(2, B, H, (N + 63) // 64 * 64, dtype=torch.float32, device=q.device)      # rows padded to whole 64-row tiles
     call("ldmae_attention_bwd", dt(q.dtype), ptr(q), ptr(k), ptr(v), ptr(o), ptr(_c(do)), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta),
@@ -468,6 +491,8 @@ def attention_fwd_qkv(qkv, B, N, H, hd, scale):
     Long sequences of small heads (the 1024-token VMAE decoder: the kernel is bound by vector issue) first take one pass over the k slots
     for max |k|^2 per (image, head): with each query's own norm it bounds the scores, and the softmax runs with that static shift instead of
     a running maximum (same result; ldmae_k_norm_max + ldmae_attention_fwd_qkv_bounded)."""
+    if hd not in _ATTN_HDS:                                   # (see attention_fwd: head-major zero-padded copies)
+        return attention_fwd(*heads_split(qkv, B, N, H, hd), scale)
     o = torch.empty(B, N, H * hd, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
     if qkv.dtype == torch.bfloat16 and hd <= 32 and N >= 512 and B * H * N * N >= BOUNDED_ATTENTION_MIN_SCORES:
@@ -481,6 +506,9 @@ def attention_fwd_qkv(qkv, B, N, H, hd, scale):
 
 def attention_bwd_qkv(qkv, o, do, lse, B, N, H, hd, scale):
     """-> dqkv [B*N, 3*H*hd] (dq / dk / dv written in the packed layout)."""
+    if hd not in _ATTN_HDS:                                   # (see attention_fwd: head-major zero-padded copies)
+        q, k, v = heads_split(qkv, B, N, H, hd)
+        return heads_merge(*attention_bwd(q, k, v, o, do, lse, scale), B, N, H, hd)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(2, B, H, (N + 63) // 64 * 64, dtype=torch.float32, device=qkv.device)
     call("ldmae_attention_bwd_qkv", dt(qkv.dtype), ptr(qkv), ptr(o), ptr(_c(do)), ptr(lse), ptr(dqkv), ptr(delta), B, H, N, hd, float(scale), stream())

@@ -119,6 +119,44 @@ def test_masked_encoder_gradients_vs_oracle(ratio):
             assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 6e-2, k
 
 
+def test_head_dim_24_arch_pretraining_step_vs_oracle():
+    """mae_for_ldmae_f8d16_prev_large's geometry (384 wide, 16 heads of 24: a head dim the attention kernels are not instantiated for -- they run
+    on zero-padded heads, ops.attention_fwd) at depth 1: loss and every parameter gradient of the pre-training step against the oracle in f32,
+    and bf16 autocast close to it."""
+    cfg = omae.MAEConfig(img_size=64, embed_dim=384, num_heads=16, depth=1, decoder_embed_dim=384, decoder_num_heads=16, decoder_depth=1)
+    sd = full_sd(cfg, seed=8)
+    from ldmae_amd.tokenizer import models_mae
+    m = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=8, embed_dim=384, depth=1, num_heads=16, decoder_embed_dim=384, decoder_depth=1,
+                                        decoder_num_heads=16, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
+                                        kl_loss_weight=1e-3, smooth_output=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    imgs = det_randn("img64p", (2, 3, 64, 64), 4).clamp(-1, 1)
+    noise = torch.rand(2, 64, generator=torch.Generator().manual_seed(9))
+    eps = det_randn("peps24", (2, 16, 16), 5)
+    keys = [k for k in omae.param_shapes(cfg)]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    osd = dict(sd)
+    osd.update(leaves)
+    ol = omae.forward_vanilla(osd, imgs, noise, eps, 0.75, 0.5, 1e-3, cfg)[0]
+    ol.backward()
+    loss = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())[0]
+    assert abs(float(loss) - float(ol)) < 1e-4 * abs(float(ol))
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k in keys:
+        assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 2e-4, k
+    m.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss16 = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())[0]
+    loss16.backward()
+    assert abs(float(loss16) - float(ol)) < 2e-2 * abs(float(ol))
+    assert rel_err(params["blocks.0.attn.qkv.weight"].grad.cpu(), leaves["blocks.0.attn.qkv.weight"].grad) < 8e-2
+    with torch.no_grad():                                        # docking calls of the same arch
+        rec = m.decode(m._encode(imgs.cuda())[:, :16]).sample
+    assert rec.shape == (2, 3, 64, 64) and bool(torch.isfinite(rec).all())
+
+
 def test_pretraining_step_loss_and_all_grads_vs_oracle():
     """SURVEY 8(f)4 minimal slice: the VMAE pre-training forward (masked encoder -> KL posterior -> decoder with mask tokens and the
     RGB smoothing conv -> masked / visible loss, models_mae.py:733-790) and EVERY parameter gradient against torch autograd on the
