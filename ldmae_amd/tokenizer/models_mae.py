@@ -7,8 +7,8 @@ fc1 GEMM + exact GELU, fc2 GEMM + residual) -> LayerNorm.  Each block is one aut
 kernel sequences).  head_dim is 16: under bf16 autocast the attention core is the bf16 flash kernel with the K/V images and
 fragments zero-padded to 32 columns in LDS / registers (attention.hip); in f32 mode everything runs on the exact-f32 MFMA path.
 The decoder / ``encode`` / ``decode`` / ``decode_to_images`` docking functions re-use the same block kernels
-(inference only for the RGB smoothing conv).  Unshipped variants (gradual_resol, down_nonlinear, cls token,
-pred_with_conv, perceptual loss) raise NotImplementedError.
+(inference only for the RGB smoothing conv).  Unshipped variants (gradual_resol, cls token, pred_with_conv, perceptual loss) raise
+NotImplementedError; `down_nonlinear` (MLP latent maps of the f8d16 / f8d16_flexible archs) is implemented.
 """
 from __future__ import annotations
 
@@ -343,6 +343,24 @@ class Block(nn.Module):
                                  self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
 
 
+class MLP_dim_resize(nn.Module):
+    """:232-242 -- to_latent / from_latent of the `down_nonlinear` archs (mae_for_ldmae_f8d16, _flexible): Linear -> exact GELU -> Linear, hidden
+    width 4 * latent_dim.  The two Linears run on the GEMM kernels (_LinearFn); the GELU between them acts on [tokens, 64] and stays in torch."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Linear(input_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, output_dim))
+
+    def forward(self, x):
+        h = torch.nn.functional.gelu(_LinearFn.apply(x, self.layers[0].weight, self.layers[0].bias))
+        return _LinearFn.apply(h, self.layers[2].weight, self.layers[2].bias)
+
+
+def _latent_map(mod, x):
+    """to_latent / from_latent: a plain Linear (:316-317) or MLP_dim_resize (:311-314)."""
+    return mod(x) if isinstance(mod, MLP_dim_resize) else _LinearFn.apply(x, mod.weight, mod.bias)
+
+
 class conv_decoder_pred(nn.Module):
     """:244-281 with pred_with_conv=False: linear -> unpatchify -> 3x3 conv on RGB -> patchify."""
 
@@ -374,13 +392,17 @@ class MaskedAutoencoderViT(nn.Module):
                  ldmae_mode=False, scaling_factor=0.9654248952865601, no_cls=True, gradual_resol=False, finetune_downsample_layer=None,
                  down_nonlinear=False, kl_loss_weight=None, smooth_output=False, pred_with_conv=False, perceptual_loss=None):
         super().__init__()
-        if gradual_resol or down_nonlinear or not no_cls or perceptual_loss is not None:
-            raise NotImplementedError("ldmae_amd MaskedAutoencoderViT: gradual_resol / down_nonlinear / cls token / perceptual loss are "
+        if gradual_resol or not no_cls or perceptual_loss is not None:
+            raise NotImplementedError("ldmae_amd MaskedAutoencoderViT: gradual_resol / cls token / perceptual loss are "
                                       "not used by the shipped tokenizer (mae_for_ldmae_f8d16_prev, inference.py:133-137)")
         self.perceptual_loss, self.smooth_output, self.gradual_resol, self.kl_loss_weight = None, smooth_output, False, kl_loss_weight
         enc_lat = 2 * latent_dim if kl_loss_weight is not None else latent_dim
-        self.to_latent = nn.Linear(embed_dim, enc_lat)
-        self.from_latent = nn.Linear(latent_dim, decoder_embed_dim)
+        if down_nonlinear:                                   # :311-314 (from_latent ends at EMBED_dim; decoder_embed then maps it to the decoder width)
+            self.to_latent = MLP_dim_resize(embed_dim, latent_dim * 4, enc_lat)
+            self.from_latent = MLP_dim_resize(latent_dim, latent_dim * 4, embed_dim)
+        else:
+            self.to_latent = nn.Linear(embed_dim, enc_lat)
+            self.from_latent = nn.Linear(latent_dim, decoder_embed_dim)
         self.config = Config(scaling_factor=scaling_factor)
         self.ldmae_mode, self.img_size, self.patch_size = ldmae_mode, img_size, patch_size
         self.latent_resolution = img_size // patch_size
@@ -559,7 +581,7 @@ class MaskedAutoencoderViT(nn.Module):
         dtype = _act_dtype(self.precision, allow_f16=True)           # read before autocast is switched off below
         latent, mask, ids_restore = self.forward_encoder(imgs, mask_ratio, noise=_noise)
         with torch.autocast(device_type="cuda", enabled=False):
-            latent = _LinearFn.apply(latent, self.to_latent.weight, self.to_latent.bias)
+            latent = _latent_map(self.to_latent, latent)
             kl_loss = None
             if self.kl_loss_weight is not None:
                 B, N, D = latent.shape
@@ -567,7 +589,7 @@ class MaskedAutoencoderViT(nn.Module):
                 kl = posterior.kl()
                 kl_loss = torch.sum(kl) / kl.shape[0] / N
                 latent = (posterior.sample() if _eps is None else posterior.mean + posterior.std * _eps).permute(0, 2, 1)
-            latent = _LinearFn.apply(latent.contiguous(), self.from_latent.weight, self.from_latent.bias)
+            latent = _latent_map(self.from_latent, latent.contiguous())
             pe = self.patch_embed.patch_size[0]
             if isinstance(self.decoder_pred, conv_decoder_pred) and not self.norm_pix_loss and pe % 4 == 0 and imgs.shape[1] == 3:
                 # the loss straight from the smoothing conv's output image (no patchify of target or prediction, one kernel each way)
@@ -594,7 +616,7 @@ class MaskedAutoencoderViT(nn.Module):
             else:
                 x = self._run(self.blocks, x, dtype)
                 x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
-            x = _LinearFn.apply(x, self.to_latent.weight, self.to_latent.bias)
+            x = _latent_map(self.to_latent, x)
         g = self.latent_resolution
         return x.reshape(x.shape[0], g, g, -1).permute(0, 3, 1, 2)
 
@@ -608,7 +630,7 @@ class MaskedAutoencoderViT(nn.Module):
         with torch.autocast(device_type="cuda", enabled=False):
             B = z.shape[0]
             x = z.float().permute(0, 2, 3, 1).reshape(B, -1, z.shape[1]).contiguous()
-            x = _LinearFn.apply(x, self.from_latent.weight, self.from_latent.bias)
+            x = _latent_map(self.from_latent, x)
             x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias) + self.decoder_pos_embed
             if (self.fused_encoder and dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled() and
                     fused_encoder.supported(self, x.shape[1], x.shape[2], tiled=True, which="dec") and
@@ -687,8 +709,8 @@ def mae_for_ldmae_f16d32(**kwargs):
                                 decoder_num_heads=12, mlp_ratio=4, norm_layer=_ln(), latent_dim=32, **kwargs)
 
 
-# The rest of the reference's registry (:1006-1083), as thin entries over the same class: geometries only.  `down_nonlinear` (the f8d16 /
-# f8d16_flexible archs) is a flag the class does not implement -- those two raise NotImplementedError naming it, from the constructor.
+# The rest of the reference's registry (:1006-1083), as thin entries over the same class: geometries only.  The f8d16 / f8d16_flexible archs
+# (`down_nonlinear`: MLP_dim_resize latent maps; 384-wide decoder with 24 heads of 16) run on the per-layer kernels.
 def mae_for_ldmae_f8d16(**kwargs):
     return MaskedAutoencoderViT(patch_size=8, embed_dim=192, depth=12, num_heads=12, decoder_embed_dim=384, decoder_depth=12,
                                 decoder_num_heads=24, mlp_ratio=4, norm_layer=_ln(), latent_dim=16, down_nonlinear=True, **kwargs)

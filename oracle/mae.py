@@ -30,6 +30,7 @@ class MAEConfig:
     kl: bool = True            # kl_loss_weight is not None -> encoder predicts mean & logvar (:300-303)
     ldmae_mode: bool = False   # False -> decoder owns a learnable mask_token (:380-381)
     ln_eps: float = 1e-6
+    down_nonlinear: bool = False   # to_latent / from_latent = MLP_dim_resize (Linear -> GELU -> Linear, hidden 4*latent; models_mae.py:232-242, 311-314)
 
     @property
     def grid(self):
@@ -124,13 +125,21 @@ def forward_encoder(sd, imgs, noise, mask_ratio, cfg: MAEConfig):
     return x, mask, ids_restore
 
 
+def latent_map(sd, x, name):
+    """to_latent / from_latent: a Linear (models_mae.py:316-317) or, with down_nonlinear, MLP_dim_resize (:232-242: Linear -> exact GELU -> Linear)."""
+    if name + ".weight" in sd:
+        return F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
+    h = F.gelu(F.linear(x, sd[name + ".layers.0.weight"], sd[name + ".layers.0.bias"]))
+    return F.linear(h, sd[name + ".layers.2.weight"], sd[name + ".layers.2.bias"])
+
+
 def encode_moments(sd, imgs, cfg: MAEConfig):
     """models_mae.py:819-838 (_encode): full-sequence encoder -> to_latent -> [B, 2*latent, h, w]."""
     x = patch_embed(sd, imgs, cfg)
     for i in range(cfg.depth):
         x = mae_block(sd, f"blocks.{i}.", x, cfg.num_heads, cfg.ln_eps)
     x = F.layer_norm(x, (cfg.embed_dim,), sd["norm.weight"], sd["norm.bias"], cfg.ln_eps)
-    x = F.linear(x, sd["to_latent.weight"], sd["to_latent.bias"])
+    x = latent_map(sd, x, "to_latent")
     B = x.shape[0]
     return x.reshape(B, cfg.grid, cfg.grid, -1).permute(0, 3, 1, 2)
 
@@ -151,7 +160,7 @@ def decode(sd, z, cfg: MAEConfig):
     """models_mae.py:865-887: latent [B, latent, h, w] -> image [B, 3, H, W]."""
     B = z.shape[0]
     x = z.permute(0, 2, 3, 1).reshape(B, cfg.num_patches, -1)
-    x = F.linear(x, sd["from_latent.weight"], sd["from_latent.bias"])
+    x = latent_map(sd, x, "from_latent")
     x = F.linear(x, sd["decoder_embed.weight"], sd["decoder_embed.bias"]) + sd["decoder_pos_embed"]
     for i in range(cfg.decoder_depth):
         x = mae_block(sd, f"decoder_blocks.{i}.", x, cfg.decoder_num_heads, cfg.ln_eps)
@@ -174,7 +183,7 @@ def forward_vanilla(sd, imgs, noise, eps, mask_ratio, visible_loss_ratio, kl_los
     random draws supplied by the caller: `noise` [B, L] (random_masking, :480) and `eps` [B, latent, kept] (posterior.sample,
     util/misc.py:87-96).  Returns (loss, pred, mask, vis_loss, mask_loss, kl_loss)."""
     latent, mask, ids_restore = forward_encoder(sd, imgs, noise, mask_ratio, cfg)
-    latent = F.linear(latent, sd["to_latent.weight"], sd["to_latent.bias"])
+    latent = latent_map(sd, latent, "to_latent")
     B, N, D = latent.shape
     mom = latent.permute(0, 2, 1)                                     # B D HW
     mean, logvar = torch.chunk(mom, 2, dim=1)
@@ -182,7 +191,7 @@ def forward_vanilla(sd, imgs, noise, eps, mask_ratio, visible_loss_ratio, kl_los
     kl = 0.5 * torch.sum(mean ** 2 + torch.exp(logvar) - 1.0 - logvar, dim=[1, 2])     # misc.py:98-107
     kl_loss = torch.sum(kl) / kl.shape[0] / N
     latent = (mean + torch.exp(0.5 * logvar) * eps).permute(0, 2, 1)
-    x = F.linear(latent, sd["from_latent.weight"], sd["from_latent.bias"])
+    x = latent_map(sd, latent, "from_latent")
     x = F.linear(x, sd["decoder_embed.weight"], sd["decoder_embed.bias"])
     mask_tokens = sd["mask_token"].repeat(x.shape[0], ids_restore.shape[1] - x.shape[1], 1)
     x_ = torch.cat([x, mask_tokens], dim=1)
@@ -218,11 +227,20 @@ def param_shapes(cfg: MAEConfig, with_decoder: bool = True) -> dict:
                 pre + "mlp.fc2.weight": (d, hm), pre + "mlp.fc2.bias": (d,)}
     for i in range(cfg.depth):
         s.update(blk(f"blocks.{i}.", D, Hm))
-    s.update({"norm.weight": (D,), "norm.bias": (D,),
-              "to_latent.weight": (enc_lat, D), "to_latent.bias": (enc_lat,)})
+    s.update({"norm.weight": (D,), "norm.bias": (D,)})
+    hid = 4 * cfg.latent_dim
+    if cfg.down_nonlinear:              # MLP_dim_resize(embed_dim, 4 latent, enc_lat) / (latent, 4 latent, EMBED_dim) (:313-314)
+        s.update({"to_latent.layers.0.weight": (hid, D), "to_latent.layers.0.bias": (hid,),
+                  "to_latent.layers.2.weight": (enc_lat, hid), "to_latent.layers.2.bias": (enc_lat,)})
+    else:
+        s.update({"to_latent.weight": (enc_lat, D), "to_latent.bias": (enc_lat,)})
     if with_decoder:
-        s.update({"from_latent.weight": (Dd, cfg.latent_dim), "from_latent.bias": (Dd,),
-                  "decoder_embed.weight": (Dd, D), "decoder_embed.bias": (Dd,)})
+        if cfg.down_nonlinear:
+            s.update({"from_latent.layers.0.weight": (hid, cfg.latent_dim), "from_latent.layers.0.bias": (hid,),
+                      "from_latent.layers.2.weight": (D, hid), "from_latent.layers.2.bias": (D,)})
+        else:
+            s.update({"from_latent.weight": (Dd, cfg.latent_dim), "from_latent.bias": (Dd,)})
+        s.update({"decoder_embed.weight": (Dd, D), "decoder_embed.bias": (Dd,)})
         if not cfg.ldmae_mode:
             s["mask_token"] = (1, 1, Dd)
         for i in range(cfg.decoder_depth):

@@ -143,22 +143,23 @@ def test_image_folder_order_and_labels(tmp_path):
 
 
 def test_mae_arch_registry_has_every_reference_constructor():
-    """tokenizer/models_mae.py:977-1083: sixteen constructor names + four aliases.  All build (on the meta device: geometry only) except the
-    two `down_nonlinear` archs, which raise naming the flag."""
-    import pytest
+    """tokenizer/models_mae.py:977-1083: sixteen constructor names + four aliases.  All build (on the meta device: geometry only); the two
+    `down_nonlinear` archs carry MLP_dim_resize latent maps with the reference's state-dict keys (:232-242, 311-314)."""
     from ldmae_amd.tokenizer import models_mae as mm
     names = ["mae_for_ldmae", "mae_for_ldmae_f8d32", "mae_for_ldmae_f8d16_prev", "mae_for_ldmae_f8d16_prev_large", "mae_for_ldmae_f8d16",
              "mae_for_ldmae_f8d16_flexible", "mae_for_ldmae_f16d32", "mae_for_ldmae_f16d32_large", "mae_for_ldmae_f8d32_flexible", "mae_for_ldmae_16d",
              "mae_vit_base_patch16_dec512d8b", "mae_vit_base_patch16_dec128d8b", "mae_vit_large_patch16_dec512d8b", "mae_vit_huge_patch14_dec512d8b",
              "mae_vit_base_patch16", "mae_vit_large_patch16", "mae_vit_huge_patch14", "mae_vit_base_patch16_128"]
     geo = {"mae_for_ldmae_f16d32_large": (384, 12, 384, 64), "mae_vit_base_patch16_dec128d8b": (768, 12, 128, 196), "mae_vit_large_patch16": (1024, 24, 512, 196),
-           "mae_for_ldmae_f8d16_prev": (192, 12, 192, 784)}
+           "mae_for_ldmae_f8d16_prev": (192, 12, 192, 784), "mae_for_ldmae_f8d16": (192, 12, 384, 784)}
     for n in names:
         f = getattr(mm, n)
         if n in ("mae_for_ldmae_f8d16", "mae_for_ldmae_f8d16_flexible"):
-            with pytest.raises(NotImplementedError, match="down_nonlinear"):
-                f()
-            continue
+            m = f(kl_loss_weight=1e-6)
+            sd = m.state_dict()
+            assert sd["to_latent.layers.0.weight"].shape == (64, 192) and sd["to_latent.layers.2.weight"].shape == (32, 64)
+            assert sd["from_latent.layers.0.weight"].shape == (64, 16) and sd["from_latent.layers.2.weight"].shape == (192, 64)
+            assert sd["decoder_embed.weight"].shape == (384, 192) and m.decoder_blocks[0].attn.num_heads == 24
         if n in geo:
             with torch.device("meta"):
                 try:

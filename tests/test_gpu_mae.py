@@ -157,6 +157,40 @@ def test_head_dim_24_arch_pretraining_step_vs_oracle():
     assert rec.shape == (2, 3, 64, 64) and bool(torch.isfinite(rec).all())
 
 
+def test_down_nonlinear_wide_decoder_arch_vs_oracle():
+    """mae_for_ldmae_f8d16's geometry (models_mae.py:1006-1011: 192-wide encoder, 384-wide decoder with 24 heads of 16, MLP_dim_resize latent
+    maps) at depth 1: the pre-training step (loss, every gradient) and the docking encode / decode against the oracle in f32."""
+    cfg = omae.MAEConfig(img_size=64, depth=1, decoder_embed_dim=384, decoder_num_heads=24, decoder_depth=1, down_nonlinear=True)
+    sd = full_sd(cfg, seed=9)
+    from ldmae_amd.tokenizer import models_mae
+    m = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=8, embed_dim=192, depth=1, num_heads=12, decoder_embed_dim=384, decoder_depth=1,
+                                        decoder_num_heads=24, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
+                                        kl_loss_weight=1e-3, smooth_output=True, down_nonlinear=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    imgs = det_randn("img64d", (2, 3, 64, 64), 4).clamp(-1, 1)
+    noise = torch.rand(2, 64, generator=torch.Generator().manual_seed(9))
+    eps = det_randn("pepsd", (2, 16, 16), 5)
+    keys = [k for k in omae.param_shapes(cfg)]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    osd = dict(sd)
+    osd.update(leaves)
+    ol = omae.forward_vanilla(osd, imgs, noise, eps, 0.75, 0.5, 1e-3, cfg)[0]
+    ol.backward()
+    loss = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())[0]
+    assert abs(float(loss) - float(ol)) < 1e-4 * abs(float(ol))
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k in keys:
+        assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 2e-4, k
+    with torch.no_grad():
+        mom = m.eval()._encode(imgs.cuda())
+        rec = m.decode(mom[:, :16]).sample
+        omom = omae.encode_moments(sd, imgs, cfg)
+        orec = omae.decode(sd, omom[:, :16], cfg)
+    assert rel_err(mom.cpu(), omom) < 1e-4 and rel_err(rec.cpu(), orec) < 1e-4
+
+
 def test_pretraining_step_loss_and_all_grads_vs_oracle():
     """SURVEY 8(f)4 minimal slice: the VMAE pre-training forward (masked encoder -> KL posterior -> decoder with mask tokens and the
     RGB smoothing conv -> masked / visible loss, models_mae.py:733-790) and EVERY parameter gradient against torch autograd on the
