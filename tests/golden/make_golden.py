@@ -327,6 +327,55 @@ def gen_mae_train(out):
         misc.randn_tensor = orig
 
 
+def gen_mae_archs(out):
+    """The registry's other geometries, pinned on the reference itself at depth 1 / 64 px (f32, eager; same recording of the two random draws
+    as gen_mae_train): 'dn' = mae_for_ldmae_f8d16 (:1006-1011: down_nonlinear MLP_dim_resize latent maps, 384-wide decoder with 24 heads of 16),
+    'h24' = mae_for_ldmae_f8d16_prev_large (:999-1004: 384 wide, 16 heads of 24)."""
+    from functools import partial
+    sys.path.insert(0, os.path.join(REF, "tokenizer"))
+    from tokenizer import models_mae
+    misc = sys.modules[models_mae.DiagonalGaussianDistribution.__module__]
+    archs = {"dn": (dict(embed_dim=192, num_heads=12, decoder_embed_dim=384, decoder_num_heads=24, down_nonlinear=True), 9, "img64d", "pepsd"),
+             "h24": (dict(embed_dim=384, num_heads=16, decoder_embed_dim=384, decoder_num_heads=16), 8, "img64p", "peps24")}
+    captured = []
+    orig = misc.randn_tensor
+
+    def spy(*a, **k):
+        t = orig(*a, **k)
+        captured.append(t.detach().clone())
+        return t
+    misc.randn_tensor = spy
+    try:
+        for tag, (kw, seed, iname, _) in archs.items():
+            m = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=8, depth=1, decoder_depth=1, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                                latent_dim=16, no_cls=True, kl_loss_weight=1e-3, smooth_output=True, **kw)
+            load_det(m, seed=seed, skip=("pos_embed", "decoder_pos_embed"))
+            m.train()
+            imgs = det_randn(iname, (2, 3, 64, 64), 4).clamp(-1, 1)
+            captured.clear()
+            torch.manual_seed(78)
+            noise = torch.rand(2, 64)
+            assert (np.diff(np.sort(noise.numpy(), axis=1), axis=1) > 0).all(), "noise has ties; pick another seed"
+            torch.manual_seed(78)
+            loss, pred, mask, vis, mask_loss, kl = m(imgs, 0.75, 0.5)
+            assert len(captured) == 1
+            loss.backward()
+            keys = sorted(k for k, p in m.named_parameters() if p.requires_grad)
+            out.update({f"ar_{tag}_keys": np.array(keys), f"ar_{tag}_noise": noise.numpy(), f"ar_{tag}_eps": captured[0].numpy(),
+                        f"ar_{tag}_loss": np.array([float(loss), float(vis), float(mask_loss), float(kl)], dtype=np.float64),
+                        f"ar_{tag}_mask": mask.detach().numpy(), f"ar_{tag}_pred_head": pred.detach()[:, :6, :24].numpy().copy(),
+                        f"ar_{tag}_pred_norm": np.array(float(pred.detach().double().norm())),
+                        f"ar_{tag}_grad_norms": np.array([float(dict(m.named_parameters())[k].grad.double().norm()) for k in keys], dtype=np.float64)})
+            m.eval()
+            with torch.no_grad():
+                mom = m._encode(imgs)
+                rec = m.decode(mom[:, :16]).sample
+            out.update({f"ar_{tag}_moments_head": mom[:, :, :2, :2].numpy().copy(), f"ar_{tag}_moments_norm": np.array(float(mom.double().norm())),
+                        f"ar_{tag}_rec_head": rec[:, :, :4, :4].numpy().copy(), f"ar_{tag}_rec_norm": np.array(float(rec.double().norm()))})
+    finally:
+        misc.randn_tensor = orig
+
+
 # --------------------------------------------------------------------------- 100-step loss curve, B/1 bs=4
 def gen_dataset(out):
     """the reference's own ``ImgLatentDataset`` (datasets/img_latent_dataset.py:16-93) on a tiny generated shard
@@ -455,14 +504,14 @@ def main():
     ap.add_argument("--curve", action="store_true", help="also run the 100-step B/1 bs=4 loss curve (~15 min)")
     ap.add_argument("--only-curve", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,dataset,images}")
+    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,mae_archs,dataset,images}")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     install_shims()
     sys.path.insert(0, REF)
     if not args.only_curve:
         gens = (("dit_tiny", gen_dit_tiny), ("kernels", gen_tables_and_kernels), ("mae", gen_mae), ("mae_train", gen_mae_train),
-                ("dataset", gen_dataset), ("images", gen_images))
+                ("mae_archs", gen_mae_archs), ("dataset", gen_dataset), ("images", gen_images))
         for name, fn in gens:
             if args.only and name not in args.only.split(","):
                 continue

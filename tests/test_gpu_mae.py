@@ -119,7 +119,7 @@ def test_masked_encoder_gradients_vs_oracle(ratio):
             assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 6e-2, k
 
 
-def test_head_dim_24_arch_pretraining_step_vs_oracle():
+def test_head_dim_24_arch_pretraining_step_vs_oracle(golden):
     """mae_for_ldmae_f8d16_prev_large's geometry (384 wide, 16 heads of 24: a head dim the attention kernels are not instantiated for -- they run
     on zero-padded heads, ops.attention_fwd) at depth 1: loss and every parameter gradient of the pre-training step against the oracle in f32,
     and bf16 autocast close to it."""
@@ -132,20 +132,23 @@ def test_head_dim_24_arch_pretraining_step_vs_oracle():
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
     imgs = det_randn("img64p", (2, 3, 64, 64), 4).clamp(-1, 1)
-    noise = torch.rand(2, 64, generator=torch.Generator().manual_seed(9))
-    eps = det_randn("peps24", (2, 16, 16), 5)
+    g = golden("mae_archs")                                     # the reference's own run of this geometry (make_golden.py: gen_mae_archs)
+    noise, eps = torch.from_numpy(g["ar_h24_noise"]), torch.from_numpy(g["ar_h24_eps"])
     keys = [k for k in omae.param_shapes(cfg)]
     leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
     osd = dict(sd)
     osd.update(leaves)
     ol = omae.forward_vanilla(osd, imgs, noise, eps, 0.75, 0.5, 1e-3, cfg)[0]
     ol.backward()
-    loss = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())[0]
+    loss, pred = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())[:2]
     assert abs(float(loss) - float(ol)) < 1e-4 * abs(float(ol))
+    assert abs(float(loss) - float(g["ar_h24_loss"][0])) < 1e-4 * abs(float(ol)) and rel_err(pred.detach()[:, :6, :24].cpu(), g["ar_h24_pred_head"]) < 1e-4
     loss.backward()
     params = dict(m.named_parameters())
     for k in keys:
         assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 2e-4, k
+    norms = np.array([float(params[k].grad.double().norm()) for k in sorted(keys)])
+    np.testing.assert_allclose(norms, g["ar_h24_grad_norms"], rtol=5e-4, atol=1e-8)      # ... and the reference's own gradient norms
     m.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         loss16 = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())[0]
@@ -157,7 +160,7 @@ def test_head_dim_24_arch_pretraining_step_vs_oracle():
     assert rec.shape == (2, 3, 64, 64) and bool(torch.isfinite(rec).all())
 
 
-def test_down_nonlinear_wide_decoder_arch_vs_oracle():
+def test_down_nonlinear_wide_decoder_arch_vs_oracle(golden):
     """mae_for_ldmae_f8d16's geometry (models_mae.py:1006-1011: 192-wide encoder, 384-wide decoder with 24 heads of 16, MLP_dim_resize latent
     maps) at depth 1: the pre-training step (loss, every gradient) and the docking encode / decode against the oracle in f32."""
     cfg = omae.MAEConfig(img_size=64, depth=1, decoder_embed_dim=384, decoder_num_heads=24, decoder_depth=1, down_nonlinear=True)
@@ -169,8 +172,8 @@ def test_down_nonlinear_wide_decoder_arch_vs_oracle():
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
     imgs = det_randn("img64d", (2, 3, 64, 64), 4).clamp(-1, 1)
-    noise = torch.rand(2, 64, generator=torch.Generator().manual_seed(9))
-    eps = det_randn("pepsd", (2, 16, 16), 5)
+    g = golden("mae_archs")                                     # the reference's own run of this geometry
+    noise, eps = torch.from_numpy(g["ar_dn_noise"]), torch.from_numpy(g["ar_dn_eps"])
     keys = [k for k in omae.param_shapes(cfg)]
     leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
     osd = dict(sd)
@@ -189,6 +192,10 @@ def test_down_nonlinear_wide_decoder_arch_vs_oracle():
         omom = omae.encode_moments(sd, imgs, cfg)
         orec = omae.decode(sd, omom[:, :16], cfg)
     assert rel_err(mom.cpu(), omom) < 1e-4 and rel_err(rec.cpu(), orec) < 1e-4
+    assert abs(float(loss) - float(g["ar_dn_loss"][0])) < 1e-4 * abs(float(ol))
+    norms = np.array([float(params[k].grad.double().norm()) for k in sorted(keys)])
+    np.testing.assert_allclose(norms, g["ar_dn_grad_norms"], rtol=5e-4, atol=1e-8)
+    assert rel_err(mom[:, :, :2, :2].cpu(), g["ar_dn_moments_head"]) < 1e-4 and rel_err(rec[:, :, :4, :4].cpu(), g["ar_dn_rec_head"]) < 1e-4
 
 
 def test_pretraining_step_loss_and_all_grads_vs_oracle():

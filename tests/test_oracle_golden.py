@@ -199,3 +199,35 @@ def test_mae_pretraining_forward_and_grads_vs_reference_golden(golden):
         np.testing.assert_allclose(norms, g[f"mt{tag}_grad_norms"], rtol=2e-4, atol=1e-9)
         assert rel_err(leaves["decoder_pred.conv_smoother.weight"].grad, g[f"mt{tag}_grad_smoother"]) < 1e-4
         assert rel_err(leaves["to_latent.weight"].grad[:4, :8], g[f"mt{tag}_grad_to_latent_head"]) < 1e-4
+
+
+def test_other_registry_geometries_vs_reference_golden(golden):
+    """The reference itself on the registry's other geometries (tests/golden/make_golden.py: gen_mae_archs): 'dn' = mae_for_ldmae_f8d16
+    (down_nonlinear MLP_dim_resize latent maps, 384-wide decoder, 24 heads of 16), 'h24' = mae_for_ldmae_f8d16_prev_large (16 heads of 24) --
+    pins oracle.mae's restatement of both (pre-training step with its gradients, docking encode / decode)."""
+    g = golden("mae_archs")
+    cfgs = {"dn": (mae.MAEConfig(img_size=64, depth=1, decoder_embed_dim=384, decoder_num_heads=24, decoder_depth=1, down_nonlinear=True), 9, "img64d"),
+            "h24": (mae.MAEConfig(img_size=64, embed_dim=384, num_heads=16, depth=1, decoder_embed_dim=384, decoder_num_heads=16, decoder_depth=1), 8, "img64p")}
+    for tag, (cfg, seed, iname) in cfgs.items():
+        sd = det_weights(mae.param_shapes(cfg), seed)
+        sd.update(mae.fixed_tables(cfg))
+        keys = sorted(mae.param_shapes(cfg))
+        assert keys == [str(k) for k in g[f"ar_{tag}_keys"]]                     # the reference's parameter names (incl. to_latent.layers.0 / .2)
+        imgs = det_randn(iname, (2, 3, 64, 64), 4).clamp(-1, 1)
+        leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+        osd = dict(sd)
+        osd.update(leaves)
+        loss, pred, mask, vis, mloss, kl = mae.forward_vanilla(osd, imgs, torch.from_numpy(g[f"ar_{tag}_noise"]), torch.from_numpy(g[f"ar_{tag}_eps"]),
+                                                               0.75, 0.5, 1e-3, cfg)
+        np.testing.assert_array_equal(mask.numpy(), g[f"ar_{tag}_mask"])
+        np.testing.assert_allclose([float(loss), float(vis), float(mloss), float(kl)], g[f"ar_{tag}_loss"], rtol=2e-5)
+        assert rel_err(pred.detach()[:, :6, :24], g[f"ar_{tag}_pred_head"]) < 1e-5
+        loss.backward()
+        norms = np.array([float(leaves[k].grad.double().norm()) for k in keys])
+        np.testing.assert_allclose(norms, g[f"ar_{tag}_grad_norms"], rtol=2e-4, atol=1e-9)
+        with torch.no_grad():
+            mom = mae.encode_moments(sd, imgs, cfg)
+            rec = mae.decode(sd, mom[:, :16], cfg)
+        assert rel_err(mom[:, :, :2, :2], g[f"ar_{tag}_moments_head"]) < 1e-5 and rel_err(rec[:, :, :4, :4], g[f"ar_{tag}_rec_head"]) < 1e-5
+        assert abs(float(rec.double().norm()) - float(g[f"ar_{tag}_rec_norm"])) < 1e-5 * float(g[f"ar_{tag}_rec_norm"])
+
