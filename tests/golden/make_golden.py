@@ -330,13 +330,14 @@ def gen_mae_train(out):
 def gen_mae_archs(out):
     """The registry's other geometries, pinned on the reference itself at depth 1 / 64 px (f32, eager; same recording of the two random draws
     as gen_mae_train): 'dn' = mae_for_ldmae_f8d16 (:1006-1011: down_nonlinear MLP_dim_resize latent maps, 384-wide decoder with 24 heads of 16),
-    'h24' = mae_for_ldmae_f8d16_prev_large (:999-1004: 384 wide, 16 heads of 24)."""
+    'h24' = mae_for_ldmae_f8d16_prev_large (:999-1004: 384 wide, 16 heads of 24), 'p16' = the patch-16 tokenizers (mae_for_ldmae_f16d32, :1020-1025)."""
     from functools import partial
     sys.path.insert(0, os.path.join(REF, "tokenizer"))
     from tokenizer import models_mae
     misc = sys.modules[models_mae.DiagonalGaussianDistribution.__module__]
     archs = {"dn": (dict(embed_dim=192, num_heads=12, decoder_embed_dim=384, decoder_num_heads=24, down_nonlinear=True), 9, "img64d", "pepsd"),
-             "h24": (dict(embed_dim=384, num_heads=16, decoder_embed_dim=384, decoder_num_heads=16), 8, "img64p", "peps24")}
+             "h24": (dict(embed_dim=384, num_heads=16, decoder_embed_dim=384, decoder_num_heads=16), 8, "img64p", "peps24"),
+             "p16": (dict(embed_dim=192, num_heads=12, decoder_embed_dim=192, decoder_num_heads=12, patch_size=16), 7, "img64q", "peps16")}
     captured = []
     orig = misc.randn_tensor
 
@@ -347,14 +348,16 @@ def gen_mae_archs(out):
     misc.randn_tensor = spy
     try:
         for tag, (kw, seed, iname, _) in archs.items():
-            m = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=8, depth=1, decoder_depth=1, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+            kw = dict(kw)
+            ps = kw.pop("patch_size", 8)
+            m = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=ps, depth=1, decoder_depth=1, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
                                                 latent_dim=16, no_cls=True, kl_loss_weight=1e-3, smooth_output=True, **kw)
             load_det(m, seed=seed, skip=("pos_embed", "decoder_pos_embed"))
             m.train()
             imgs = det_randn(iname, (2, 3, 64, 64), 4).clamp(-1, 1)
             captured.clear()
             torch.manual_seed(78)
-            noise = torch.rand(2, 64)
+            noise = torch.rand(2, (64 // ps) ** 2)
             assert (np.diff(np.sort(noise.numpy(), axis=1), axis=1) > 0).all(), "noise has ties; pick another seed"
             torch.manual_seed(78)
             loss, pred, mask, vis, mask_loss, kl = m(imgs, 0.75, 0.5)

@@ -198,6 +198,34 @@ def test_down_nonlinear_wide_decoder_arch_vs_oracle(golden):
     assert rel_err(mom[:, :, :2, :2].cpu(), g["ar_dn_moments_head"]) < 1e-4 and rel_err(rec[:, :, :4, :4].cpu(), g["ar_dn_rec_head"]) < 1e-4
 
 
+def test_patch16_tokenizer_geometry_vs_reference_golden(golden):
+    """The patch-16 tokenizers of the registry (mae_for_ldmae_f16d32, models_mae.py:1020-1025) at depth 1 / 64 px: 16 tokens per image (every
+    attention tile ragged), 768-element patches through the patch embed, the RGB conv and the image-space loss -- the pre-training step and the
+    docking calls against the reference's own run (tests/golden/mae_archs.npz)."""
+    g = golden("mae_archs")
+    cfg = omae.MAEConfig(img_size=64, patch_size=16, depth=1, decoder_depth=1)
+    sd = full_sd(cfg, seed=7)
+    from ldmae_amd.tokenizer import models_mae
+    m = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=16, embed_dim=192, depth=1, num_heads=12, decoder_embed_dim=192, decoder_depth=1,
+                                        decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
+                                        kl_loss_weight=1e-3, smooth_output=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    imgs = det_randn("img64q", (2, 3, 64, 64), 4).clamp(-1, 1).cuda()
+    loss, pred, mask = m(imgs, 0.75, 0.5, _noise=torch.from_numpy(g["ar_p16_noise"]).cuda(), _eps=torch.from_numpy(g["ar_p16_eps"]).cuda())[:3]
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["ar_p16_mask"])
+    assert abs(float(loss) - float(g["ar_p16_loss"][0])) < 1e-4 * abs(float(g["ar_p16_loss"][0]))
+    assert rel_err(pred.detach()[:, :6, :24].cpu(), g["ar_p16_pred_head"]) < 1e-4
+    loss.backward()
+    params = dict(m.named_parameters())
+    keys = [str(k) for k in g["ar_p16_keys"]]
+    np.testing.assert_allclose(np.array([float(params[k].grad.double().norm()) for k in keys]), g["ar_p16_grad_norms"], rtol=5e-4, atol=1e-8)
+    with torch.no_grad():
+        mom = m.eval()._encode(imgs)
+        rec = m.decode(mom[:, :16]).sample
+    assert rel_err(mom[:, :, :2, :2].cpu(), g["ar_p16_moments_head"]) < 1e-4 and rel_err(rec[:, :, :4, :4].cpu(), g["ar_p16_rec_head"]) < 1e-4
+
+
 def test_pretraining_step_loss_and_all_grads_vs_oracle():
     """SURVEY 8(f)4 minimal slice: the VMAE pre-training forward (masked encoder -> KL posterior -> decoder with mask tokens and the
     RGB smoothing conv -> masked / visible loss, models_mae.py:733-790) and EVERY parameter gradient against torch autograd on the

@@ -207,7 +207,8 @@ def test_other_registry_geometries_vs_reference_golden(golden):
     pins oracle.mae's restatement of both (pre-training step with its gradients, docking encode / decode)."""
     g = golden("mae_archs")
     cfgs = {"dn": (mae.MAEConfig(img_size=64, depth=1, decoder_embed_dim=384, decoder_num_heads=24, decoder_depth=1, down_nonlinear=True), 9, "img64d"),
-            "h24": (mae.MAEConfig(img_size=64, embed_dim=384, num_heads=16, depth=1, decoder_embed_dim=384, decoder_num_heads=16, decoder_depth=1), 8, "img64p")}
+            "h24": (mae.MAEConfig(img_size=64, embed_dim=384, num_heads=16, depth=1, decoder_embed_dim=384, decoder_num_heads=16, decoder_depth=1), 8, "img64p"),
+            "p16": (mae.MAEConfig(img_size=64, patch_size=16, depth=1, decoder_depth=1), 7, "img64q")}
     for tag, (cfg, seed, iname) in cfgs.items():
         sd = det_weights(mae.param_shapes(cfg), seed)
         sd.update(mae.fixed_tables(cfg))
