@@ -327,6 +327,24 @@ def gen_mae_train(out):
         misc.randn_tensor = orig
 
 
+def gen_dit_variants(out):
+    """The reference's LightningDiT on the geometries the shipped config does not exercise (eval forward, f32): 'p2' = patch size 2 with
+    learn_sigma (the /2 registry entries; x_embedder conv stride 2, unpatchify with p = 2, 2x out channels), 'hd72' = head_dim 72 (XL's heads)
+    at width 576.  Same deterministic weights / inputs as tests/test_gpu_dit.py."""
+    from models.lightningdit import LightningDiT
+    for tag, kw, seed, xs in (("p2", dict(input_size=16, patch_size=2, in_channels=4, hidden_size=192, depth=1, num_heads=3, num_classes=10,
+                                          class_dropout_prob=0.1, learn_sigma=True), 3, (2, 4, 16, 16)),
+                              ("hd72", dict(input_size=8, patch_size=1, in_channels=16, hidden_size=576, depth=1, num_heads=8, num_classes=10,
+                                            class_dropout_prob=0.1), 4, (2, 16, 8, 8))):
+        m = LightningDiT(**kw, **FLAGS)
+        load_det(m, seed=seed)
+        m.eval()
+        x, t, y = det_randn("x", xs, 1), torch.tensor([0.2, 0.7]), torch.tensor([1, 5])
+        with torch.no_grad():
+            o = m(x, t, y)
+        out.update({f"dv_{tag}_out": o.numpy(), f"dv_{tag}_norm": np.array(float(o.double().norm()))})
+
+
 def gen_mae_archs(out):
     """The registry's other geometries, pinned on the reference itself at depth 1 / 64 px (f32, eager; same recording of the two random draws
     as gen_mae_train): 'dn' = mae_for_ldmae_f8d16 (:1006-1011: down_nonlinear MLP_dim_resize latent maps, 384-wide decoder with 24 heads of 16),
@@ -507,14 +525,14 @@ def main():
     ap.add_argument("--curve", action="store_true", help="also run the 100-step B/1 bs=4 loss curve (~15 min)")
     ap.add_argument("--only-curve", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,mae_archs,dataset,images}")
+    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,mae_archs,dit_variants,dataset,images}")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     install_shims()
     sys.path.insert(0, REF)
     if not args.only_curve:
         gens = (("dit_tiny", gen_dit_tiny), ("kernels", gen_tables_and_kernels), ("mae", gen_mae), ("mae_train", gen_mae_train),
-                ("mae_archs", gen_mae_archs), ("dataset", gen_dataset), ("images", gen_images))
+                ("mae_archs", gen_mae_archs), ("dit_variants", gen_dit_variants), ("dataset", gen_dataset), ("images", gen_images))
         for name, fn in gens:
             if args.only and name not in args.only.split(","):
                 continue

@@ -123,6 +123,27 @@ def test_patch2_learn_sigma_variant_vs_oracle():
     assert rel_err(out.cpu(), odit.dit_forward(sd, x, t, y, cfg, train=False)) < 1e-4
 
 
+def test_dit_variants_match_reference_golden(golden):
+    """Patch size 2 with learn_sigma (the /2 registry entries) and head_dim 72 (XL's heads): the HIP model's eval forward DIRECTLY against the
+    reference's own output (tests/golden/dit_variants.npz), f32 at 1e-4 and bf16 autocast at bf16's margin."""
+    g = golden("dit_variants")
+    variants = {"p2": (odit.DiTConfig(input_size=16, patch_size=2, in_channels=4, hidden_size=192, depth=1, num_heads=3, num_classes=10,
+                                      class_dropout_prob=0.1, learn_sigma=True), 3, (2, 4, 16, 16)),
+                "hd72": (odit.DiTConfig(input_size=8, patch_size=1, in_channels=16, hidden_size=576, depth=1, num_heads=8, num_classes=10,
+                                        class_dropout_prob=0.1), 4, (2, 16, 8, 8))}
+    for tag, (cfg, seed, xs) in variants.items():
+        sd = det_weights(odit.param_shapes(cfg), seed)
+        sd.update(odit.fixed_tables(cfg))
+        m = build(cfg, sd).eval()
+        x, t, y = det_randn("x", xs, 1).cuda(), torch.tensor([0.2, 0.7]).cuda(), torch.tensor([1, 5]).cuda()
+        with torch.no_grad():
+            out = m(x, t, y)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out16 = m(x, t, y)
+        assert rel_err(out.cpu(), g[f"dv_{tag}_out"]) < 1e-4, tag
+        assert rel_err(out16.float().cpu(), g[f"dv_{tag}_out"]) < 3e-2, tag
+
+
 def test_xl_head_dim_72_geometry_fp32_and_bf16():
     """LightningDiT-XL geometry in small: head_dim 72 (hidden 576 = 8 heads, XL is 1152 = 16 heads), SwiGLU hidden
     int(2/3*4*576) = 1536; forward and every parameter gradient vs the oracle in fp32; bf16 autocast (the head_dim-72 flash kernels,

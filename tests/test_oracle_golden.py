@@ -232,3 +232,22 @@ def test_other_registry_geometries_vs_reference_golden(golden):
         assert rel_err(mom[:, :, :2, :2], g[f"ar_{tag}_moments_head"]) < 1e-5 and rel_err(rec[:, :, :4, :4], g[f"ar_{tag}_rec_head"]) < 1e-5
         assert abs(float(rec.double().norm()) - float(g[f"ar_{tag}_rec_norm"])) < 1e-5 * float(g[f"ar_{tag}_rec_norm"])
 
+
+DIT_VARIANTS = {"p2": (dict(input_size=16, patch_size=2, in_channels=4, hidden_size=192, depth=1, num_heads=3, num_classes=10, class_dropout_prob=0.1,
+                            learn_sigma=True), 3, (2, 4, 16, 16)),
+                "hd72": (dict(input_size=8, patch_size=1, in_channels=16, hidden_size=576, depth=1, num_heads=8, num_classes=10, class_dropout_prob=0.1),
+                         4, (2, 16, 8, 8))}
+
+
+def test_dit_variants_vs_reference_golden(golden):
+    """oracle.dit on the geometries the shipped config does not exercise, pinned on the reference's own eval forward (make_golden.py:
+    gen_dit_variants): patch size 2 with learn_sigma (the /2 registry entries) and head_dim 72 (XL's heads)."""
+    g = golden("dit_variants")
+    for tag, (kw, seed, xs) in DIT_VARIANTS.items():
+        cfg = dit.DiTConfig(**kw)
+        sd = det_weights(dit.param_shapes(cfg), seed)
+        sd.update(dit.fixed_tables(cfg))
+        x, t, y = det_randn("x", xs, 1), torch.tensor([0.2, 0.7]), torch.tensor([1, 5])
+        out = dit.dit_forward(sd, x, t, y, cfg, train=False)
+        assert out.shape == g[f"dv_{tag}_out"].shape and rel_err(out, g[f"dv_{tag}_out"]) < 2e-6, tag
+
