@@ -152,8 +152,11 @@ class _SyntheticImages(torch.utils.data.Dataset):
         return self.n
 
     def __getitem__(self, i):
-        g = torch.Generator().manual_seed(i)
-        return torch.rand(3, self.size, self.size, generator=g) * 2 - 1, 0
+        # a pool of 64 images drawn once (a fresh 256 x 256 draw per sample made the --synthetic run host-bound: ~1 ms per image)
+        if not hasattr(self, "pool"):
+            g = torch.Generator().manual_seed(0)
+            self.pool = torch.rand(64, 3, self.size, self.size, generator=g) * 2 - 1
+        return self.pool[i % 64], 0
 
 
 # ----------------------------------------------------------------------------- image input (main_pretrain.py:111-192), PIL only
