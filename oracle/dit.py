@@ -27,6 +27,13 @@ class DiTConfig:
     class_dropout_prob: float = 0.1
     num_classes: int = 1000
     learn_sigma: bool = False
+    # block flags (lightningdit.py:292-296; defaults = the shipped imagenet YAML, configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml:26-33;
+    # configs/celeba_hq/...yaml:30 sets use_qknorm false)
+    use_qknorm: bool = True
+    use_swiglu: bool = True
+    use_rope: bool = True
+    use_rmsnorm: bool = True
+    wo_shift: bool = False
 
     @property
     def head_dim(self):
@@ -42,8 +49,9 @@ class DiTConfig:
 
     @property
     def mlp_hidden(self):
-        # LDMAE/models/lightningdit.py:213,217: int(2/3 * int(hidden*mlp_ratio))
-        return int(2 / 3 * int(self.hidden_size * self.mlp_ratio))
+        # LDMAE/models/lightningdit.py:213,217: int(2/3 * int(hidden*mlp_ratio)); :219-224 (timm Mlp): int(hidden*mlp_ratio)
+        full = int(self.hidden_size * self.mlp_ratio)
+        return int(2 / 3 * full) if self.use_swiglu else full
 
     @property
     def out_channels(self):
@@ -97,8 +105,28 @@ def rmsnorm(x, weight, eps: float = 1e-6):
 
 
 def modulate(x, shift, scale):
-    """lightningdit.py:26-30."""
+    """lightningdit.py:26-30 (shift None: wo_shift)."""
+    if shift is None:
+        return x * (1 + scale.unsqueeze(1))
     return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+
+
+def block_norm(sd, key, x, cfg):
+    """norm1 / norm2 / norm_final: RMSNorm with weight (lightningdit.py:203-204,259), or -- use_rmsnorm=False -- LayerNorm without affine,
+    eps 1e-6 (:200-201,257)."""
+    if cfg.use_rmsnorm:
+        return rmsnorm(x, sd[key + ".weight"])
+    return F.layer_norm(x, (x.shape[-1],), None, None, 1e-6)
+
+
+def qk_norm(sd, key, x, cfg):
+    """q_norm / k_norm (lightningdit.py:56-61): Identity without use_qknorm; RMSNorm(head_dim), or nn.LayerNorm(head_dim) (affine, eps 1e-5)
+    when use_rmsnorm is off."""
+    if not cfg.use_qknorm:
+        return x
+    if cfg.use_rmsnorm:
+        return rmsnorm(x, sd[key + ".weight"])
+    return F.layer_norm(x, (x.shape[-1],), sd[key + ".weight"], sd[key + ".bias"], 1e-5)
 
 
 def rotate_pairs(x):
@@ -145,14 +173,15 @@ def patch_embed(sd, x, cfg: DiTConfig):
 
 
 def attention(sd, pre, x, cfg: DiTConfig, cos, sin, taps=None):
-    """lightningdit.py:66-91 (qk-norm + rope + SDPA, scale 1/sqrt(hd))."""
+    """lightningdit.py:66-91 (qk-norm [optional] + rope [optional] + SDPA, scale 1/sqrt(hd))."""
     B, N, C = x.shape
     H, hd = cfg.num_heads, cfg.head_dim
     qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
     qkv = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    q = apply_rope(rmsnorm(q, sd[pre + "q_norm.weight"]), cos, sin)
-    k = apply_rope(rmsnorm(k, sd[pre + "k_norm.weight"]), cos, sin)
+    q, k = qk_norm(sd, pre + "q_norm", q, cfg), qk_norm(sd, pre + "k_norm", k, cfg)
+    if cfg.use_rope:                                                                 # :71-73
+        q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
     s = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
     o = s.softmax(dim=-1) @ v
     o = o.transpose(1, 2).reshape(B, N, C)
@@ -168,25 +197,35 @@ def swiglu(sd, pre, x):
     return F.linear(F.silu(x1) * x2, sd[pre + "w3.weight"], sd[pre + "w3.bias"])
 
 
+def gelu_mlp(sd, pre, x):
+    """timm Mlp as built at lightningdit.py:219-224: fc1 -> GELU(approximate="tanh") -> fc2 (drop = 0)."""
+    h = F.gelu(F.linear(x, sd[pre + "fc1.weight"], sd[pre + "fc1.bias"]), approximate="tanh")
+    return F.linear(h, sd[pre + "fc2.weight"], sd[pre + "fc2.bias"])
+
+
 def block(sd, i, x, c, cfg: DiTConfig, cos, sin, taps=None):
-    """lightningdit.py:239-250 (wo_shift=False)."""
+    """lightningdit.py:239-250."""
     p = f"blocks.{i}."
     mod = F.linear(F.silu(c), sd[p + "adaLN_modulation.1.weight"], sd[p + "adaLN_modulation.1.bias"])
-    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod.chunk(6, dim=1)
-    xm = modulate(rmsnorm(x, sd[p + "norm1.weight"]), shift_msa, scale_msa)
+    if cfg.wo_shift:                                                                 # :241-244
+        scale_msa, gate_msa, scale_mlp, gate_mlp = mod.chunk(4, dim=1)
+        shift_msa = shift_mlp = None
+    else:
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mod.chunk(6, dim=1)
+    xm = modulate(block_norm(sd, p + "norm1", x, cfg), shift_msa, scale_msa)
     x = x + gate_msa.unsqueeze(1) * attention(sd, p + "attn.", xm, cfg, cos, sin, taps)
-    xm2 = modulate(rmsnorm(x, sd[p + "norm2.weight"]), shift_mlp, scale_mlp)
-    x = x + gate_mlp.unsqueeze(1) * swiglu(sd, p + "mlp.", xm2)
+    xm2 = modulate(block_norm(sd, p + "norm2", x, cfg), shift_mlp, scale_mlp)
+    x = x + gate_mlp.unsqueeze(1) * (swiglu if cfg.use_swiglu else gelu_mlp)(sd, p + "mlp.", xm2)
     if taps is not None:
         taps[p + "xm1"], taps[p + "xm2"], taps[p + "out"] = xm, xm2, x
     return x
 
 
-def final_layer(sd, x, c):
+def final_layer(sd, x, c, cfg: DiTConfig = None):
     """lightningdit.py:267-272."""
     mod = F.linear(F.silu(c), sd["final_layer.adaLN_modulation.1.weight"], sd["final_layer.adaLN_modulation.1.bias"])
     shift, scale = mod.chunk(2, dim=1)
-    x = modulate(rmsnorm(x, sd["final_layer.norm_final.weight"]), shift, scale)
+    x = modulate(block_norm(sd, "final_layer.norm_final", x, cfg or DiTConfig()), shift, scale)
     return F.linear(x, sd["final_layer.linear.weight"], sd["final_layer.linear.bias"])
 
 
@@ -201,14 +240,14 @@ def unpatchify(x, cfg: DiTConfig):
 
 def dit_forward(sd, x, t, y, cfg: DiTConfig, train: bool = True, drop_ids=None, taps=None):
     """LightningDiT.forward, lightningdit.py:391-418."""
-    cos, sin = sd["feat_rope.freqs_cos"], sd["feat_rope.freqs_sin"]
+    cos, sin = (sd["feat_rope.freqs_cos"], sd["feat_rope.freqs_sin"]) if cfg.use_rope else (None, None)     # :317-325
     h = patch_embed(sd, x, cfg)
     c = t_embedder(sd, t) + y_embedder(sd, y, cfg, train, drop_ids)
     if taps is not None:
         taps["x_embed"], taps["c"] = h, c
     for i in range(cfg.depth):
         h = block(sd, i, h, c, cfg, cos, sin, taps)
-    out = unpatchify(final_layer(sd, h, c), cfg)
+    out = unpatchify(final_layer(sd, h, c, cfg), cfg)
     if cfg.learn_sigma:
         out, _ = out.chunk(2, dim=1)
     return out
@@ -238,19 +277,27 @@ def param_shapes(cfg: DiTConfig) -> dict:
         "t_embedder.mlp.2.weight": (D, D), "t_embedder.mlp.2.bias": (D,),
         "y_embedder.embedding_table.weight": (cfg.num_classes + (1 if cfg.class_dropout_prob > 0 else 0), D),
     }
+    nmod = 4 if cfg.wo_shift else 6
     for i in range(cfg.depth):
         b = f"blocks.{i}."
         s.update({
-            b + "norm1.weight": (D,), b + "norm2.weight": (D,),
             b + "attn.qkv.weight": (3 * D, D), b + "attn.qkv.bias": (3 * D,),
-            b + "attn.q_norm.weight": (cfg.head_dim,), b + "attn.k_norm.weight": (cfg.head_dim,),
             b + "attn.proj.weight": (D, D), b + "attn.proj.bias": (D,),
-            b + "mlp.w12.weight": (2 * Hs, D), b + "mlp.w12.bias": (2 * Hs,),
-            b + "mlp.w3.weight": (D, Hs), b + "mlp.w3.bias": (D,),
-            b + "adaLN_modulation.1.weight": (6 * D, D), b + "adaLN_modulation.1.bias": (6 * D,),
+            b + "adaLN_modulation.1.weight": (nmod * D, D), b + "adaLN_modulation.1.bias": (nmod * D,),
         })
+        if cfg.use_rmsnorm:                   # LayerNorm(elementwise_affine=False) has no parameters (:200-201)
+            s.update({b + "norm1.weight": (D,), b + "norm2.weight": (D,)})
+        if cfg.use_qknorm:                    # nn.Identity otherwise (:60-61); nn.LayerNorm carries a bias
+            s.update({b + "attn.q_norm.weight": (cfg.head_dim,), b + "attn.k_norm.weight": (cfg.head_dim,)})
+            if not cfg.use_rmsnorm:
+                s.update({b + "attn.q_norm.bias": (cfg.head_dim,), b + "attn.k_norm.bias": (cfg.head_dim,)})
+        if cfg.use_swiglu:
+            s.update({b + "mlp.w12.weight": (2 * Hs, D), b + "mlp.w12.bias": (2 * Hs,), b + "mlp.w3.weight": (D, Hs), b + "mlp.w3.bias": (D,)})
+        else:
+            s.update({b + "mlp.fc1.weight": (Hs, D), b + "mlp.fc1.bias": (Hs,), b + "mlp.fc2.weight": (D, Hs), b + "mlp.fc2.bias": (D,)})
+    if cfg.use_rmsnorm:
+        s["final_layer.norm_final.weight"] = (D,)
     s.update({
-        "final_layer.norm_final.weight": (D,),
         "final_layer.linear.weight": (p * p * cfg.out_channels, D),
         "final_layer.linear.bias": (p * p * cfg.out_channels,),
         "final_layer.adaLN_modulation.1.weight": (2 * D, D),
@@ -261,8 +308,10 @@ def param_shapes(cfg: DiTConfig) -> dict:
 
 def fixed_tables(cfg: DiTConfig) -> dict:
     """pos_embed (frozen parameter, lightningdit.py:350-351) + RoPE buffers."""
-    cos, sin = rope_tables(cfg.head_dim, cfg.grid)
     pe = torch.from_numpy(sincos_pos_embed_2d(cfg.hidden_size, cfg.grid)).float().unsqueeze(0)
+    if not cfg.use_rope:                      # feat_rope = None (:324-325): no buffers
+        return {"pos_embed": pe}
+    cos, sin = rope_tables(cfg.head_dim, cfg.grid)
     return {"pos_embed": pe, "feat_rope.freqs_cos": cos, "feat_rope.freqs_sin": sin}
 
 

@@ -31,7 +31,7 @@ import torch.nn as nn
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference/LDMAE"
 sys.path.insert(0, HERE)
-from weights import det_weights, det_randn  # noqa: E402
+from weights import det_weights, det_randn, DIT_FLAG_VARIANTS  # noqa: E402
 
 
 # --------------------------------------------------------------------------- shims
@@ -345,6 +345,42 @@ def gen_dit_variants(out):
         out.update({f"dv_{tag}_out": o.numpy(), f"dv_{tag}_norm": np.array(float(o.double().norm()))})
 
 
+def gen_dit_flags(out):
+    """The reference's LightningDiT with each block flag flipped away from the shipped imagenet YAML (f32, eager): per variant a TRAIN-mode
+    forward at the tiny geometry (label drop drawn inside forward from a re-seeded torch RNG and recorded), a quadratic loss against a fixed
+    target and every parameter gradient; for 'noqk' (the CelebA-HQ configuration) also an eval forward at the real B/1 width (768, 12 heads
+    of 64, depth 1).  Same deterministic weights / inputs as the tests."""
+    from models.lightningdit import LightningDiT
+    B = 2
+    xt, t, tgt = det_randn("xt", (B, 16, 8, 8), 7), torch.tensor([0.3, 0.8]), det_randn("tgt", (B, 16, 8, 8), 11)
+    for n, (tag, over) in enumerate(DIT_FLAG_VARIANTS.items()):
+        kw = {**TINY, **FLAGS, **over}
+        m = LightningDiT(**kw)
+        load_det(m, seed=20 + n)
+        m.train()
+        y = torch.tensor([0, 0]) if kw["num_classes"] == 1 else torch.tensor([3, 7])
+        torch.manual_seed(40 + n)
+        drop = torch.rand(B) < kw["class_dropout_prob"]
+        torch.manual_seed(40 + n)
+        o = m(xt, t, y)
+        loss = ((o - tgt) ** 2).mean()
+        loss.backward()
+        names = [k for k, p in m.named_parameters() if p.grad is not None]
+        grads = dict(m.named_parameters())
+        out.update({f"df_{tag}_drop": drop.numpy(), f"df_{tag}_y": y.numpy(), f"df_{tag}_out": o.detach().numpy(), f"df_{tag}_loss": np.array(float(loss)),
+                    f"df_{tag}_keys": np.array(sorted(m.state_dict().keys())), f"df_{tag}_grad_names": np.array(names),
+                    f"df_{tag}_grad_norm": np.array([float(grads[k].grad.double().norm()) for k in names]),
+                    f"df_{tag}_grad_head": np.stack([grads[k].grad.flatten()[:8].numpy().copy() for k in names])})
+    kw = dict(input_size=8, patch_size=1, in_channels=16, hidden_size=768, depth=1, num_heads=12, num_classes=1, class_dropout_prob=0.1)
+    m = LightningDiT(**kw, **{**FLAGS, "use_qknorm": False})
+    load_det(m, seed=31)
+    m.eval()
+    x = det_randn("x", (2, 16, 8, 8), 1)
+    with torch.no_grad():
+        o = m(x, torch.tensor([0.2, 0.7]), torch.tensor([0, 0]))
+    out.update(df_noqk768_out=o.numpy(), df_noqk768_norm=np.array(float(o.double().norm())))
+
+
 def gen_mae_archs(out):
     """The registry's other geometries, pinned on the reference itself at depth 1 / 64 px (f32, eager; same recording of the two random draws
     as gen_mae_train): 'dn' = mae_for_ldmae_f8d16 (:1006-1011: down_nonlinear MLP_dim_resize latent maps, 384-wide decoder with 24 heads of 16),
@@ -525,14 +561,14 @@ def main():
     ap.add_argument("--curve", action="store_true", help="also run the 100-step B/1 bs=4 loss curve (~15 min)")
     ap.add_argument("--only-curve", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,mae_archs,dit_variants,dataset,images}")
+    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,mae_archs,dit_variants,dit_flags,dataset,images}")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     install_shims()
     sys.path.insert(0, REF)
     if not args.only_curve:
         gens = (("dit_tiny", gen_dit_tiny), ("kernels", gen_tables_and_kernels), ("mae", gen_mae), ("mae_train", gen_mae_train),
-                ("mae_archs", gen_mae_archs), ("dit_variants", gen_dit_variants), ("dataset", gen_dataset), ("images", gen_images))
+                ("mae_archs", gen_mae_archs), ("dit_variants", gen_dit_variants), ("dit_flags", gen_dit_flags), ("dataset", gen_dataset), ("images", gen_images))
         for name, fn in gens:
             if args.only and name not in args.only.split(","):
                 continue

@@ -56,3 +56,15 @@ def ref_style_init(shapes: dict, seed: int = 10) -> dict:
             fan_out, fan_in = shp[0], int(np.prod(shp[1:]))
             out[k] = z * math.sqrt(2.0 / (fan_in + fan_out))
     return out
+
+
+# one entry per constructor flag of LightningDiTBlock the shipped imagenet YAML leaves at its default (lightningdit.py:292-296), the reference's
+# CelebA-HQ configuration first (configs/celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml:13-35: use_qknorm false, num_classes 1).  Shared with the tests.
+DIT_FLAG_VARIANTS = {
+    "noqk": dict(use_qknorm=False, num_classes=1),
+    "woshift": dict(wo_shift=True),
+    "norope": dict(use_rope=False),
+    "ln": dict(use_rmsnorm=False),
+    "mlp": dict(use_swiglu=False),
+    "plain": dict(use_qknorm=False, use_swiglu=False, use_rope=False, use_rmsnorm=False, wo_shift=True),
+}

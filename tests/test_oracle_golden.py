@@ -8,7 +8,7 @@ import torch
 
 from conftest import rel_err
 from oracle import dit, mae, train, transport
-from weights import det_randn, det_weights
+from weights import DIT_FLAG_VARIANTS, det_randn, det_weights
 
 TINY = dit.DiTConfig(input_size=8, patch_size=1, in_channels=16, hidden_size=192, depth=2, num_heads=3,
                      num_classes=10, class_dropout_prob=0.5)
@@ -251,3 +251,34 @@ def test_dit_variants_vs_reference_golden(golden):
         out = dit.dit_forward(sd, x, t, y, cfg, train=False)
         assert out.shape == g[f"dv_{tag}_out"].shape and rel_err(out, g[f"dv_{tag}_out"]) < 2e-6, tag
 
+
+
+def test_dit_block_flags_vs_reference_golden(golden):
+    """oracle.dit with every LightningDiTBlock flag flipped away from the shipped imagenet YAML -- first of all use_qknorm=False, the reference's
+    CelebA-HQ configuration (configs/celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml:30; README.md:108-110) -- pinned on the reference's own
+    train-mode forward, loss and every parameter gradient (make_golden.py: gen_dit_flags), plus the state-dict key set each variant has."""
+    g = golden("dit_flags")
+    xt, t, tgt = det_randn("xt", (2, 16, 8, 8), 7), torch.tensor([0.3, 0.8]), det_randn("tgt", (2, 16, 8, 8), 11)
+    base = dict(input_size=8, patch_size=1, in_channels=16, hidden_size=192, depth=2, num_heads=3, num_classes=10, class_dropout_prob=0.5)
+    for n, (tag, over) in enumerate(DIT_FLAG_VARIANTS.items()):
+        cfg = dit.DiTConfig(**{**base, **over})
+        sd = det_weights(dit.param_shapes(cfg), 20 + n)
+        tabs = dit.fixed_tables(cfg)
+        assert sorted(list(sd) + list(tabs)) == [str(k) for k in g[f"df_{tag}_keys"]], tag
+        sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        sd.update(tabs)
+        out = dit.dit_forward(sd, xt, t, torch.from_numpy(g[f"df_{tag}_y"]), cfg, True, torch.from_numpy(g[f"df_{tag}_drop"]))
+        loss = ((out - tgt) ** 2).mean()
+        loss.backward()
+        assert rel_err(out, g[f"df_{tag}_out"]) < 2e-6, tag
+        assert abs(float(loss) - float(g[f"df_{tag}_loss"])) < 2e-6 * float(g[f"df_{tag}_loss"]), tag
+        names = [str(k) for k in g[f"df_{tag}_grad_names"]]
+        assert sorted(names) == sorted(k for k in sd if sd[k].requires_grad), tag
+        for k, gn, gh in zip(names, g[f"df_{tag}_grad_norm"], g[f"df_{tag}_grad_head"]):
+            assert abs(float(sd[k].grad.double().norm()) - gn) <= 2e-5 * gn + 1e-9, (tag, k)
+            assert rel_err(sd[k].grad.flatten()[:8], gh) < 1e-4 or float(np.abs(gh).max()) < 1e-6, (tag, k)
+    cfg = dit.DiTConfig(input_size=8, hidden_size=768, depth=1, num_heads=12, num_classes=1, use_qknorm=False)
+    sd = det_weights(dit.param_shapes(cfg), 31)
+    sd.update(dit.fixed_tables(cfg))
+    out = dit.dit_forward(sd, det_randn("x", (2, 16, 8, 8), 1), torch.tensor([0.2, 0.7]), torch.tensor([0, 0]), cfg, train=False)
+    assert rel_err(out, g["df_noqk768_out"]) < 2e-6
