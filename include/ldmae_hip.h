@@ -133,7 +133,10 @@ int ldmae_rmsnorm_modulate_bwd_gate(int dtype, const void* dout, const float* x,
 /* ---- attention front end (lightningdit.py:68-74; rmsnorm.py on head_dim; pos_embed.py:38-42,135) */
 /* qkv [B,N,3,H,hd] -> q,k = rope(rmsnorm(.)*w) and v, each [B,H,N,hd]. cos/sin [N,hd] f32.
  * wq = wk = cos = sin = NULL: plain head-major relayout (VMAE attention has no QK-norm / RoPE, models_mae.py:133-134).
- * v = NULL (fwd) / dv = NULL (bwd), norm + rope form only: v stays in the packed buffer (see ldmae_attention_fwd_pv / _bwd_pv);
+ * wq = wk = NULL with cos / sin given: RoPE only -- the block built with use_qknorm=False, q_norm = k_norm = nn.Identity
+ * (lightningdit.py:60-61,69; the reference's configs/celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml:30); backward: the rotation's adjoint, qkv /
+ * dwq / dwk may be NULL.
+ * v = NULL (fwd) / dv = NULL (bwd), forms with RoPE only: v stays in the packed buffer (see ldmae_attention_fwd_pv / _bwd_pv);
  * the backward then reads dv from the v slot of dqkv for the bias-gradient sums and leaves it in place. */
 int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq, const float* wk, const float* cos, const float* sin,
                           void* q, void* k, void* v, int B, int N, int H, int hd, float eps, void* stream);
@@ -192,7 +195,8 @@ int ldmae_attention_bwd_pv(int dtype, const void* q, const void* k, const void* 
                            void* dq, void* dk, void* dqkv, float* delta, int B, int H, int N, int hd, float scale, void* stream);
 /* ldmae_attention_bwd_pv + ldmae_qknorm_rope_bwd in one (bf16, head_dim 64 / 128): the QK-RMSNorm / RoPE backward (lightningdit.py:70-75
  * read backwards) runs in the epilogues of the dQ and dK/dV kernels, dq / dk are never written head-major.  dqkv [B,N,3,H,hd] complete;
- * dwq, dwk [hd] norm-weight gradients; dbias [3*H*hd] = column sums of dqkv (the qkv Linear's bias gradient). */
+ * dwq, dwk [hd] norm-weight gradients; dbias [3*H*hd] = column sums of dqkv (the qkv Linear's bias gradient).
+ * wq = wk = dwq = dwk = NULL: RoPE adjoint only in the epilogues (use_qknorm=False, see ldmae_qknorm_rope_fwd). */
 long ldmae_attention_bwd_pv_qknorm_workspace_bytes(int B, int H, int N, int hd);
 int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const void* k, const void* qkv, const void* o, const void* do_, const float* lse,
                                   const float* wq, const float* wk, const float* cos, const float* sin, float eps, void* dqkv, float* dwq,

@@ -296,7 +296,11 @@ __device__ __forceinline__ void qk_prefetch(QkPref<HD>& p, const QkNormBwd& a, i
 #pragma unroll
   for (int it = 0; it < 32 * CPR / 64; ++it) {
     const int row = (it * 64 + lane) / CPR, ch = lane % CPR;
-    p.x[it] = *(const bf16x8*)(a.qkv + (((size_t)b * N + n0 + row) * 3 + which) * H * HD + (size_t)hh * HD + ch * 8);
+    if (a.wq) p.x[it] = *(const bf16x8*)(a.qkv + (((size_t)b * N + n0 + row) * 3 + which) * H * HD + (size_t)hh * HD + ch * 8);
+    else {                                   // RoPE only (use_qknorm=False): the pre-norm rows are not needed; zeros keep the row math finite
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p.x[it][j] = (bf16)0.f;
+    }
   }
 }
 // The row math of the fused QK-norm / RoPE backward: lane = (row, 16-B chunk) of a wave's 32 rows, `grad(it)` = the lane's 8 incoming
@@ -308,10 +312,11 @@ __device__ __forceinline__ void qknorm_rows_math(GRAD&& grad, int lane, const Qk
   static_assert(HD == 64 || HD == 128, "fused QK-norm backward: 8 or 16 chunks per row");
   constexpr int CPR = HD / 8, NIT = 32 * CPR / 64;
   const int ch = lane % CPR;                      // 64 % CPR == 0: a lane keeps its chunk column in every iteration
+  const bool norm = a.wq != nullptr;              // false: q_norm = k_norm = nn.Identity (lightningdit.py:60-61): w = 1, rstd = 1, n = 0 -> the stored row is rope^T(g)
   const float* wsrc = (which ? a.wk : a.wq) + ch * 8;
   float w8[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { w8[j] = wsrc[j]; aw[j] = 0.f; ab[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) { w8[j] = norm ? wsrc[j] : 1.f; aw[j] = 0.f; ab[j] = 0.f; }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = (it * 64 + lane) / CPR, n = n0 + row;
@@ -322,7 +327,7 @@ __device__ __forceinline__ void qknorm_rows_math(GRAD&& grad, int lane, const Qk
     float x[8], g[8], ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { x[j] = (float)pf.x[it][j]; g[j] = (float)gv[j]; ss += x[j] * x[j]; }
-    const float rs = rsqrtf(row_sum<CPR>(ss) / (float)HD + a.eps);
+    const float rs = norm ? rsqrtf(row_sum<CPR>(ss) / (float)HD + a.eps) : 1.f;
     float nq[8], dn[8], dot = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {              // rope^T on the pair (j, j+1): elementwise.hip rope_apply_bwd
@@ -1939,7 +1944,8 @@ extern "C" int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const voi
                                              const float* lse, const float* wq, const float* wk, const float* cos, const float* sin, float eps,
                                              void* dqkv, float* dwq, float* dwk, float* dbias, float* workspace, int B, int H, int N, int hd,
                                              float scale, void* stream) {
-  LDMAE_REQUIRE(q && k && qkv && o && do_ && lse && wq && wk && cos && sin && dqkv && dwq && dwk && dbias && workspace, "attention_bwd_pv_qknorm: null pointer");
+  LDMAE_REQUIRE(q && k && qkv && o && do_ && lse && cos && sin && dqkv && dbias && workspace, "attention_bwd_pv_qknorm: null pointer");
+  LDMAE_REQUIRE(!wq == !wk && (!wq || (dwq && dwk)), "attention_bwd_pv_qknorm: pass wq, wk, dwq, dwk (QK-norm + RoPE) or none of them (RoPE only: use_qknorm=False)");
   LDMAE_REQUIRE(dtype == LDMAE_BF16, "attention_bwd_pv_qknorm: bf16 only");
   LDMAE_REQUIRE(hd == 64 || hd == 128, "attention_bwd_pv_qknorm: head_dim %d (64 or 128; others: attention_bwd_pv + qknorm_rope_bwd)", hd);
   if (int e = attn_check("attention_bwd_pv_qknorm", dtype, B, H, N, hd)) return e;
@@ -1978,7 +1984,8 @@ extern "C" int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const voi
   if (hd == 64) L(64) else L(128)
 #undef L
   LDMAE_CHECK_LAUNCH("attention_bwd_pv_qknorm");
-  if (dwk == dwq + hd) {        // the caller keeps dwq | dwk adjacent: reduce straight into them
+  if (!wq) {}                   // RoPE only: no norm-weight gradients
+  else if (dwk == dwq + hd) {        // the caller keeps dwq | dwk adjacent: reduce straight into them
     if (int e = ldmae_colsum(LDMAE_F32, Pw, 2 * hd, (int)(blk * H), 2 * hd, dwq, 0.f, cws, stream)) return e;
   } else {
     if (int e = ldmae_colsum(LDMAE_F32, Pw, 2 * hd, (int)(blk * H), 2 * hd, dw2, 0.f, cws, stream)) return e;

@@ -463,8 +463,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const T* __restric
   const bool act = c4 < hd;
   const long items = (long)B * N * H;
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / LPR, gstride = (long)gridDim.x * 256 / LPR;
-  const bool plain = wq == nullptr;     // VMAE attention: head-major relayout only (models_mae.py:133-134)
-  const float4 wqv = (act && !plain) ? *(const float4*)(wq + c4) : f4(0.f), wkv = (act && !plain) ? *(const float4*)(wk + c4) : f4(0.f);
+  const bool plain = cosT == nullptr;    // VMAE attention: head-major relayout only (models_mae.py:133-134)
+  const bool norm = wq != nullptr;       // false with tables: RoPE only (use_qknorm=False: q_norm = k_norm = nn.Identity, lightningdit.py:60-61)
+  const float4 wqv = (act && norm) ? *(const float4*)(wq + c4) : f4(1.f), wkv = (act && norm) ? *(const float4*)(wk + c4) : f4(1.f);
   for (long it = gid; it < items; it += gstride) {
     const int h = it % H, n = (it / H) % N, b = it / ((long)H * N);
     const T* src = qkv + ((size_t)(b * N + n) * 3 * H + h) * hd + c4;
@@ -479,8 +480,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(const T* __restric
       if (act) { store4<T>(q + dst, qv); store4<T>(k + dst, kv); store4<T>(v + dst, vv); }
       continue;
     }
-    const float rq = rsqrtf(group_sum<LPR>(hsum(qv * qv)) / (float)hd + eps);
-    const float rk = rsqrtf(group_sum<LPR>(hsum(kv * kv)) / (float)hd + eps);
+    const float rq = norm ? rsqrtf(group_sum<LPR>(hsum(qv * qv)) / (float)hd + eps) : 1.f;
+    const float rk = norm ? rsqrtf(group_sum<LPR>(hsum(kv * kv)) / (float)hd + eps) : 1.f;
     if (act) {
       store4<T>(q + dst, rope_apply((qv * rq) * wqv, cs, sn));
       store4<T>(k + dst, rope_apply((kv * rk) * wkv, cs, sn));
@@ -500,8 +501,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd8_kernel(const bf16* __res
   const long items = (long)B * N * H;
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / LPR, gstride = (long)gridDim.x * 256 / LPR;
   float wqv[8], wkv[8];
+  const bool norm = wq != nullptr;       // false: RoPE only (use_qknorm=False); x * 1 * 1 is exact
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { wqv[j] = wq[c8 + j]; wkv[j] = wk[c8 + j]; }
+  for (int j = 0; j < 8; ++j) { wqv[j] = norm ? wq[c8 + j] : 1.f; wkv[j] = norm ? wk[c8 + j] : 1.f; }
   auto one = [&](long it, bf16x8 qi, bf16x8 ki) {
     const int h = it % H, n = (it / H) % N, b = it / ((long)H * N);
     const float4 c0 = *(const float4*)(cosT + (size_t)n * hd + c8), c1 = *(const float4*)(cosT + (size_t)n * hd + c8 + 4);
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd8_kernel(const bf16* __res
     // same association as the 4-element form: (x0^2 + x1^2) + (x2^2 + x3^2) per 4-chunk, chunks summed by the lane-group butterfly
     sq = ((qv[0] * qv[0] + qv[1] * qv[1]) + (qv[2] * qv[2] + qv[3] * qv[3])) + ((qv[4] * qv[4] + qv[5] * qv[5]) + (qv[6] * qv[6] + qv[7] * qv[7]));
     sk = ((kv[0] * kv[0] + kv[1] * kv[1]) + (kv[2] * kv[2] + kv[3] * kv[3])) + ((kv[4] * kv[4] + kv[5] * kv[5]) + (kv[6] * kv[6] + kv[7] * kv[7]));
-    const float rq = rsqrtf(group_sum<LPR>(sq) / (float)hd + eps), rk = rsqrtf(group_sum<LPR>(sk) / (float)hd + eps);
+    const float rq = norm ? rsqrtf(group_sum<LPR>(sq) / (float)hd + eps) : 1.f, rk = norm ? rsqrtf(group_sum<LPR>(sk) / (float)hd + eps) : 1.f;
     const float4 a0 = rope_apply(make_float4(qv[0] * rq * wqv[0], qv[1] * rq * wqv[1], qv[2] * rq * wqv[2], qv[3] * rq * wqv[3]), c0, s0);
     const float4 a1 = rope_apply(make_float4(qv[4] * rq * wqv[4], qv[5] * rq * wqv[5], qv[6] * rq * wqv[6], qv[7] * rq * wqv[7]), c1, s1);
     const float4 b0 = rope_apply(make_float4(kv[0] * rk * wkv[0], kv[1] * rk * wkv[1], kv[2] * rk * wkv[2], kv[3] * rk * wkv[3]), c0, s0);
@@ -661,8 +663,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
   const bool act = c4 < hd;
   const long items = (long)B * N * H;
   const long gid = ((long)blockIdx.x * 256 + threadIdx.x) / LPR, gstride = (long)gridDim.x * 256 / LPR;
-  const bool plain = wq == nullptr;
-  const float4 wqv = (act && !plain) ? *(const float4*)(wq + c4) : f4(0.f), wkv = (act && !plain) ? *(const float4*)(wk + c4) : f4(0.f);
+  const bool plain = cosT == nullptr;
+  const bool norm = wq != nullptr;       // false with tables: RoPE adjoint only (use_qknorm=False); the pre-norm rows are then not read
+  const float4 wqv = (act && norm) ? *(const float4*)(wq + c4) : f4(1.f), wkv = (act && norm) ? *(const float4*)(wk + c4) : f4(1.f);
   float4 awq = f4(0.f), awk = f4(0.f), bq = f4(0.f), bk = f4(0.f), bv = f4(0.f);
   auto rnd = [](float4 v) { return make_float4(to_f<T>(from_f<T>(v.x)), to_f<T>(from_f<T>(v.y)), to_f<T>(from_f<T>(v.z)), to_f<T>(from_f<T>(v.w))); };
   for (long it = gid; it < items; it += gstride) {
@@ -681,15 +684,15 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
     }
     float4 qv = f4(0.f), kv = f4(0.f), gq = f4(0.f), gk = f4(0.f), gv = f4(0.f), cs = f4(0.f), sn = f4(0.f);
     if (act) {
-      qv = load4<T>(qkv + so); kv = load4<T>(qkv + so + (size_t)H * hd);
+      if (norm) { qv = load4<T>(qkv + so); kv = load4<T>(qkv + so + (size_t)H * hd); }
       gq = load4<T>(dq + go); gk = load4<T>(dk + go);
       // dv == NULL: the attention backward has already written dv into the v slot of dqkv (ldmae_attention_bwd_pv); it is only
       // read back for the bias-gradient column sums
       if (dv) gv = load4<T>(dv + go); else if (Pb) gv = load4<T>(dqkv + so + (size_t)2 * H * hd);
       cs = *(const float4*)(cosT + (size_t)n * hd + c4); sn = *(const float4*)(sinT + (size_t)n * hd + c4);
     }
-    const float rq = rsqrtf(group_sum<LPR>(hsum(qv * qv)) / (float)hd + eps);
-    const float rk = rsqrtf(group_sum<LPR>(hsum(kv * kv)) / (float)hd + eps);
+    const float rq = norm ? rsqrtf(group_sum<LPR>(hsum(qv * qv)) / (float)hd + eps) : 1.f;      // RoPE only: n = 0, m = 0, r = 1 -> the
+    const float rk = norm ? rsqrtf(group_sum<LPR>(hsum(kv * kv)) / (float)hd + eps) : 1.f;      // stored rows are exactly rope^T(g)
     const float4 nq = qv * rq, nk = kv * rk;
     const float4 tq = rope_apply_bwd(gq, cs, sn), tk = rope_apply_bwd(gk, cs, sn);   // grad wrt (n * w)
     awq = awq + tq * nq; awk = awk + tk * nk;
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(const T* __restric
     float* row = Pb + (size_t)gid * 3 * hd + c4;
     *(float4*)row = bq; *(float4*)(row + hd) = bk; *(float4*)(row + 2 * hd) = bv;
   }
-  if (plain) return;
+  if (!norm) return;
   red[threadIdx.x][0] = awq; red[threadIdx.x][1] = awk;
   __syncthreads();
   if (threadIdx.x < LPR && act) {
@@ -725,8 +728,8 @@ static unsigned qk_grid(long items, int lpr) {
 
 extern "C" int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq, const float* wk, const float* cos, const float* sin,
                                      void* q, void* k, void* v, int B, int N, int H, int hd, float eps, void* stream) {
-  LDMAE_REQUIRE(qkv && q && k && (v || wq), "qknorm_rope_fwd: null pointer (v may be NULL only with QK-norm / RoPE: v then stays in the packed qkv)");
-  LDMAE_REQUIRE((wq && wk && cos && sin) || (!wq && !wk), "qknorm_rope_fwd: pass all of wq/wk/cos/sin, or none (plain head-major relayout)");
+  LDMAE_REQUIRE(qkv && q && k && (v || cos), "qknorm_rope_fwd: null pointer (v may be NULL only with RoPE: v then stays in the packed qkv)");
+  LDMAE_REQUIRE(!wq == !wk && !cos == !sin && (!wq || cos), "qknorm_rope_fwd: pass wq/wk/cos/sin (QK-norm + RoPE), cos/sin alone (RoPE only: use_qknorm=False), or none (plain head-major relayout)");
   LDMAE_REQUIRE(hd % 8 == 0 && hd <= 128 && B > 0 && N > 0 && H > 0, "qknorm_rope_fwd: head_dim=%d must be a multiple of 8 and <= 128", hd);
   hipStream_t st = as_stream(stream);
   const long items = (long)B * N * H;
@@ -742,7 +745,7 @@ extern "C" int ldmae_qknorm_rope_fwd(int dtype, const void* qkv, const float* wq
     }
     else hipLaunchKernelGGL(qknorm_rope_fwd_dense_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)qkv, wq, wk, cos, sin, (float*)q, (float*)k, (float*)v, B, N, H, hd, eps);
   }
-  else if (dtype == LDMAE_BF16 && wq && !v && (hd == 64 || hd == 128) && items % (256 / (hd / 8)) == 0) {
+  else if (dtype == LDMAE_BF16 && cos && !v && (hd == 64 || hd == 128) && items % (256 / (hd / 8)) == 0) {
     // the LightningDiT block's form (v stays in the packed qkv): 16-B accesses, whole lane groups
     const unsigned grid = qk_grid(items, hd / 8);
     if (hd == 64) hipLaunchKernelGGL(qknorm_rope_fwd8_kernel<8>, dim3(grid), dim3(256), 0, st, (const bf16*)qkv, wq, wk, cos, sin, (bf16*)q, (bf16*)k, B, N, H, eps);
@@ -777,8 +780,9 @@ extern "C" long ldmae_qknorm_rope_bwd_workspace_bytes(int B, int N, int H, int h
 extern "C" int ldmae_qknorm_rope_bwd(int dtype, const void* dq, const void* dk, const void* dv, const void* qkv, const float* wq,
                                      const float* wk, const float* cos, const float* sin, void* dqkv, float* dwq, float* dwk, float beta_w,
                                      float* dbias_hqd, int B, int N, int H, int hd, float eps, float* workspace, void* stream) {
-  LDMAE_REQUIRE(dq && dk && dqkv && (dv || wq), "qknorm_rope_bwd: null pointer (dv may be NULL only with QK-norm / RoPE: dv is then already in dqkv)");
-  LDMAE_REQUIRE((qkv && wq && wk && cos && sin && dwq && dwk && workspace) || (!wq && !wk), "qknorm_rope_bwd: pass all norm/rope arguments, or none of wq/wk (plain relayout)");
+  LDMAE_REQUIRE(dq && dk && dqkv && (dv || cos), "qknorm_rope_bwd: null pointer (dv may be NULL only with RoPE: dv is then already in dqkv)");
+  LDMAE_REQUIRE(!wq == !wk && !cos == !sin && (!wq || (qkv && cos && dwq && dwk)) && (!cos || workspace),
+                "qknorm_rope_bwd: pass all norm/rope arguments, cos/sin without wq/wk (RoPE adjoint only: use_qknorm=False), or none of them (plain relayout)");
   LDMAE_REQUIRE(!dbias_hqd || workspace, "qknorm_rope_bwd: dbias requested without workspace");
   LDMAE_REQUIRE(hd % 8 == 0 && hd <= 128 && B > 0 && N > 0 && H > 0, "qknorm_rope_bwd: head_dim=%d must be a multiple of 8 and <= 128", hd);
   hipStream_t st = as_stream(stream);

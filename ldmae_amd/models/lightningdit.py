@@ -200,8 +200,9 @@ class _GradChain:
             return ops.rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx, dshift, dscale, N, accumulate)
         y2p, modp = prev
         dmodp = self.dmod(j - 1, modp)
-        dw, dy2p, db3p = ops.rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx, dshift, dscale, y2p, modp[:, 5 * D:6 * D],
-                                                       dmodp[:, 5 * D:6 * D], N, dtype, accumulate)
+        gc = modp.shape[1] - D                      # gate_mlp: the last chunk (:246 six chunks; :242 four with wo_shift)
+        dw, dy2p, db3p = ops.rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx, dshift, dscale, y2p, modp[:, gc:gc + D],
+                                                       dmodp[:, gc:gc + D], N, dtype, accumulate)
         self.pre[j - 1] = (dx.data_ptr(), dy2p, db3p, dmodp)
         return dw
 
@@ -251,11 +252,16 @@ class _DiTBlockFn(torch.autograd.Function):
         x2 = x.contiguous().view(M, D)
         sc = sc.contiguous()
         ctx.batched_ada = mod_all is not None
+        nmod = adaw.shape[0] // D                                                        # 6, or 4 with wo_shift (:227-236)
         if mod_all is not None:                                                          # _AdaLNAllFn ran the Linear of every block at once
-            mod = mod_all[:, idx * 6 * D:(idx + 1) * 6 * D]
+            mod = mod_all[:, idx * nmod * D:(idx + 1) * nmod * D]
         else:
             mod = ops.gemm_nt(sc, adaw, adab, out_dtype=torch.float32)                   # [B, 6D] f32
-        sh1, s1, g1, sh2, s2, g2 = (mod[:, i * D:(i + 1) * D] for i in range(6))          # :246 chunk order
+        if nmod == 6:
+            sh1, s1, g1, sh2, s2, g2 = (mod[:, i * D:(i + 1) * D] for i in range(6))      # :246 chunk order
+        else:
+            s1, g1, s2, g2 = (mod[:, i * D:(i + 1) * D] for i in range(4))                # :242 (wo_shift: modulate without the shift)
+            sh1 = sh2 = None
         # forward-only calls (torch.no_grad sampling: forward_with_cfg) skip everything only the backward pass reads: the transposed
         # weight copies, the pre-gate branch outputs y1 / y2 and h12 = [x1 | x2] of the SwiGLU (1.6 GB per XL/1 block at batch 128).
         # The flag comes from the module (grad mode is always off in here and needs_input_grad ignores torch.no_grad()).
@@ -270,8 +276,9 @@ class _DiTBlockFn(torch.autograd.Function):
         if dtype == torch.bfloat16:      # v is consumed where the qkv Linear wrote it: no head-major copy of v (nor of dv in backward)
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps, copy_v=False)
             # QK-RMSNorm bounds |q|, |k| by max|w| sqrt(hd) and the rotation keeps norms: a proven score bound, so the softmax runs with a
-            # static shift (no running maximum in the kernel)
-            o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5, bound=ops.qk_score_bound(qnw, knw, hd, hd ** -0.5))      # [B,N,D]
+            # static shift (no running maximum in the kernel).  use_qknorm=False (qnw None; q_norm = nn.Identity, :60-61): nothing bounds the
+            # scores, the kernel tracks the running maximum.
+            o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5, bound=ops.qk_score_bound(qnw, knw, hd, hd ** -0.5) if qnw is not None else None)      # [B,N,D]
         else:
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
             o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)
@@ -285,6 +292,7 @@ class _DiTBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2, sc, cos, sin, mod, rstd1, xm1, qkv, q, k, v, o, lse, y1, xmid, rstd2, xm2, h12, hid, y2,
                               n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T)
         ctx.dims = (B, N, D, H, hd, eps, dtype)
+        ctx.nmod = nmod
         ctx.inplace = bool(inplace)
         ctx.chain, ctx.idx = chain, idx
         ctx.direct, ctx.wparams = bool(direct), (qkvw, pw, w12, w3)
@@ -307,7 +315,10 @@ class _DiTBlockFn(torch.autograd.Function):
         if not ctx.inplace and dx.data_ptr() == gout.data_ptr():
             dx = dx.clone()
         chain, idx = ctx.chain, ctx.idx
-        s1, g1, s2, g2 = mod[:, D:2 * D], mod[:, 2 * D:3 * D], mod[:, 4 * D:5 * D], mod[:, 5 * D:6 * D]
+        # column chunk of each modulation vector in mod / dmod: (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp), :246; no shifts with wo_shift, :242
+        c_sh1, c_s1, c_g1, c_sh2, c_s2, c_g2 = (0, 1, 2, 3, 4, 5) if ctx.nmod == 6 else (None, 0, 1, None, 2, 3)
+        col = lambda t_, c_: None if c_ is None else t_[:, c_ * D:(c_ + 1) * D]      # noqa: E731
+        s1, g1, s2, g2 = col(mod, c_s1), col(mod, c_g1), col(mod, c_s2), col(mod, c_g2)
         sg = ops.SideGemms(dx.device, enabled=dtype == torch.bfloat16)      # weight gradients: off the critical path
         # ---- MLP branch
         pre = chain.pre.pop(idx, None) if chain is not None else None
@@ -315,7 +326,7 @@ class _DiTBlockFn(torch.autograd.Function):
             _, dy2, db3, dmod = pre
         else:
             dmod = chain.dmod(idx, mod) if chain is not None else torch.empty(mod.shape, dtype=mod.dtype, device=mod.device)
-            dy2, db3 = ops.gate_bwd(dx, y2, g2, dmod[:, 5 * D:6 * D], N, dtype, with_bias=True)   # bias grads where dy is produced
+            dy2, db3 = ops.gate_bwd(dx, y2, g2, col(dmod, c_g2), N, dtype, with_bias=True)   # bias grads where dy is produced
         qkvw_p, pw_p, w12_p, w3_p = ctx.wparams
         notify = []
         dW3, r = _dw_into_grad(sg, dy2, hid, w3_p, ctx.direct); notify.append((r, w3_p))
@@ -323,8 +334,8 @@ class _DiTBlockFn(torch.autograd.Function):
         dW12, r = _dw_into_grad(sg, dh12, xm2, w12_p, ctx.direct); notify.append((r, w12_p))
         dxm2 = ops.gemm_nt(dh12, W12T)
         # norm2 backward and the attention branch's gate backward in one pass (the updated dx is consumed from registers)
-        dn2, dy1, dbp = ops.rmsnorm_modulate_bwd_gate(dxm2, xmid, n2w, s2, rstd2, dx, dmod[:, 3 * D:4 * D], dmod[:, 4 * D:5 * D],
-                                                      y1, g1, dmod[:, 2 * D:3 * D], N, dtype)
+        dn2, dy1, dbp = ops.rmsnorm_modulate_bwd_gate(dxm2, xmid, n2w, s2, rstd2, dx, col(dmod, c_sh2), col(dmod, c_s2),
+                                                      y1, g1, col(dmod, c_g1), N, dtype)
         # ---- attention branch
         dWp, r = _dw_into_grad(sg, dy1, o.view(M, D), pw_p, ctx.direct); notify.append((r, pw_p))
         do = ops.gemm_nt(dy1, WpT)
@@ -340,9 +351,9 @@ class _DiTBlockFn(torch.autograd.Function):
         dWqkv, r = _dw_into_grad(sg, dqkv, xm1, qkvw_p, ctx.direct); notify.append((r, qkvw_p))
         dxm1 = ops.gemm_nt(dqkv, WqkvT)
         if chain is not None:
-            dn1 = chain.norm_bwd(idx, dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N, dtype)
+            dn1 = chain.norm_bwd(idx, dxm1, x2, n1w, s1, rstd1, dx, col(dmod, c_sh1), col(dmod, c_s1), N, dtype)
         else:
-            dn1 = ops.rmsnorm_modulate_bwd(dxm1, x2, n1w, s1, rstd1, dx, dmod[:, 0:D], dmod[:, D:2 * D], N)
+            dn1 = ops.rmsnorm_modulate_bwd(dxm1, x2, n1w, s1, rstd1, dx, col(dmod, c_sh1), col(dmod, c_s1), N)
         # ---- adaLN: per block in f32, or (batched) nothing here -- block 0, the last to run, returns the shared dmod buffer for mod_all
         dmod_all = None
         if ctx.batched_ada:
@@ -356,11 +367,13 @@ class _DiTBlockFn(torch.autograd.Function):
         # the eight small gradients of the block (norm weights, biases, QK-norm weights): with `direct`, ONE launch adds them into their .grad
         # views instead of one AccumulateGrad add each
         small = [dn1, dbqkv, dqn, dkn, dbp, dn2, db12, db3]
-        if ctx.sparams is not None and all(g_ is not None and p_.grad is not None and p_.grad.dtype == torch.float32 and
-                                           p_.grad.is_contiguous() and p_.grad.shape == g_.shape for p_, g_ in zip(ctx.sparams, small)):
-            ops.multi_add_([p_.grad for p_ in ctx.sparams], small)
-            notify.extend((getattr(p_, "_ldmae_grad_ready", None), p_) for p_ in ctx.sparams)
-            dn1 = dbqkv = dqn = dkn = dbp = dn2 = db12 = db3 = None
+        if ctx.sparams is not None:
+            pairs = [(p_, g_) for p_, g_ in zip(ctx.sparams, small) if p_ is not None]      # use_qknorm=False: no q_norm / k_norm weights
+            if all(g_ is not None and p_.grad is not None and p_.grad.dtype == torch.float32 and p_.grad.is_contiguous() and p_.grad.shape == g_.shape
+                   for p_, g_ in pairs):
+                ops.multi_add_([p_.grad for p_, _ in pairs], [g_ for _, g_ in pairs])
+                notify.extend((getattr(p_, "_ldmae_grad_ready", None), p_) for p_, _ in pairs)
+                dn1 = dbqkv = dqn = dkn = dbp = dn2 = db12 = db3 = None
         for r, p_ in notify:          # gradients written straight into .grad: tell the reducer (no-op without one)
             if r is not None:
                 r(p_)
@@ -382,7 +395,7 @@ class _AttentionFn(torch.autograd.Function):
         qkv = ops.gemm_nt(xa, Wqkv, qkvb)
         if dtype == torch.bfloat16:
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps, copy_v=False)
-            o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5, bound=ops.qk_score_bound(qnw, knw, hd, hd ** -0.5))
+            o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5, bound=ops.qk_score_bound(qnw, knw, hd, hd ** -0.5) if qnw is not None else None)
         else:
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
             o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)
@@ -532,6 +545,8 @@ class Attention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_norm=False, use_rmsnorm=False, **_):
         super().__init__()
         assert dim % num_heads == 0, 'dim should be divisible by num_heads'
+        if qk_norm and not use_rmsnorm:
+            raise NotImplementedError("ldmae_amd Attention: qk_norm with nn.LayerNorm (use_rmsnorm=False) is not accelerated; RMSNorm or no QK-norm")
         self.num_heads = num_heads
         self.head_dim = dim // num_heads
         self.scale = self.head_dim ** -0.5
@@ -541,49 +556,62 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.precision = None
 
+    def norm_args(self):
+        """(eps, q_norm weight, k_norm weight); the weights are None with qk_norm=False (q_norm = k_norm = nn.Identity, :60-61)."""
+        if isinstance(self.q_norm, RMSNorm):
+            return self.q_norm.eps, self.q_norm.weight, self.k_norm.weight
+        return 1e-6, None, None
+
     def forward(self, x, rope=None):
-        if not isinstance(self.q_norm, RMSNorm):
-            raise NotImplementedError("ldmae_amd Attention: qk_norm=True with RMSNorm only (the shipped configuration)")
         B, N, C = x.shape
-        if rope is not None:
-            cos, sin = rope.freqs_cos, rope.freqs_sin
-        else:                                            # :71 -- no rotation: identity tables
-            cos = torch.ones(N, self.head_dim, device=x.device)
-            sin = torch.zeros(N, self.head_dim, device=x.device)
+        cos, sin = (rope.freqs_cos, rope.freqs_sin) if rope is not None else _identity_rope(N, self.head_dim, x.device)      # :71
         dtype = _act_dtype(self.precision)
         with torch.autocast(device_type="cuda", enabled=False):
-            return _AttentionFn.apply(x, cos, sin, self.num_heads, self.q_norm.eps, dtype, self.qkv.weight, self.qkv.bias,
-                                      self.q_norm.weight, self.k_norm.weight, self.proj.weight, self.proj.bias)
+            eps, qnw, knw = self.norm_args()
+            return _AttentionFn.apply(x, cos, sin, self.num_heads, eps, dtype, self.qkv.weight, self.qkv.bias, qnw, knw, self.proj.weight, self.proj.bias)
+
+
+_IDENTITY_ROPE: dict = {}
+
+
+def _identity_rope(N, hd, device):
+    """cos = 1, sin = 0 tables: the RoPE kernels then return their input bit for bit (x * 1 - y * 0) -- the call without a rotation
+    (use_rope=False: feat_rope = None, :71,324-325) on the same kernels."""
+    key = (N, hd, str(device))
+    t = _IDENTITY_ROPE.get(key)
+    if t is None:
+        t = _IDENTITY_ROPE[key] = (torch.ones(N, hd, device=device), torch.zeros(N, hd, device=device))
+    return t
 
 
 class LightningDiTBlock(nn.Module):
-    """:171-250.  Accelerated configuration = the shipped one (use_qknorm, use_swiglu, use_rmsnorm,
-    wo_shift=False; configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml:26-33)."""
+    """:171-250.  Accelerated: RMSNorm + SwiGLU blocks (use_rmsnorm = use_swiglu = True, both shipped YAMLs) with or without QK-norm
+    (configs/imagenet/...yaml:28 true; configs/celeba_hq/...yaml:30 false), with or without the adaLN shift (wo_shift) and RoPE."""
 
     def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, use_qknorm=False, use_swiglu=False, use_rmsnorm=False,
                  wo_shift=False, **block_kwargs):
         super().__init__()
-        if not (use_qknorm and use_swiglu and use_rmsnorm) or wo_shift:
+        if not (use_swiglu and use_rmsnorm):
             raise NotImplementedError(
-                "ldmae_amd accelerates the shipped LightningDiT configuration only: use_qknorm=use_swiglu=use_rmsnorm=True, "
-                "wo_shift=False (reference configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml:26-33)")
+                "ldmae_amd accelerates the RMSNorm + SwiGLU form of the LightningDiT block (use_swiglu=use_rmsnorm=True, as in both shipped "
+                "configs: reference configs/imagenet|celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml:26-33); LayerNorm / timm Mlp blocks are not built")
         self.norm1 = RMSNorm(hidden_size)
         self.norm2 = RMSNorm(hidden_size)
-        self.attn = Attention(hidden_size, num_heads=num_heads, qkv_bias=True, qk_norm=True, use_rmsnorm=True)
+        self.attn = Attention(hidden_size, num_heads=num_heads, qkv_bias=True, qk_norm=use_qknorm, use_rmsnorm=True)
         self.mlp = SwiGLUFFN(hidden_size, int(2 / 3 * int(hidden_size * mlp_ratio)))
-        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, (4 if wo_shift else 6) * hidden_size, bias=True))
         self.wo_shift = wo_shift
         self.precision = None
 
     def forward(self, x, c, feat_rope=None, _silu_c=None, _dtype=None, _inplace_grad=False, _chain=None, _idx=0, _direct=False, _mod_all=None):
-        if feat_rope is None:
-            raise NotImplementedError("ldmae_amd LightningDiTBlock needs feat_rope (use_rope=True)")
         sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
         a, m = self.attn, self.mlp
+        cos, sin = (feat_rope.freqs_cos, feat_rope.freqs_sin) if feat_rope is not None else _identity_rope(x.shape[1], a.head_dim, x.device)
+        _, qnw, knw = a.norm_args()
         return _DiTBlockFn.apply(
-            x.float(), sc, feat_rope.freqs_cos, feat_rope.freqs_sin, a.num_heads, self.norm1.eps, _dtype or _act_dtype(self.precision),
+            x.float(), sc, cos, sin, a.num_heads, self.norm1.eps, _dtype or _act_dtype(self.precision),
             _inplace_grad, _chain, _idx, _direct, not torch.is_grad_enabled(), _mod_all,
-            self.norm1.weight, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.k_norm.weight, a.proj.weight, a.proj.bias,
+            self.norm1.weight, a.qkv.weight, a.qkv.bias, qnw, knw, a.proj.weight, a.proj.bias,
             self.norm2.weight, m.w12.weight, m.w12.bias, m.w3.weight, m.w3.bias,
             self.adaLN_modulation[1].weight, self.adaLN_modulation[1].bias)
 
@@ -615,8 +643,6 @@ class LightningDiT(nn.Module):
                  class_dropout_prob=0.1, num_classes=1000, learn_sigma=False, use_qknorm=False, use_swiglu=False,
                  use_rope=False, use_rmsnorm=False, wo_shift=False, use_checkpoint=False):
         super().__init__()
-        if not use_rope:
-            raise NotImplementedError("ldmae_amd LightningDiT: use_rope=True only (the shipped configuration)")
         # opt-in of the training driver (which owns a gradient slab and calls plain loss.backward()): the four Linear weight gradients
         # of every block are accumulated straight into param.grad by the GEMM's reduce instead of through autograd's AccumulateGrad
         self.direct_param_grads = False
@@ -642,7 +668,7 @@ class LightningDiT(nn.Module):
         self.y_embedder = LabelEmbedder(num_classes, hidden_size, class_dropout_prob)
         num_patches = self.x_embedder.num_patches
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches, hidden_size), requires_grad=False)
-        self.feat_rope = VisionRotaryEmbeddingFast(dim=hidden_size // num_heads // 2, pt_seq_len=input_size // patch_size)
+        self.feat_rope = VisionRotaryEmbeddingFast(dim=hidden_size // num_heads // 2, pt_seq_len=input_size // patch_size) if use_rope else None      # :317-325
         self.blocks = nn.ModuleList([
             LightningDiTBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio, use_qknorm=use_qknorm, use_swiglu=use_swiglu,
                               use_rmsnorm=use_rmsnorm, wo_shift=wo_shift) for _ in range(depth)])

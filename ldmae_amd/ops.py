@@ -357,7 +357,8 @@ def rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx_accum, dshift, dscale,
 
 
 def qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6, copy_v=True):
-    """copy_v=False: v gets no head-major copy (returned as None); attention then reads it from the packed qkv (attention_fwd_pv)."""
+    """copy_v=False: v gets no head-major copy (returned as None); attention then reads it from the packed qkv (attention_fwd_pv).
+    wq = wk = None: RoPE only (the block built with use_qknorm=False: q_norm = k_norm = nn.Identity, lightningdit.py:60-61)."""
     q = torch.empty(B, H, N, hd, dtype=qkv.dtype, device=qkv.device)
     k = torch.empty_like(q)
     v = torch.empty_like(q) if copy_v else None
@@ -370,8 +371,8 @@ def qknorm_rope_bwd(dq, dk, dv, qkv, wq, wk, cos, sin, B, N, H, hd, eps=1e-6, wi
     (column sums of dqkv as stored), formed in the same pass.  dv=None with dqkv given: dv already sits in the v slot of dqkv
     (attention_bwd_pv) and is left there."""
     dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
-    dwq = torch.empty(hd, dtype=torch.float32, device=qkv.device)
-    dwk = torch.empty_like(dwq)
+    dwq = torch.empty(hd, dtype=torch.float32, device=qkv.device) if wq is not None else None      # wq = wk = None: RoPE adjoint only
+    dwk = torch.empty_like(dwq) if wq is not None else None
     db = torch.empty(H, 3, hd, dtype=torch.float32, device=qkv.device) if with_bias else None
     ws = workspace(L.load().ldmae_qknorm_rope_bwd_workspace_bytes(B, N, H, hd), qkv.device)
     call("ldmae_qknorm_rope_bwd", dt(qkv.dtype), ptr(dq), ptr(dk), ptr(dv), ptr(qkv), ptr(wq), ptr(wk), ptr(cos), ptr(sin), ptr(dqkv),
@@ -473,8 +474,11 @@ def attention_bwd_pv_qknorm(q, k, qkv, o, do, lse, scale, wq, wk, cos, sin, eps=
     dbias [3*H*hd])."""
     B, H, N, hd = q.shape
     dqkv = torch.empty_like(qkv)
-    dw2 = torch.empty(2 * hd, dtype=torch.float32, device=q.device)      # dwq | dwk adjacent: the library reduces straight into them
-    dwq, dwk = dw2[:hd], dw2[hd:]
+    if wq is not None:
+        dw2 = torch.empty(2 * hd, dtype=torch.float32, device=q.device)      # dwq | dwk adjacent: the library reduces straight into them
+        dwq, dwk = dw2[:hd], dw2[hd:]
+    else:
+        dwq = dwk = None                                                      # RoPE adjoint only (use_qknorm=False)
     db = torch.empty(3 * H * hd, dtype=torch.float32, device=q.device)
     ws = workspace(L.load().ldmae_attention_bwd_pv_qknorm_workspace_bytes(B, H, N, hd), q.device)
     call("ldmae_attention_bwd_pv_qknorm", dt(q.dtype), ptr(q), ptr(k), ptr(qkv), ptr(o), ptr(_c(do)), ptr(lse), ptr(wq), ptr(wk), ptr(cos),

@@ -19,6 +19,17 @@ def test_yaml_is_the_reference_api():
     import ldmae_amd.train_accum as t
     m = t.build_model(cfg)
     assert m.hidden_size == 768 and m.depth == 12 and m.x_embedder.num_patches == 1024 and m.in_channels == 16
+    # the reference's second documented configuration (README.md:108-110): unconditional CelebA-HQ, no QK-norm; and both launcher configs
+    cel = yaml.safe_load(open(os.path.join(ROOT, "ldmae_amd/configs/celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml")))
+    assert set(cel) == set(cfg) and cel["model"] == {**cfg["model"], "use_qknorm": False}
+    assert cel["data"]["num_classes"] == 1 and cel["data"]["name"] == "celebahq" and cel["sample"]["cfg_scale"] == 0 and cel["sample"]["per_proc_batch_size"] == 128
+    assert cel["train"]["global_batch_size"] == 1024 and cel["train"]["max_steps"] == 60000 and cel["vae"]["model_name"] == "vmae"
+    mc = t.build_model(cel)
+    assert mc.depth == 12 and mc.y_embedder.dropout_prob == 0 and mc.y_embedder.embedding_table.weight.shape[0] == 1
+    assert not any("q_norm" in k for k in mc.state_dict())
+    for n, procs in (("4gpu", 4), ("8gpu", 8)):
+        acc = yaml.safe_load(open(os.path.join(ROOT, f"ldmae_amd/configs/accelerator/{n}.yaml")))
+        assert acc["num_processes"] == procs and acc["mixed_precision"] == "bf16" and acc["distributed_type"] == "MULTI_GPU"
 
 
 def test_latent_dataset_roundtrip(tmp_path):

@@ -8,7 +8,7 @@ from conftest import rel_err
 from oracle import dit as odit
 from oracle import train as otrain
 from oracle import transport as otr
-from weights import det_randn, det_weights, ref_style_init
+from weights import DIT_FLAG_VARIANTS, det_randn, det_weights, ref_style_init
 
 pytestmark = pytest.mark.gpu
 
@@ -21,7 +21,8 @@ def build(cfg, sd, precision=None):
     from ldmae_amd.models.lightningdit import LightningDiT
     m = LightningDiT(input_size=cfg.input_size, patch_size=cfg.patch_size, in_channels=cfg.in_channels, hidden_size=cfg.hidden_size,
                      depth=cfg.depth, num_heads=cfg.num_heads, num_classes=cfg.num_classes, class_dropout_prob=cfg.class_dropout_prob,
-                     learn_sigma=cfg.learn_sigma, **FLAGS)
+                     learn_sigma=cfg.learn_sigma, use_qknorm=cfg.use_qknorm, use_swiglu=cfg.use_swiglu, use_rope=cfg.use_rope,
+                     use_rmsnorm=cfg.use_rmsnorm, wo_shift=cfg.wo_shift)
     missing, unexpected = m.load_state_dict({k: v for k, v in sd.items()}, strict=True), None
     m = m.cuda().train()
     if precision is not None:
@@ -142,6 +143,96 @@ def test_dit_variants_match_reference_golden(golden):
                 out16 = m(x, t, y)
         assert rel_err(out.cpu(), g[f"dv_{tag}_out"]) < 1e-4, tag
         assert rel_err(out16.float().cpu(), g[f"dv_{tag}_out"]) < 3e-2, tag
+
+
+def _flag_cfg(over):
+    return odit.DiTConfig(**{**dict(input_size=8, patch_size=1, in_channels=16, hidden_size=192, depth=2, num_heads=3, num_classes=10,
+                                    class_dropout_prob=0.5), **over})
+
+
+@pytest.mark.parametrize("tag", ["noqk", "woshift", "norope"])
+def test_block_flag_variants_match_reference_golden(golden, tag):
+    """The block flags the shipped imagenet YAML leaves alone, on the HIP path DIRECTLY against the reference's own train-mode forward, loss
+    and parameter gradients (tests/golden/dit_flags.npz, make_golden.py: gen_dit_flags): 'noqk' = use_qknorm=False + num_classes=1, the
+    reference's CelebA-HQ configuration (configs/celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml:15,30; RoPE without a norm, tracked-maximum
+    softmax, rope-only backward epilogues), 'woshift' (four modulation vectors, :241-244), 'norope' (feat_rope = None, :324-325).  f32: output,
+    loss and every gradient within 1e-4 (gradients also in full against the oracle); bf16 autocast within bf16's margin."""
+    g = golden("dit_flags")
+    n = list(DIT_FLAG_VARIANTS).index(tag)
+    cfg = _flag_cfg(DIT_FLAG_VARIANTS[tag])
+    sd = det_weights(odit.param_shapes(cfg), 20 + n)
+    sd.update(odit.fixed_tables(cfg))
+    xt, t, tgt = det_randn("xt", (2, 16, 8, 8), 7), torch.tensor([0.3, 0.8]), det_randn("tgt", (2, 16, 8, 8), 11)
+    y, drop = torch.from_numpy(g[f"df_{tag}_y"]), torch.from_numpy(g[f"df_{tag}_drop"])
+    osd = {k: (v.clone().requires_grad_(True) if k in odit.param_shapes(cfg) and k != "pos_embed" else v) for k, v in sd.items()}
+    oout = odit.dit_forward(osd, xt, t, y, cfg, True, drop)
+    ((oout - tgt) ** 2).mean().backward()
+    m = build(cfg, sd)
+    assert sorted(m.state_dict().keys()) == [str(k) for k in g[f"df_{tag}_keys"]]
+    force_drop(m, drop)
+    out = m(xt.cuda(), t.cuda(), y.cuda())
+    loss = ((out - tgt.cuda()) ** 2).mean()
+    loss.backward()
+    assert rel_err(out.detach().cpu(), g[f"df_{tag}_out"]) < 1e-4
+    assert abs(float(loss) - float(g[f"df_{tag}_loss"])) < 1e-4 * float(g[f"df_{tag}_loss"])
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    names = [str(k) for k in g[f"df_{tag}_grad_names"]]
+    assert set(names) == set(grads)
+    for k, gn in zip(names, g[f"df_{tag}_grad_norm"]):
+        assert abs(float(grads[k].double().norm()) - gn) <= 1e-4 * gn + 1e-9, (tag, k)
+        assert rel_err(grads[k].cpu(), osd[k].grad) < 1e-4, (tag, k)
+    m.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out16 = m(xt.cuda(), t.cuda(), y.cuda())
+    assert out16.dtype == torch.float32 and rel_err(out16.detach().cpu(), g[f"df_{tag}_out"]) < 3e-2
+    ((out16 - tgt.cuda()) ** 2).mean().backward()
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        a, b = p.grad.double().flatten().cpu(), osd[k].grad.double().flatten()
+        assert float((a @ b) / (a.norm() * b.norm() + 1e-30)) > 0.99, (tag, k)
+
+
+def test_flag_combination_and_unbuilt_flags():
+    """use_qknorm=False + wo_shift + use_rope=False together (no golden: against the oracle, whose every flag is pinned on the reference one
+    at a time), with the backward chain, batched adaLN (bf16) and direct parameter gradients the B/1 train step uses; the two block forms that
+    are not built (LayerNorm, timm Mlp) refuse in the constructor."""
+    from ldmae_amd.models.lightningdit import LightningDiT
+    cfg = _flag_cfg(dict(use_qknorm=False, wo_shift=True, use_rope=False, class_dropout_prob=0.0))
+    sd = det_weights(odit.param_shapes(cfg), 77)
+    sd.update(odit.fixed_tables(cfg))
+    B = 8
+    xt, t, y, tgt = det_randn("xt8", (B, 16, 8, 8), 7), torch.linspace(0.1, 0.9, B), torch.arange(B) % 10, det_randn("tgt8", (B, 16, 8, 8), 11)
+    osd = {k: (v.clone().requires_grad_(True) if k != "pos_embed" else v) for k, v in sd.items()}
+    oout = odit.dit_forward(osd, xt, t, y, cfg, True, None)
+    ((oout - tgt) ** 2).mean().backward()
+    for prec, otol, gtol in ((torch.float32, 1e-4, 1e-4), (torch.bfloat16, 3e-2, 8e-2)):
+        m = build(cfg, sd, prec)
+        out = m(xt.cuda(), t.cuda(), y.cuda())
+        ((out - tgt.cuda()) ** 2).mean().backward()
+        assert rel_err(out.detach().cpu(), oout.detach()) < otol, prec
+        worst = max(rel_err(p.grad.cpu(), osd[k].grad) for k, p in m.named_parameters() if p.grad is not None)
+        assert worst < gtol, (prec, worst)
+    for kw in (dict(use_rmsnorm=False, use_swiglu=True), dict(use_rmsnorm=True, use_swiglu=False)):
+        with pytest.raises(NotImplementedError):
+            LightningDiT(input_size=8, patch_size=1, in_channels=16, hidden_size=192, depth=1, num_heads=3, use_qknorm=True, use_rope=True, **kw)
+
+
+def test_celeba_config_real_width_vs_reference_golden(golden):
+    """The reference's CelebA-HQ model kwargs (use_qknorm=False, num_classes=1 -> class_dropout_prob 0: train_accum.py:79-90) at the real B/1
+    width (768, 12 heads of 64; depth 1): eval forward against the reference's own output, f32 at 1e-4 and bf16 autocast at bf16's margin."""
+    g = golden("dit_flags")
+    cfg = odit.DiTConfig(input_size=8, hidden_size=768, depth=1, num_heads=12, num_classes=1, use_qknorm=False)
+    sd = det_weights(odit.param_shapes(cfg), 31)
+    sd.update(odit.fixed_tables(cfg))
+    m = build(cfg, sd).eval()
+    x, t, y = det_randn("x", (2, 16, 8, 8), 1).cuda(), torch.tensor([0.2, 0.7]).cuda(), torch.tensor([0, 0]).cuda()
+    with torch.no_grad():
+        out = m(x, t, y)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out16 = m(x, t, y)
+    assert rel_err(out.cpu(), g["df_noqk768_out"]) < 1e-4
+    assert rel_err(out16.float().cpu(), g["df_noqk768_out"]) < 3e-2
 
 
 def test_xl_head_dim_72_geometry_fp32_and_bf16():

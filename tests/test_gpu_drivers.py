@@ -11,19 +11,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def tiny_cfg(tmp_path):
-    cfg = yaml.safe_load(open(os.path.join(ROOT, "ldmae_amd/configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml")))
+def tiny_cfg(tmp_path, dataset="imagenet"):
+    cfg = yaml.safe_load(open(os.path.join(ROOT, f"ldmae_amd/configs/{dataset}/lightningdit_b_vmae_f8d16_cfg.yaml")))
     cfg = copy.deepcopy(cfg)
     cfg["data"].update(image_size=64, num_workers=0)           # 64 / 8 = 8x8 latents -> 64 tokens
     cfg["train"].update(global_batch_size=8, output_dir=str(tmp_path), exp_name="t", log_every=2, ckpt_every=3, max_steps=3)
     return cfg
 
 
-def test_train_driver_checkpoint_resume_and_sampler(tmp_path, monkeypatch):
+@pytest.mark.parametrize("dataset", ["imagenet", "celeba_hq"])      # both documented run_train.sh configurations (README.md:104-110)
+def test_train_driver_checkpoint_resume_and_sampler(tmp_path, monkeypatch, dataset):
     import ldmae_amd.train_accum as t
     from ldmae_amd.models import lightningdit as L
     monkeypatch.setitem(L.LightningDiT_models, "LightningDiT-B/1", lambda **kw: L.LightningDiT(depth=2, hidden_size=192, patch_size=1, num_heads=3, **kw))
-    cfg = tiny_cfg(tmp_path)
+    cfg = tiny_cfg(tmp_path, dataset)
     torch.manual_seed(0)
     np.random.seed(0)
     model, opt = t.do_train(cfg, synthetic=True)
@@ -37,7 +38,7 @@ def test_train_driver_checkpoint_resume_and_sampler(tmp_path, monkeypatch):
     w, e = ck["model"]["blocks.0.attn.qkv.weight"], ck["ema"]["blocks.0.attn.qkv.weight"]
     assert 0 < float((w - e).abs().max()) < 1e-2
     # resume picks the checkpoint up and continues to step 5
-    cfg2 = tiny_cfg(tmp_path)
+    cfg2 = tiny_cfg(tmp_path, dataset)
     cfg2["train"].update(resume=True, max_steps=5, ckpt_every=100)
     model2, opt2 = t.do_train(cfg2, synthetic=True)
     assert opt2.step_count == 2
@@ -48,7 +49,8 @@ def test_train_driver_checkpoint_resume_and_sampler(tmp_path, monkeypatch):
     m = m.cuda().eval()
     cfg["sample"]["num_sampling_steps"] = 5
     with torch.autocast("cuda", dtype=torch.bfloat16):
-        lat, y = sample_latents(m, build_sampler(cfg), 4, 4.0, 0.1, torch.device("cuda"), 1000)
+        lat, y = sample_latents(m, build_sampler(cfg), 4, 4.0 if dataset == "imagenet" else cfg["sample"]["cfg_scale"], 0.1, torch.device("cuda"),
+                                cfg["data"]["num_classes"])
     assert lat.shape == (4, 16, 8, 8) and torch.isfinite(lat).all()
 
 
@@ -104,20 +106,22 @@ def test_sampler_skips_the_unconditional_half_only_where_it_is_unused(tmp_path):
         assert torch.equal(y, y2) and torch.equal(lat, ref), n
 
 
-def test_do_sample_end_to_end_writes_pngs(tmp_path, monkeypatch):
+@pytest.mark.parametrize("dataset,cfg_scale", [("imagenet", 4.0), ("celeba_hq", 0)])
+def test_do_sample_end_to_end_writes_pngs(tmp_path, monkeypatch, dataset, cfg_scale):
     """SURVEY 8(f)1 end to end (reference inference.py:264-299): EMA checkpoint -> shifted-grid Euler with CFG -> latent de-normalisation
     (z * std / multiplier + mean) -> VMAE decode_to_images -> one PNG per sample, indexed i * world + rank + total; the PNG encoding runs
-    on the writer thread."""
+    on the writer thread.  'celeba_hq': the reference's unconditional configuration (cfg_scale 0 -> the branch without the doubled batch,
+    inference.py:282-284; num_classes 1; no QK-norm)."""
     from PIL import Image
     import ldmae_amd.inference as inf
     import ldmae_amd.train_accum as t
     from ldmae_amd.models import lightningdit as L
     from ldmae_amd.tokenizer import models_mae
     monkeypatch.setitem(L.LightningDiT_models, "LightningDiT-B/1", lambda **kw: L.LightningDiT(depth=2, hidden_size=192, patch_size=1, num_heads=3, **kw))
-    cfg = tiny_cfg(tmp_path)
+    cfg = tiny_cfg(tmp_path, dataset)
     cfg["data"].update(data_path=str(tmp_path / "feat"), latent_multiplier=1.0)       # 'sample' key present -> the dir gets the _sample suffix
     cfg["vae"]["weight_path"] = str(tmp_path / "vmae.pth")
-    cfg["sample"].update(num_sampling_steps=2, per_proc_batch_size=4, fid_num=8, cfg_scale=4.0)
+    cfg["sample"].update(num_sampling_steps=2, per_proc_batch_size=4, fid_num=8, cfg_scale=cfg_scale)
     torch.manual_seed(0)
     dit = t.build_model(cfg)
     g = torch.Generator().manual_seed(1)

@@ -39,12 +39,13 @@ transport = create_transport(                                           # train_
     train_config['transport']['train_eps'], train_config['transport']['sample_eps'],
     use_cosine_loss=train_config['transport']['use_cosine_loss'] if 'use_cosine_loss' in train_config['transport'] else False,
     use_lognorm=train_config['transport']['use_lognorm'] if 'use_lognorm' in train_config['transport'] else False)
-assert sum(p.numel() for p in model.parameters()) == 131122960           # SURVEY 8c: 131.12296 M for B/1
+celeba = train_config['data']['num_classes'] == 1                       # configs/celeba_hq: no QK-norm weights (12 x 2 x 64), a one-row label table
+assert sum(p.numel() for p in model.parameters()) == (131122960 - 1536 - 1000 * 768 if celeba else 131122960)   # SURVEY 8c: 131.12296 M for B/1
 assert model.in_channels == 16 and model.x_embedder.patch_size[0] == 1 and model.x_embedder.num_patches == 1024
 model = model.to("cuda").train()
 opt = torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay=0, betas=(0.9, 0.95))   # train_accum.py:121: the STOCK optimizer
 torch.manual_seed(0); np.random.seed(0)
-x = torch.randn(2, 16, 32, 32, device="cuda"); y = torch.randint(0, 1000, (2,), device="cuda")
+x = torch.randn(2, 16, 32, 32, device="cuda"); y = torch.randint(0, train_config['data']['num_classes'], (2,), device="cuda")
 with torch.autocast("cuda", dtype=torch.bfloat16):                      # what accelerate --mixed_precision bf16 sets up
     loss = transport.training_losses(model, x, dict(y=y))["loss"].mean()
 loss.backward()
@@ -58,8 +59,9 @@ print("LOSS %.6f" % float(loss))
 '''
 
 
-def test_reference_constructor_call_through_dropin_names(tmp_path):
-    cfg = os.path.join(ROOT, "ldmae_amd", "configs", "imagenet", "lightningdit_b_vmae_f8d16_cfg.yaml")
+@pytest.mark.parametrize("dataset", ["imagenet", "celeba_hq"])      # README.md:104-110: the two documented run_train.sh invocations
+def test_reference_constructor_call_through_dropin_names(tmp_path, dataset):
+    cfg = os.path.join(ROOT, "ldmae_amd", "configs", dataset, "lightningdit_b_vmae_f8d16_cfg.yaml")
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     env["PYTHONPATH"] = os.path.join(ROOT, "ldmae_amd")
     r = subprocess.run([sys.executable, "-c", f"CFG = {cfg!r}\n" + DRIVER], cwd=str(tmp_path), env=env, capture_output=True, text=True,

@@ -256,6 +256,70 @@ def test_attention_bwd_pv_qknorm_fused(ops, hd, H, N):
     assert rel_err(db_b.cpu(), dqkv_b.float().cpu().reshape(B * N, 3 * H * hd).sum(0)) < 1e-5      # = column sums of dqkv as stored
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("hd,H", [(64, 3), (72, 2), (128, 2)])
+def test_rope_only_front_end_without_qknorm(ops, dtype, hd, H):
+    """ldmae_qknorm_rope_fwd / _bwd with wq = wk = NULL and tables: the attention front end of a block built with use_qknorm=False (q_norm =
+    k_norm = nn.Identity, lightningdit.py:60-61,69-74; the reference's CelebA-HQ YAML).  Forward = the rotation of the head-major split, bit for
+    bit what ldmae_rope gives (with and without the head-major copy of v: the 16-B bf16 kernel and the generic one); backward = its adjoint
+    and the qkv bias gradient; identity tables (use_rope=False) return the split itself."""
+    B, grid = 2, 8
+    N = grid * grid
+    cos, sin = odit.rope_tables(hd, grid)
+    qkv = q(rnd(B, N, 3, H, hd, seed=1), dtype)
+    t = qkv.permute(2, 0, 3, 1, 4)
+    rq, rk = odit.apply_rope(t[0], cos, sin), odit.apply_rope(t[1], cos, sin)
+    qkv_d = dev(qkv, dtype)
+    qd, kd, vd = ops.qknorm_rope_fwd(qkv_d, None, None, dev(cos), dev(sin), B, N, H, hd)
+    tol = 1e-6 if dtype == F32 else 1e-2
+    assert rel_err(qd.float().cpu(), rq) < tol and rel_err(kd.float().cpu(), rk) < tol
+    assert torch.equal(vd.float().cpu(), t[2].contiguous())
+    qs, ks, _ = ops.heads_split(qkv_d, B, N, H, hd)
+    assert torch.equal(qd, ops.rope(qs, dev(cos), dev(sin))) and torch.equal(kd, ops.rope(ks, dev(cos), dev(sin)))
+    q2, k2, v2 = ops.qknorm_rope_fwd(qkv_d, None, None, dev(cos), dev(sin), B, N, H, hd, copy_v=False)
+    assert v2 is None and torch.equal(q2, qd) and torch.equal(k2, kd)
+    qi, ki, _ = ops.qknorm_rope_fwd(qkv_d, None, None, torch.ones_like(dev(cos)), torch.zeros_like(dev(sin)), B, N, H, hd)
+    assert torch.equal(qi, qs) and torch.equal(ki, ks)
+    gq_, gk_, gv_ = (dev(q(rnd(B, H, N, hd, seed=s_), dtype), dtype) for s_ in (4, 5, 6))
+    dqkv, dwq, dwk, db = ops.qknorm_rope_bwd(gq_, gk_, gv_, qkv_d, None, None, dev(cos), dev(sin), B, N, H, hd, with_bias=True)
+    assert dwq is None and dwk is None
+    ref = ops.heads_merge(ops.rope(gq_, dev(cos), dev(sin), transposed=True), ops.rope(gk_, dev(cos), dev(sin), transposed=True), gv_, B, N, H, hd)
+    assert torch.equal(dqkv.reshape(ref.shape), ref)
+    assert rel_err(db.cpu(), dqkv.float().cpu().reshape(B * N, 3 * H * hd).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("hd,H,N", [(64, 3, 128), (64, 12, 1024), (128, 2, 192)])
+def test_attention_bwd_pv_rope_only_fused(ops, hd, H, N):
+    """The fused attention backward with wq = wk = NULL (use_qknorm=False): the epilogues apply the rotation's adjoint only.  Against
+    attention_bwd_pv + the rope-only qknorm_rope_bwd: dv identical, dq / dk the same bf16 values (one rounding of the same f32 products
+    either way, then an exact rotation of rounded inputs -- equal up to the rounding of the rotated sum), bias gradient = column sums."""
+    B = 2
+    g = torch.Generator().manual_seed(12)
+    qkv = (torch.randn(B, N, 3, H, hd, generator=g)).to(BF16).cuda()
+    ang = torch.rand(N, hd // 2, generator=g) * 6.28
+    cos, sin = ang.cos().repeat_interleave(2, 1).cuda(), ang.sin().repeat_interleave(2, 1).cuda()
+    do = torch.randn(B, N, H * hd, generator=g).to(BF16).cuda()
+    q, k, _ = ops.qknorm_rope_fwd(qkv, None, None, cos, sin, B, N, H, hd, copy_v=False)
+    o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5)
+    dq, dk, dqkv_a = ops.attention_bwd_pv(q, k, qkv, o, do, lse, hd ** -0.5)
+    dqkv_a, _, _, db_a = ops.qknorm_rope_bwd(dq, dk, None, qkv, None, None, cos, sin, B, N, H, hd, with_bias=True, dqkv=dqkv_a)
+    dqkv_b, dwq_b, dwk_b, db_b = ops.attention_bwd_pv_qknorm(q, k, qkv, o, do, lse, hd ** -0.5, None, None, cos, sin)
+    assert dwq_b is None and dwk_b is None
+    assert torch.equal(dqkv_a[:, :, 2], dqkv_b[:, :, 2])
+    assert rel_err(dqkv_b.float().cpu(), dqkv_a.float().cpu()) < 2e-3
+    assert (dqkv_a != dqkv_b).float().mean().item() < 0.02
+    assert rel_err(db_b.cpu(), db_a.cpu()) < 1e-3
+    assert rel_err(db_b.cpu(), dqkv_b.float().cpu().reshape(B * N, 3 * H * hd).sum(0)) < 1e-5
+    # and against f64 math: softmax attention on the rotated heads, gradients rotated back
+    qd, kd = q.double().cpu().requires_grad_(True), k.double().cpu().requires_grad_(True)
+    vd = qkv[:, :, 2].permute(0, 2, 1, 3).double().cpu().requires_grad_(True)
+    ref = torch.softmax(qd @ kd.transpose(-1, -2) * hd ** -0.5, -1) @ vd
+    (ref * do.view(B, N, H, hd).permute(0, 2, 1, 3).double().cpu()).sum().backward()
+    rot_t = lambda g_: g_ * cos.double().cpu() - odit.rotate_pairs(g_ * sin.double().cpu())      # noqa: E731   (adjoint of t*cos + rot(t)*sin)
+    want = torch.stack([rot_t(qd.grad), rot_t(kd.grad), vd.grad], 0).permute(1, 3, 0, 2, 4)      # [B,N,3,H,hd]
+    assert rel_err(dqkv_b.float().cpu(), want.float()) < 2e-2
+
+
 @pytest.mark.parametrize("hd,H,N", [(64, 3, 256), (72, 2, 192), (64, 2, 200)])
 def test_attention_fwd_static_shift_from_the_qknorm_bound(ops, hd, H, N):
     """attention_fwd_pv with the score bound of QK-normalised heads (ldmae_qk_score_bound: hd max|wq| max|wk| scale log2e): the kernel then
