@@ -337,7 +337,7 @@ def rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx_accum, dshift, dscale, rows
     dw = torch.empty(D, dtype=torch.float32, device=x.device)
     ws = workspace(L.load().ldmae_rmsnorm_modulate_bwd_workspace_bytes(M, D, rows_per_batch), x.device)
     call("ldmae_rmsnorm_modulate_bwd", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(scale), scale.stride(0) if scale is not None else 0,
-         ptr(rstd), ptr(dx_accum), 1.0 if accumulate else 0.0, ptr(dshift), ptr(dscale), dshift.stride(0) if dshift is not None else 0,
+         ptr(rstd), ptr(dx_accum), 1.0 if accumulate else 0.0, ptr(dshift), ptr(dscale), (dshift if dshift is not None else dscale).stride(0) if (dshift is not None or dscale is not None) else 0,
          ptr(dw), 0.0, M, D, rows_per_batch, ptr(ws), stream())
     return dw
 
@@ -351,7 +351,7 @@ def rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx_accum, dshift, dscale,
     dbias = torch.empty(D, dtype=torch.float32, device=x.device)
     ws = workspace(L.load().ldmae_rmsnorm_modulate_bwd_gate_workspace_bytes(M, D, rows_per_batch), x.device)
     call("ldmae_rmsnorm_modulate_bwd_gate", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(scale), scale.stride(0) if scale is not None else 0,
-         ptr(rstd), ptr(dx_accum), 1.0 if accumulate else 0.0, ptr(dshift), ptr(dscale), dshift.stride(0) if dshift is not None else 0, ptr(dw), 0.0,
+         ptr(rstd), ptr(dx_accum), 1.0 if accumulate else 0.0, ptr(dshift), ptr(dscale), (dshift if dshift is not None else dscale).stride(0) if (dshift is not None or dscale is not None) else 0, ptr(dw), 0.0,
          ptr(y), ptr(gate), gate.stride(0), ptr(dy), ptr(dgate), dgate.stride(0), ptr(dbias), M, D, rows_per_batch, ptr(ws), stream())
     return dw, dy, dbias
 

@@ -128,24 +128,72 @@ class AdamWEMA:
 
     def load_state_dict(self, sd):
         """Restores the moments and the EMA.  The slabs carry their layout: a state saved under ANOTHER slab order (before `adaln_first`, other
-        groups) is re-ordered by name; one saved without a layout record is refused unless its order is known to be this one."""
+        groups) is re-ordered by name; one saved without a layout record is refused unless its order is known to be this one.  A
+        ``torch.optim.AdamW.state_dict()`` ('state' + 'param_groups': what the reference's save_model writes, VMAE/util/misc.py:474-481; LDMAE/
+        train_accum.py:275-280 'opt') goes through `load_torch_adamw_state`.  Everything is validated BEFORE this optimizer is touched: a state
+        that is refused leaves step count, moments and EMA as they were."""
+        if "param_groups" in sd and "state" in sd:
+            return self.load_torch_adamw_state(sd)
         lay = sd.get("layout")
+        if lay is None or not all(k in sd for k in ("step", "m", "v", "ema")):
+            raise RuntimeError("AdamWEMA.load_state_dict: the saved state has no 'layout' record (written before round 5) or lacks step / m / v / "
+                               "ema; the order of its slabs cannot be verified -- restore the model and the by-name EMA instead (train_accum.py does)")
+        mine = self.flat.offsets
+        same = [tuple(x) for x in lay] == self.layout()
+        if not same and ({n for n, _, _ in lay} != set(mine) or any(mine[n][1] != k for n, _, k in lay)):
+            raise RuntimeError("AdamWEMA.load_state_dict: the saved state belongs to a different set of parameters")
+        if same and (sd["m"].numel() != self.m.numel() or sd["v"].numel() != self.v.numel() or sd["ema"].numel() != self.ema.numel()):
+            raise RuntimeError("AdamWEMA.load_state_dict: slab sizes differ from the recorded layout")
         self.step_count = int(sd["step"])
-        if lay is None:
-            raise RuntimeError("AdamWEMA.load_state_dict: the saved state has no 'layout' record (written before round 5); the order of its m / v / "
-                               "ema slabs cannot be verified -- restore the model and the by-name EMA instead (train_accum.py does)")
-        if [tuple(x) for x in lay] == self.layout():
+        if same:
             self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.ema.copy_(sd["ema"])
             return
-        mine = self.flat.offsets
-        if {n for n, _, _ in lay} != set(mine) or any(mine[n][1] != k for n, _, k in lay):
-            raise RuntimeError("AdamWEMA.load_state_dict: the saved state belongs to a different set of parameters")
         n_tr = self.flat.n_trainable
         for n, o, k in lay:                                  # same parameters, other order: copy slab by slab, by name
             d = mine[n][0]
             self.ema[d:d + k].copy_(sd["ema"][o:o + k])
             if d < n_tr:
                 self.m[d:d + k].copy_(sd["m"][o:o + k]); self.v[d:d + k].copy_(sd["v"][o:o + k])
+
+    @torch.no_grad()
+    def load_torch_adamw_state(self, sd):
+        """Moments of a ``torch.optim.AdamW.state_dict()`` into the slabs.  torch numbers the parameters group by group in the order the groups
+        list them; the reference builds its groups either as ONE list of ``model.parameters()`` (LDMAE/train_accum.py:121) or with timm's
+        ``param_groups_weight_decay`` (VMAE/main_pretrain.py:258-259: [no_decay, decay], each in named_parameters order, no_decay = 1-D
+        parameters and names ending in '.bias'; frozen parameters in neither).  Both orders are reconstructed from this module and every state
+        tensor must have its parameter's size, or the state is refused untouched.  The EMA is not part of a torch optimizer: it is left as it
+        is (the caller restores it by name, or keeps the freshly initialised copy of the loaded parameters)."""
+        named = [(n, p) for n, p in self.module.named_parameters() if p.requires_grad]
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if len(groups) == 1:
+            order = [n for n, _ in named]
+        elif len(groups) == 2:
+            nd = lambda n, p: p.ndim <= 1 or n.endswith(".bias")      # noqa: E731
+            first, second = [n for n, p in named if nd(n, p)], [n for n, p in named if not nd(n, p)]
+            if (len(groups[0]["params"]), len(groups[1]["params"])) != (len(first), len(second)):
+                raise RuntimeError("AdamWEMA.load_torch_adamw_state: the two parameter groups are not timm's [no_decay, decay] split of this model")
+            order = first + second
+        else:
+            raise RuntimeError(f"AdamWEMA.load_torch_adamw_state: {len(groups)} parameter groups; one (model.parameters()) or timm's two are understood")
+        if len(ids) != len(order):
+            raise RuntimeError(f"AdamWEMA.load_torch_adamw_state: the state lists {len(ids)} parameters, this model has {len(order)} trainable ones")
+        shapes, st, steps = dict(named), sd["state"], []
+        for i, n in zip(ids, order):
+            e = st.get(i)
+            if e is None:
+                continue                                                 # never stepped (no gradient so far): zero moments, as torch would create them
+            if any(k not in e for k in ("exp_avg", "exp_avg_sq", "step")) or e["exp_avg"].numel() != shapes[n].numel() or e["exp_avg_sq"].numel() != shapes[n].numel():
+                raise RuntimeError(f"AdamWEMA.load_torch_adamw_state: state entry {i} does not fit parameter {n}")
+            steps.append(int(e["step"]))
+        self.m.zero_(); self.v.zero_()
+        for i, n in zip(ids, order):
+            e = st.get(i)
+            if e is None:
+                continue
+            o, k = self.flat.offsets[n]
+            self.m[o:o + k].copy_(e["exp_avg"].reshape(-1)); self.v[o:o + k].copy_(e["exp_avg_sq"].reshape(-1))
+        self.step_count = max(steps) if steps else 0                     # one bias-correction step for the fused kernel: torch's per-parameter steps agree
 
     @torch.no_grad()
     def swap_in_ema(self):

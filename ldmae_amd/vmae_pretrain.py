@@ -306,7 +306,15 @@ def load_model(args, model, opt, scaler, log=print):
     start = args.start_epoch
     if "optimizer" in ck and "epoch" in ck:
         if not resized:                     # (a resized grid changes the slab: the moments of the old layout do not apply)
-            opt.load_state_dict(ck["optimizer"])
+            # our own checkpoints carry the slab state with its layout record; the reference's save_model (misc.py:474-481) writes
+            # torch.optim.AdamW.state_dict() -- its moments are mapped by parameter order (AdamWEMA.load_torch_adamw_state).  A state that fits
+            # neither is skipped with a message (model / epoch / scaler are still restored); the 'optimizer' entry written HERE is
+            # framework-specific and not loadable by the reference.
+            try:
+                opt.load_state_dict(ck["optimizer"])
+                opt.ema.copy_(opt.flat.params) if "param_groups" in ck["optimizer"] else None     # a torch state has no EMA: restart it from the weights
+            except (RuntimeError, KeyError, TypeError) as ex:
+                log(f"optimizer state of {args.resume} not restored ({type(ex).__name__}: {ex}); continuing with fresh moments")
         start = int(ck["epoch"]) + 1
         if scaler is not None and ck.get("scaler") is not None:
             scaler.load_state_dict(ck["scaler"])

@@ -3,6 +3,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import yaml
 
@@ -233,3 +234,60 @@ def test_vmae_pretrain_pos_embed_resize():
     ref = torch.nn.functional.interpolate(pe.reshape(1, 16, 16, 24).permute(0, 3, 1, 2), size=(32, 32), mode="bilinear", align_corners=False)
     assert out.shape == (1, 1024, 24) and torch.equal(out, ref.permute(0, 2, 3, 1).reshape(1, -1, 24))
     assert torch.equal(vp.resize_pos_embed(pe, 16), pe)
+
+
+def test_resume_from_a_reference_style_optimizer_state(tmp_path):
+    """A checkpoint as the REFERENCE's save_model writes it (VMAE/util/misc.py:474-481): 'optimizer' = torch.optim.AdamW.state_dict() over
+    timm's [no_decay, decay] groups (main_pretrain.py:258-259).  load_model maps its moments by parameter order into the slabs (step count
+    included); a state that fits nothing is refused BEFORE the optimizer is touched, and load_model then still restores model / epoch / scaler."""
+    import argparse
+    from ldmae_amd import vmae_pretrain as vp
+    from ldmae_amd.optim import AdamWEMA, FlatParams
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pos_embed = torch.nn.Parameter(torch.zeros(1, 4, 8), requires_grad=False)
+            self.decoder_pos_embed = torch.nn.Parameter(torch.zeros(1, 4, 8), requires_grad=False)
+            self.a, self.n, self.b = torch.nn.Linear(8, 16), torch.nn.LayerNorm(16), torch.nn.Linear(16, 4)
+    torch.manual_seed(0)
+    ref = Net()
+    named = [(n, p) for n, p in ref.named_parameters() if p.requires_grad]
+    nd = [p for n, p in named if p.ndim <= 1 or n.endswith(".bias")]
+    dc = [p for n, p in named if not (p.ndim <= 1 or n.endswith(".bias"))]
+    topt = torch.optim.AdamW([{"params": nd, "weight_decay": 0.0}, {"params": dc, "weight_decay": 0.05}], lr=1e-3, betas=(0.9, 0.95))
+    for _ in range(3):
+        topt.zero_grad()
+        ref.b(ref.n(ref.a(torch.randn(5, 8)))).pow(2).sum().backward()
+        topt.step()
+    path = tmp_path / "checkpoint-7.pth"
+    torch.save({"model": ref.state_dict(), "optimizer": topt.state_dict(), "epoch": 7, "scaler": {"scale": 1024.0, "_growth_tracker": 5}, "args": None}, path)
+    net = Net()
+    opt = AdamWEMA(net, flat=FlatParams(net, group_fn=vp.no_decay))
+    scaler = vp.LossScaler()
+    args = argparse.Namespace(resume=str(path), start_epoch=0)
+    msgs = []
+    assert vp.load_model(args, net, opt, scaler, log=msgs.append) == 8
+    assert opt.step_count == 3 and scaler.scale == 1024.0
+    tstate = {id(p): topt.state[p] for g in topt.param_groups for p in g["params"]}
+    for n, p in named:
+        o, k = opt.flat.offsets[n]
+        assert torch.equal(opt.m[o:o + k], tstate[id(p)]["exp_avg"].reshape(-1)) and torch.equal(opt.v[o:o + k], tstate[id(p)]["exp_avg_sq"].reshape(-1)), n
+        assert torch.equal(dict(net.named_parameters())[n], p)
+    assert torch.equal(opt.ema, opt.flat.params)                      # a torch state has no EMA: restarted from the loaded weights
+    # one list of model.parameters() (LDMAE/train_accum.py:121) is understood too
+    t1 = torch.optim.AdamW([p for _, p in named], lr=1e-3)
+    t1.zero_grad(); ref.b(ref.n(ref.a(torch.randn(5, 8)))).pow(2).sum().backward(); t1.step()
+    opt.load_state_dict(t1.state_dict())
+    assert opt.step_count == 1
+    # states that fit nothing: refused with the optimizer untouched; load_model logs and goes on
+    m0, step0 = opt.m.clone(), opt.step_count
+    bad = topt.state_dict()
+    bad["state"][0]["exp_avg"] = torch.zeros(3)
+    for broken in (bad, {"step": 9, "m": opt.m}, {"state": {}, "param_groups": [{"params": [0]}, {"params": [1]}, {"params": [2]}]}):
+        with pytest.raises(RuntimeError):
+            opt.load_state_dict(broken)
+        assert opt.step_count == step0 and torch.equal(opt.m, m0)
+    torch.save({"model": ref.state_dict(), "optimizer": bad, "epoch": 2, "scaler": None, "args": None}, path)
+    msgs.clear()
+    assert vp.load_model(args, net, opt, scaler, log=msgs.append) == 3 and any("not restored" in str(m) for m in msgs)
