@@ -250,6 +250,14 @@ int ldmae_latent_prologue(const float* moments, const float* noise, const float*
 /* out[n,j,:] = x[n, ids[n,j], :]  (torch.gather on dim 1, :486); bwd scatters (ids unique per n) */
 int ldmae_gather_rows(const float* x, const long long* ids, float* out, int N, int L, int keep, int D, void* stream);
 int ldmae_scatter_rows(const float* dout, const long long* ids, float* dx, int N, int L, int keep, int D, void* stream);
+/* Decoder input of the pre-training step (models_mae.py:536-541: cat([x, mask_token.repeat]) -> gather(ids_restore) -> + decoder_pos_embed) in
+ * one pass: out[b,l,:] = (ids_restore[b,l] < keep ? x[b, ids_restore[b,l], :] : mask_token[:]) + pos[l,:].  x [B,keep,D], out [B,L,D] f32.
+ * Backward: dx [B,keep,D] = the kept rows of dout (ids_restore[b,:] is a permutation), dmask_token [D] = column sums of the other rows. */
+int ldmae_restore_tokens(const float* x, const float* mask_token, const float* pos, const long long* ids_restore, float* out, int B, int L,
+                         int keep, int D, void* stream);
+long ldmae_restore_tokens_bwd_workspace_bytes(int B, int L, int D);
+int ldmae_restore_tokens_bwd(const float* dout, const long long* ids_restore, float* dx, float* dmask_token, int B, int L, int keep, int D,
+                             float* workspace, void* stream);
 /* The whole encoder stack after the gather -- nblocks x Block (models_mae.py:149-187) + the closing LayerNorm (:369, 521) -- as ONE kernel
  * for the shipped geometry at mask_ratio 0.75 (tokens = 256 kept tokens per image, dim 192, 12 heads, hidden 768; anything else returns
  * LDMAE_ERR_INVALID: use the per-layer entry points).  Inference only, bf16 MFMA, f32 residual stream held in registers: one workgroup

@@ -76,6 +76,9 @@ SIGNATURES = {
     "ldmae_latent_prologue": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_gather_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_scatter_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ldmae_restore_tokens": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ldmae_restore_tokens_bwd_workspace_bytes": (_l, [_i, _i, _i]),
+    "ldmae_restore_tokens_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldmae_vmae_encoder_blob_bytes": (_l, [_i]),
     "ldmae_vmae_encoder_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ldmae_vmae_encoder_fwd_tiled_workspace_bytes": (_l, [_i, _i]),

@@ -141,6 +141,93 @@ extern "C" int ldmae_scatter_rows(const float* dout, const long long* ids, float
   return LDMAE_OK;
 }
 
+// ------------------------------------------------------------------ decoder input: kept tokens back in place + mask tokens + position embedding
+// (models_mae.py:536-541: cat([x, mask_token.repeat]) -> gather(ids_restore) -> + decoder_pos_embed, as ONE pass: the reference's form moves the
+// [B, L, D] tensor four times forward -- and an int64 index tensor twice its size -- and three more times backward.)
+// out[b, l, :] = (ids[b, l] < keep ? x[b, ids[b, l], :] : mtok[:]) + pos[l, :].   16 lanes per row, 16 B per lane and access.
+__global__ __launch_bounds__(256) void restore_tokens_kernel(const float* __restrict__ x, const float* __restrict__ mtok, const float* __restrict__ pos,
+                                                             const long long* __restrict__ ids, float* __restrict__ out, long rows, int L, int keep, int D) {
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  for (long r = (long)blockIdx.x * 16 + grp; r < rows; r += (long)gridDim.x * 16) {
+    const long b = r / L;
+    const int l = (int)(r - b * L);
+    const long long j = ids[r];
+    const float* src = j < keep ? x + ((size_t)b * keep + j) * D : mtok;
+    for (int c = 4 * sub; c < D; c += 64) {
+      const float4 v = *(const float4*)(src + c), p = *(const float4*)(pos + (size_t)l * D + c);
+      *(float4*)(out + (size_t)r * D + c) = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+    }
+  }
+}
+// backward: dx[b, ids[b, l], :] = dout[b, l, :] where ids[b, l] < keep (ids[b, :] is a permutation: every kept row is written exactly once);
+// the other rows are the mask token's: P[workgroup][D] = their column sums (lane-owned columns, the 16 row groups added in order through LDS),
+// summed over workgroups by ldmae_colsum.  NV = ceil(D / 64).
+template <int NV>
+__global__ __launch_bounds__(256) void restore_tokens_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ ids, float* __restrict__ dx,
+                                                                 float* __restrict__ P, long rows, int L, int keep, int D) {
+  __shared__ float red[16][NV * 64];
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  float acc[NV][4];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f; }
+  for (long r = (long)blockIdx.x * 16 + grp; r < rows; r += (long)gridDim.x * 16) {
+    const long b = r / L;
+    const long long j = ids[r];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * (sub + 16 * i);
+      if (c >= D) continue;
+      const float4 g = *(const float4*)(dout + (size_t)r * D + c);
+      if (j < keep) *(float4*)(dx + ((size_t)b * keep + j) * D + c) = g;
+      else { acc[i][0] += g.x; acc[i][1] += g.y; acc[i][2] += g.z; acc[i][3] += g.w; }
+    }
+  }
+  if (!P) return;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[grp][4 * (sub + 16 * i) + k] = acc[i][k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float s2 = 0.f;
+    for (int g = 0; g < 16; ++g) s2 += red[g][c];
+    P[(size_t)blockIdx.x * D + c] = s2;
+  }
+}
+extern "C" long ldmae_colsum_workspace_bytes(int M, int N);
+extern "C" int ldmae_colsum(int dtype, const void* X, int ldx, int M, int N, float* out, float beta, float* workspace, void* stream);
+static unsigned restore_grid(long rows) { const long g = (rows + 15) / 16; return (unsigned)(g < 2048 ? (g > 0 ? g : 1) : 2048); }
+extern "C" int ldmae_restore_tokens(const float* x, const float* mask_token, const float* pos, const long long* ids_restore, float* out, int B, int L,
+                                    int keep, int D, void* stream) {
+  LDMAE_REQUIRE(x && mask_token && pos && ids_restore && out && B > 0 && L > 0 && keep > 0 && keep <= L, "restore_tokens: null pointer or empty input");
+  LDMAE_REQUIRE(D % 4 == 0, "restore_tokens: D=%d must be a multiple of 4", D);
+  const long rows = (long)B * L;
+  hipLaunchKernelGGL(restore_tokens_kernel, dim3(restore_grid(rows)), dim3(256), 0, as_stream(stream), x, mask_token, pos, ids_restore, out, rows, L, keep, D);
+  LDMAE_CHECK_LAUNCH("restore_tokens");
+  return LDMAE_OK;
+}
+extern "C" long ldmae_restore_tokens_bwd_workspace_bytes(int B, int L, int D) {
+  const long g = restore_grid((long)B * L);
+  return g * D * 4 + ldmae_colsum_workspace_bytes((int)g, D);
+}
+// dx [B, keep, D] (every row written), dmask_token [D] (NULL: not formed; workspace may then be NULL)
+extern "C" int ldmae_restore_tokens_bwd(const float* dout, const long long* ids_restore, float* dx, float* dmask_token, int B, int L, int keep, int D,
+                                        float* workspace, void* stream) {
+  LDMAE_REQUIRE(dout && ids_restore && dx && B > 0 && L > 0 && keep > 0 && keep <= L, "restore_tokens_bwd: null pointer or empty input");
+  LDMAE_REQUIRE(D % 4 == 0 && D <= 512, "restore_tokens_bwd: D=%d must be a multiple of 4, at most 512", D);
+  LDMAE_REQUIRE(!dmask_token || workspace, "restore_tokens_bwd: the mask-token gradient needs the workspace");
+  const long rows = (long)B * L;
+  const unsigned grid = restore_grid(rows);
+  float* P = dmask_token ? workspace : nullptr;
+#define RT(NV) hipLaunchKernelGGL(restore_tokens_bwd_kernel<NV>, dim3(grid), dim3(256), 0, as_stream(stream), dout, ids_restore, dx, P, rows, L, keep, D)
+  const int nv = (D + 63) / 64;
+  if (nv <= 3) RT(3); else if (nv <= 6) RT(6); else RT(8);
+#undef RT
+  LDMAE_CHECK_LAUNCH("restore_tokens_bwd");
+  if (dmask_token) return ldmae_colsum(LDMAE_F32, P, D, (int)grid, D, dmask_token, 0.f, P + (size_t)grid * D, stream);
+  return LDMAE_OK;
+}
+
 // ------------------------------------------------------------------ LayerNorm (affine)
 // 16 lanes per row, 16 B per lane and access (float4 / 4 x bf16): a 256-thread workgroup streams 16 rows at a time.  A lane owns
 // the same columns {4 * (sub + 16 * i)} in every row it visits, so w / b live in registers and the dw / db partial sums of the

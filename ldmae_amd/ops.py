@@ -688,6 +688,26 @@ def scatter_rows(dout, ids, Lq):
     return dx
 
 
+def restore_tokens(x, mask_token, pos, ids_restore):
+    """Decoder input of the pre-training step (models_mae.py:536-541) in one pass: x [B, keep, D] f32, mask_token [D], pos [L, D], ids_restore
+    [B, L] i64 -> [B, L, D] = (kept row or mask token) + pos."""
+    B, keep, D = x.shape
+    Lq = ids_restore.shape[1]
+    out = torch.empty(B, Lq, D, dtype=torch.float32, device=x.device)
+    call("ldmae_restore_tokens", ptr(_c(x)), ptr(_c(mask_token)), ptr(_c(pos)), ptr(_c(ids_restore)), ptr(out), B, Lq, keep, D, stream())
+    return out
+
+
+def restore_tokens_bwd(dout, ids_restore, keep, need_mask_grad=True):
+    """-> (dx [B, keep, D], dmask_token [D] or None)."""
+    B, Lq, D = dout.shape
+    dx = torch.empty(B, keep, D, dtype=torch.float32, device=dout.device)
+    dm = torch.empty(D, dtype=torch.float32, device=dout.device) if need_mask_grad else None
+    ws = workspace(L.load().ldmae_restore_tokens_bwd_workspace_bytes(B, Lq, D), dout.device) if need_mask_grad else None
+    call("ldmae_restore_tokens_bwd", ptr(_c(dout)), ptr(_c(ids_restore)), ptr(dx), ptr(dm), B, Lq, keep, D, ptr(ws), stream())
+    return dx, dm
+
+
 def vmae_encoder_fwd(x, blob, nblocks, dim, heads, hidden, eps=1e-6):
     """The whole VMAE encoder stack (blocks + closing LayerNorm) in one launch: x [B, tokens, dim] f32 -> same shape (inference, bf16 MFMA,
     f32 residual stream in registers).  `blob`: weights packed by tokenizer/fused_encoder.py."""

@@ -292,6 +292,23 @@ class _GatherFn(torch.autograd.Function):
         return ops.scatter_rows(g, ids_keep, ctx.L), None
 
 
+class _RestoreTokensFn(torch.autograd.Function):
+    """The decoder's input (:536-541): cat([x, mask_token.repeat]) -> gather(ids_restore) -> + decoder_pos_embed as one kernel each way
+    (ops.restore_tokens; backward: kept rows gathered back, the mask token's gradient = column sums of the masked rows)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_token, pos, ids_restore):
+        ctx.save_for_backward(ids_restore)
+        ctx.keep, ctx.mshape = x.shape[1], mask_token.shape
+        return ops.restore_tokens(x, mask_token.reshape(-1), pos.reshape(pos.shape[-2], pos.shape[-1]), ids_restore)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids_restore,) = ctx.saved_tensors
+        dx, dm = ops.restore_tokens_bwd(g, ids_restore, ctx.keep, need_mask_grad=ctx.needs_input_grad[1])
+        return (dx if ctx.needs_input_grad[0] else None), (dm.view(ctx.mshape) if dm is not None else None), None, None
+
+
 # ----------------------------------------------------------------------------- modules
 class Mlp(nn.Module):
     """timm Mlp parameter layout (fc1 / fc2), computed inside _ViTBlockFn."""
@@ -549,10 +566,14 @@ class MaskedAutoencoderViT(nn.Module):
         1024-token decoder of the pre-training step did: 250 of its 304 ms)."""
         dtype = dtype if dtype is not None else _act_dtype(self.precision, allow_f16=True)
         x = _LinearFn.apply(x, self.decoder_embed.weight, self.decoder_embed.bias)
-        mask_tokens = self.mask_token.repeat(x.shape[0], ids_restore.shape[1] - x.shape[1], 1)
-        x_ = torch.cat([x, mask_tokens], dim=1)
-        x = torch.gather(x_, dim=1, index=ids_restore.unsqueeze(-1).repeat(1, 1, x.shape[2]))
-        x = x + self.decoder_pos_embed
+        if x.dtype == torch.float32 and x.shape[2] % 4 == 0 and x.shape[2] <= 512 and not self.decoder_pos_embed.requires_grad and x.shape[1] <= ids_restore.shape[1]:
+            # kept rows back in place + mask tokens + position embedding in ONE pass each way (ldmae_restore_tokens)
+            x = _RestoreTokensFn.apply(x, self.mask_token, self.decoder_pos_embed, ids_restore)
+        else:                                # (a trainable position table, odd widths: the reference's four tensor ops)
+            mask_tokens = self.mask_token.repeat(x.shape[0], ids_restore.shape[1] - x.shape[1], 1)
+            x_ = torch.cat([x, mask_tokens], dim=1)
+            x = torch.gather(x_, dim=1, index=ids_restore.unsqueeze(-1).repeat(1, 1, x.shape[2]))
+            x = x + self.decoder_pos_embed
         x = self._run(self.decoder_blocks, x, dtype)
         x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
         if return_image:                     # (pred, smoothed image): only with the conv_decoder_pred head

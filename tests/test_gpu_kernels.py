@@ -577,6 +577,34 @@ def test_random_masking_bit_exact(ops, L, ratio):
     assert torch.equal(back, x * (1 - torch.from_numpy(rm)).unsqueeze(-1))
 
 
+@pytest.mark.parametrize("L,ratio,D", [(1024, 0.75, 192), (256, 0.5, 384), (200, 0.25, 512), (64, 0.0, 192)])
+def test_restore_tokens_is_the_references_cat_gather_add(ops, L, ratio, D):
+    """ldmae_restore_tokens / _bwd against the four tensor ops of the reference's forward_decoder (models_mae.py:536-541: mask_token.repeat,
+    cat, gather by ids_restore, + decoder_pos_embed) and their autograd: forward and the kept rows' gradient bit for bit (an add / a copy),
+    the mask token's gradient to summation order."""
+    B = 3
+    keep = omae.len_keep(L, ratio)
+    noise = torch.rand(B, L, generator=torch.Generator().manual_seed(L + D))
+    _, _, ids_restore = ops.random_masking(dev(noise), keep)
+    x = rnd(B, keep, D, seed=1).requires_grad_(True)
+    mtok, pos = rnd(1, 1, D, seed=2).requires_grad_(True), rnd(1, L, D, seed=3)
+    ids = ids_restore.cpu()
+    x_ = torch.cat([x, mtok.repeat(B, L - keep, 1)], dim=1)
+    ref = torch.gather(x_, 1, ids.unsqueeze(-1).repeat(1, 1, D)) + pos
+    g = rnd(B, L, D, seed=4)
+    ref.backward(g)
+    out = ops.restore_tokens(dev(x.detach()), dev(mtok.detach().reshape(-1)), dev(pos[0]), ids_restore)
+    assert torch.equal(out.cpu(), ref.detach())
+    dx, dm = ops.restore_tokens_bwd(dev(g), ids_restore, keep)
+    assert torch.equal(dx.cpu(), x.grad)
+    if keep < L:
+        assert rel_err(dm.cpu(), mtok.grad.reshape(-1)) < 1e-5
+    else:
+        assert float(dm.abs().max()) == 0.0
+    dx2, dm2 = ops.restore_tokens_bwd(dev(g), ids_restore, keep, need_mask_grad=False)
+    assert dm2 is None and torch.equal(dx2, dx)
+
+
 def test_random_masking_golden(ops, golden):
     g = golden("mae")
     for tag, ratio in (("75", 0.75), ("25", 0.25)):
