@@ -18,6 +18,8 @@ from functools import partial
 from typing import Optional
 
 import numpy as np
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -139,6 +141,7 @@ class _ViTBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2, h1, mu1, rs1, qkv, q, k, v, o, lse, oa, xmid, h2, mu2, rs2, act, pre, n1w, n2w, WqkvT, WpT, W1T, W2T)
         ctx.dims = (B, N, D, H, hd, dtype)
         ctx.inplace = bool(inplace)
+        ctx.x_ref = weakref.ref(x)            # backward looks for TENSOR hooks on the block's input (see the `_ldmae_cast` hand-off there)
         # opt-in of the training driver (MaskedAutoencoderViT.direct_param_grads; every .grad is a view of its gradient slab): the block's
         # twelve parameter gradients are ADDED into their .grad by the producing kernels (the TN GEMM's reduce with beta = 1; one
         # ldmae_multi_add for the eight vectors) instead of by twelve AccumulateGrad passes -- as models/lightningdit.py does for the DiT
@@ -198,7 +201,11 @@ class _ViTBlockFn(torch.autograd.Function):
                     r(p_)
             dn1w = dn1b = dbqkv = dbp = dn2w = dn2b = db1 = db2 = None
         gx = dx.view(B, N, D)
-        if dxc is not None:
+        # the rounded copy rides on the returned tensor only while nothing can touch the gradient between the two blocks: module hooks switch
+        # `inplace` off (_chain_ok), and a TENSOR hook on the block's input (x.register_hook: it runs on gx before the previous block's backward,
+        # and one that edits it through a raw-pointer op would not bump `_version`) drops the hand-off -- the previous block then casts dx itself
+        xin = ctx.x_ref()
+        if dxc is not None and xin is not None and not xin._backward_hooks:
             gx._ldmae_cast = (dxc, gx._version, dx.data_ptr())
         return (gx, None, None, None, None, None, None, None, dn1w, dn1b, dWqkv, dbqkv, dWp, dbp, dn2w, dn2b, dW1, db1, dW2, db2)
 
@@ -346,15 +353,18 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
         self.precision = None
 
-    def forward(self, x, _inplace_grad=False, dtype=None):
+    def forward(self, x, _inplace_grad=False, dtype=None, tf32_class=False):
         """dtype: the activation type of THIS call (the model's encoder / decoder loops pass the type they resolved -- a caller that has
         switched autocast off around the stack passes what it read before doing so); None: the block's own `precision` setting / autocast.
-        `last_dtype` records what the call ran in (tests)."""
+        tf32_class: the call is one of the TF32-class docking calls (decided where the type is resolved, MaskedAutoencoderViT._docking_dtype --
+        never here: the model's loops run with autocast switched off, so the ambient autocast state says nothing about the caller's): fp16
+        operands with the branch outputs joining the residual stream UNROUNDED, as a TF32 Linear's do.  fp16 autocast training is fp16 with
+        tf32_class False: Linear outputs rounded to fp16, as torch's autocast produces them.  `last_dtype` / `last_tf32_class` record what the
+        call ran in (tests)."""
         a, m = self.attn, self.mlp
         dtype = dtype if dtype is not None else _act_dtype(self.precision, allow_f16=True)
         self.last_dtype = dtype
-        # fp16 WITHOUT autocast = the TF32-class docking call (MaskedAutoencoderViT._docking_dtype): unrounded branch outputs
-        yres_f32 = dtype == torch.float16 and not torch.is_autocast_enabled("cuda") and self.precision is None
+        yres_f32 = self.last_tf32_class = bool(tf32_class) and dtype == torch.float16
         return _ViTBlockFn.apply(x.float(), a.num_heads, self.norm1.eps, dtype, _inplace_grad,
                                  not torch.is_grad_enabled(), bool(getattr(self, "direct_param_grads", False)), yres_f32, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                                  self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
@@ -507,8 +517,8 @@ class MaskedAutoencoderViT(nn.Module):
     def _embed(self, x, dtype=None):
         return self.patch_embed(x, self.pos_embed[0], dtype if dtype != torch.float16 else torch.float32)
 
-    def _docking_dtype(self, blocks):
-        """Activation type of a forward-only stack call.  f32 calls (no autocast, no `set_precision`) made while the caller has set
+    def _docking_dtype(self, blocks, rows=None):
+        """(activation type, tf32_class) of a forward-only stack call.  f32 calls (no autocast, no `set_precision`) made while the caller has set
         ``torch.backends.cuda.matmul.allow_tf32 = True`` -- what the reference's drivers do before they call `_encode` / `decode`
         (inference.py:79, extract_features.py:2-3) -- run TF32-CLASS: gfx950 has no TF32 MFMA, but fp16 has exactly TF32's 10-bit mantissa at the
         bf16 rate, and the operands it is used for (LayerNorm outputs, q / k / v, softmax probabilities, GELU outputs) are O(1); accumulation,
@@ -517,9 +527,12 @@ class MaskedAutoencoderViT(nn.Module):
         the 1e-4 parity path.  LDMAE_TF32=0 keeps them there regardless."""
         dtype = _act_dtype(self.precision, allow_f16=True)
         if dtype != torch.float32 or torch.is_grad_enabled() or not torch.backends.cuda.matmul.allow_tf32 or os.environ.get("LDMAE_TF32", "1") == "0":
-            return dtype
+            return dtype, False
+        # the fp16 whole-line GEMM has no fallback kernel: token rows in whole groups of 8 (M % 8 == 0; `rows` = B * tokens of this call) and widths on
+        # 128-B lines, or the call stays on the exact-f32 kernels (an odd batch of an odd-grid image, e.g. 72 px -> 81 tokens at patch 8)
         ok = all(b.norm1.weight.numel() // b.attn.num_heads == 16 and b.norm1.weight.numel() % 64 == 0 and b.mlp.fc1.weight.shape[0] % 64 == 0 for b in blocks)
-        return torch.float16 if ok else dtype
+        ok = ok and (rows is None or rows % 8 == 0)
+        return (torch.float16, True) if ok else (dtype, False)
 
     @staticmethod
     def _chain_ok(blk):
@@ -527,14 +540,14 @@ class MaskedAutoencoderViT(nn.Module):
         gradient buffer it hands on) unless a module hook taps it: only then may its backward re-use the incoming gradient."""
         return not (blk._forward_hooks or blk._forward_pre_hooks or blk._backward_hooks)
 
-    def _run(self, blocks, x, dtype=None):
+    def _run(self, blocks, x, dtype=None, tf32_class=False):
         for blk in blocks:
-            x = blk(x, self._chain_ok(blk), dtype)
+            x = blk(x, self._chain_ok(blk), dtype, tf32_class)
         return x
 
     def forward_encoder(self, x, mask_ratio, noise=None):
         """:499-523."""
-        dtype = self._docking_dtype(self.blocks)
+        dtype, tf32 = self._docking_dtype(self.blocks, rows=x.shape[0] * int(self.patch_embed.num_patches * (1 - mask_ratio)))
         with torch.autocast(device_type="cuda", enabled=False):
             # inference in bf16 on the shipped geometry with 256 kept tokens (mask_ratio 0.75): mask FIRST (it depends on the noise alone),
             # embed only the kept quarter of the patches, then the whole stack + the closing LayerNorm as ONE kernel, one workgroup per
@@ -556,7 +569,7 @@ class MaskedAutoencoderViT(nn.Module):
                 return fused_encoder.encoder_forward_tiled(self, xk, dtype=dtype), mask, ids_restore
             x = self._embed(x, dtype)
             x, mask, ids_restore = self.random_masking(x, mask_ratio, noise)
-            x = self._run(self.blocks, x, dtype)
+            x = self._run(self.blocks, x, dtype, tf32)
             x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x, mask, ids_restore
 
@@ -626,7 +639,7 @@ class MaskedAutoencoderViT(nn.Module):
 
     # ---- docking functions (:817-973)
     def _encode(self, x):
-        dtype = self._docking_dtype(self.blocks)
+        dtype, tf32 = self._docking_dtype(self.blocks, rows=x.shape[0] * self.patch_embed.num_patches)
         with torch.autocast(device_type="cuda", enabled=False):
             x = self._embed(x, dtype)
             if (self.fused_encoder and dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled() and x.dim() == 3 and
@@ -635,7 +648,7 @@ class MaskedAutoencoderViT(nn.Module):
                 # tile in registers through proj / LayerNorm / MLP (csrc/vmae_fused.hip, MODE 1 / 2), the closing LayerNorm in the last of them
                 x = fused_encoder.encoder_forward_tiled(self, x.float(), dtype=dtype)
             else:
-                x = self._run(self.blocks, x, dtype)
+                x = self._run(self.blocks, x, dtype, tf32)
                 x = _LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
             x = _latent_map(self.to_latent, x)
         g = self.latent_resolution
@@ -647,7 +660,7 @@ class MaskedAutoencoderViT(nn.Module):
         return MAEOutput(latent_dist=p) if return_dict else (p,)
 
     def decode(self, z, return_dict=True, generator=None):
-        dtype = self._docking_dtype(self.decoder_blocks)
+        dtype, tf32 = self._docking_dtype(self.decoder_blocks, rows=z.shape[0] * z.shape[2] * z.shape[3])
         with torch.autocast(device_type="cuda", enabled=False):
             B = z.shape[0]
             x = z.float().permute(0, 2, 3, 1).reshape(B, -1, z.shape[1]).contiguous()
@@ -659,7 +672,7 @@ class MaskedAutoencoderViT(nn.Module):
                 # the shipped decoder has the encoder's geometry (192 wide, 12 heads): bf16 / TF32-class inference runs it on the tiled fused kernels too
                 x = fused_encoder.encoder_forward_tiled(self, x.float().contiguous(), which="dec", dtype=dtype)
             else:
-                x = self._run(self.decoder_blocks, x, dtype)
+                x = self._run(self.decoder_blocks, x, dtype, tf32)
                 x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
             x = self.decoder_pred(x) if not isinstance(self.decoder_pred, nn.Linear) else \
                 _LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)

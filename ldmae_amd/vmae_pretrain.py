@@ -74,7 +74,10 @@ class LossScaler:
         """grad_scale: what the gradient slab still has to be multiplied by besides 1 / scale (1 / world after a summing all-reduce)."""
         g = opt.flat.grads
         norm = torch.linalg.vector_norm(g)                       # inf / nan anywhere in the slab makes the norm non-finite
-        if self.enabled and not bool(torch.isfinite(norm)):
+        if not bool(torch.isfinite(norm)):                      # (the one host read of the step; after a data-parallel all-reduce every rank sees the same slab)
+            if not self.enabled:
+                # no loss scaling (fp32): a non-finite gradient is a non-finite loss (engine_pretrain.py:68-70 stops there) -- never step on it
+                raise RuntimeError("Loss is not finite, stopping training (non-finite gradient slab)")
             self.skipped += 1
             self._good = 0
             self.scale *= self.backoff_factor
@@ -106,11 +109,18 @@ def train_one_epoch(model, loader, opt, epoch, args, log=print, scaler=None, red
     model.train(True)
     opt.zero_grad()
     n = len(loader)
-    stats, bad = None, torch.zeros((), dtype=torch.bool, device="cuda")
+    stats, bad = None, torch.zeros((), dtype=torch.float32, device="cuda")
     world = reducer.world if reducer is not None else 1
+    if scaler is None:
+        scaler = LossScaler(enabled=False)        # plain steps, but never on a non-finite gradient slab (LossScaler.step raises: all ranks, same step)
 
     def read(st):
-        if bool(bad):
+        # a non-finite LOSS stops the run where the reference prints it; the ranks agree first (MAX), so nobody is left waiting in a collective.
+        # Steps taken since it appeared were skipped (scaler on) or refused (scaler off) by LossScaler.step: no update was made from it.
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if float(bad) > 0:
             raise RuntimeError("Loss is not finite, stopping training")
         return {k: (float(v) if torch.is_tensor(v) else v) for k, v in st.items()}
     for it, (samples, _) in enumerate(loader):
@@ -119,17 +129,14 @@ def train_one_epoch(model, loader, opt, epoch, args, log=print, scaler=None, red
         samples = samples.cuda(non_blocking=True)
         with torch.autocast("cuda", dtype=torch.float16 if args.precision == "fp16" else torch.bfloat16, enabled=args.precision in ("bf16", "fp16")):
             loss, _, _, vis_loss, mask_loss, kl_loss = model(samples, mask_ratio=args.mask_ratio, visible_loss_ratio=args.visible_loss_ratio)
-        bad |= ~torch.isfinite(loss.detach())
+        bad.clamp_(min=(~torch.isfinite(loss.detach())).float())
         last = (it + 1) % args.accum_iter == 0
         if reducer is not None:
             reducer.sync = last
-        (loss * (scaler.scale if scaler is not None else 1.0) / args.accum_iter).backward()
+        (loss * scaler.scale / args.accum_iter).backward()
         if last:
             gscale = reducer.finish() if reducer is not None else 1.0          # 1 / world: the mean over the ranks, as DDP
-            if scaler is not None:
-                scaler.step(opt, gscale)
-            else:
-                opt.step(grad_scale=gscale)
+            scaler.step(opt, gscale)
             opt.zero_grad()
         stats = dict(loss=loss.detach(), vis_loss=vis_loss.detach(), mask_loss=mask_loss.detach(),
                      kl_loss=kl_loss.detach() if kl_loss is not None else 0.0, lr=opt.lr)

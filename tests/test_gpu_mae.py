@@ -721,3 +721,68 @@ def test_fp16_pretraining_loss_scaler_backs_off_on_overflow():
     print("skipped", scaler.skipped, "scale", scaler.scale, "steps", opt.step_count, "loss", losses[0], losses[-1])
     assert scaler.skipped >= 5 and scaler.scale == 2.0 ** 36 * 0.5 ** scaler.skipped and opt.step_count == 40 - scaler.skipped and opt.step_count >= 10
     assert all(torch.isfinite(p).all() for p in m.parameters()) and np.isfinite(losses).all() and losses[-1] < losses[0]
+    # fp16 AUTOCAST training is fp16 with ROUNDED branch outputs (what torch's autocast Linear hands to the residual add); only the TF32-class
+    # docking calls join the residual stream unrounded -- decided where the type is resolved, not from the (switched-off) autocast state in the block
+    blocks = list(m.blocks) + list(m.decoder_blocks)
+    assert all(b.last_dtype == torch.float16 and b.last_tf32_class is False for b in blocks)
+    prev = torch.backends.cuda.matmul.allow_tf32
+    try:
+        torch.backends.cuda.matmul.allow_tf32 = True
+        m.fused_encoder = False
+        with torch.no_grad():
+            mom = m.eval()._encode(x.cuda())                      # 8 x 256 tokens: whole groups of 8 rows -> TF32-class
+            assert all(b.last_dtype == torch.float16 and b.last_tf32_class is True for b in m.blocks)
+            m.decode(mom[:3, :16])                                 # 3 x 256 rows: fine too
+            # rows that are not whole groups of 8 (an odd batch of an odd grid: 81 tokens): the fp16 GEMM has no fallback -> exact f32 kernels
+            assert m._docking_dtype(m.blocks, rows=81) == (torch.float32, False) and m._docking_dtype(m.blocks, rows=88) == (torch.float16, True)
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+
+
+def test_tensor_hook_between_blocks_sees_and_changes_the_gradient():
+    """The block backward hands the bf16-rounded residual gradient to the previous block on the gradient tensor itself (`_ldmae_cast`).  A
+    TENSOR hook on a block's input runs in between and may edit that gradient -- also through an op that never bumps torch's version
+    counter (every kernel of this library writes through raw pointers): the hand-off must then be dropped, not used stale.  A hook that adds
+    a fixed perturbation through such a raw-pointer op must give exactly the gradients of the same hook written with torch's own in-place
+    add, and a hook that does nothing must give the unhooked gradients bit for bit."""
+    from ldmae_amd import ops
+    from ldmae_amd.tokenizer import models_mae
+    torch.manual_seed(0)
+    m = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192, decoder_depth=3,
+                                        decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
+                                        kl_loss_weight=1e-6, smooth_output=True).cuda().train()
+    imgs = (torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 2 - 1).cuda()
+    noise = torch.rand(4, 64, generator=torch.Generator().manual_seed(2)).cuda()
+    eps = torch.randn(4, 16, 16, generator=torch.Generator().manual_seed(3)).cuda()
+    delta = (torch.randn(4 * 64 * 192, generator=torch.Generator().manual_seed(4)) * 1e-3).cuda()
+
+    def grads(hook):
+        run = m._run
+
+        def hooked_run(blocks, x, dtype=None, tf32_class=False):
+            for i, blk in enumerate(blocks):
+                x = blk(x, m._chain_ok(blk), dtype, tf32_class)
+                if hook is not None and blocks is m.decoder_blocks and i == 0:
+                    x.register_hook(hook)
+            return x
+        m._run = hooked_run
+        try:
+            m.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = m(imgs, 0.75, 0.5, _noise=noise, _eps=eps)[0]
+            loss.backward()
+        finally:
+            m._run = run
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    base = grads(None)
+    idle = grads(lambda g: None)
+    assert all(torch.equal(base[k], idle[k]) for k in base)
+
+    def raw(g):                                   # edits the gradient in place through the C ABI: no version bump
+        ops.multi_add_([g.view(-1)], [delta])
+
+    def plain(g):
+        g.view(-1).add_(delta)
+    a, b = grads(raw), grads(plain)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert any(not torch.equal(a[k], base[k]) for k in a)         # and the perturbation did reach the earlier blocks
