@@ -129,6 +129,18 @@ int ldmae_rmsnorm_modulate_bwd_gate(int dtype, const void* dout, const float* x,
                                     const float* rstd, float* dx_accum, float beta_x, float* dshift, float* dscale, int dmod_ld, float* dw,
                                     float beta_w, const void* y, const float* gate, int gate_ld, void* dy, float* dgate, int dgate_ld,
                                     float* dbias, int M, int D, int rows_per_batch, float* workspace, void* stream);
+/* The three entry points above for blocks built with use_rmsnorm=False: nn.LayerNorm(hidden, elementwise_affine=False, eps=1e-6) + modulate
+ * (lightningdit.py:200-201,257; modulate :26-30).  y = (x - mean) * rstd * (1 + scale[b]) + shift[b]; rstd [M] = rsqrt(var + eps) is saved, the
+ * backward recomputes the row mean from x.  No weight, no weight gradient; workspaces: ldmae_rmsnorm_modulate_bwd(_gate)_workspace_bytes. */
+int ldmae_layernorm_modulate_fwd(int out_dtype, const float* x, const float* shift, const float* scale, int mod_ld, void* out, float* rstd,
+                                 int M, int D, int rows_per_batch, float eps, void* stream);
+int ldmae_layernorm_modulate_bwd(int dtype, const void* dout, const float* x, const float* scale, int mod_ld, const float* rstd, float* dx_accum,
+                                 float beta_x, float* dshift, float* dscale, int dmod_ld, int M, int D, int rows_per_batch, float* workspace,
+                                 void* stream);
+int ldmae_layernorm_modulate_bwd_gate(int dtype, const void* dout, const float* x, const float* scale, int mod_ld, const float* rstd,
+                                      float* dx_accum, float beta_x, float* dshift, float* dscale, int dmod_ld, const void* y, const float* gate,
+                                      int gate_ld, void* dy, float* dgate, int dgate_ld, float* dbias, int M, int D, int rows_per_batch,
+                                      float* workspace, void* stream);
 
 /* ---- attention front end (lightningdit.py:68-74; rmsnorm.py on head_dim; pos_embed.py:38-42,135) */
 /* qkv [B,N,3,H,hd] -> q,k = rope(rmsnorm(.)*w) and v, each [B,H,N,hd]. cos/sin [N,hd] f32.
@@ -291,6 +303,9 @@ int ldmae_layernorm_bwd_cast(int dtype, const void* dout, const float* x, const 
 /* exact-erf GELU (timm Mlp act, models_mae.py:172) */
 int ldmae_gelu_fwd(int dtype, const void* x, void* out, long n, void* stream);
 int ldmae_gelu_bwd(int dtype, const void* dout, const void* x, void* dx, long n, void* stream);
+/* nn.GELU(approximate="tanh"): the timm Mlp of a LightningDiT block built with use_swiglu=False (lightningdit.py:208,219-224); f32 / bf16 */
+int ldmae_gelu_tanh_fwd(int dtype, const void* x, void* out, long n, void* stream);
+int ldmae_gelu_tanh_bwd(int dtype, const void* dout, const void* x, void* dx, long n, void* stream);
 /* 3x3 / stride 1 / pad 1 convolution on [B,C,H,W] f32 (conv_decoder_pred.conv_smoother, models_mae.py:254,275) */
 int ldmae_conv3x3(const float* x, const float* w, const float* b, float* out, int B, int C, int H, int W, void* stream);
 /* its backward (VMAE pre-training trains the smoother, engine_pretrain.py:51-76): dx (optional) [B,C,H,W], dw [C,C,3,3], db [C]; C = 3 */

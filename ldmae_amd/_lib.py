@@ -93,6 +93,11 @@ SIGNATURES = {
     "ldmae_layernorm_bwd_cast": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp]),
     "ldmae_gelu_fwd": (_i, [_i, _vp, _vp, _l, _vp]),
     "ldmae_gelu_bwd": (_i, [_i, _vp, _vp, _vp, _l, _vp]),
+    "ldmae_gelu_tanh_fwd": (_i, [_i, _vp, _vp, _l, _vp]),
+    "ldmae_gelu_tanh_bwd": (_i, [_i, _vp, _vp, _vp, _l, _vp]),
+    "ldmae_layernorm_modulate_fwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "ldmae_layernorm_modulate_bwd": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ldmae_layernorm_modulate_bwd_gate": (_i, [_i, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "ldmae_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ldmae_conv3x3_bwd_workspace_bytes": (_l, [_i]),
     "ldmae_conv3x3_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -88,11 +88,13 @@ template <int NCH, typename OutT, bool FULL = false>
 __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ shift, const float* __restrict__ scale,
                                                               int mod_ld, OutT* __restrict__ out, float* __restrict__ rstd, int M, int D,
-                                                              int rpb, float eps) {
+                                                              int rpb, float eps, int center = 0) {
+  // center (guarded form only): LayerNorm WITHOUT affine parameters (the use_rmsnorm=False blocks, lightningdit.py:200-201) = the RMS norm of
+  // the centred row, w = NULL -> 1: y = (x - mean) * rsqrt(mean((x - mean)^2) + eps) * (1 + scale) + shift
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nch = D >> 2;
   float4 wv[NCH];
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) { const int c = lane + 64 * i; wv[i] = c < nch ? *(const float4*)(w + 4 * c) : f4(0.f); }
+  for (int i = 0; i < NCH; ++i) { const int c = lane + 64 * i; wv[i] = c < nch ? (w ? *(const float4*)(w + 4 * c) : f4(1.f)) : f4(0.f); }
   if constexpr (FULL) {
     const int m0 = (blockIdx.x * 4 + wave) * 4, b = m0 / rpb;
     float4 sc1[NCH], sh[NCH];
@@ -134,6 +136,18 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __res
       xv[i] = c < nch ? *(const float4*)(x + (size_t)m * D + 4 * c) : f4(0.f);
       ss += hsum(xv[i] * xv[i]);
     }
+    if (center) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) s1 += hsum(xv[i]);
+      const float mean = wave_sum(s1) / (float)D;
+      ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        if (lane + 64 * i < nch) xv[i] = xv[i] - f4(mean);
+        ss += hsum(xv[i] * xv[i]);
+      }
+    }
     ss = wave_sum(ss);
     const float rs = rsqrtf(ss / (float)D + eps);
     if (lane == 0 && rstd) rstd[m] = rs;
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_fwd_kernel(const float* __res
 // gradient is consumed while it is in registers -- dy = dx_new * gate[b] (rounded to T), dgate partials sum dx_new * y, bias-gradient
 // partials sum dy -- instead of being re-read by a separate gate_bwd pass (805 MB per block).  Same arithmetic, same partial layout
 // and same summation order as gate_bwd_kernel.
-struct GateBwdArgs { const void* y; const float* gate; int gate_ld; void* dy; float* Pg; float* Pb; int dx_overwrite; };
+struct GateBwdArgs { const void* y; const float* gate; int gate_ld; void* dy; float* Pg; float* Pb; int dx_overwrite; int center; };
 template <int NCH, typename T, bool GATE, bool FULL = false>
 __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x,
                                                               const float* __restrict__ w, const float* __restrict__ scale, int mod_ld,
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
   float* cg = red + 2 * D;
   if constexpr (GATE) {
     for (int c = threadIdx.x; c < nch; c += 256) {
-      *(float4*)(cw + 4 * c) = *(const float4*)(w + 4 * c);
+      *(float4*)(cw + 4 * c) = w ? *(const float4*)(w + 4 * c) : f4(1.f);
       *(float4*)(cs + 4 * c) = scale ? f4(1.f) + *(const float4*)(scale + (size_t)b * mod_ld + 4 * c) : f4(1.f);
       *(float4*)(cg + 4 * c) = *(const float4*)(ga.gate + (size_t)b * ga.gate_ld + 4 * c);
     }
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     if constexpr (!GATE) {
-      wv[i] = c < nch ? *(const float4*)(w + 4 * c) : f4(0.f);
+      wv[i] = c < nch ? (w ? *(const float4*)(w + 4 * c) : f4(1.f)) : f4(0.f);
       sc1[i] = (c < nch && scale) ? f4(1.f) + *(const float4*)(scale + (size_t)b * mod_ld + 4 * c) : f4(1.f);
     }
     a_sh[i] = a_sc[i] = a_w[i] = f4(0.f);
@@ -243,14 +257,23 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
     if (m >= M) break;
     const float rs = rstd[m];
     float4 nv[NCH], dn[NCH];
-    float dot = 0.f;
+    float dot = 0.f, mean = 0.f;
+    // center (LayerNorm without affine parameters: the norm of the CENTRED row): the row mean is recomputed from x (a second, cache-resident
+    // read), n = (x - mean) * rstd, and the centring's own backward takes the mean of dn out of the result below.  mean = msum = 0 otherwise:
+    // x - 0 and d - 0 leave every bit of the RMS form as it was.
+    if (ga.center) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) { const int c = lane + 64 * i; if (c < nch) s1 += hsum(*(const float4*)(x + (size_t)m * D + 4 * c)); }
+      mean = wave_sum(s1) / (float)D;
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         const float4 g = load4<T>(dout + (size_t)m * D + 4 * c);
         const float4 wc = GATE ? *(const float4*)(cw + 4 * c) : wv[i], sc = GATE ? *(const float4*)(cs + 4 * c) : sc1[i];
-        nv[i] = *(const float4*)(x + (size_t)m * D + 4 * c) * rs;
+        nv[i] = (*(const float4*)(x + (size_t)m * D + 4 * c) - f4(mean)) * rs;
         const float4 dy = g * sc;
         a_sh[i] = a_sh[i] + g;
         a_sc[i] = a_sc[i] + g * (nv[i] * wc);
@@ -260,12 +283,19 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_bwd_kernel(const T* __restric
       } else { nv[i] = dn[i] = f4(0.f); }
     }
     dot = wave_sum(dot) / (float)D;
+    float msum = 0.f;
+    if (ga.center) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) s1 += hsum(dn[i]);
+      msum = wave_sum(s1) / (float)D;
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         float* p = dx + (size_t)m * D + 4 * c;
-        const float4 d0 = (dn[i] - nv[i] * dot) * rs;
+        const float4 d0 = ((dn[i] - nv[i] * dot) - f4(msum)) * rs;
         const float4 g = ga.dx_overwrite ? d0 : *(const float4*)p + d0;        // beta_x = 0: dx is written, not read (no memset by the caller)
         *(float4*)p = g;
         if constexpr (GATE) {
@@ -353,22 +383,32 @@ __global__ void mod_partials_reduce_kernel(const float* __restrict__ P, int D, i
     case 8: { constexpr int NCH = 8; CALL; } break;             \
     default: LDMAE_FAIL(LDMAE_ERR_INVALID, "row width D=%d > 2048 unsupported", (D)); }
 
-extern "C" int ldmae_rmsnorm_modulate_fwd(int out_dtype, const float* x, const float* w, const float* shift, const float* scale,
-                                          int mod_ld, void* out, float* rstd, int M, int D, int rows_per_batch, float eps, void* stream) {
-  LDMAE_REQUIRE(x && w && out && M > 0 && D > 0, "rmsnorm_modulate_fwd: null pointer or empty");
+static int norm_modulate_fwd(int out_dtype, const float* x, const float* w, const float* shift, const float* scale,
+                             int mod_ld, void* out, float* rstd, int M, int D, int rows_per_batch, float eps, int center, void* stream) {
+  LDMAE_REQUIRE(x && (w || center) && out && M > 0 && D > 0, "rmsnorm_modulate_fwd: null pointer or empty");
   LDMAE_REQUIRE(D % 4 == 0 && (mod_ld % 4 == 0 || (!shift && !scale)), "rmsnorm_modulate_fwd: D=%d mod_ld=%d must be multiples of 4", D, mod_ld);
   LDMAE_REQUIRE(rows_per_batch > 0 && M % rows_per_batch == 0, "rmsnorm_modulate_fwd: M=%d %% rows_per_batch=%d != 0", M, rows_per_batch);
   hipStream_t st = as_stream(stream);
   const unsigned grid = cdiv(M, 16);
-  if (out_dtype == LDMAE_BF16 && D % 256 == 0 && M % 16 == 0 && rows_per_batch % 16 == 0) {
-    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, bf16, true>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (bf16*)out, rstd, M, D, rows_per_batch, eps));
+  if (out_dtype == LDMAE_BF16 && D % 256 == 0 && M % 16 == 0 && rows_per_batch % 16 == 0 && !center) {
+    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, bf16, true>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (bf16*)out, rstd, M, D, rows_per_batch, eps, 0));
   } else if (out_dtype == LDMAE_BF16) {
-    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, bf16>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (bf16*)out, rstd, M, D, rows_per_batch, eps));
+    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, bf16>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (bf16*)out, rstd, M, D, rows_per_batch, eps, center));
   } else {
-    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, float>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (float*)out, rstd, M, D, rows_per_batch, eps));
+    DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_fwd_kernel<NCH, float>), dim3(grid), dim3(256), 0, st, x, w, shift, scale, mod_ld, (float*)out, rstd, M, D, rows_per_batch, eps, center));
   }
   LDMAE_CHECK_LAUNCH("rmsnorm_modulate_fwd");
   return LDMAE_OK;
+}
+extern "C" int ldmae_rmsnorm_modulate_fwd(int out_dtype, const float* x, const float* w, const float* shift, const float* scale,
+                                          int mod_ld, void* out, float* rstd, int M, int D, int rows_per_batch, float eps, void* stream) {
+  return norm_modulate_fwd(out_dtype, x, w, shift, scale, mod_ld, out, rstd, M, D, rows_per_batch, eps, 0, stream);
+}
+// LayerNorm(elementwise_affine=False) + modulate: the norm of the blocks built with use_rmsnorm=False (lightningdit.py:200-201,257; eps 1e-6).
+// rstd [M] = rsqrt(var + eps) (the backward recomputes the row mean from x).
+extern "C" int ldmae_layernorm_modulate_fwd(int out_dtype, const float* x, const float* shift, const float* scale, int mod_ld, void* out,
+                                            float* rstd, int M, int D, int rows_per_batch, float eps, void* stream) {
+  return norm_modulate_fwd(out_dtype, x, nullptr, shift, scale, mod_ld, out, rstd, M, D, rows_per_batch, eps, 1, stream);
 }
 
 extern "C" long ldmae_rmsnorm_modulate_bwd_workspace_bytes(int M, int D, int rows_per_batch) {
@@ -384,8 +424,8 @@ extern "C" long ldmae_gate_bwd_workspace_bytes(int M, int D, int rows_per_batch)
 static int rmsnorm_modulate_bwd_core(int dtype, const void* dout, const float* x, const float* w, const float* scale, int mod_ld,
                                      const float* rstd, float* dx_accum, float beta_x, float* dshift, float* dscale, int dmod_ld, float* dw,
                                      float beta_w, int M, int D, int rows_per_batch, float* workspace, const GateBwdArgs* gate,
-                                     float* dgate, int dgate_ld, float* dbias, void* stream) {
-  LDMAE_REQUIRE(dout && x && w && rstd && dx_accum && dw && workspace, "rmsnorm_modulate_bwd: null pointer");
+                                     float* dgate, int dgate_ld, float* dbias, void* stream, int center = 0) {
+  LDMAE_REQUIRE(dout && x && (w || center) && rstd && dx_accum && (dw || center) && workspace, "rmsnorm_modulate_bwd: null pointer");
   LDMAE_REQUIRE(D % 4 == 0 && M > 0 && rows_per_batch > 0 && M % rows_per_batch == 0, "rmsnorm_modulate_bwd: bad shape M=%d D=%d rpb=%d", M, D, rows_per_batch);
   const int rw = pick_rows_per_wg(rows_per_batch);
   LDMAE_REQUIRE(rw > 0, "rmsnorm_modulate_bwd: rows_per_batch=%d must be a multiple of 4", rows_per_batch);
@@ -396,12 +436,14 @@ static int rmsnorm_modulate_bwd_core(int dtype, const void* dout, const float* x
   float* gws = dwb + (size_t)B * D;                     // gate partials (fused form): [G][D] dgate, [G][D] bias, colsum scratch
   const size_t lds = (size_t)4 * 3 * D * sizeof(float);
   LDMAE_REQUIRE(beta_x == 0.f || beta_x == 1.f, "rmsnorm_modulate_bwd: beta_x must be 0 (write dx) or 1 (accumulate into dx)");
-  GateBwdArgs ga{nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
+  GateBwdArgs ga{nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0};
   if (gate) { ga = *gate; ga.Pg = gws; ga.Pb = gws + (size_t)G * D; }
   ga.dx_overwrite = beta_x == 0.f;
+  ga.center = center;
+  if (center && !dw) dw = P;             // LayerNorm without affine parameters: no weight gradient; the last reduce (stream-ordered behind the consumers of P) writes its [D] sums there
 #define LAUNCH(T, GATE) DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NCH, T, GATE>), dim3(G), dim3(256), lds, st, (const T*)dout, x, w, scale, mod_ld, rstd, dx_accum, P, M, D, rows_per_batch, rw, ga))
 #define LAUNCH_FULL(T, GATE) DISPATCH_NCH(D, hipLaunchKernelGGL((rmsnorm_mod_bwd_kernel<NCH, T, GATE, true>), dim3(G), dim3(256), lds, st, (const T*)dout, x, w, scale, mod_ld, rstd, dx_accum, P, M, D, rows_per_batch, rw, ga))
-  if (dtype == LDMAE_BF16 && D % 256 == 0) { if (gate) { LAUNCH_FULL(bf16, true); } else { LAUNCH_FULL(bf16, false); } }
+  if (dtype == LDMAE_BF16 && D % 256 == 0 && !center) { if (gate) { LAUNCH_FULL(bf16, true); } else { LAUNCH_FULL(bf16, false); } }
   else if (dtype == LDMAE_BF16) { if (gate) { LAUNCH(bf16, true); } else { LAUNCH(bf16, false); } }
   else { if (gate) { LAUNCH(float, true); } else { LAUNCH(float, false); } }
 #undef LAUNCH
@@ -440,9 +482,27 @@ extern "C" int ldmae_rmsnorm_modulate_bwd_gate(int dtype, const void* dout, cons
                                                int dgate_ld, float* dbias, int M, int D, int rows_per_batch, float* workspace, void* stream) {
   LDMAE_REQUIRE(y && gate && dy && dgate && dbias, "rmsnorm_modulate_bwd_gate: null pointer");
   LDMAE_REQUIRE(gate_ld % 4 == 0, "rmsnorm_modulate_bwd_gate: gate_ld=%d must be a multiple of 4", gate_ld);
-  const GateBwdArgs ga{y, gate, gate_ld, dy, nullptr, nullptr, 0};
+  const GateBwdArgs ga{y, gate, gate_ld, dy, nullptr, nullptr, 0, 0};
   return rmsnorm_modulate_bwd_core(dtype, dout, x, w, scale, mod_ld, rstd, dx_accum, beta_x, dshift, dscale, dmod_ld, dw, beta_w, M, D, rows_per_batch,
                                    workspace, &ga, dgate, dgate_ld, dbias, stream);
+}
+// The LayerNorm(elementwise_affine=False) forms of the two entry points above (use_rmsnorm=False blocks): same arguments without w / dw, same
+// workspaces (ldmae_rmsnorm_modulate_bwd(_gate)_workspace_bytes).
+extern "C" int ldmae_layernorm_modulate_bwd(int dtype, const void* dout, const float* x, const float* scale, int mod_ld, const float* rstd,
+                                            float* dx_accum, float beta_x, float* dshift, float* dscale, int dmod_ld, int M, int D, int rows_per_batch,
+                                            float* workspace, void* stream) {
+  return rmsnorm_modulate_bwd_core(dtype, dout, x, nullptr, scale, mod_ld, rstd, dx_accum, beta_x, dshift, dscale, dmod_ld, nullptr, 0.f, M, D, rows_per_batch,
+                                   workspace, nullptr, nullptr, 0, nullptr, stream, 1);
+}
+extern "C" int ldmae_layernorm_modulate_bwd_gate(int dtype, const void* dout, const float* x, const float* scale, int mod_ld, const float* rstd,
+                                                 float* dx_accum, float beta_x, float* dshift, float* dscale, int dmod_ld, const void* y, const float* gate,
+                                                 int gate_ld, void* dy, float* dgate, int dgate_ld, float* dbias, int M, int D, int rows_per_batch,
+                                                 float* workspace, void* stream) {
+  LDMAE_REQUIRE(y && gate && dy && dgate && dbias, "layernorm_modulate_bwd_gate: null pointer");
+  LDMAE_REQUIRE(gate_ld % 4 == 0, "layernorm_modulate_bwd_gate: gate_ld=%d must be a multiple of 4", gate_ld);
+  const GateBwdArgs ga{y, gate, gate_ld, dy, nullptr, nullptr, 0, 1};
+  return rmsnorm_modulate_bwd_core(dtype, dout, x, nullptr, scale, mod_ld, rstd, dx_accum, beta_x, dshift, dscale, dmod_ld, nullptr, 0.f, M, D, rows_per_batch,
+                                   workspace, &ga, dgate, dgate_ld, dbias, stream, 1);
 }
 
 // ------------------------------------------------------------------ QK-RMSNorm + RoPE + head-major relayout

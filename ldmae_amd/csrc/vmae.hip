@@ -446,6 +446,43 @@ extern "C" int ldmae_gelu_bwd(int dtype, const void* dout, const void* x, void* 
   return LDMAE_OK;
 }
 
+// ------------------------------------------------------------------ tanh-approximated GELU
+// nn.GELU(approximate="tanh"): the activation of the timm Mlp a LightningDiT block gets with use_swiglu=False (lightningdit.py:208,219-224):
+// y = 0.5 x (1 + tanh(k (x + 0.044715 x^3))), k = sqrt(2 / pi).  tanh(u) = 1 - 2 / (exp(2u) + 1) (exact at both infinities).
+// Backward: dy/dx = 0.5 (1 + t) + 0.5 x (1 - t^2) k (1 + 3 * 0.044715 x^2).  No shipped configuration runs this block: plain elementwise passes.
+__device__ __forceinline__ float tanh_exp(float u) { return 1.f - 2.f / (__expf(2.f * u) + 1.f); }
+template <typename T>
+__global__ void gelu_tanh_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = to_f<T>(x[i]);
+    out[i] = from_f<T>(0.5f * v * (1.f + tanh_exp(0.7978845608028654f * (v + 0.044715f * v * v * v))));
+  }
+}
+template <typename T>
+__global__ void gelu_tanh_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x, T* __restrict__ dx, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = to_f<T>(x[i]), t = tanh_exp(0.7978845608028654f * (v + 0.044715f * v * v * v));
+    const float d = 0.5f * (1.f + t) + 0.5f * v * (1.f - t * t) * 0.7978845608028654f * (1.f + 0.134145f * v * v);
+    dx[i] = from_f<T>(to_f<T>(dout[i]) * d);
+  }
+}
+extern "C" int ldmae_gelu_tanh_fwd(int dtype, const void* x, void* out, long n, void* stream) {
+  LDMAE_REQUIRE(x && out && n > 0, "gelu_tanh_fwd: bad arguments");
+  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "gelu_tanh_fwd: f32 or bf16");
+  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(gelu_tanh_fwd_kernel<bf16>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const bf16*)x, (bf16*)out, n);
+  else hipLaunchKernelGGL(gelu_tanh_fwd_kernel<float>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)out, n);
+  LDMAE_CHECK_LAUNCH("gelu_tanh_fwd");
+  return LDMAE_OK;
+}
+extern "C" int ldmae_gelu_tanh_bwd(int dtype, const void* dout, const void* x, void* dx, long n, void* stream) {
+  LDMAE_REQUIRE(dout && x && dx && n > 0, "gelu_tanh_bwd: bad arguments");
+  LDMAE_REQUIRE(dtype == LDMAE_F32 || dtype == LDMAE_BF16, "gelu_tanh_bwd: f32 or bf16");
+  if (dtype == LDMAE_BF16) hipLaunchKernelGGL(gelu_tanh_bwd_kernel<bf16>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const bf16*)dout, (const bf16*)x, (bf16*)dx, n);
+  else hipLaunchKernelGGL(gelu_tanh_bwd_kernel<float>, dim3(gelu_grid(n)), dim3(256), 0, as_stream(stream), (const float*)dout, (const float*)x, (float*)dx, n);
+  LDMAE_CHECK_LAUNCH("gelu_tanh_bwd");
+  return LDMAE_OK;
+}
+
 // ------------------------------------------------------------------ 3x3 conv on RGB (conv_decoder_pred.conv_smoother, models_mae.py:254,275)
 // direct convolution, stride 1, zero padding 1, C channels in/out (C = 3); one thread per output pixel.
 __global__ void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out,

@@ -167,6 +167,30 @@ def _dw_into_grad(sg, dy, x, param, direct):
 
 _FUSED_QKN_BWD = os.environ.get("LDMAE_FUSED_QKN_BWD", "1") != "0"      # A/B switch (tools/): 0 = attention_bwd_pv + qknorm_rope_bwd
 
+_QK_LN_EPS = 1e-5      # nn.LayerNorm's default: Attention builds q_norm / k_norm as norm_layer(head_dim) (:60-61)
+
+
+def _qk_layernorm_fwd(qkv, qnw, qnb, knw, knb, cos, sin, B, N, H, hd, dtype):
+    """Attention front end of a block with use_qknorm=True and use_rmsnorm=False: q_norm / k_norm = nn.LayerNorm(head_dim) WITH weight and bias
+    (:54-61), then RoPE (:71-73).  No shipped YAML builds it, so it is composed from kernels that exist: head-major split, the affine LayerNorm
+    of the VMAE blocks on rows of head_dim (f32 statistics), the standalone rotation.  -> (q, k, v head-major, saved tuple for the backward)."""
+    qs, ks, v = ops.heads_split(qkv, B, N, H, hd)
+    q32, k32 = ops.cast(qs, torch.float32).view(-1, hd), ops.cast(ks, torch.float32).view(-1, hd)
+    qn, muq, rsq = ops.layernorm_fwd(q32, qnw, qnb, dtype, _QK_LN_EPS)
+    kn, muk, rsk = ops.layernorm_fwd(k32, knw, knb, dtype, _QK_LN_EPS)
+    q, k = ops.rope(qn.view(B, H, N, hd), cos, sin), ops.rope(kn.view(B, H, N, hd), cos, sin)
+    return q, k, v, (q32, k32, muq, rsq, muk, rsk)
+
+
+def _qk_layernorm_bwd(dq, dk, dv, saved, qnw, knw, cos, sin, B, N, H, hd, dtype):
+    """-> (dqkv [B*N, 3*H*hd], dqnw, dqnb, dknw, dknb, dbqkv)."""
+    q32, k32, muq, rsq, muk, rsk = saved
+    dxq, dxk = torch.zeros_like(q32), torch.zeros_like(k32)
+    dqw, dqb = ops.layernorm_bwd(ops.rope(dq, cos, sin, transposed=True).view(-1, hd), q32, qnw, muq, rsq, dxq)
+    dkw, dkb = ops.layernorm_bwd(ops.rope(dk, cos, sin, transposed=True).view(-1, hd), k32, knw, muk, rsk, dxk)
+    dqkv = ops.heads_merge(ops.cast(dxq, dtype).view(B, H, N, hd), ops.cast(dxk, dtype).view(B, H, N, hd), dv, B, N, H, hd)
+    return dqkv, dqw, dqb, dkw, dkb, ops.colsum(dqkv)
+
 
 class _GradChain:
     """Hand-off between the backward passes of consecutive members of LightningDiT.forward's block chain (one object per forward).
@@ -245,8 +269,10 @@ class _DiTBlockFn(torch.autograd.Function):
     """LightningDiTBlock.forward (:239-250) with RMSNorm, QK-norm, RoPE, SwiGLU, shift."""
 
     @staticmethod
-    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace, chain, idx, direct, fwd_only, mod_all,
-                n1w, qkvw, qkvb, qnw, knw, pw, pb, n2w, w12, b12, w3, b3, adaw, adab):
+    def forward(ctx, x, sc, cos, sin, H, eps, dtype, inplace, chain, idx, direct, fwd_only, mod_all, swiglu,
+                n1w, qkvw, qkvb, qnw, knw, qnb, knb, pw, pb, n2w, w12, b12, w3, b3, adaw, adab):
+        """n1w / n2w None: LayerNorm without affine parameters (use_rmsnorm=False).  qnw / knw None: no QK-norm; with qnb / knb: nn.LayerNorm
+        QK-norm (use_qknorm without use_rmsnorm).  swiglu False: w12 / b12 / w3 / b3 are fc1 / fc2 of the timm Mlp with tanh-GELU (use_swiglu=False)."""
         B, N, D = x.shape
         M, hd = B * N, D // H
         x2 = x.contiguous().view(M, D)
@@ -273,7 +299,11 @@ class _DiTBlockFn(torch.autograd.Function):
         # attention branch (:248)
         xm1, rstd1 = ops.rmsnorm_modulate_fwd(x2, n1w, sh1, s1, N, dtype, eps)
         qkv = ops.gemm_nt(xm1, Wqkv, qkvb)                                               # [M, 3D] == [B,N,3,H,hd]
-        if dtype == torch.bfloat16:      # v is consumed where the qkv Linear wrote it: no head-major copy of v (nor of dv in backward)
+        qk_saved = None
+        if qnb is not None:              # nn.LayerNorm QK-norm: composed path (see _qk_layernorm_fwd)
+            q, k, v, qk_saved = _qk_layernorm_fwd(qkv, qnw, qnb, knw, knb, cos, sin, B, N, H, hd, dtype)
+            o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)
+        elif dtype == torch.bfloat16:    # v is consumed where the qkv Linear wrote it: no head-major copy of v (nor of dv in backward)
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps, copy_v=False)
             # QK-RMSNorm bounds |q|, |k| by max|w| sqrt(hd) and the rotation keeps norms: a proven score bound, so the softmax runs with a
             # static shift (no running maximum in the kernel).  use_qknorm=False (qnw None; q_norm = nn.Identity, :60-61): nothing bounds the
@@ -285,18 +315,23 @@ class _DiTBlockFn(torch.autograd.Function):
         xmid, y1 = ops.gemm_nt_gate_res(o.view(M, D), Wp, pb, x2, g1, N, save_y=bwd)
         # MLP branch (:249)
         xm2, rstd2 = ops.rmsnorm_modulate_fwd(xmid, n2w, sh2, s2, N, dtype, eps)
-        h12, hid = ops.gemm_nt_swiglu(xm2, W12, b12, save_h12=bwd)
+        if swiglu:
+            h12, hid = ops.gemm_nt_swiglu(xm2, W12, b12, save_h12=bwd)
+        else:                            # timm Mlp (:219-224): fc1 -> GELU(tanh) -> fc2; h12 = fc1's pre-activation, hid = the activation
+            h12 = ops.gemm_nt(xm2, W12, b12)
+            hid = ops.gelu_tanh_fwd(h12)
         xout, y2 = ops.gemm_nt_gate_res(hid, W3, b3, xmid, g2, N, save_y=bwd)
         if not bwd:
             return xout.view(B, N, D)
         ctx.save_for_backward(x2, sc, cos, sin, mod, rstd1, xm1, qkv, q, k, v, o, lse, y1, xmid, rstd2, xm2, h12, hid, y2,
-                              n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T)
+                              n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T, *(qk_saved or ()))
         ctx.dims = (B, N, D, H, hd, eps, dtype)
+        ctx.swiglu, ctx.qk_ln = bool(swiglu), qk_saved is not None
         ctx.nmod = nmod
         ctx.inplace = bool(inplace)
         ctx.chain, ctx.idx = chain, idx
         ctx.direct, ctx.wparams = bool(direct), (qkvw, pw, w12, w3)
-        ctx.sparams = (n1w, qkvb, qnw, knw, pb, n2w, b12, b3) if direct else None
+        ctx.sparams = (n1w, qkvb, qnw, knw, pb, n2w, b12, b3, qnb, knb) if direct else None
         if chain is not None:
             chain.up[idx] = (y2, mod)
         return xout.view(B, N, D)
@@ -304,7 +339,8 @@ class _DiTBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         (x2, sc, cos, sin, mod, rstd1, xm1, qkv, q, k, v, o, lse, y1, xmid, rstd2, xm2, h12, hid, y2,
-         n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T) = ctx.saved_tensors
+         n1w, qnw, knw, n2w, adaw, WqkvT, WpT, W12T, W3T) = ctx.saved_tensors[:29]
+        qk_saved = ctx.saved_tensors[29:] if ctx.qk_ln else None
         B, N, D, H, hd, eps, dtype = ctx.dims
         M = B * N
         # f32 residual-stream gradient.  `inplace` (set by LightningDiT.forward for its own block chain, where a block output
@@ -330,7 +366,11 @@ class _DiTBlockFn(torch.autograd.Function):
         qkvw_p, pw_p, w12_p, w3_p = ctx.wparams
         notify = []
         dW3, r = _dw_into_grad(sg, dy2, hid, w3_p, ctx.direct); notify.append((r, w3_p))
-        dh12, db12 = ops.gemm_nt_swiglu_bwd(dy2, W3T, h12, with_bias=True)
+        if ctx.swiglu:
+            dh12, db12 = ops.gemm_nt_swiglu_bwd(dy2, W3T, h12, with_bias=True)
+        else:                            # timm Mlp: fc2's input gradient through the tanh-GELU backward; fc1's bias gradient = its column sums
+            dh12 = ops.gelu_tanh_bwd(ops.gemm_nt(dy2, W3T), h12)
+            db12 = ops.colsum(dh12)
         dW12, r = _dw_into_grad(sg, dh12, xm2, w12_p, ctx.direct); notify.append((r, w12_p))
         dxm2 = ops.gemm_nt(dh12, W12T)
         # norm2 backward and the attention branch's gate backward in one pass (the updated dx is consumed from registers)
@@ -339,7 +379,11 @@ class _DiTBlockFn(torch.autograd.Function):
         # ---- attention branch
         dWp, r = _dw_into_grad(sg, dy1, o.view(M, D), pw_p, ctx.direct); notify.append((r, pw_p))
         do = ops.gemm_nt(dy1, WpT)
-        if v is None and hd in (64, 128) and N % 64 == 0 and _FUSED_QKN_BWD:      # QK-norm / RoPE backward inside the attention backward's epilogues: no head-major dq / dk
+        dqnb = dknb = None
+        if qk_saved is not None:         # nn.LayerNorm QK-norm (composed path)
+            dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
+            dqkv, dqn, dqnb, dkn, dknb, dbqkv = _qk_layernorm_bwd(dq, dk, dv, qk_saved, qnw, knw, cos, sin, B, N, H, hd, dtype)
+        elif v is None and hd in (64, 128) and N % 64 == 0 and _FUSED_QKN_BWD:      # QK-norm / RoPE backward inside the attention backward's epilogues: no head-major dq / dk
             dqkv, dqn, dkn, dbqkv = ops.attention_bwd_pv_qknorm(q, k, qkv, o, do, lse, hd ** -0.5, qnw, knw, cos, sin, eps)
         elif v is None:
             dq, dk, dqkv = ops.attention_bwd_pv(q, k, qkv, o, do, lse, hd ** -0.5)          # dv lands in the v slot of dqkv
@@ -366,19 +410,19 @@ class _DiTBlockFn(torch.autograd.Function):
         sg.join()
         # the eight small gradients of the block (norm weights, biases, QK-norm weights): with `direct`, ONE launch adds them into their .grad
         # views instead of one AccumulateGrad add each
-        small = [dn1, dbqkv, dqn, dkn, dbp, dn2, db12, db3]
+        small = [dn1, dbqkv, dqn, dkn, dbp, dn2, db12, db3, dqnb, dknb]
         if ctx.sparams is not None:
             pairs = [(p_, g_) for p_, g_ in zip(ctx.sparams, small) if p_ is not None]      # use_qknorm=False: no q_norm / k_norm weights
             if all(g_ is not None and p_.grad is not None and p_.grad.dtype == torch.float32 and p_.grad.is_contiguous() and p_.grad.shape == g_.shape
                    for p_, g_ in pairs):
                 ops.multi_add_([p_.grad for p_, _ in pairs], [g_ for _, g_ in pairs])
                 notify.extend((getattr(p_, "_ldmae_grad_ready", None), p_) for p_, _ in pairs)
-                dn1 = dbqkv = dqn = dkn = dbp = dn2 = db12 = db3 = None
+                dn1 = dbqkv = dqn = dkn = dbp = dn2 = db12 = db3 = dqnb = dknb = None
         for r, p_ in notify:          # gradients written straight into .grad: tell the reducer (no-op without one)
             if r is not None:
                 r(p_)
-        return (dx.view(B, N, D), dsc, None, None, None, None, None, None, None, None, None, None, dmod_all,
-                dn1, dWqkv, dbqkv, dqn, dkn, dWp, dbp, dn2, dW12, db12, dW3, db3, dadaw, dadab)
+        return (dx.view(B, N, D), dsc, None, None, None, None, None, None, None, None, None, None, dmod_all, None,
+                dn1, dWqkv, dbqkv, dqn, dkn, dqnb, dknb, dWp, dbp, dn2, dW12, db12, dW3, db3, dadaw, dadab)
 
 
 class _AttentionFn(torch.autograd.Function):
@@ -386,33 +430,42 @@ class _AttentionFn(torch.autograd.Function):
     uses.  Activations in `dtype` (bf16 under autocast, like the reference's autocast Linear / SDPA; else f32)."""
 
     @staticmethod
-    def forward(ctx, x, cos, sin, H, eps, dtype, qkvw, qkvb, qnw, knw, pw, pb):
+    def forward(ctx, x, cos, sin, H, eps, dtype, qkvw, qkvb, qnw, knw, qnb, knb, pw, pb):
         B, N, D = x.shape
         M, hd = B * N, D // H
         xa = ops.cast(x.contiguous().view(M, D), dtype)
         Wqkv, WqkvT = _wcopies(qkvw, dtype, True)
         Wp, WpT = _wcopies(pw, dtype, True)
         qkv = ops.gemm_nt(xa, Wqkv, qkvb)
-        if dtype == torch.bfloat16:
+        qk_saved = None
+        if qnb is not None:              # nn.LayerNorm QK-norm (use_rmsnorm=False): composed path
+            q, k, v, qk_saved = _qk_layernorm_fwd(qkv, qnw, qnb, knw, knb, cos, sin, B, N, H, hd, dtype)
+            o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)
+        elif dtype == torch.bfloat16:
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps, copy_v=False)
             o, lse = ops.attention_fwd_pv(q, k, qkv, hd ** -0.5, bound=ops.qk_score_bound(qnw, knw, hd, hd ** -0.5) if qnw is not None else None)
         else:
             q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps)
             o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)
         out = ops.gemm_nt(o.view(M, D), Wp, pb)
-        ctx.save_for_backward(xa, cos, sin, qkv, q, k, v, o, lse, qnw, knw, WqkvT, WpT)
+        ctx.save_for_backward(xa, cos, sin, qkv, q, k, v, o, lse, qnw, knw, WqkvT, WpT, *(qk_saved or ()))
         ctx.dims = (B, N, D, H, hd, eps, x.dtype)
+        ctx.qk_ln = qk_saved is not None
         return out.view(B, N, D)
 
     @staticmethod
     def backward(ctx, g):
-        xa, cos, sin, qkv, q, k, v, o, lse, qnw, knw, WqkvT, WpT = ctx.saved_tensors
+        xa, cos, sin, qkv, q, k, v, o, lse, qnw, knw, WqkvT, WpT = ctx.saved_tensors[:13]
         B, N, D, H, hd, eps, xdt = ctx.dims
         M = B * N
         dy = ops.cast(g.contiguous().view(M, D), xa.dtype)
         dWp, dbp = ops.gemm_tn(dy, o.view(M, D), with_bias=True)
         do = ops.gemm_nt(dy, WpT)
-        if v is None:
+        dqnb = dknb = None
+        if ctx.qk_ln:
+            dq, dk, dv = ops.attention_bwd(q, k, v, o, do, lse, hd ** -0.5)
+            dqkv, dqn, dqnb, dkn, dknb, dbqkv = _qk_layernorm_bwd(dq, dk, dv, ctx.saved_tensors[13:], qnw, knw, cos, sin, B, N, H, hd, xa.dtype)
+        elif v is None:
             dq, dk, dqkv = ops.attention_bwd_pv(q, k, qkv, o, do, lse, hd ** -0.5)
             dqkv, dqn, dkn, dbqkv = ops.qknorm_rope_bwd(dq, dk, None, qkv, qnw, knw, cos, sin, B, N, H, hd, eps, with_bias=True, dqkv=dqkv)
         else:
@@ -421,7 +474,7 @@ class _AttentionFn(torch.autograd.Function):
         dqkv = dqkv.view(M, 3 * D)
         dWqkv = ops.gemm_tn(dqkv, xa)
         dx = ops.gemm_nt(dqkv, WqkvT).view(B, N, D).to(xdt) if ctx.needs_input_grad[0] else None
-        return dx, None, None, None, None, None, dWqkv, dbqkv, dqn, dkn, dWp, dbp
+        return dx, None, None, None, None, None, dWqkv, dbqkv, dqn, dkn, dqnb, dknb, dWp, dbp
 
 
 class _FinalLayerFn(torch.autograd.Function):
@@ -545,30 +598,33 @@ class Attention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_norm=False, use_rmsnorm=False, **_):
         super().__init__()
         assert dim % num_heads == 0, 'dim should be divisible by num_heads'
-        if qk_norm and not use_rmsnorm:
-            raise NotImplementedError("ldmae_amd Attention: qk_norm with nn.LayerNorm (use_rmsnorm=False) is not accelerated; RMSNorm or no QK-norm")
+
         self.num_heads = num_heads
         self.head_dim = dim // num_heads
         self.scale = self.head_dim ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
-        self.q_norm = RMSNorm(self.head_dim) if qk_norm else nn.Identity()
-        self.k_norm = RMSNorm(self.head_dim) if qk_norm else nn.Identity()
+        norm_layer = RMSNorm if use_rmsnorm else nn.LayerNorm                 # :54-61
+        self.q_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
+        self.k_norm = norm_layer(self.head_dim) if qk_norm else nn.Identity()
         self.proj = nn.Linear(dim, dim)
         self.precision = None
 
     def norm_args(self):
-        """(eps, q_norm weight, k_norm weight); the weights are None with qk_norm=False (q_norm = k_norm = nn.Identity, :60-61)."""
+        """(eps, q_norm weight, k_norm weight, q_norm bias, k_norm bias): weights None with qk_norm=False (q_norm = k_norm = nn.Identity, :60-61);
+        biases only for the nn.LayerNorm form (use_rmsnorm=False)."""
         if isinstance(self.q_norm, RMSNorm):
-            return self.q_norm.eps, self.q_norm.weight, self.k_norm.weight
-        return 1e-6, None, None
+            return self.q_norm.eps, self.q_norm.weight, self.k_norm.weight, None, None
+        if isinstance(self.q_norm, nn.LayerNorm):
+            return self.q_norm.eps, self.q_norm.weight, self.k_norm.weight, self.q_norm.bias, self.k_norm.bias
+        return 1e-6, None, None, None, None
 
     def forward(self, x, rope=None):
         B, N, C = x.shape
         cos, sin = (rope.freqs_cos, rope.freqs_sin) if rope is not None else _identity_rope(N, self.head_dim, x.device)      # :71
         dtype = _act_dtype(self.precision)
         with torch.autocast(device_type="cuda", enabled=False):
-            eps, qnw, knw = self.norm_args()
-            return _AttentionFn.apply(x, cos, sin, self.num_heads, eps, dtype, self.qkv.weight, self.qkv.bias, qnw, knw, self.proj.weight, self.proj.bias)
+            eps, qnw, knw, qnb, knb = self.norm_args()
+            return _AttentionFn.apply(x, cos, sin, self.num_heads, eps, dtype, self.qkv.weight, self.qkv.bias, qnw, knw, qnb, knb, self.proj.weight, self.proj.bias)
 
 
 _IDENTITY_ROPE: dict = {}
@@ -584,21 +640,36 @@ def _identity_rope(N, hd, device):
     return t
 
 
+class Mlp(nn.Module):
+    """timm.models.vision_transformer.Mlp's parameter layout (fc1 / fc2) as the block builds it with use_swiglu=False (:219-224: GELU with the
+    tanh approximation, no dropout); computed inside _DiTBlockFn."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=None, drop=0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = nn.GELU(approximate="tanh")
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+
 class LightningDiTBlock(nn.Module):
-    """:171-250.  Accelerated: RMSNorm + SwiGLU blocks (use_rmsnorm = use_swiglu = True, both shipped YAMLs) with or without QK-norm
-    (configs/imagenet/...yaml:28 true; configs/celeba_hq/...yaml:30 false), with or without the adaLN shift (wo_shift) and RoPE."""
+    """:171-250, every constructor flag.  Tuned for the shipped form (RMSNorm + SwiGLU, both YAMLs), with or without QK-norm (configs/imagenet/
+    ...yaml:28 true; configs/celeba_hq/...yaml:30 false), the adaLN shift (wo_shift) and RoPE.  use_rmsnorm=False (LayerNorm without affine
+    parameters on the same norm kernels; nn.LayerNorm QK-norm composed from the VMAE LayerNorm + rotation kernels) and use_swiglu=False (timm
+    Mlp with tanh-GELU: GEMMs + an elementwise pass) run on kernels too, but no shipped YAML builds them and they are not tuned."""
 
     def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, use_qknorm=False, use_swiglu=False, use_rmsnorm=False,
                  wo_shift=False, **block_kwargs):
         super().__init__()
-        if not (use_swiglu and use_rmsnorm):
-            raise NotImplementedError(
-                "ldmae_amd accelerates the RMSNorm + SwiGLU form of the LightningDiT block (use_swiglu=use_rmsnorm=True, as in both shipped "
-                "configs: reference configs/imagenet|celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml:26-33); LayerNorm / timm Mlp blocks are not built")
-        self.norm1 = RMSNorm(hidden_size)
-        self.norm2 = RMSNorm(hidden_size)
-        self.attn = Attention(hidden_size, num_heads=num_heads, qkv_bias=True, qk_norm=use_qknorm, use_rmsnorm=True)
-        self.mlp = SwiGLUFFN(hidden_size, int(2 / 3 * int(hidden_size * mlp_ratio)))
+        if use_rmsnorm:
+            self.norm1, self.norm2 = RMSNorm(hidden_size), RMSNorm(hidden_size)
+        else:                                                                             # :199-201
+            self.norm1 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+            self.norm2 = nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)
+        self.attn = Attention(hidden_size, num_heads=num_heads, qkv_bias=True, qk_norm=use_qknorm, use_rmsnorm=use_rmsnorm)
+        if use_swiglu:
+            self.mlp = SwiGLUFFN(hidden_size, int(2 / 3 * int(hidden_size * mlp_ratio)))
+        else:                                                                             # :219-224
+            self.mlp = Mlp(in_features=hidden_size, hidden_features=int(hidden_size * mlp_ratio))
         self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, (4 if wo_shift else 6) * hidden_size, bias=True))
         self.wo_shift = wo_shift
         self.precision = None
@@ -607,12 +678,14 @@ class LightningDiTBlock(nn.Module):
         sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
         a, m = self.attn, self.mlp
         cos, sin = (feat_rope.freqs_cos, feat_rope.freqs_sin) if feat_rope is not None else _identity_rope(x.shape[1], a.head_dim, x.device)
-        _, qnw, knw = a.norm_args()
+        _, qnw, knw, qnb, knb = a.norm_args()
+        swiglu = isinstance(m, SwiGLUFFN)
+        l1, l2 = (m.w12, m.w3) if swiglu else (m.fc1, m.fc2)
         return _DiTBlockFn.apply(
             x.float(), sc, cos, sin, a.num_heads, self.norm1.eps, _dtype or _act_dtype(self.precision),
-            _inplace_grad, _chain, _idx, _direct, not torch.is_grad_enabled(), _mod_all,
-            self.norm1.weight, a.qkv.weight, a.qkv.bias, qnw, knw, a.proj.weight, a.proj.bias,
-            self.norm2.weight, m.w12.weight, m.w12.bias, m.w3.weight, m.w3.bias,
+            _inplace_grad, _chain, _idx, _direct, not torch.is_grad_enabled(), _mod_all, swiglu,
+            self.norm1.weight, a.qkv.weight, a.qkv.bias, qnw, knw, qnb, knb, a.proj.weight, a.proj.bias,
+            self.norm2.weight, l1.weight, l1.bias, l2.weight, l2.bias,
             self.adaLN_modulation[1].weight, self.adaLN_modulation[1].bias)
 
 
@@ -621,9 +694,7 @@ class FinalLayer(nn.Module):
 
     def __init__(self, hidden_size, patch_size, out_channels, use_rmsnorm=False):
         super().__init__()
-        if not use_rmsnorm:
-            raise NotImplementedError("ldmae_amd FinalLayer: use_rmsnorm=True only")
-        self.norm_final = RMSNorm(hidden_size)
+        self.norm_final = RMSNorm(hidden_size) if use_rmsnorm else nn.LayerNorm(hidden_size, elementwise_affine=False, eps=1e-6)      # :256-259
         self.linear = nn.Linear(hidden_size, patch_size * patch_size * out_channels, bias=True)
         self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 2 * hidden_size, bias=True))
         self.precision = None

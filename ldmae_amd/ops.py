@@ -321,10 +321,15 @@ def cast_stack(tensors, dtype):
 
 # ----------------------------------------------------------------------------- norms / elementwise
 def rmsnorm_modulate_fwd(x, w, shift, scale, rows_per_batch, out_dtype, eps=1e-6):
+    """modulate(norm(x), shift, scale) (lightningdit.py:26-30,248-249).  w: the RMSNorm weight; w=None: nn.LayerNorm(elementwise_affine=False)
+    -- the blocks built with use_rmsnorm=False (:200-201) -- on the same kernels (the norm of the centred row)."""
     M, D = x.shape
     out = torch.empty(M, D, dtype=out_dtype, device=x.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
     ld = shift.stride(0) if shift is not None else (scale.stride(0) if scale is not None else 0)
+    if w is None:
+        call("ldmae_layernorm_modulate_fwd", dt(out_dtype), ptr(x), ptr(shift), ptr(scale), ld, ptr(out), ptr(rstd), M, D, rows_per_batch, eps, stream())
+        return out, rstd
     call("ldmae_rmsnorm_modulate_fwd", dt(out_dtype), ptr(x), ptr(w), ptr(shift), ptr(scale), ld, ptr(out), ptr(rstd), M, D,
          rows_per_batch, eps, stream())
     return out, rstd
@@ -334,8 +339,13 @@ def rmsnorm_modulate_bwd(dout, x, w, scale, rstd, dx_accum, dshift, dscale, rows
     """dx_accum += dx (in place; accumulate=False: dx_accum = dx, the buffer may be uninitialised); writes dshift/dscale views ([B,D], any
     row stride); returns dw [D]."""
     M, D = x.shape
-    dw = torch.empty(D, dtype=torch.float32, device=x.device)
     ws = workspace(L.load().ldmae_rmsnorm_modulate_bwd_workspace_bytes(M, D, rows_per_batch), x.device)
+    dld = (dshift if dshift is not None else dscale).stride(0) if (dshift is not None or dscale is not None) else 0
+    if w is None:                      # LayerNorm without affine parameters (use_rmsnorm=False): no weight gradient
+        call("ldmae_layernorm_modulate_bwd", dt(dout.dtype), ptr(dout), ptr(x), ptr(scale), scale.stride(0) if scale is not None else 0, ptr(rstd), ptr(dx_accum),
+             1.0 if accumulate else 0.0, ptr(dshift), ptr(dscale), dld, M, D, rows_per_batch, ptr(ws), stream())
+        return None
+    dw = torch.empty(D, dtype=torch.float32, device=x.device)
     call("ldmae_rmsnorm_modulate_bwd", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(scale), scale.stride(0) if scale is not None else 0,
          ptr(rstd), ptr(dx_accum), 1.0 if accumulate else 0.0, ptr(dshift), ptr(dscale), (dshift if dshift is not None else dscale).stride(0) if (dshift is not None or dscale is not None) else 0,
          ptr(dw), 0.0, M, D, rows_per_batch, ptr(ws), stream())
@@ -346,10 +356,16 @@ def rmsnorm_modulate_bwd_gate(dout, x, w, scale, rstd, dx_accum, dshift, dscale,
     """rmsnorm_modulate_bwd followed by gate_bwd(dx_accum, y, gate, dgate, with_bias=True) in one pass over the rows.
     Returns (dw [D], dy [M,D] act dtype, dbias [D])."""
     M, D = x.shape
-    dw = torch.empty(D, dtype=torch.float32, device=x.device)
     dy = torch.empty(M, D, dtype=act_dtype, device=x.device)
     dbias = torch.empty(D, dtype=torch.float32, device=x.device)
     ws = workspace(L.load().ldmae_rmsnorm_modulate_bwd_gate_workspace_bytes(M, D, rows_per_batch), x.device)
+    if w is None:                      # LayerNorm without affine parameters (use_rmsnorm=False)
+        dld = (dshift if dshift is not None else dscale).stride(0) if (dshift is not None or dscale is not None) else 0
+        call("ldmae_layernorm_modulate_bwd_gate", dt(dout.dtype), ptr(dout), ptr(x), ptr(scale), scale.stride(0) if scale is not None else 0, ptr(rstd),
+             ptr(dx_accum), 1.0 if accumulate else 0.0, ptr(dshift), ptr(dscale), dld, ptr(y), ptr(gate), gate.stride(0), ptr(dy), ptr(dgate), dgate.stride(0),
+             ptr(dbias), M, D, rows_per_batch, ptr(ws), stream())
+        return None, dy, dbias
+    dw = torch.empty(D, dtype=torch.float32, device=x.device)
     call("ldmae_rmsnorm_modulate_bwd_gate", dt(dout.dtype), ptr(dout), ptr(x), ptr(w), ptr(scale), scale.stride(0) if scale is not None else 0,
          ptr(rstd), ptr(dx_accum), 1.0 if accumulate else 0.0, ptr(dshift), ptr(dscale), (dshift if dshift is not None else dscale).stride(0) if (dshift is not None or dscale is not None) else 0, ptr(dw), 0.0,
          ptr(y), ptr(gate), gate.stride(0), ptr(dy), ptr(dgate), dgate.stride(0), ptr(dbias), M, D, rows_per_batch, ptr(ws), stream())
@@ -810,4 +826,17 @@ def layernorm_bwd(dout, x, w, mean, rstd, dx_accum, cast=False):
 def gelu_bwd(dout, pre):
     dx = torch.empty_like(pre)
     call("ldmae_gelu_bwd", dt(pre.dtype), ptr(dout), ptr(pre), ptr(dx), pre.numel(), stream())
+    return dx
+
+
+def gelu_tanh_fwd(x):
+    """nn.GELU(approximate="tanh") (the timm Mlp of a use_swiglu=False LightningDiT block, lightningdit.py:208,219-224)."""
+    out = torch.empty_like(x)
+    call("ldmae_gelu_tanh_fwd", dt(x.dtype), ptr(_c(x)), ptr(out), x.numel(), stream())
+    return out
+
+
+def gelu_tanh_bwd(dout, pre):
+    dx = torch.empty_like(pre)
+    call("ldmae_gelu_tanh_bwd", dt(pre.dtype), ptr(_c(dout)), ptr(pre), ptr(dx), pre.numel(), stream())
     return dx

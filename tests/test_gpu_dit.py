@@ -150,13 +150,15 @@ def _flag_cfg(over):
                                     class_dropout_prob=0.5), **over})
 
 
-@pytest.mark.parametrize("tag", ["noqk", "woshift", "norope"])
+@pytest.mark.parametrize("tag", list(DIT_FLAG_VARIANTS))
 def test_block_flag_variants_match_reference_golden(golden, tag):
-    """The block flags the shipped imagenet YAML leaves alone, on the HIP path DIRECTLY against the reference's own train-mode forward, loss
-    and parameter gradients (tests/golden/dit_flags.npz, make_golden.py: gen_dit_flags): 'noqk' = use_qknorm=False + num_classes=1, the
-    reference's CelebA-HQ configuration (configs/celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml:15,30; RoPE without a norm, tracked-maximum
-    softmax, rope-only backward epilogues), 'woshift' (four modulation vectors, :241-244), 'norope' (feat_rope = None, :324-325).  f32: output,
-    loss and every gradient within 1e-4 (gradients also in full against the oracle); bf16 autocast within bf16's margin."""
+    """Every constructor flag of LightningDiTBlock flipped away from the shipped imagenet YAML, on the HIP path DIRECTLY against the reference's
+    own train-mode forward, loss and parameter gradients (tests/golden/dit_flags.npz, make_golden.py: gen_dit_flags): 'noqk' = use_qknorm=False
+    + num_classes=1, the reference's CelebA-HQ configuration (configs/celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml:15,30; RoPE without a norm,
+    tracked-maximum softmax, rope-only backward epilogues), 'woshift' (four modulation vectors, :241-244), 'norope' (feat_rope = None,
+    :324-325), 'ln' (use_rmsnorm=False: LayerNorm without affine parameters + nn.LayerNorm QK-norm, :199-201,54-61), 'mlp' (use_swiglu=False:
+    timm Mlp with tanh-GELU, :219-224), 'plain' (all five at once).  f32: output, loss and every gradient within 1e-4 (gradients also in full
+    against the oracle); bf16 autocast within bf16's margin."""
     g = golden("dit_flags")
     n = list(DIT_FLAG_VARIANTS).index(tag)
     cfg = _flag_cfg(DIT_FLAG_VARIANTS[tag])
@@ -193,12 +195,12 @@ def test_block_flag_variants_match_reference_golden(golden, tag):
         assert float((a @ b) / (a.norm() * b.norm() + 1e-30)) > 0.99, (tag, k)
 
 
-def test_flag_combination_and_unbuilt_flags():
-    """use_qknorm=False + wo_shift + use_rope=False together (no golden: against the oracle, whose every flag is pinned on the reference one
-    at a time), with the backward chain, batched adaLN (bf16) and direct parameter gradients the B/1 train step uses; the two block forms that
-    are not built (LayerNorm, timm Mlp) refuse in the constructor."""
-    from ldmae_amd.models.lightningdit import LightningDiT
-    cfg = _flag_cfg(dict(use_qknorm=False, wo_shift=True, use_rope=False, class_dropout_prob=0.0))
+@pytest.mark.parametrize("over", [dict(use_qknorm=False, wo_shift=True, use_rope=False), dict(use_rmsnorm=False, use_swiglu=False, wo_shift=True),
+                                  dict(use_rmsnorm=False, use_qknorm=False)])
+def test_flag_combinations_vs_oracle(over):
+    """Flag combinations without a golden of their own (against the oracle, whose every flag is pinned on the reference), at batch 8: the
+    backward chain and -- in bf16 -- batched adaLN, as the B/1 train step runs them."""
+    cfg = _flag_cfg(dict(class_dropout_prob=0.0, **over))
     sd = det_weights(odit.param_shapes(cfg), 77)
     sd.update(odit.fixed_tables(cfg))
     B = 8
@@ -213,9 +215,6 @@ def test_flag_combination_and_unbuilt_flags():
         assert rel_err(out.detach().cpu(), oout.detach()) < otol, prec
         worst = max(rel_err(p.grad.cpu(), osd[k].grad) for k, p in m.named_parameters() if p.grad is not None)
         assert worst < gtol, (prec, worst)
-    for kw in (dict(use_rmsnorm=False, use_swiglu=True), dict(use_rmsnorm=True, use_swiglu=False)):
-        with pytest.raises(NotImplementedError):
-            LightningDiT(input_size=8, patch_size=1, in_channels=16, hidden_size=192, depth=1, num_heads=3, use_qknorm=True, use_rope=True, **kw)
 
 
 def test_celeba_config_real_width_vs_reference_golden(golden):

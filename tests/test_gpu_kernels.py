@@ -965,3 +965,58 @@ def test_f16_layernorm_cast_colsum(ops):
     assert torch.equal(wt, dev(rnd(192, 576, seed=4)).half()) and torch.equal(wtt, wt.t().contiguous())
     assert torch.isinf(ops.cast(x * 1e6, F16)).any()                          # plain casts overflow to infinity (gradients under a loss scaler)
     assert rel_err(ops.colsum(y).cpu(), y.double().cpu().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,D,rpb,shift", [(128, 768, 64, True), (96, 192, 32, True), (64, 1152, 16, False)])
+def test_layernorm_modulate_without_affine(ops, dtype, M, D, rpb, shift):
+    """ldmae_layernorm_modulate_fwd / _bwd / _bwd_gate (rmsnorm_modulate_* with w=None): nn.LayerNorm(D, elementwise_affine=False, eps=1e-6)
+    + modulate, the norm of a block built with use_rmsnorm=False (lightningdit.py:200-201,26-30), against torch autograd; the gate-fused form
+    against the unfused pair bit for bit."""
+    B = M // rpb
+    x = rnd(M, D, seed=1).add(0.3).requires_grad_(True)                 # a non-zero row mean: the centring matters
+    mod = (0.2 * rnd(B, 3 * D, seed=2)).requires_grad_(True)
+    sh, sc = (mod[:, :D] if shift else None), mod[:, D:2 * D]
+    xn = torch.nn.functional.layer_norm(x, (D,), None, None, 1e-6).view(B, rpb, D)
+    ref = (xn * (1 + sc.unsqueeze(1)) + (sh.unsqueeze(1) if shift else 0)).view(M, D)
+    g = q(rnd(M, D, seed=3), dtype)
+    ref.backward(g)
+    modd = dev(mod.detach())
+    shd, scd = (modd[:, :D] if shift else None), modd[:, D:2 * D]
+    out, rstd = ops.rmsnorm_modulate_fwd(dev(x.detach()), None, shd, scd, rpb, dtype, 1e-6)
+    assert rel_err(out.float().cpu(), ref.detach()) < (1e-5 if dtype == F32 else 1e-2)
+    dmod = torch.zeros(B, 3 * D, device="cuda")
+    dx = dev(rnd(M, D, seed=4))
+    dx0 = dx.clone()
+    dw = ops.rmsnorm_modulate_bwd(dev(g, dtype), dev(x.detach()), None, scd, rstd, dx, dmod[:, :D] if shift else None, dmod[:, D:2 * D], rpb)
+    assert dw is None
+    assert rel_err((dx - dx0).cpu(), x.grad) < 1e-4
+    assert rel_err(dmod[:, D:2 * D].cpu(), mod.grad[:, D:2 * D]) < 1e-4
+    if shift:
+        assert rel_err(dmod[:, :D].cpu(), mod.grad[:, :D]) < 1e-4
+    # the gate-fused form == the unfused pair (rmsnorm_modulate_bwd, then gate_bwd of the updated dx)
+    y, gate = dev(q(rnd(M, D, seed=5), dtype), dtype), modd[:, 2 * D:]
+    dxa, dxb = dx0.clone(), dx0.clone()
+    dma, dmb = torch.zeros_like(dmod), torch.zeros_like(dmod)
+    ops.rmsnorm_modulate_bwd(dev(g, dtype), dev(x.detach()), None, scd, rstd, dxa, dma[:, :D] if shift else None, dma[:, D:2 * D], rpb)
+    dya, dba = ops.gate_bwd(dxa, y, gate, dma[:, 2 * D:], rpb, dtype, with_bias=True)
+    _, dyb, dbb = ops.rmsnorm_modulate_bwd_gate(dev(g, dtype), dev(x.detach()), None, scd, rstd, dxb, dmb[:, :D] if shift else None, dmb[:, D:2 * D],
+                                                y, gate, dmb[:, 2 * D:], rpb, dtype)
+    assert torch.equal(dxa, dxb) and torch.equal(dya, dyb) and torch.equal(dma, dmb) and torch.equal(dba, dbb)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gelu_tanh(ops, dtype):
+    """nn.GELU(approximate="tanh") and its backward (the timm Mlp of a use_swiglu=False block, lightningdit.py:208,219-224)."""
+    x = (3 * rnd(300, 512, seed=1)).requires_grad_(True)
+    xq = q(x.detach(), dtype).requires_grad_(True)
+    ref = torch.nn.functional.gelu(xq, approximate="tanh")
+    g = q(rnd(300, 512, seed=2), dtype)
+    ref.backward(g)
+    out = ops.gelu_tanh_fwd(dev(xq.detach(), dtype))
+    dx = ops.gelu_tanh_bwd(dev(g, dtype), dev(xq.detach(), dtype))
+    tol = 1e-6 if dtype == F32 else 1e-2
+    assert rel_err(out.float().cpu(), ref.detach()) < tol and rel_err(dx.float().cpu(), xq.grad) < tol
+    big = torch.tensor([-40.0, -12.0, 12.0, 40.0, 0.0])
+    ob = ops.gelu_tanh_fwd(dev(big))
+    assert torch.isfinite(ob).all() and rel_err(ob.cpu(), torch.nn.functional.gelu(big, approximate="tanh")) < 1e-6

@@ -41,21 +41,24 @@ def test_module_api_and_state_dict_keys(golden):
     assert hasattr(m, "forward_with_cfg")
 
 
-def test_unbuilt_block_forms_raise_and_celeba_kwargs_construct(golden):
-    """LayerNorm / timm-Mlp blocks (no shipped YAML) refuse in the constructor; the reference's CelebA-HQ kwargs (use_qknorm=False, num_classes=1,
-    class_dropout_prob=0: train_accum.py:79-90 on configs/celeba_hq/...yaml) build a model whose state dict has the reference's keys -- no
-    q_norm / k_norm entries (nn.Identity, lightningdit.py:60-61), a one-row label table."""
+def test_every_block_flag_constructs_with_the_references_keys(golden):
+    """Every LightningDiTBlock flag combination the reference's constructor takes builds a model whose state dict has the reference's keys
+    (tests/golden/dit_flags.npz: key sets of the reference's own modules) -- LayerNorm blocks have no norm parameters, nn.LayerNorm QK-norm has
+    biases, the timm Mlp has fc1 / fc2, no QK-norm has no q_norm / k_norm entries (nn.Identity, lightningdit.py:60-61), wo_shift a 4x adaLN.
+    The reference's CelebA-HQ kwargs (train_accum.py:79-90 on configs/celeba_hq/...yaml) at B/1: a one-row label table, 12 x 2 x 64 fewer weights."""
     from ldmae_amd.models.lightningdit import LightningDiT, LightningDiT_models
-    with pytest.raises(NotImplementedError, match="RMSNorm"):
-        LightningDiT(input_size=8, patch_size=1, in_channels=4, hidden_size=64, depth=1, num_heads=1, use_rope=True, use_rmsnorm=True)
+    from weights import DIT_FLAG_VARIANTS
+    g = golden("dit_flags")
+    base = dict(use_qknorm=True, use_swiglu=True, use_rope=True, use_rmsnorm=True, wo_shift=False, num_classes=10)
+    for tag, over in DIT_FLAG_VARIANTS.items():
+        t = LightningDiT(input_size=8, patch_size=1, in_channels=16, hidden_size=192, depth=2, num_heads=3, class_dropout_prob=0.5, **{**base, **over})
+        assert sorted(t.state_dict().keys()) == [str(k) for k in g[f"df_{tag}_keys"]], tag
     m = LightningDiT_models['LightningDiT-B/1'](input_size=32, num_classes=1, use_qknorm=False, use_swiglu=True, use_rope=True,
                                                  use_rmsnorm=True, wo_shift=False, in_channels=16, use_checkpoint=False, class_dropout_prob=0)
     keys = set(m.state_dict().keys())
     assert not any("q_norm" in k or "k_norm" in k for k in keys) and m.y_embedder.embedding_table.weight.shape == (1, 768)
     assert keys == {str(k) for k in golden("kernels")["b1_keys"] if "q_norm" not in str(k) and "k_norm" not in str(k)}
-    t = LightningDiT(input_size=8, patch_size=1, in_channels=16, hidden_size=192, depth=2, num_heads=3, num_classes=1, class_dropout_prob=0.5,
-                     use_qknorm=False, use_swiglu=True, use_rope=True, use_rmsnorm=True)
-    assert sorted(t.state_dict().keys()) == [str(k) for k in golden("dit_flags")["df_noqk_keys"]]
+    assert sum(p.numel() for p in m.parameters()) == 131122960 - 12 * 2 * 64 - 1000 * 768
 
 
 def test_no_cpu_fallback():
