@@ -212,6 +212,10 @@ template <int PPW, int STAGES> __device__ __forceinline__ void ring_wait(int ahe
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
 constexpr int ATT_STAGES = 3;
 template <int I> struct IC { static constexpr int value = I; };
+// f(IC<0>{}), f(IC<1>{}), ... f(IC<N-1>{}): a loop whose index is a compile-time constant in the body
+template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(IC<I>{}); static_for<N, I + 1>(f); }
+}
 // running-max update threshold (log2 units): the O / l rescale is skipped while no query of the wave saw its
 // maximum grow by more than this (P then stays <= 2^RESCALE_THR; exact softmax either way after the final 1/l)
 constexpr float RESCALE_THR = 6.0f;
@@ -637,7 +641,9 @@ __global__ void attn_delta_kernel(const T* __restrict__ O, const T* __restrict__
 // ROWC = [2][B*H*N] f32 written by the dQ kernel (which runs first): slot 0 = -delta, slot 1 = -lse * log2(e).  They are the INITIAL
 // ACCUMULATORS of the dP and S chains (a query row = an accumulator element here, so they come from the LDS copy of the tile's 64 values
 // by ds_read_b128), k carries scale*log2(e): p = exp2(S) and dS = p * dP are one instruction per element each.
-template <int HD, bool QKN = false, bool RAGGED = false, bool F16 = false>      // F16: fp16 operands / outputs (VMAE pre-training under fp16 autocast), QKN = false only
+// PF (round 6): LDS operand fragments are requested PF MFMAs ahead of the one that consumes them (a ring of PF + 1 fragments in registers, the
+// reads pinned in place against the scheduler), instead of right in front of it behind an `s_waitcnt lgkmcnt(0)` each
+template <int HD, bool QKN = false, bool RAGGED = false, bool F16 = false, int PF = 0>      // F16: fp16 operands / outputs (VMAE pre-training under fp16 autocast), QKN = false only
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                  const bf16* __restrict__ dO, const float* __restrict__ ROWC, long rc_stride,
                                                                  bf16* __restrict__ dK, bf16* __restrict__ dV,
@@ -707,7 +713,49 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
     const char* dOt = Qt + TB;
     const float* nl = (const float*)(Qt + 2 * TB);
     const float* nd = nl + 64;
-    // (fragments are read where they are used: batching them ahead, as the forward kernel does, costs this kernel its third wave per SIMD
+    if constexpr (PF > 0) {
+      // the 2 x (2 KS + 4 DB) MFMAs of the tile in their order, each with ONE operand fragment from LDS: fragment i + PF is requested before MFMA i
+      constexpr int N1 = 2 * KS, N2 = 4 * DB, NQ = N1 + N2, NF = 2 * NQ;
+      auto frag = [&](auto I) -> bf16x8 {
+        constexpr int i = decltype(I)::value, qb = i / NQ, j = i % NQ;
+        if constexpr (j < N1) {
+          if constexpr ((j & 1) != 0) return frag_row<HDP>(dOt, qb * 32, j / 2, lane); else return frag_row<HDP>(Qt, qb * 32, j / 2, lane);
+        } else {
+          constexpr int t = j - N1, s2 = t / (2 * DB), d = (t % (2 * DB)) / 2;
+          if constexpr ((t & 1) != 0) return frag_tr<HDP>(Qt, qb * 32 + 16 * s2, d * 32, lane); else return frag_tr<HDP>(dOt, qb * 32 + 16 * s2, d * 32, lane);
+        }
+      };
+      bf16x8 win[PF + 1];
+      static_for<PF>([&](auto I) { win[decltype(I)::value] = frag(I); });
+      f32x16 s, dp;
+      bf16x8 pf, dsf;
+      static_for<NF>([&](auto I) {
+        constexpr int i = decltype(I)::value, qb = i / NQ, j = i % NQ;
+        if constexpr (i + PF < NF) win[(i + PF) % (PF + 1)] = frag(IC<i + PF>{});
+        if constexpr (j == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 a = *(const f32x4*)(nl + qb * 32 + 8 * g + 4 * h), e = *(const f32x4*)(nd + qb * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { s[4 * g + jj] = a[jj]; dp[4 * g + jj] = e[jj]; }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0x6);          // vector / scalar ALU may move across; LDS reads and MFMAs keep this order
+        if constexpr (j == N1) {
+#pragma unroll
+          for (int t = 0; t < 16; ++t) { const float p = EXP2(s[t]); s[t] = p; dp[t] *= p; }
+        }
+        if constexpr (j >= N1 && (j - N1) % (2 * DB) == 0) { pf = acc_frag_t<F16>(s, (j - N1) / (2 * DB)); dsf = acc_frag_t<F16>(dp, (j - N1) / (2 * DB)); }
+        const bf16x8 a = win[i % (PF + 1)];
+        if constexpr (j < N1) {
+          if constexpr ((j & 1) != 0) dp = mfma_att<F16>(a, vf[j / 2], dp); else s = mfma_att<F16>(a, kf[j / 2], s);
+        } else {
+          constexpr int d = ((j - N1) % (2 * DB)) / 2;
+          if constexpr (((j - N1) & 1) != 0) dkacc[d] = mfma_att<F16>(a, dsf, dkacc[d]); else dvacc[d] = mfma_att<F16>(a, pf, dvacc[d]);
+        }
+      });
+    } else
+    // (fragments are read where they are used: batching them ALL ahead, as the forward kernel does, costs this kernel its third wave per SIMD
     // and measured slower: 1.64 vs 1.56 ms)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -771,7 +819,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
 }
 
 // ================================================================================================ backward dQ, bf16
-template <int HD, bool QKN = false, bool RAGGED = false, bool F16 = false>      // F16: fp16 operands / outputs (VMAE pre-training under fp16 autocast), QKN = false only
+template <int HD, bool QKN = false, bool RAGGED = false, bool F16 = false, int PF = 0>      // F16: fp16 operands / outputs (VMAE pre-training under fp16 autocast), QKN = false only; PF: see the dK/dV kernel
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                const bf16* __restrict__ O, const bf16* __restrict__ dO,
                                                                const float* __restrict__ LSE, float* __restrict__ ROWC, long rc_stride,
@@ -853,6 +901,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16* __res
     if (kt + ATT_STAGES - 1 < nt) stage(kt + ATT_STAGES - 1);
     const char* Kt = smem + st * 2 * TB;
     const char* Vt = Kt + TB;
+    if constexpr (PF > 0) {
+      // the 2 x (2 KS + 2 DB) MFMAs of the tile in their order, each with ONE operand fragment from LDS (K / V rows for the score chains, transposed
+      // K for dQ): fragment i + PF is requested before MFMA i; replaces the batch of transposed reads (BTR) of the PF = 0 form
+      constexpr int N1 = 2 * KS, N2 = 2 * DB, NQ = N1 + N2, NF = 2 * NQ;
+      auto frag = [&](auto I) -> bf16x8 {
+        constexpr int i = decltype(I)::value, kb = i / NQ, j = i % NQ;
+        if constexpr (j < N1) {
+          if constexpr ((j & 1) != 0) return frag_row<HDP>(Vt, kb * 32, j / 2, lane); else return frag_row<HDP>(Kt, kb * 32, j / 2, lane);
+        } else return frag_tr<HDP>(Kt, kb * 32 + 16 * ((j - N1) / DB), ((j - N1) % DB) * 32, lane);
+      };
+      bf16x8 win[PF + 1];
+      static_for<PF>([&](auto I) { win[decltype(I)::value] = frag(I); });
+      f32x16 s, dp;
+      bf16x8 dsf;
+      static_for<NF>([&](auto I) {
+        constexpr int i = decltype(I)::value, kb = i / NQ, j = i % NQ;
+        if constexpr (i + PF < NF) win[(i + PF) % (PF + 1)] = frag(IC<i + PF>{});
+        __builtin_amdgcn_sched_barrier(0x6);          // vector / scalar ALU may move across; LDS reads and MFMAs keep this order
+        if constexpr (j == N1) {
+          if (ragged && kt == nt - 1) mask_rows_past(s, kt * 64 + kb * 32, h, N);
+#pragma unroll
+          for (int t = 0; t < 16; ++t) dp[t] *= EXP2(s[t]);
+        }
+        if constexpr (j >= N1 && (j - N1) % DB == 0) dsf = acc_frag_t<F16>(dp, (j - N1) / DB);
+        const bf16x8 a = win[i % (PF + 1)];
+        if constexpr (j < N1) {
+          if constexpr ((j & 1) != 0) dp = mfma_att<F16>(a, dof[j / 2], j == 1 ? nd : dp); else s = mfma_att<F16>(a, qf[j / 2], j == 0 ? nl : s);
+        } else dqacc[(j - N1) % DB] = mfma_att<F16>(a, dsf, dqacc[(j - N1) % DB]);
+      });
+    } else
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s, dp;
@@ -1790,6 +1868,11 @@ extern "C" int ldmae_attention_fwd_qkv_bounded(int dtype, const void* qkv, void*
   return attention_fwd_core(dtype, p, p + hw, p + 2 * hw, o, lse, B, H, N, hd, scale, pk, pk, as_stream(stream), qk_max2, 1);
 }
 
+// operand-fragment prefetch depth (template parameter PF of the backward kernels) of the plain (no QK-norm epilogue) pair per head dim, whole tiles
+// only: 1 at head_dim 64 (-2.4 % as in the fused pair); head_dim 16 (the VMAE blocks' backward, bound by vector issue) measured NEUTRAL with it
+// (1.225 vs 1.221 ms at 256 x 12 x 1024^2, profiles/r06_attn_prefetch_ab.txt) and keeps PF 0, like the head dims that were not measured.
+// Diagnostic build: tune key 25 = 1 forces PF 1, 3 forces PF 0 (tools/bench_attn16.py --prefetch).
+#define ATTN_PF_PLAIN(HD) ((HD) == 64 ? 1 : 0)
 static int attention_bwd_core(int dtype, const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
                               void* dq, void* dk, void* dv, float* delta, int B, int H, int N, int hd, float scale, QkvLayout Lq, QkvLayout Lv, hipStream_t st) {
   const unsigned grid = (unsigned)B * H * ((N + 127) / 128);
@@ -1814,24 +1897,36 @@ static int attention_bwd_core(int dtype, const void* q, const void* k, const voi
   if (dtype == LDMAE_F16) {
     // fp16 operands / gradients (VMAE pre-training under fp16 autocast; head_dim 16): the bf16 kernels with the f16 MFMAs and conversions
     LDMAE_REQUIRE(hd == 16, "attention_bwd(fp16): head_dim 16 only (the VMAE heads)");
-#define LRH(R) { \
-    hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<16, false, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(16, 0)); \
-    hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<16, false, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(16, 1024)); \
-    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<16, false, R, true>), dim3(grid), dim3(256), attn_lds(16, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, rcs, (bf16*)dq, H, N, scale, Lq, Lv, QkNormBwd{}); \
-    hipLaunchKernelGGL((attn_bwd_dkdv_bf16_kernel<16, false, R, true>), dim3(grid), dim3(256), attn_lds(16, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, delta, rcs, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv, QkNormBwd{}); }
-    if (N % 64 == 0) LRH(false) else LRH(true)
+#define LRHP(R, P) { \
+    hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<16, false, R, true, P>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(16, 0)); \
+    hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<16, false, R, true, P>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(16, 1024)); \
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<16, false, R, true, P>), dim3(grid), dim3(256), attn_lds(16, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, rcs, (bf16*)dq, H, N, scale, Lq, Lv, QkNormBwd{}); \
+    hipLaunchKernelGGL((attn_bwd_dkdv_bf16_kernel<16, false, R, true, P>), dim3(grid), dim3(256), attn_lds(16, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, delta, rcs, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv, QkNormBwd{}); }
+#ifdef LDMAE_DIAG
+#define LRH(R) { const int k25 = ldmae_tune_get(25); if (k25 == 3) LRHP(R, 0) else if (k25 == 1) LRHP(R, 1) else LRHP(R, ATTN_PF_PLAIN(16)) }
+#else
+#define LRH(R) LRHP(R, ATTN_PF_PLAIN(16))
+#endif
+    if (N % 64 == 0) LRH(false) else LRHP(true, 0)
 #undef LRH
+#undef LRHP
   } else if (dtype == LDMAE_BF16) {
     // dQ first: it forms delta = rowsum(dO * O) from its own fragments and publishes it for the dK/dV kernel
-#define LR(HD, R) { \
-    hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD, false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
-    hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD, false, R>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
-    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<HD, false, R>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, rcs, (bf16*)dq, H, N, scale, Lq, Lv, QkNormBwd{}); \
-    hipLaunchKernelGGL((attn_bwd_dkdv_bf16_kernel<HD, false, R>), dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, delta, rcs, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv, QkNormBwd{}); }
-#define L(HD) if (N % 64 == 0) LR(HD, false) else LR(HD, true)
+#define LRP(HD, R, P) { \
+    hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD, false, R, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
+    hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD, false, R, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<HD, false, R, false, P>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)o, (const bf16*)do_, lse, delta, rcs, (bf16*)dq, H, N, scale, Lq, Lv, QkNormBwd{}); \
+    hipLaunchKernelGGL((attn_bwd_dkdv_bf16_kernel<HD, false, R, false, P>), dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, (const bf16*)v, (const bf16*)do_, delta, rcs, (bf16*)dk, (bf16*)dv, H, N, scale, Lq, Lv, QkNormBwd{}); }
+#ifdef LDMAE_DIAG
+#define LR(HD, R) { const int k25 = ldmae_tune_get(25); if (k25 == 3) LRP(HD, R, 0) else if (k25 == 1) LRP(HD, R, 1) else LRP(HD, R, ATTN_PF_PLAIN(HD)) }
+#else
+#define LR(HD, R) LRP(HD, R, ATTN_PF_PLAIN(HD))
+#endif
+#define L(HD) if (N % 64 == 0) LR(HD, false) else LRP(HD, true, 0)
     ATTN_HD_DISPATCH(hd, L);
 #undef L
 #undef LR
+#undef LRP
   } else {
     LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd && Lv.ld == hd && Lv.sh == (long)N * hd, "attention_bwd(f32): head-major q/k/v only");
     LDMAE_REQUIRE((size_t)(128 + 128 + 64 + 64) * (hd + 1) * 4 + 512 <= 160 * 1024,
@@ -1976,11 +2071,24 @@ extern "C" int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const voi
     hipLaunchKernelGGL(attn_dq_finish_kernel<64>, dim3(grid), dim3(256), 0, st, (const float*)dqs, H, N, qn);
   } else
 #endif
+  // Operand-fragment prefetch depth of the fused backward pair (template parameter PF).  Shipped: 1 at head_dim 64 (the B/1 step; bitwise equal to
+  // PF = 0 and 2-3 % faster: profiles/r06_attn_prefetch_ab.txt), 0 at head_dim 128 (one wave per SIMD either way, not measured).  Diagnostic build:
+  // tune keys 23 (dK/dV) / 24 (dQ): 0 = the shipped depth, 1 / 2 = that depth, 3 = no prefetch (tools/bench_attn.py --prefetch).
+#define ATTN_PF_DEFAULT(HD) ((HD) == 64 ? 1 : 0)
+#define ATTN_DKDV_GO(HD, P) { hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD, true, false, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
+    hipLaunchKernelGGL((attn_bwd_dkdv_bf16_kernel<HD, true, false, false, P>), dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, v, (const bf16*)do_, rowc, items, (bf16*)nullptr, dv, H, N, scale, hm, pk, qn); }
+#define ATTN_DQ_GO(HD, P) { hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD, true, false, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<HD, true, false, false, P>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, v, (const bf16*)o, (const bf16*)do_, lse, rowc, items, (bf16*)nullptr, H, N, scale, hm, pk, qn); }
+#ifdef LDMAE_DIAG
+#define ATTN_DKDV_QKN(HD) { switch (ldmae_tune_get(23)) { case 1: ATTN_DKDV_GO(HD, 1) break; case 2: ATTN_DKDV_GO(HD, 2) break; case 3: ATTN_DKDV_GO(HD, 0) break; default: ATTN_DKDV_GO(HD, ATTN_PF_DEFAULT(HD)) } }
+#define ATTN_DQ_QKN(HD) { switch (ldmae_tune_get(24)) { case 1: ATTN_DQ_GO(HD, 1) break; case 2: ATTN_DQ_GO(HD, 2) break; case 3: ATTN_DQ_GO(HD, 0) break; default: ATTN_DQ_GO(HD, ATTN_PF_DEFAULT(HD)) } }
+#else
+#define ATTN_DKDV_QKN(HD) ATTN_DKDV_GO(HD, ATTN_PF_DEFAULT(HD))
+#define ATTN_DQ_QKN(HD) ATTN_DQ_GO(HD, ATTN_PF_DEFAULT(HD))
+#endif
 #define L(HD) { \
-    hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
-    hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
-    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<HD, true>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, v, (const bf16*)o, (const bf16*)do_, lse, rowc, items, (bf16*)nullptr, H, N, scale, hm, pk, qn); \
-    hipLaunchKernelGGL((attn_bwd_dkdv_bf16_kernel<HD, true>), dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, v, (const bf16*)do_, rowc, items, (bf16*)nullptr, dv, H, N, scale, hm, pk, qn); }
+    ATTN_DQ_QKN(HD) \
+    ATTN_DKDV_QKN(HD) }
   if (hd == 64) L(64) else L(128)
 #undef L
   LDMAE_CHECK_LAUNCH("attention_bwd_pv_qknorm");

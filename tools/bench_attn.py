@@ -23,12 +23,50 @@ def timed(fn, iters=5):
     return a.elapsed_time(b) / iters
 
 
+def prefetch_ab(B):
+    """Round 6: each MFMA of the backward kernels took its LDS operand fragment right in front of it behind `s_waitcnt lgkmcnt(0)`; PF = n requests it n
+    MFMAs ahead (csrc/attention.hip, template parameter PF).  Same arithmetic in the same order: outputs must be bitwise equal."""
+    from ldmae_amd import _lib
+    lib = _lib.load()
+    if not hasattr(lib, "ldmae_tune"):
+        sys.exit("needs the diagnostic build: LDMAE_HIP_LIB=ldmae_amd/libldmae_hip_diag.so")
+    H, N, hd = 12, 1024, 64
+    g = torch.Generator(device="cuda").manual_seed(0)
+    scale = hd ** -0.5
+    qkv = torch.randn(B, N, 3, H, hd, device="cuda", generator=g).to(torch.bfloat16)
+    do = torch.randn(B, N, H * hd, device="cuda", generator=g).to(torch.bfloat16)
+    wq, wk = 1 + 0.1 * torch.randn(hd, device="cuda", generator=g), 1 + 0.1 * torch.randn(hd, device="cuda", generator=g)
+    cos, sin = torch.rand(N, hd, device="cuda", generator=g), torch.rand(N, hd, device="cuda", generator=g)
+    q2, k2, _ = ops.qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, copy_v=False)
+    o2, lse2 = ops.attention_fwd_pv(q2, k2, qkv, scale)
+    run = lambda: ops.attention_bwd_pv_qknorm(q2, k2, qkv, o2, do, lse2, scale, wq, wk, cos, sin)      # noqa: E731
+    combos = [(3, 3), (1, 3), (3, 1), (1, 1), (2, 3), (3, 2), (2, 2), (0, 0)]       # tune values: 3 = no prefetch, 1 / 2 = that depth, 0 = the shipped default
+    base = None
+    for kv, kq in combos:
+        lib.ldmae_tune(23, kv); lib.ldmae_tune(24, kq)
+        out = run()
+        if base is None:
+            base = out
+        print(f"dK/dV key {kv}, dQ key {kq}: bitwise equal to the form without prefetch:", all(torch.equal(x, y) for x, y in zip(out, base)))
+    for r in range(3):
+        line = []
+        for kv, kq in combos:
+            lib.ldmae_tune(23, kv); lib.ldmae_tune(24, kq)
+            line.append(f"({kv},{kq}) {timed(run, 8):.3f}")
+        print(f"round {r} [ms, (dK/dV key, dQ key); 3 = no prefetch, 0 = shipped]: " + " | ".join(line))
+    lib.ldmae_tune(23, 0); lib.ldmae_tune(24, 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=256)
     ap.add_argument("--ref", action="store_true")
     ap.add_argument("--fused", action="store_true")
+    ap.add_argument("--prefetch", action="store_true", help="diagnostic build: operand-fragment prefetch depth of the fused dK/dV (tune key 23) and dQ (24) kernels, "
+                                                            "every combination against the shipped form: timing (interleaved rounds) and bitwise equality")
     args = ap.parse_args()
+    if args.prefetch:
+        return prefetch_ab(args.b)
     B, H, N, hd = args.b, 12, 1024, 64
     g = torch.Generator(device="cuda").manual_seed(0)
     q, k, v = (torch.randn(B, H, N, hd, device="cuda", generator=g).to(torch.bfloat16) for _ in range(3))

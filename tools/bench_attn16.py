@@ -35,6 +35,25 @@ def main():
         sys.exit("needs the diagnostic build: LDMAE_HIP_LIB=ldmae_amd/libldmae_hip_diag.so")
     dtype = torch.float16 if "--f16" in sys.argv else torch.bfloat16
     B, H, hd = 256, 12, 16
+    if "--prefetch" in sys.argv:
+        # round 6: operand-fragment prefetch (template parameter PF of the backward pair; tune key 25: 1 = PF 1, 3 = none; shipped at head_dim 16: none) -- timing and bitwise equality
+        for N in (1024, 256):
+            g = torch.Generator().manual_seed(0)
+            qkv = torch.randn(B * N, 3 * H * hd, generator=g).to(dtype).cuda()
+            do = torch.randn(B, N, H * hd, generator=g).to(dtype).cuda()
+            o, lse = ops.attention_fwd_qkv(qkv, B, N, H, hd, hd ** -0.5)
+            bwd = lambda: ops.attention_bwd_qkv(qkv, o, do, lse, B, N, H, hd, hd ** -0.5)      # noqa: E731
+            res = {1: [], 3: []}
+            for mode in (3, 1, 3, 1, 3, 1):
+                lib.ldmae_tune(25, mode)
+                res[mode].append(ms(bwd))
+            lib.ldmae_tune(25, 3)
+            a_ = bwd()
+            lib.ldmae_tune(25, 1)
+            b_ = bwd()
+            lib.ldmae_tune(25, 0)
+            print(f"N {N:5d} {str(dtype)[6:]}: backward pair without prefetch {min(res[3]):.3f} ms ({res[3]}) | PF 1 {min(res[1]):.3f} ms ({res[1]}) | bitwise equal {torch.equal(a_, b_)}", flush=True)
+        return
     for N in (1024, 256, 512, 768):
         g = torch.Generator().manual_seed(0)
         qkv = torch.randn(B * N, 3 * H * hd, generator=g).to(dtype).cuda()
