@@ -21,6 +21,9 @@ def key(name):
     if "gemm_nt_lines" in name or "gemm_nt_persist" in name: return "gemm_nt"
     if "gemm_tn_ring" in name: return "gemm_tn"
     if "rmsnorm_mod_bwd" in name: return "rmsnorm_mod_bwd"
+    if "attn_bwd_dkdv" in name: return "attn_bwd_dkdv"
+    if "attn_bwd_dq" in name: return "attn_bwd_dq"
+    if "attn_fwd" in name: return "attn_fwd"
     return None
 out = collections.defaultdict(dict)
 for tag in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
