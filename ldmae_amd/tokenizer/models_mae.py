@@ -417,8 +417,13 @@ class MaskedAutoencoderViT(nn.Module):
     def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16, decoder_embed_dim=512,
                  decoder_depth=8, decoder_num_heads=16, mlp_ratio=4., norm_layer=nn.LayerNorm, norm_pix_loss=False, latent_dim=32,
                  ldmae_mode=False, scaling_factor=0.9654248952865601, no_cls=True, gradual_resol=False, finetune_downsample_layer=None,
-                 down_nonlinear=False, kl_loss_weight=None, smooth_output=False, pred_with_conv=False, perceptual_loss=None):
+                 down_nonlinear=False, kl_loss_weight=None, smooth_output=False, pred_with_conv=False, perceptual_loss=None,
+                 perceptual_loss_ratio=1.0, fixed_std=None):
+        """The constructor of BOTH reference trees: LDMAE/tokenizer/models_mae.py:287-292 and the pre-training tree's VMAE/models_mae.py:288-293, which
+        adds `perceptual_loss_ratio` and `fixed_std`.  `kl_form` (attribute; "tokenizer" | "vmae"): which tree's posterior KL the training forward
+        uses -- they differ (tokenizer/util/misc.DiagonalGaussianDistribution); passing `fixed_std` selects "vmae", ldmae_amd/vmae_pretrain.py sets it."""
         super().__init__()
+        self.fixed_std, self.kl_form = fixed_std, ("vmae" if fixed_std is not None else "tokenizer")
         if gradual_resol or not no_cls or perceptual_loss is not None:
             raise NotImplementedError("ldmae_amd MaskedAutoencoderViT: gradual_resol / cls token / perceptual loss are "
                                       "not used by the shipped tokenizer (mae_for_ldmae_f8d16_prev, inference.py:133-137)")
@@ -619,7 +624,7 @@ class MaskedAutoencoderViT(nn.Module):
             kl_loss = None
             if self.kl_loss_weight is not None:
                 B, N, D = latent.shape
-                posterior = DiagonalGaussianDistribution(latent.permute(0, 2, 1))
+                posterior = DiagonalGaussianDistribution(latent.permute(0, 2, 1), fixed_std=self.fixed_std, pretrain_tree=self.kl_form == "vmae")
                 kl = posterior.kl()
                 kl_loss = torch.sum(kl) / kl.shape[0] / N
                 latent = (posterior.sample() if _eps is None else posterior.mean + posterior.std * _eps).permute(0, 2, 1)

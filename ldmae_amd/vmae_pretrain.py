@@ -8,6 +8,12 @@ checkpoint save / resume with the position-embedding resize (VMAE/util/misc.py:4
     python -m torch.distributed.run --nproc-per-node 8 ldmae_amd/vmae_pretrain.py --data_path ...          # one rank per GPU over RCCL
     python ldmae_amd/vmae_pretrain.py --synthetic --epochs 1 --steps-per-epoch 10 --batch_size 64
 
+The command line takes main_pretrain.py:37-91's flag set (VMAE/train_ae.sh:26-46 parses; `--perceptual_loss_ratio`, `--tune_decoder`, `--pred_with_conv`,
+`--gradual_resol` are refused by name).  The posterior KL is the PRE-TRAINING tree's (round 6): VMAE/util/misc.py:103-125 differs from the tokenizer copy the
+LDMAE drivers import -- no mean^2 term, and `--fixed_std s` (train_ae.sh:33 passes 1e-3) = KL against N(mean, s^2); `--kl_form tokenizer` restores the other.
+One deliberate difference: the reference parses `--visible_loss_ratio` and never passes it on (engine_pretrain.py:57 calls model(samples, mask_ratio=...): its
+runs train with the model's default 0.5); here the flag takes effect -- pass 0.5 (the default) to reproduce the reference's runs.
+
 What is kept: forward_vanilla loss (masked / visible MSE + KL), per-iteration half-cycle cosine LR with linear warm-up
 (util/lr_sched.py:9-25), AdamW(betas 0.9 / 0.95) with timm's ``param_groups_weight_decay`` split (no decay on biases and other
 1-D parameters, main_pretrain.py:258-259), gradient accumulation, and the GradScaler PROTOCOL of the reference's
@@ -358,9 +364,32 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--num_workers", type=int, default=8)
     ap.add_argument("--no_pin_mem", action="store_false", dest="pin_mem")
+    # ---- the rest of VMAE/main_pretrain.py:37-91's flag set, so that the command line of VMAE/train_ae.sh:26-46 parses here
+    ap.add_argument("--fixed_std", type=float, default=None, help="main_pretrain.py:43 -> the posterior KL against N(mean, fixed_std^2) (VMAE/util/misc.py:105-116)")
+    ap.add_argument("--kl_form", default="vmae", choices=["vmae", "tokenizer"],
+                    help="which tree's posterior KL: 'vmae' = the pre-training tree this driver mirrors (VMAE/util/misc.py:103-125: no mean^2 term; --fixed_std form), "
+                         "'tokenizer' = LDMAE/tokenizer/util/misc.py:102-107 (with mean^2)")
+    ap.add_argument("--no_cls", action="store_true", help="accepted (train_ae.sh passes it): this driver always builds the tokenizer without a class token")
+    ap.add_argument("--smooth_output", action="store_true", help="accepted (train_ae.sh passes it): the RGB smoothing convolution is always on")
+    ap.add_argument("--norm_pix_loss", action="store_true")
+    ap.add_argument("--perceptual_loss_ratio", type=float, default=None, help="LPIPS term (main_pretrain.py:189-203): NOT available (needs the VGG weights); refused if given")
+    ap.add_argument("--tune_decoder", action="store_true", help="stage 3 of train_ae.sh (decoder fine-tuning with LPIPS): out of scope, refused")
+    ap.add_argument("--pred_with_conv", action="store_true", help="refused: not a shipped form")
+    ap.add_argument("--gradual_resol", action="store_true", help="refused: not a shipped form")
+    ap.add_argument("--log_dir", default=None, help="accepted and ignored (TensorBoard is out of scope)")
+    ap.add_argument("--device", default="cuda", help="accepted; must be cuda")
+    ap.add_argument("--world_size", type=int, default=1, help="accepted and ignored: WORLD_SIZE of the launcher's environment counts")
+    ap.add_argument("--local-rank", "--local_rank", dest="local_rank_arg", type=int, default=-1, help="accepted and ignored: LOCAL_RANK of the environment counts")
+    ap.add_argument("--dist_on_itp", action="store_true", help="accepted and ignored")
+    ap.add_argument("--dist_url", default="env://", help="accepted and ignored")
+    ap.add_argument("--pin_mem", action="store_true", dest="pin_mem_flag", help="accepted (pinning is the default here; --no_pin_mem turns it off)")
     args = ap.parse_args(argv)
     if not args.synthetic and not args.data_path:
         ap.error("--data_path (an image folder) or --synthetic")
+    refused = [n for n in ("tune_decoder", "pred_with_conv", "gradual_resol") if getattr(args, n)] + (["perceptual_loss_ratio"] if args.perceptual_loss_ratio is not None else [])
+    if refused or args.device != "cuda":
+        ap.error(f"not available in ldmae_amd/vmae_pretrain.py: {refused or args.device} (LPIPS needs the VGG weights -- SURVEY 2.1 #18 marks the LPIPS "
+                 "decoder fine-tuning OUT; pred_with_conv / gradual_resol are not shipped forms)")
     import torch.distributed as dist
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     # LDMAE_DIST_BACKEND=gloo + LDMAE_DEVICE=0: several ranks share ONE GPU (rehearsal of the multi-rank launch on a 1-GPU box), as train_accum.py
@@ -388,8 +417,9 @@ def main(argv=None):
         loader = torch.utils.data.DataLoader(dataset, sampler=sampler, batch_size=args.batch_size, num_workers=args.num_workers, pin_memory=args.pin_mem,
                                              drop_last=True, multiprocessing_context="forkserver" if args.num_workers > 0 else None)
     torch.manual_seed(args.seed)                                              # every rank builds the same initial weights
-    model = getattr(models_mae, args.model)(ldmae_mode=False, no_cls=True, kl_loss_weight=args.kl_loss_weight, smooth_output=True,
-                                            img_size=args.input_size).cuda()
+    model = getattr(models_mae, args.model)(ldmae_mode=False, no_cls=True, kl_loss_weight=args.kl_loss_weight, smooth_output=True, norm_pix_loss=args.norm_pix_loss,
+                                            img_size=args.input_size, fixed_std=args.fixed_std).cuda()          # main_pretrain.py:193-205
+    model.kl_form = args.kl_form          # the pre-training tree's posterior KL (VMAE/util/misc.py) unless asked otherwise
     torch.manual_seed(args.seed + rank)
     opt = build_optimizer(model, args.lr, args.weight_decay)
     scaler = LossScaler(enabled=args.precision in ("bf16", "fp16"))           # main_pretrain.py:260: loss_scaler = NativeScaler()

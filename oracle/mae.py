@@ -178,17 +178,33 @@ def patchify(imgs, cfg: MAEConfig):
     return torch.einsum("nchpwq->nhwpqc", x).reshape(imgs.shape[0], g * g, p * p * 3)
 
 
-def forward_vanilla(sd, imgs, noise, eps, mask_ratio, visible_loss_ratio, kl_loss_weight, cfg: MAEConfig):
+def posterior_kl(mean, logvar, kl_form="tokenizer", fixed_std=None):
+    """DiagonalGaussianDistribution.kl() per sample (sum over every other dim), the two trees of the reference:
+    "tokenizer" = LDMAE/tokenizer/util/misc.py:102-107: 0.5 sum(mean^2 + var - 1 - logvar);
+    "vmae" = the PRE-TRAINING tree, VMAE/util/misc.py:103-125: with fixed_std 0.5 sum(var / s^2 - 1 - logvar + log s^2) (:105-116),
+    without it the variance-only form 0.5 sum(var - 1 - logvar) (:118-125: the mean^2 line is commented out there)."""
+    var = torch.exp(logvar)
+    if kl_form == "tokenizer":
+        assert fixed_std is None
+        return 0.5 * torch.sum(mean ** 2 + var - 1.0 - logvar, dim=[1, 2])
+    if fixed_std is not None:
+        fv = torch.tensor(fixed_std) ** 2
+        return 0.5 * torch.sum(var / fv - 1.0 - logvar + torch.log(fv), dim=[1, 2])
+    return 0.5 * torch.sum(var - 1.0 - logvar, dim=[1, 2])
+
+
+def forward_vanilla(sd, imgs, noise, eps, mask_ratio, visible_loss_ratio, kl_loss_weight, cfg: MAEConfig, kl_form="tokenizer", fixed_std=None):
     """MaskedAutoencoderViT.forward_vanilla + forward_decoder + forward_loss (models_mae.py:756-790, 525-554, 733-754) with the two
     random draws supplied by the caller: `noise` [B, L] (random_masking, :480) and `eps` [B, latent, kept] (posterior.sample,
-    util/misc.py:87-96).  Returns (loss, pred, mask, vis_loss, mask_loss, kl_loss)."""
+    util/misc.py:87-96).  kl_form / fixed_std: which tree's KL (posterior_kl; VMAE/models_mae.py:773-807 is otherwise the same function).
+    Returns (loss, pred, mask, vis_loss, mask_loss, kl_loss)."""
     latent, mask, ids_restore = forward_encoder(sd, imgs, noise, mask_ratio, cfg)
     latent = latent_map(sd, latent, "to_latent")
     B, N, D = latent.shape
     mom = latent.permute(0, 2, 1)                                     # B D HW
     mean, logvar = torch.chunk(mom, 2, dim=1)
     logvar = torch.clamp(logvar, -30.0, 20.0)
-    kl = 0.5 * torch.sum(mean ** 2 + torch.exp(logvar) - 1.0 - logvar, dim=[1, 2])     # misc.py:98-107
+    kl = posterior_kl(mean, logvar, kl_form, fixed_std)
     kl_loss = torch.sum(kl) / kl.shape[0] / N
     latent = (mean + torch.exp(0.5 * logvar) * eps).permute(0, 2, 1)
     x = latent_map(sd, latent, "from_latent")

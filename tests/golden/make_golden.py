@@ -327,6 +327,49 @@ def gen_mae_train(out):
         misc.randn_tensor = orig
 
 
+def gen_vmae_tree(out):
+    """The PRE-TRAINING tree's own step (VMAE/models_mae.py:773-807 -> forward_loss :741-771, KL from VMAE/util/misc.py:103-135), which is what
+    VMAE/engine_pretrain.py:51-57 runs: same geometry, weights and draws as gen_mae_train, three KL settings -- `fixed_std=None` (the VARIANCE-ONLY
+    KL 0.5 sum(var - 1 - logvar): no mean^2 term in this tree, misc.py:118-125), `fixed_std=1e-3` (train_ae.sh:33: 0.5 sum(var / s^2 - 1 - logvar + log s^2),
+    :105-116) and 0.5.  Must run in its own process (`--only vmae_tree`): the tree's top-level `util` package collides with LDMAE/tokenizer/util."""
+    from functools import partial
+    assert "util" not in sys.modules and "models_mae" not in sys.modules, "run with --only vmae_tree (fresh process)"
+    sys.path.insert(0, "/root/reference/VMAE")
+    import models_mae
+    misc = sys.modules[models_mae.DiagonalGaussianDistribution.__module__]
+    assert misc.__file__.startswith("/root/reference/VMAE/"), misc.__file__
+    imgs = det_randn("img128p", (2, 3, 128, 128), 4).clamp(-1, 1)
+    for tag, fixed_std, ratio, vlr in (("n", None, 0.75, 0.5), ("f", 1e-3, 0.25, 0.5), ("h", 0.5, 0.5, 0.25)):
+        m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192,
+                                            decoder_depth=2, decoder_num_heads=12, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                                            latent_dim=16, no_cls=True, kl_loss_weight=1e-3, smooth_output=True, fixed_std=fixed_std)
+        load_det(m, seed=6, skip=("pos_embed", "decoder_pos_embed"))
+        m.train()
+        captured = []
+        orig = misc.randn_tensor
+
+        def spy(*a, **k):
+            t = orig(*a, **k)
+            captured.append(t.detach().clone())
+            return t
+        misc.randn_tensor = spy
+        try:
+            torch.manual_seed(77)
+            noise = torch.rand(2, 256)
+            torch.manual_seed(77)
+            loss, pred, mask, vis, mask_loss, kl, p_loss = m(imgs, ratio, vlr)
+            assert len(captured) == 1
+            loss.backward()
+        finally:
+            misc.randn_tensor = orig
+        out.update({f"vt{tag}_cfg": np.array([ratio, vlr, -1.0 if fixed_std is None else fixed_std]), f"vt{tag}_noise": noise.numpy(), f"vt{tag}_eps": captured[0].numpy(),
+                    f"vt{tag}_loss": np.array([float(loss), float(vis), float(mask_loss), float(kl)], dtype=np.float64),
+                    f"vt{tag}_mask": mask.detach().numpy(), f"vt{tag}_pred_norm": np.array(float(pred.detach().double().norm())),
+                    f"vt{tag}_grad_norms": np.array([float(p.grad.double().norm()) for k, p in sorted(m.named_parameters()) if p.requires_grad], dtype=np.float64),
+                    f"vt{tag}_grad_to_latent_head": m.to_latent.weight.grad[:4, :8].numpy().copy(), f"vt{tag}_grad_to_latent_bias": m.to_latent.bias.grad.numpy().copy()})
+    out["vt_keys"] = np.array(sorted(k for k, p in m.named_parameters() if p.requires_grad))
+
+
 def gen_dit_variants(out):
     """The reference's LightningDiT on the geometries the shipped config does not exercise (eval forward, f32): 'p2' = patch size 2 with
     learn_sigma (the /2 registry entries; x_embedder conv stride 2, unpatchify with p = 2, 2x out channels), 'hd72' = head_dim 72 (XL's heads)
@@ -561,17 +604,19 @@ def main():
     ap.add_argument("--curve", action="store_true", help="also run the 100-step B/1 bs=4 loss curve (~15 min)")
     ap.add_argument("--only-curve", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,mae_archs,dit_variants,dit_flags,dataset,images}")
+    ap.add_argument("--only", default="", help="comma-separated subset of {dit_tiny,kernels,mae,mae_train,mae_archs,dit_variants,dit_flags,vmae_tree,dataset,images}")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     install_shims()
     sys.path.insert(0, REF)
     if not args.only_curve:
         gens = (("dit_tiny", gen_dit_tiny), ("kernels", gen_tables_and_kernels), ("mae", gen_mae), ("mae_train", gen_mae_train),
-                ("mae_archs", gen_mae_archs), ("dit_variants", gen_dit_variants), ("dit_flags", gen_dit_flags), ("dataset", gen_dataset), ("images", gen_images))
+                ("mae_archs", gen_mae_archs), ("dit_variants", gen_dit_variants), ("dit_flags", gen_dit_flags), ("vmae_tree", gen_vmae_tree), ("dataset", gen_dataset), ("images", gen_images))
         for name, fn in gens:
             if args.only and name not in args.only.split(","):
                 continue
+            if name == "vmae_tree" and args.only != "vmae_tree":
+                continue                      # own process only: `--only vmae_tree` (its `util` package collides with LDMAE/tokenizer/util)
             out = {}
             fn(out)
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)

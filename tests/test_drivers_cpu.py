@@ -291,3 +291,14 @@ def test_resume_from_a_reference_style_optimizer_state(tmp_path):
     torch.save({"model": ref.state_dict(), "optimizer": bad, "epoch": 2, "scaler": None, "args": None}, path)
     msgs.clear()
     assert vp.load_model(args, net, opt, scaler, log=msgs.append) == 3 and any("not restored" in str(m) for m in msgs)
+
+
+def test_vmae_pretrain_cli_takes_the_references_flag_set():
+    """VMAE/main_pretrain.py:37-91's flags parse here; what this driver cannot do is refused by name BEFORE anything touches the GPU: the LPIPS term
+    (`--perceptual_loss_ratio`, needs the VGG weights), decoder fine-tuning (`--tune_decoder`), and the two forms no shipped script uses."""
+    from ldmae_amd import vmae_pretrain as vp
+    for bad in (["--perceptual_loss_ratio", "0.5"], ["--tune_decoder"], ["--pred_with_conv"], ["--gradual_resol"], ["--device", "cpu"]):
+        with pytest.raises(SystemExit) as e:
+            vp.main(["--synthetic", "--no_cls", "--smooth_output", "--fixed_std", "1e-3", "--log_dir", "x", "--pin_mem", "--world_size", "8", "--local-rank", "0",
+                     "--dist_url", "env://"] + bad)
+        assert e.value.code == 2

@@ -297,7 +297,11 @@ def test_vmae_pretrain_two_ranks_on_a_folder_of_pngs(tmp_path):
     losses = [float(l.split("loss: ")[1].split()[0]) for l in r.stdout.splitlines() if l.startswith("Epoch: [")]
     assert len(losses) == 4 and all(np.isfinite(losses)) and losses[-1] < losses[0]
     # resume on one rank at 128 px: 64 -> 256 positions
-    r2 = subprocess.run([sys.executable, script, "--input_size", "128", "--epochs", "3", "--resume", str(out / "checkpoint-1.pth")] + common,
+    # ... with the flag set VMAE/train_ae.sh:26-46 passes to main_pretrain.py (minus the LPIPS term, which needs the VGG weights): --no_cls / --smooth_output /
+    # --log_dir are accepted, --fixed_std selects the pre-training tree's KL against N(mean, fixed_std^2) (VMAE/util/misc.py:105-116)
+    r2 = subprocess.run([sys.executable, script, "--input_size", "128", "--epochs", "3", "--resume", str(out / "checkpoint-1.pth"), "--no_cls", "--smooth_output",
+                         "--fixed_std", "1e-3", "--mask_ratio", "0.25", "--visible_loss_ratio", "0.75", "--kl_loss_weight", "1e-6", "--log_dir", str(out),
+                         "--blr", "1.0e-4", "--weight_decay", "0.05"] + common,
                         env=env, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stdout[-1500:] + r2.stderr[-3000:]
     assert "reshape pos embedding" in r2.stdout and "Epoch: [2]" in r2.stdout and "Epoch: [1]" not in r2.stdout

@@ -500,6 +500,36 @@ def test_pretraining_forward_and_grads_vs_reference_golden(golden):
         assert rel_err(params["decoder_pred.conv_smoother.weight"].grad.cpu(), g[f"mt{tag}_grad_smoother"]) < 2e-4
 
 
+def test_pretraining_tree_kl_forms_vs_reference_golden(golden):
+    """The step VMAE/engine_pretrain.py:51-57 actually runs is the PRE-TRAINING tree's (VMAE/models_mae.py:773-807), whose posterior KL differs from the
+    tokenizer tree's: variance-only without `fixed_std` (VMAE/util/misc.py:118-125), against N(mean, fixed_std^2) with it (train_ae.sh:33: 1e-3).  The
+    product with `kl_form = "vmae"` / `fixed_std` -- what ldmae_amd/vmae_pretrain.py builds -- against that tree's own outputs and gradient norms
+    (tests/golden/vmae_tree.npz, generated from /root/reference/VMAE)."""
+    g = golden("vmae_tree")
+    cfg = omae.MAEConfig(img_size=128, depth=2, decoder_depth=2)
+    sd = full_sd(cfg, seed=6)
+    from ldmae_amd.tokenizer import models_mae
+    imgs = det_randn("img128p", (2, 3, 128, 128), 4).clamp(-1, 1).cuda()
+    for tag in ("n", "f", "h"):
+        ratio, vlr, fs = (float(v) for v in g[f"vt{tag}_cfg"])
+        m = models_mae.MaskedAutoencoderViT(img_size=128, patch_size=8, embed_dim=192, depth=2, num_heads=12, decoder_embed_dim=192,
+                                            decoder_depth=2, decoder_num_heads=12, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16,
+                                            no_cls=True, kl_loss_weight=1e-3, smooth_output=True, fixed_std=None if fs < 0 else fs)
+        m.kl_form = "vmae"
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train()
+        names = sorted(k for k, p in m.named_parameters() if p.requires_grad)
+        assert names == [str(k) for k in g["vt_keys"]]
+        loss, pred, mask, vis, msk, kl = m(imgs, ratio, vlr, _noise=torch.from_numpy(g[f"vt{tag}_noise"]).cuda(), _eps=torch.from_numpy(g[f"vt{tag}_eps"]).cuda())
+        np.testing.assert_array_equal(mask.cpu().numpy(), g[f"vt{tag}_mask"])
+        np.testing.assert_allclose([float(loss), float(vis), float(msk), float(kl)], g[f"vt{tag}_loss"], rtol=1e-4)
+        loss.backward()
+        params = dict(m.named_parameters())
+        norms = np.array([float(params[k].grad.double().norm()) for k in names])
+        np.testing.assert_allclose(norms, g[f"vt{tag}_grad_norms"], rtol=3e-4, atol=1e-8)
+        assert rel_err(params["to_latent.bias"].grad.cpu(), g[f"vt{tag}_grad_to_latent_bias"]) < 2e-4
+
+
 def test_loss_scaler_protocol_skips_non_finite_steps():
     """The reference's GradScaler protocol (VMAE/util/misc.py:406-435, engine_pretrain.py:72-76) on the flat slab: a non-finite gradient
     skips the step and halves the scale; clean steps apply 1/scale inside the fused AdamW kernel and grow the scale on schedule."""

@@ -282,3 +282,33 @@ def test_dit_block_flags_vs_reference_golden(golden):
     sd.update(dit.fixed_tables(cfg))
     out = dit.dit_forward(sd, det_randn("x", (2, 16, 8, 8), 1), torch.tensor([0.2, 0.7]), torch.tensor([0, 0]), cfg, train=False)
     assert rel_err(out, g["df_noqk768_out"]) < 2e-6
+
+
+def test_pretraining_tree_kl_forms_vs_reference_golden(golden):
+    """The PRE-TRAINING tree's own step (VMAE/models_mae.py:773-807 with the KL of VMAE/util/misc.py:103-125 -- what VMAE/engine_pretrain.py:51-57 runs;
+    tests/golden/vmae_tree.npz, make_golden.py: gen_vmae_tree, generated from /root/reference/VMAE): the variance-only KL without fixed_std (no mean^2 term in
+    that tree), and the fixed_std form (train_ae.sh:33 passes 1e-3) at two values.  oracle.mae.forward_vanilla(kl_form="vmae", fixed_std=...): loss terms,
+    mask and every gradient norm."""
+    g = golden("vmae_tree")
+    cfg = mae.MAEConfig(img_size=128, depth=2, decoder_depth=2)
+    sd = det_weights(mae.param_shapes(cfg), 6)
+    sd.update(mae.fixed_tables(cfg))
+    keys = sorted(mae.param_shapes(cfg))
+    assert keys == [str(k) for k in g["vt_keys"]]
+    imgs = det_randn("img128p", (2, 3, 128, 128), 4).clamp(-1, 1)
+    for tag in ("n", "f", "h"):
+        ratio, vlr, fs = (float(v) for v in g[f"vt{tag}_cfg"])
+        leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+        osd = dict(sd)
+        osd.update(leaves)
+        loss, pred, mask, vis, mloss, kl = mae.forward_vanilla(osd, imgs, torch.from_numpy(g[f"vt{tag}_noise"]), torch.from_numpy(g[f"vt{tag}_eps"]),
+                                                               ratio, vlr, 1e-3, cfg, kl_form="vmae", fixed_std=None if fs < 0 else fs)
+        np.testing.assert_array_equal(mask.numpy(), g[f"vt{tag}_mask"])
+        np.testing.assert_allclose([float(loss), float(vis), float(mloss), float(kl)], g[f"vt{tag}_loss"], rtol=3e-5)
+        loss.backward()
+        norms = np.array([float(leaves[k].grad.double().norm()) for k in keys])
+        np.testing.assert_allclose(norms, g[f"vt{tag}_grad_norms"], rtol=3e-4, atol=1e-9)
+        assert rel_err(leaves["to_latent.bias"].grad, g[f"vt{tag}_grad_to_latent_bias"]) < 1e-4
+    # and the two trees really differ: the tokenizer tree's KL on the same draws is another number
+    tk = mae.forward_vanilla(sd, imgs, torch.from_numpy(g["vtn_noise"]), torch.from_numpy(g["vtn_eps"]), 0.75, 0.5, 1e-3, cfg)[5]
+    assert abs(float(tk) - float(g["vtn_loss"][3])) > 1e-2 * float(g["vtn_loss"][3])
