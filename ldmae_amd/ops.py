@@ -755,6 +755,11 @@ def vmae_encoder_fwd_tiled(x, blob, nblocks, dim, heads, hidden, eps=1e-6, f16=F
 
 def heads_split(qkv, B, N, H, hd):
     """[B,N,3,H,hd] -> q,k,v [B,H,N,hd] (no norm / rope)."""
+    if hd % 8 != 0:
+        # head dims off the kernels' 8-element grid (12: the pre-training tree's mae_for_ldmae_f8d16_small, VMAE/models_mae.py:1036-1041): a pure
+        # re-layout, done by torch's copy; the attention wrappers then zero-pad the heads to the next instantiated head dim
+        t = qkv.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+        return t[0].contiguous(), t[1].contiguous(), t[2].contiguous()
     q = torch.empty(B, H, N, hd, dtype=qkv.dtype, device=qkv.device)
     k, v = torch.empty_like(q), torch.empty_like(q)
     call("ldmae_qknorm_rope_fwd", dt(qkv.dtype), ptr(qkv), None, None, None, None, ptr(q), ptr(k), ptr(v), B, N, H, hd, 0.0, stream())
@@ -763,6 +768,8 @@ def heads_split(qkv, B, N, H, hd):
 
 def heads_merge(dq, dk, dv, B, N, H, hd):
     """inverse of heads_split for the gradients: -> [B*N, 3*H*hd]."""
+    if hd % 8 != 0:                                   # (see heads_split)
+        return torch.stack((dq, dk, dv), 0).permute(1, 3, 0, 2, 4).reshape(B * N, 3 * H * hd)
     dqkv = torch.empty(B * N, 3 * H * hd, dtype=dq.dtype, device=dq.device)
     call("ldmae_qknorm_rope_bwd", dt(dq.dtype), ptr(dq), ptr(dk), ptr(dv), None, None, None, None, None, ptr(dqkv), None, None, 0.0,
          None, B, N, H, hd, 0.0, None, stream())

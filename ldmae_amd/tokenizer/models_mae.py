@@ -363,6 +363,10 @@ class Block(nn.Module):
         call ran in (tests)."""
         a, m = self.attn, self.mlp
         dtype = dtype if dtype is not None else _act_dtype(self.precision, allow_f16=True)
+        if dtype != torch.float32 and (self.norm1.weight.numel() % 64 != 0 or m.fc1.weight.shape[0] % 64 != 0):
+            # the 16-bit MFMA GEMMs contract in steps of 64: widths off that grid (96: the pre-training tree's mae_for_ldmae_f8d16_small,
+            # VMAE/models_mae.py:1036-1048) keep f32 activations on the exact-f32 kernels -- more precision than the caller's autocast asked for, never less
+            dtype = torch.float32
         self.last_dtype = dtype
         yres_f32 = self.last_tf32_class = bool(tf32_class) and dtype == torch.float16
         return _ViTBlockFn.apply(x.float(), a.num_heads, self.norm1.eps, dtype, _inplace_grad,
@@ -434,7 +438,10 @@ class MaskedAutoencoderViT(nn.Module):
             self.from_latent = MLP_dim_resize(latent_dim, latent_dim * 4, embed_dim)
         else:
             self.to_latent = nn.Linear(embed_dim, enc_lat)
-            self.from_latent = nn.Linear(latent_dim, decoder_embed_dim)
+            # VMAE/models_mae.py:320 (the pre-training tree): the latent maps back to the ENCODER width, and decoder_embed (:371) takes it to the decoder's.
+            # LDMAE/tokenizer/models_mae.py:317 says decoder_embed_dim here, which only runs when the two widths are equal (decoder_embed expects embed_dim):
+            # same shapes wherever that copy works at all; the asymmetric archs (mae_for_ldmae_f8d16_asym_small, mae_vit_*_dec512d8b) need this form
+            self.from_latent = nn.Linear(latent_dim, embed_dim)
         self.config = Config(scaling_factor=scaling_factor)
         self.ldmae_mode, self.img_size, self.patch_size = ldmae_mode, img_size, patch_size
         self.latent_resolution = img_size // patch_size
@@ -725,6 +732,18 @@ mae_for_ldmae_f8d32 = mae_for_ldmae
 
 def mae_for_ldmae_f8d16_prev(**kwargs):
     return MaskedAutoencoderViT(patch_size=8, embed_dim=192, depth=12, num_heads=12, decoder_embed_dim=192, decoder_depth=12,
+                                decoder_num_heads=12, mlp_ratio=4, norm_layer=_ln(), latent_dim=16, **kwargs)
+
+
+def mae_for_ldmae_f8d16_small(**kwargs):
+    """VMAE/models_mae.py:1036-1041 (the pre-training tree's registry only): 96 wide, 8 heads of 12 -- zero-padded to the head-dim-16 kernels."""
+    return MaskedAutoencoderViT(patch_size=8, embed_dim=96, depth=12, num_heads=8, decoder_embed_dim=96, decoder_depth=12,
+                                decoder_num_heads=8, mlp_ratio=4, norm_layer=_ln(), latent_dim=16, **kwargs)
+
+
+def mae_for_ldmae_f8d16_asym_small(**kwargs):
+    """VMAE/models_mae.py:1043-1048 (the pre-training tree's registry only): 96-wide encoder (8 heads of 12), the shipped 192-wide decoder."""
+    return MaskedAutoencoderViT(patch_size=8, embed_dim=96, depth=12, num_heads=8, decoder_embed_dim=192, decoder_depth=12,
                                 decoder_num_heads=12, mlp_ratio=4, norm_layer=_ln(), latent_dim=16, **kwargs)
 
 

@@ -255,7 +255,9 @@ def param_shapes(cfg: MAEConfig, with_decoder: bool = True) -> dict:
             s.update({"from_latent.layers.0.weight": (hid, cfg.latent_dim), "from_latent.layers.0.bias": (hid,),
                       "from_latent.layers.2.weight": (D, hid), "from_latent.layers.2.bias": (D,)})
         else:
-            s.update({"from_latent.weight": (Dd, cfg.latent_dim), "from_latent.bias": (Dd,)})
+            # VMAE/models_mae.py:320: back to the ENCODER width (decoder_embed, :371, then maps it to the decoder's); the tokenizer copy's
+            # decoder_embed_dim (LDMAE/tokenizer/models_mae.py:317) is the same shape wherever that copy runs at all (equal widths)
+            s.update({"from_latent.weight": (D, cfg.latent_dim), "from_latent.bias": (D,)})
         s.update({"decoder_embed.weight": (Dd, D), "decoder_embed.bias": (Dd,)})
         if not cfg.ldmae_mode:
             s["mask_token"] = (1, 1, Dd)

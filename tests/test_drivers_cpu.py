@@ -161,9 +161,11 @@ def test_mae_arch_registry_has_every_reference_constructor():
     names = ["mae_for_ldmae", "mae_for_ldmae_f8d32", "mae_for_ldmae_f8d16_prev", "mae_for_ldmae_f8d16_prev_large", "mae_for_ldmae_f8d16",
              "mae_for_ldmae_f8d16_flexible", "mae_for_ldmae_f16d32", "mae_for_ldmae_f16d32_large", "mae_for_ldmae_f8d32_flexible", "mae_for_ldmae_16d",
              "mae_vit_base_patch16_dec512d8b", "mae_vit_base_patch16_dec128d8b", "mae_vit_large_patch16_dec512d8b", "mae_vit_huge_patch14_dec512d8b",
-             "mae_vit_base_patch16", "mae_vit_large_patch16", "mae_vit_huge_patch14", "mae_vit_base_patch16_128"]
+             "mae_vit_base_patch16", "mae_vit_large_patch16", "mae_vit_huge_patch14", "mae_vit_base_patch16_128",
+             "mae_for_ldmae_f8d16_small", "mae_for_ldmae_f8d16_asym_small"]       # the last two: the pre-training tree's registry only (VMAE/models_mae.py:1036-1048)
     geo = {"mae_for_ldmae_f16d32_large": (384, 12, 384, 64), "mae_vit_base_patch16_dec128d8b": (768, 12, 128, 196), "mae_vit_large_patch16": (1024, 24, 512, 196),
-           "mae_for_ldmae_f8d16_prev": (192, 12, 192, 784), "mae_for_ldmae_f8d16": (192, 12, 384, 784)}
+           "mae_for_ldmae_f8d16_prev": (192, 12, 192, 784), "mae_for_ldmae_f8d16": (192, 12, 384, 784),
+           "mae_for_ldmae_f8d16_small": (96, 12, 96, 784), "mae_for_ldmae_f8d16_asym_small": (96, 12, 192, 784)}
     for n in names:
         f = getattr(mm, n)
         if n in ("mae_for_ldmae_f8d16", "mae_for_ldmae_f8d16_flexible"):

@@ -119,6 +119,48 @@ def test_masked_encoder_gradients_vs_oracle(ratio):
             assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 6e-2, k
 
 
+def test_small_archs_of_the_pretraining_tree_vs_oracle():
+    """The two archs only the pre-training tree registers (VMAE/models_mae.py:1036-1048): mae_for_ldmae_f8d16_small (96 wide, 8 heads of 12) and
+    _asym_small (that encoder, the 192-wide decoder), at depth 1 / 64 px with the tree's own KL (variance-only): loss and every gradient against
+    the oracle in f32, bf16 autocast close to it, the docking calls finite.  Head dim 12 runs the head-dim-16 kernels on zero-padded heads."""
+    from ldmae_amd.tokenizer import models_mae
+    imgs = det_randn("img64s", (2, 3, 64, 64), 4).clamp(-1, 1)
+    noise = torch.rand(2, 64, generator=torch.Generator().manual_seed(5))
+    eps = torch.randn(2, 16, 16, generator=torch.Generator().manual_seed(6))
+    for dec_dim, dec_heads in ((96, 8), (192, 12)):
+        cfg = omae.MAEConfig(img_size=64, embed_dim=96, num_heads=8, depth=1, decoder_embed_dim=dec_dim, decoder_num_heads=dec_heads, decoder_depth=1)
+        sd = full_sd(cfg, seed=11)
+        m = models_mae.MaskedAutoencoderViT(img_size=64, patch_size=8, embed_dim=96, depth=1, num_heads=8, decoder_embed_dim=dec_dim, decoder_depth=1,
+                                            decoder_num_heads=dec_heads, mlp_ratio=4, norm_layer=models_mae._ln(), latent_dim=16, no_cls=True,
+                                            kl_loss_weight=1e-3, smooth_output=True)
+        m.kl_form = "vmae"
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train()
+        keys = [k for k in omae.param_shapes(cfg)]
+        leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+        osd = dict(sd)
+        osd.update(leaves)
+        ol = omae.forward_vanilla(osd, imgs, noise, eps, 0.75, 0.5, 1e-3, cfg, kl_form="vmae")[0]
+        ol.backward()
+        loss = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())[0]
+        assert abs(float(loss) - float(ol)) < 1e-4 * abs(float(ol)), dec_dim
+        loss.backward()
+        params = dict(m.named_parameters())
+        for k in keys:
+            assert rel_err(params[k].grad.cpu(), leaves[k].grad) < 2e-4, (dec_dim, k)
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss16 = m(imgs.cuda(), 0.75, 0.5, _noise=noise.cuda(), _eps=eps.cuda())[0]
+        loss16.backward()
+        assert abs(float(loss16) - float(ol)) < 2e-2 * abs(float(ol)), dec_dim
+        with torch.no_grad():
+            rec = m.decode(m._encode(imgs.cuda())[:, :16]).sample
+        assert rec.shape == (2, 3, 64, 64) and bool(torch.isfinite(rec).all())
+    sm, asym = models_mae.mae_for_ldmae_f8d16_small(img_size=64, no_cls=True), models_mae.mae_for_ldmae_f8d16_asym_small(img_size=64, no_cls=True)
+    assert sm.pos_embed.shape[-1] // sm.blocks[0].attn.num_heads == 12 and asym.decoder_pos_embed.shape[-1] // asym.decoder_blocks[0].attn.num_heads == 16
+    assert asym.from_latent.weight.shape == (96, 16) and asym.decoder_embed.weight.shape == (192, 96)      # VMAE/models_mae.py:320,371
+
+
 def test_head_dim_24_arch_pretraining_step_vs_oracle(golden):
     """mae_for_ldmae_f8d16_prev_large's geometry (384 wide, 16 heads of 24: a head dim the attention kernels are not instantiated for -- they run
     on zero-padded heads, ops.attention_fwd) at depth 1: loss and every parameter gradient of the pre-training step against the oracle in f32,
