@@ -11,7 +11,9 @@
  *  - plain device pointers + explicit sizes, no torch types; `stream` is a hipStream_t (NULL = default).
  *  - every call only ENQUEUES on `stream`: no allocation, no synchronisation; compute entry points keep no state
  *    between calls and are callable from the Python main thread and the autograd thread concurrently.
- *    Workspaces are caller-owned.  The only process-wide mutable state is the event list of the opt-in ldmae_prof_*
+ *    Workspaces are caller-owned and used only inside the launches of the call that received them: two calls may share one
+ *    workspace exactly when they are ordered on one stream (ldmae_amd/ops.py keys its scratch buffers by device, purpose AND stream).
+ *    The only process-wide mutable state is the event list of the opt-in ldmae_prof_*
  *    timing hook (mutex-protected, off by default); per-device launch attributes (CU count, dynamic-LDS opt-in) are looked
  *    up per call.  A/B knobs and timeline stamps live in the separate diagnostic build only (csrc/probe/ldmae_diag.h).
  *  - return 0 on success, negative on error; ldmae_last_error() gives the thread-local message.

@@ -19,8 +19,10 @@ _ws = {}
 
 
 def workspace(nbytes: int, device, slot: str = "main") -> torch.Tensor:
-    """Grow-only f32 scratch buffer per (device, slot)."""
-    key = (device, slot)
+    """Grow-only f32 scratch buffer per (device, slot, STREAM): the library's entry points take their scratch from the caller and use it only inside
+    the launches they enqueue, so two calls may share a buffer exactly when they are ordered on one stream -- work enqueued on different streams
+    (the weight-gradient side stream, a data-parallel reducer, two modules driven from two host threads) gets buffers of its own."""
+    key = (device, slot, torch.cuda.current_stream(device).cuda_stream)
     n = max(1, (int(nbytes) + 3) // 4)
     t = _ws.get(key)
     if t is None or t.numel() < n:
