@@ -643,7 +643,10 @@ __global__ void attn_delta_kernel(const T* __restrict__ O, const T* __restrict__
 // by ds_read_b128), k carries scale*log2(e): p = exp2(S) and dS = p * dP are one instruction per element each.
 // PF (round 6): LDS operand fragments are requested PF MFMAs ahead of the one that consumes them (a ring of PF + 1 fragments in registers, the
 // reads pinned in place against the scheduler), instead of right in front of it behind an `s_waitcnt lgkmcnt(0)` each
-template <int HD, bool QKN = false, bool RAGGED = false, bool F16 = false, int PF = 0>      // F16: fp16 operands / outputs (VMAE pre-training under fp16 autocast), QKN = false only
+// PIPE (round 6, diagnostic A/B only; needs PF > 0): the two 32-row halves of a tile run software-pipelined -- order [S / dP of half 0] [S / dP of half 1]
+// [dV / dK of half 0] [dV / dK of half 1], so the exponentials / conversions of one half have the other half's MFMAs to run beside (verdict r05 item 3b); both
+// halves' score blocks are live at once: +32 VGPRs, 2 waves per SIMD
+template <int HD, bool QKN = false, bool RAGGED = false, bool F16 = false, int PF = 0, int PIPE = 0>      // F16: fp16 operands / outputs (VMAE pre-training under fp16 autocast), QKN = false only
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ V,
                                                                  const bf16* __restrict__ dO, const float* __restrict__ ROWC, long rc_stride,
                                                                  bf16* __restrict__ dK, bf16* __restrict__ dV,
@@ -716,8 +719,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
     if constexpr (PF > 0) {
       // the 2 x (2 KS + 4 DB) MFMAs of the tile in their order, each with ONE operand fragment from LDS: fragment i + PF is requested before MFMA i
       constexpr int N1 = 2 * KS, N2 = 4 * DB, NQ = N1 + N2, NF = 2 * NQ;
+      // sequence position i -> (half qb, step j of that half's N1 + N2 MFMAs)
+      constexpr auto half_of = [](int i) { return PIPE ? (i < 2 * N1 ? i / N1 : (i - 2 * N1) / N2) : i / NQ; };
+      constexpr auto step_of = [](int i) { return PIPE ? (i < 2 * N1 ? i % N1 : N1 + (i - 2 * N1) % N2) : i % NQ; };
       auto frag = [&](auto I) -> bf16x8 {
-        constexpr int i = decltype(I)::value, qb = i / NQ, j = i % NQ;
+        constexpr int i = decltype(I)::value, qb = half_of(i), j = step_of(i);
         if constexpr (j < N1) {
           if constexpr ((j & 1) != 0) return frag_row<HDP>(dOt, qb * 32, j / 2, lane); else return frag_row<HDP>(Qt, qb * 32, j / 2, lane);
         } else {
@@ -727,10 +733,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
       };
       bf16x8 win[PF + 1];
       static_for<PF>([&](auto I) { win[decltype(I)::value] = frag(I); });
-      f32x16 s, dp;
+      f32x16 sx[PIPE ? 2 : 1], dpx[PIPE ? 2 : 1];
       bf16x8 pf, dsf;
       static_for<NF>([&](auto I) {
-        constexpr int i = decltype(I)::value, qb = i / NQ, j = i % NQ;
+        constexpr int i = decltype(I)::value, qb = half_of(i), j = step_of(i);
+        f32x16& s = sx[PIPE ? qb : 0];
+        f32x16& dp = dpx[PIPE ? qb : 0];
         if constexpr (i + PF < NF) win[(i + PF) % (PF + 1)] = frag(IC<i + PF>{});
         if constexpr (j == 0) {
 #pragma unroll
@@ -741,9 +749,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_bf16_kernel(const bf16* __r
           }
         }
         __builtin_amdgcn_sched_barrier(0x6);          // vector / scalar ALU may move across; LDS reads and MFMAs keep this order
-        if constexpr (j == N1) {
+        // the exponentials of a half: written where its score chains end (PIPE: in front of the OTHER half's next section, beside whose MFMAs they can run)
+        if constexpr (PIPE ? (i == N1 || i == 2 * N1) : j == N1) {
+          constexpr int qe = PIPE ? (i == N1 ? 0 : 1) : 0;
+          f32x16& se = sx[PIPE ? qe : 0];
+          f32x16& de = dpx[PIPE ? qe : 0];
 #pragma unroll
-          for (int t = 0; t < 16; ++t) { const float p = EXP2(s[t]); s[t] = p; dp[t] *= p; }
+          for (int t = 0; t < 16; ++t) { const float p = EXP2(se[t]); se[t] = p; de[t] *= p; }
         }
         if constexpr (j >= N1 && (j - N1) % (2 * DB) == 0) { pf = acc_frag_t<F16>(s, (j - N1) / (2 * DB)); dsf = acc_frag_t<F16>(dp, (j - N1) / (2 * DB)); }
         const bf16x8 a = win[i % (PF + 1)];
@@ -2080,7 +2092,10 @@ extern "C" int ldmae_attention_bwd_pv_qknorm(int dtype, const void* q, const voi
 #define ATTN_DQ_GO(HD, P) { hipFuncSetAttribute((const void*)attn_bwd_dq_bf16_kernel<HD, true, false, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 0)); \
     hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<HD, true, false, false, P>), dim3(grid), dim3(256), attn_lds(HD, 0), st, (const bf16*)q, (const bf16*)k, v, (const bf16*)o, (const bf16*)do_, lse, rowc, items, (bf16*)nullptr, H, N, scale, hm, pk, qn); }
 #ifdef LDMAE_DIAG
-#define ATTN_DKDV_QKN(HD) { switch (ldmae_tune_get(23)) { case 1: ATTN_DKDV_GO(HD, 1) break; case 2: ATTN_DKDV_GO(HD, 2) break; case 3: ATTN_DKDV_GO(HD, 0) break; default: ATTN_DKDV_GO(HD, ATTN_PF_DEFAULT(HD)) } }
+#define ATTN_DKDV_GO_PIPE(HD, P) { hipFuncSetAttribute((const void*)attn_bwd_dkdv_bf16_kernel<HD, true, false, false, P, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_lds(HD, 1024)); \
+    hipLaunchKernelGGL((attn_bwd_dkdv_bf16_kernel<HD, true, false, false, P, 1>), dim3(grid), dim3(256), attn_lds(HD, 1024), st, (const bf16*)q, (const bf16*)k, v, (const bf16*)do_, rowc, items, (bf16*)nullptr, dv, H, N, scale, hm, pk, qn); }
+#define ATTN_DKDV_QKN(HD) { switch (ldmae_tune_get(23)) { case 1: ATTN_DKDV_GO(HD, 1) break; case 2: ATTN_DKDV_GO(HD, 2) break; case 3: ATTN_DKDV_GO(HD, 0) break; \
+    case 4: ATTN_DKDV_GO_PIPE(HD, 1) break; case 5: ATTN_DKDV_GO_PIPE(HD, 2) break; default: ATTN_DKDV_GO(HD, ATTN_PF_DEFAULT(HD)) } }
 #define ATTN_DQ_QKN(HD) { switch (ldmae_tune_get(24)) { case 1: ATTN_DQ_GO(HD, 1) break; case 2: ATTN_DQ_GO(HD, 2) break; case 3: ATTN_DQ_GO(HD, 0) break; default: ATTN_DQ_GO(HD, ATTN_PF_DEFAULT(HD)) } }
 #else
 #define ATTN_DKDV_QKN(HD) ATTN_DKDV_GO(HD, ATTN_PF_DEFAULT(HD))

@@ -40,7 +40,8 @@ def prefetch_ab(B):
     q2, k2, _ = ops.qknorm_rope_fwd(qkv, wq, wk, cos, sin, B, N, H, hd, copy_v=False)
     o2, lse2 = ops.attention_fwd_pv(q2, k2, qkv, scale)
     run = lambda: ops.attention_bwd_pv_qknorm(q2, k2, qkv, o2, do, lse2, scale, wq, wk, cos, sin)      # noqa: E731
-    combos = [(3, 3), (1, 3), (3, 1), (1, 1), (2, 3), (3, 2), (2, 2), (0, 0)]       # tune values: 3 = no prefetch, 1 / 2 = that depth, 0 = the shipped default
+    # tune values: 3 = no prefetch, 1 / 2 = that depth, 0 = the shipped default; dK/dV only: 4 / 5 = depth 1 / 2 with the two 32-row halves software-pipelined (PIPE)
+    combos = [(3, 3), (1, 3), (3, 1), (1, 1), (2, 3), (3, 2), (2, 2), (4, 1), (5, 1), (0, 0)]
     base = None
     for kv, kq in combos:
         lib.ldmae_tune(23, kv); lib.ldmae_tune(24, kq)
