@@ -165,6 +165,30 @@ def _dw_into_grad(sg, dy, x, param, direct):
     return sg.tn(dy, x), None
 
 
+def _pad_swiglu(w12, b12, w3):
+    """SwiGLU hidden sizes off the kernels' grid -- int(2/3 * 4 * hidden) is 2730 for LightningDiT-L (hidden 1024) and 4778 for 1p6B (1792), :213,217 -- are
+    ZERO-PADDED to the next multiple of 128: padded units compute silu(0) * 0 = 0 and meet zero columns of w3, so outputs and every gradient of the real
+    units are exactly those of the unpadded block.  -> (w12 [2 Hp, D] as [x1 rows, 0 | x2 rows, 0], b12 [2 Hp], w3 [D, Hp], Hs, Hp); identity when Hs % 128 == 0."""
+    Hs = w3.shape[1]
+    Hp = (Hs + 127) // 128 * 128
+    if Hp == Hs:
+        return w12, b12, w3, Hs, Hp
+    D = w3.shape[0]
+    z = w12.new_zeros(Hp - Hs, D)
+    w12p = torch.cat([w12[:Hs], z, w12[Hs:], z], 0)
+    zb = b12.new_zeros(Hp - Hs)
+    b12p = torch.cat([b12[:Hs], zb, b12[Hs:], zb], 0)
+    w3p = torch.cat([w3, w3.new_zeros(D, Hp - Hs)], 1)
+    return w12p, b12p, w3p, Hs, Hp
+
+
+def _unpad_swiglu_grads(dW12, db12, dW3, Hs, Hp):
+    if Hp == Hs:
+        return dW12, db12, dW3
+    cut = lambda t_: None if t_ is None else torch.cat([t_[:Hs], t_[Hp:Hp + Hs]], 0)      # noqa: E731
+    return cut(dW12), cut(db12), (None if dW3 is None else dW3[:, :Hs].contiguous())
+
+
 _FUSED_QKN_BWD = os.environ.get("LDMAE_FUSED_QKN_BWD", "1") != "0"      # A/B switch (tools/): 0 = attention_bwd_pv + qknorm_rope_bwd
 
 _QK_LN_EPS = 1e-5      # nn.LayerNorm's default: Attention builds q_norm / k_norm as norm_layer(head_dim) (:60-61)
@@ -294,6 +318,10 @@ class _DiTBlockFn(torch.autograd.Function):
         bwd = not fwd_only and any(ctx.needs_input_grad)
         Wqkv, WqkvT = _wcopies(qkvw, dtype, bwd)
         Wp, WpT = _wcopies(pw, dtype, bwd)
+        ctx.hs = None
+        if swiglu and w3.shape[1] % 128 != 0:          # LightningDiT-L / 1p6B: hidden 2730 / 4778 (see _pad_swiglu); b12 below is the padded bias
+            w12, b12, w3, Hs_, Hp_ = _pad_swiglu(w12, b12, w3)
+            ctx.hs = (Hs_, Hp_)
         W12, W12T = _wcopies(w12, dtype, bwd)
         W3, W3T = _wcopies(w3, dtype, bwd)
         # attention branch (:248)
@@ -330,7 +358,7 @@ class _DiTBlockFn(torch.autograd.Function):
         ctx.nmod = nmod
         ctx.inplace = bool(inplace)
         ctx.chain, ctx.idx = chain, idx
-        ctx.direct, ctx.wparams = bool(direct), (qkvw, pw, w12, w3)
+        ctx.direct, ctx.wparams = bool(direct), (qkvw, pw, w12, w3)      # (padded hidden: w12 / w3 are the padded copies -- no .grad, so the direct path declines them)
         ctx.sparams = (n1w, qkvb, qnw, knw, pb, n2w, b12, b3, qnb, knb) if direct else None
         if chain is not None:
             chain.up[idx] = (y2, mod)
@@ -407,6 +435,8 @@ class _DiTBlockFn(torch.autograd.Function):
         else:
             dadaw, dadab = ops.gemm_tn(dmod, sc), ops.colsum(dmod)
             dsc = _dmod_times_w(dmod, adaw)
+        if ctx.hs is not None:                         # padded SwiGLU hidden: hand autograd the real units' rows / columns
+            dW12, db12, dW3 = _unpad_swiglu_grads(dW12, db12, dW3, *ctx.hs)
         sg.join()
         # the eight small gradients of the block (norm weights, biases, QK-norm weights): with `direct`, ONE launch adds them into their .grad
         # views instead of one AccumulateGrad add each

@@ -234,6 +234,29 @@ def test_celeba_config_real_width_vs_reference_golden(golden):
     assert rel_err(out16.float().cpu(), g["df_noqk768_out"]) < 3e-2
 
 
+@pytest.mark.parametrize("name,D,H", [("L", 1024, 16), ("1p0B", 1536, 24), ("1p6B", 1792, 28)])
+def test_other_registry_widths_vs_oracle(name, D, H):
+    """The registry's other widths (lightningdit.py:498-531) at depth 1: LightningDiT-L (1024: SwiGLU hidden int(2/3 * 4096) = 2730), 1p0B (1536: 4096) and 1p6B
+    (1792: 4778).  2730 and 4778 are off every kernel's grid: the block zero-pads the hidden units to a multiple of 128 (exact: silu(0) * 0 = 0 against zero
+    columns of w3) and hands autograd the real units' gradients.  f32: output and every gradient against the oracle at 1e-4; bf16 autocast close to it."""
+    cfg = odit.DiTConfig(input_size=8, patch_size=1, in_channels=16, hidden_size=D, depth=1, num_heads=H, num_classes=10, class_dropout_prob=0.0)
+    assert cfg.mlp_hidden == {"L": 2730, "1p0B": 4096, "1p6B": 4778}[name]
+    sd = det_weights(odit.param_shapes(cfg), 41)
+    sd.update(odit.fixed_tables(cfg))
+    x, t, y, tgt = det_randn("xw", (2, 16, 8, 8), 3), torch.tensor([0.25, 0.75]), torch.tensor([2, 8]), det_randn("tw", (2, 16, 8, 8), 5)
+    osd = {k: (v.clone().requires_grad_(True) if k != "pos_embed" and not k.startswith("feat_rope") else v) for k, v in sd.items()}
+    oout = odit.dit_forward(osd, x, t, y, cfg, True, None)
+    ((oout - tgt) ** 2).mean().backward()
+    for prec, otol, gtol in ((torch.float32, 1e-4, 1e-4), (torch.bfloat16, 3e-2, 8e-2)):
+        m = build(cfg, sd, prec)
+        out = m(x.cuda(), t.cuda(), y.cuda())
+        ((out - tgt.cuda()) ** 2).mean().backward()
+        assert rel_err(out.detach().cpu(), oout.detach()) < otol, (name, prec)
+        worst = max(rel_err(p.grad.cpu(), osd[k].grad) for k, p in m.named_parameters() if p.grad is not None)
+        assert worst < gtol, (name, prec, worst)
+        assert m.blocks[0].mlp.w12.weight.grad.shape == (2 * cfg.mlp_hidden, D) and m.blocks[0].mlp.w3.weight.grad.shape == (D, cfg.mlp_hidden)
+
+
 def test_xl_head_dim_72_geometry_fp32_and_bf16():
     """LightningDiT-XL geometry in small: head_dim 72 (hidden 576 = 8 heads, XL is 1152 = 16 heads), SwiGLU hidden
     int(2/3*4*576) = 1536; forward and every parameter gradient vs the oracle in fp32; bf16 autocast (the head_dim-72 flash kernels,
