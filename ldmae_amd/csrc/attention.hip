@@ -1760,8 +1760,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __res
   switch (hd) { case 16: MACRO(16); break; case 32: MACRO(32); break; case 64: MACRO(64); break; case 72: MACRO(72); break; case 128: MACRO(128); break; \
     default: LDMAE_FAIL(LDMAE_ERR_INVALID, "attention(bf16): head_dim %d unsupported (16, 32, 64, 72, 128)", hd); }
 #define ATTN_HD_DISPATCH_F32(hd, MACRO) \
-  switch (hd) { case 16: MACRO(16); break; case 32: MACRO(32); break; case 64: MACRO(64); break; case 72: MACRO(72); break; case 128: MACRO(128); break; \
-    default: LDMAE_FAIL(LDMAE_ERR_INVALID, "attention(f32): head_dim %d unsupported (16, 32, 64, 72, 128)", hd); }
+  switch (hd) { case 16: MACRO(16); break; case 32: MACRO(32); break; case 64: MACRO(64); break; case 72: MACRO(72); break; case 80: MACRO(80); break; \
+    case 96: MACRO(96); break; case 128: MACRO(128); break; /* 80 / 96: mae_vit_huge's heads of 80 and anything up to 96 -- the f32 BACKWARD's LDS tiles do not fit at 128 */ \
+    default: LDMAE_FAIL(LDMAE_ERR_INVALID, "attention(f32): head_dim %d unsupported (16, 32, 64, 72, 80, 96, 128)", hd); }
 
 // dynamic LDS of the bf16 kernels: the K/V (Q/dO) ring, and at least the 4 per-wave store images that re-use it at the end
 static int attn_lds(int hd, int extra) {
@@ -1942,7 +1943,7 @@ static int attention_bwd_core(int dtype, const void* q, const void* k, const voi
   } else {
     LDMAE_REQUIRE(Lq.ld == hd && Lq.sh == (long)N * hd && Lv.ld == hd && Lv.sh == (long)N * hd, "attention_bwd(f32): head-major q/k/v only");
     LDMAE_REQUIRE((size_t)(128 + 128 + 64 + 64) * (hd + 1) * 4 + 512 <= 160 * 1024,
-                  "attention_bwd(f32): head_dim %d needs more than the 160 KiB of LDS (f32 backward: head dims up to 72; bf16 covers 128)", hd);
+                  "attention_bwd(f32): head_dim %d needs more than the 160 KiB of LDS (f32 backward: head dims up to 96; bf16 covers 128)", hd);
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(dgrid), dim3(256), 0, st, (const float*)o, (const float*)do_, delta, B, H, N, hd);
 #define L(HD) { const size_t l1 = (size_t)(128 + 128 + 64 + 64) * (HD + 1) * 4 + 512; \
     hipFuncSetAttribute((const void*)attn_bwd_dkdv_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); \

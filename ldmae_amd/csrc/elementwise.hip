@@ -68,7 +68,7 @@ static void group_reduce(const float* P, int p_ld, int nout, int cols, int group
 // rows per workgroup for the per-sample reductions: largest of 64/32/16/8/4 dividing rows_per_batch
 static int pick_rows_per_wg(int rows_per_batch) {
   const int cap = ldmae_tune_get(10) > 0 ? ldmae_tune_get(10) : 64;      // tune key 10: A/B knob
-  for (int r = cap; r >= 4; r >>= 1) if (rows_per_batch % r == 0) return r;
+  for (int r = cap; r >= 1; r >>= 1) if (rows_per_batch % r == 0) return r;      // (odd token counts -- a 5 x 5 grid -- end at 1 row per workgroup: correct, slow)
   return 0;
 }
 

@@ -373,10 +373,10 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
 constexpr int LN_ROWS = 128;
 #define LN_NV_DISPATCH(D, MACRO) \
   { const int nv_ = (D + 63) / 64; \
-    if (nv_ <= 3) MACRO(3) else if (nv_ <= 6) MACRO(6) else if (nv_ <= 12) MACRO(12) else MACRO(16) }
+    if (nv_ <= 3) MACRO(3) else if (nv_ <= 6) MACRO(6) else if (nv_ <= 12) MACRO(12) else if (nv_ <= 16) MACRO(16) else MACRO(20) }      /* 20: D = 1280, mae_vit_huge_patch14 */
 extern "C" int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w, const float* b, void* out, float* mean, float* rstd,
                                    int M, int D, float eps, void* stream) {
-  LDMAE_REQUIRE(x && w && b && out && M > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_fwd: bad arguments (D=%d: multiple of 4, <= 1024)", D);
+  LDMAE_REQUIRE(x && w && b && out && M > 0 && D > 0 && D % 4 == 0 && D <= 1280, "layernorm_fwd: bad arguments (D=%d: multiple of 4, <= 1280)", D);
   const unsigned grid = cdiv(M, 16) < 4096 ? cdiv(M, 16) : 4096;
 #define LN_F(NV) { if (out_dtype == LDMAE_F16) hipLaunchKernelGGL((layernorm_fwd_kernel<f16, NV>), dim3(grid), dim3(256), 0, as_stream(stream), x, w, b, (f16*)out, mean, rstd, M, D, eps); \
                    else if (out_dtype == LDMAE_BF16) hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, NV>), dim3(grid), dim3(256), 0, as_stream(stream), x, w, b, (bf16*)out, mean, rstd, M, D, eps); \
@@ -389,8 +389,8 @@ extern "C" int ldmae_layernorm_fwd(int out_dtype, const float* x, const float* w
 extern "C" long ldmae_layernorm_bwd_workspace_bytes(int M, int D) { return (long)cdiv(M, LN_ROWS) * 2 * D * 4; }
 extern "C" int ldmae_layernorm_bwd_cast(int dtype, const void* dout, const float* x, const float* w, const float* mean, const float* rstd,
                                         float* dx_accum, void* dx_cast, float* dw, float* db, float beta_w, int M, int D, float* workspace, void* stream) {
-  LDMAE_REQUIRE(dout && x && w && mean && rstd && dx_accum && dw && db && workspace && M > 0 && D > 0 && D % 4 == 0 && D <= 1024,
-                "layernorm_bwd: bad arguments (D=%d: multiple of 4, <= 1024)", D);
+  LDMAE_REQUIRE(dout && x && w && mean && rstd && dx_accum && dw && db && workspace && M > 0 && D > 0 && D % 4 == 0 && D <= 1280,
+                "layernorm_bwd: bad arguments (D=%d: multiple of 4, <= 1280)", D);
   LDMAE_REQUIRE(!dx_cast || dtype != LDMAE_F32, "layernorm_bwd: dx_cast is a copy in the (16-bit) type of dout");
   hipStream_t st = as_stream(stream);
   const int G = cdiv(M, LN_ROWS);

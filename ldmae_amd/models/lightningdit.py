@@ -575,7 +575,11 @@ class PatchEmbed(nn.Module):
         w2d = self.proj.weight.view(self.proj.weight.shape[0], -1)
         if pos is None:
             pos = torch.zeros(self.num_patches, w2d.shape[0], device=x.device)
-        return _PatchEmbedFn.apply(self.tokens(x), w2d, self.proj.bias, pos, self.num_patches,
+        tok = self.tokens(x)
+        if w2d.shape[1] % 16 != 0:        # C * p * p off the GEMMs' 16-grid (4-channel latents at patch size 1: K = 4): zero columns on both operands -- exact,
+            pad = (-w2d.shape[1]) % 16    # and the weight gradient comes back through the pad sliced to the real columns
+            tok, w2d = torch.nn.functional.pad(tok, (0, pad)), torch.nn.functional.pad(w2d, (0, pad))
+        return _PatchEmbedFn.apply(tok, w2d, self.proj.bias, pos, self.num_patches,
                                    dtype or torch.float32).view(B, self.num_patches, -1)
 
 
@@ -731,10 +735,14 @@ class FinalLayer(nn.Module):
 
     def forward(self, x, c, _silu_c=None, _dtype=None, _chain=None, _idx=0):
         sc = _silu_c if _silu_c is not None else _SiluFn.apply(c.float())
-        return _FinalLayerFn.apply(x.float(), sc, self.norm_final.eps, _dtype or _act_dtype(self.precision), _chain, _idx,
-                                   self.norm_final.weight,
-                                   self.linear.weight, self.linear.bias, self.adaLN_modulation[1].weight,
-                                   self.adaLN_modulation[1].bias)
+        lw, lb = self.linear.weight, self.linear.bias
+        nout = lw.shape[0]
+        if nout % 16 != 0:                # p * p * out_channels off the GEMMs' grid (4- or 3-channel latents at patch size 1): zero rows, sliced off below
+            pad = (-nout) % 16
+            lw, lb = torch.nn.functional.pad(lw, (0, 0, 0, pad)), torch.nn.functional.pad(lb, (0, pad))
+        out = _FinalLayerFn.apply(x.float(), sc, self.norm_final.eps, _dtype or _act_dtype(self.precision), _chain, _idx,
+                                  self.norm_final.weight, lw, lb, self.adaLN_modulation[1].weight, self.adaLN_modulation[1].bias)
+        return out if out.shape[-1] == nout else out[..., :nout]
 
 
 class LightningDiT(nn.Module):
@@ -824,6 +832,8 @@ class LightningDiT(nn.Module):
         autocast disabled so the few torch re-layout ops around the kernels stay f32 (the reference's output is
         f32 too: accelerate converts outputs to fp32)."""
         dtype = _act_dtype(self.precision)
+        if dtype != torch.float32 and self.hidden_size % 64 != 0:
+            dtype = torch.float32         # the 16-bit MFMA GEMMs contract in steps of 64: other widths (no registry entry has one) keep f32 activations
         with torch.autocast(device_type="cuda", enabled=False):
             x = self.x_embedder(x, self.pos_embed[0])
             t = self.t_embedder(t)

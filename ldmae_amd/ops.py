@@ -413,10 +413,15 @@ def rope(t, cos, sin, transposed=False):
 
 
 _ATTN_HDS = (16, 32, 64, 72, 128)            # head dims the attention kernels are instantiated for (csrc/attention.hip: ATTN_HD_DISPATCH)
+_ATTN_HDS_F32 = (16, 32, 64, 72, 80, 96, 128)      # ... and the f32 kernels (ATTN_HD_DISPATCH_F32): their backward's LDS tiles end at head_dim 96
 
 
-def _attn_pad(hd: int) -> int:
-    for h in _ATTN_HDS:
+def _attn_hds(dtype):
+    return _ATTN_HDS_F32 if dtype == torch.float32 else _ATTN_HDS
+
+
+def _attn_pad(hd: int, dtype=None) -> int:
+    for h in _attn_hds(dtype):
         if h >= hd:
             return h
     raise RuntimeError(f"ldmae_amd attention: head_dim {hd} is above the largest instantiated kernel (128)")
@@ -427,11 +432,11 @@ def attention_fwd(q, k, v, scale):
     bf16 head dims that are not a multiple of 32 (LightningDiT-XL: 72, VMAE: 16) are zero-padded to the next multiple of 32
     INSIDE the kernels (LDS images and register fragments); HBM tensors keep the true head dim."""
     B, H, N, hd = q.shape
-    if hd not in _ATTN_HDS:
+    if hd not in _attn_hds(q.dtype):
         # Head dims outside the instantiated set (16, 32, 64, 72, 128) -- e.g. 24 (mae_for_ldmae_f8d16_prev_large), 80 (mae_vit_huge), 8: zero
         # columns add nothing to q . k and produce zero output columns, so the next larger kernel on zero-padded copies is exact (`scale` is
         # the caller's, from the true head dim).  Costs the copies; the shipped archs never come here.
-        P = _attn_pad(hd)
+        P = _attn_pad(hd, q.dtype)
         pad = lambda t: torch.nn.functional.pad(t, (0, P - hd))      # noqa: E731
         o, lse = attention_fwd(pad(q), pad(k), pad(v), scale)
         return o.view(B, N, H, P)[..., :hd].reshape(B, N, H * hd), lse
@@ -443,8 +448,8 @@ def attention_fwd(q, k, v, scale):
 
 def attention_bwd(q, k, v, o, do, lse, scale):
     B, H, N, hd = q.shape
-    if hd not in _ATTN_HDS:                                   # head dims the kernels are not instantiated for: zero-padded (see attention_fwd)
-        P = _attn_pad(hd)
+    if hd not in _attn_hds(q.dtype):                          # head dims the kernels are not instantiated for: zero-padded (see attention_fwd)
+        P = _attn_pad(hd, q.dtype)
         pad, padt = (lambda t: torch.nn.functional.pad(t, (0, P - hd))), (lambda t: torch.nn.functional.pad(t.reshape(B, N, H, hd), (0, P - hd)).reshape(B, N, H * P))
         dq, dk, dv = attention_bwd(pad(q), pad(k), pad(v), padt(o), padt(_c(do)), lse, scale)
         return dq[..., :hd].contiguous(), dk[..., :hd].contiguous(), dv[..., :hd].contiguous()
@@ -513,7 +518,7 @@ def attention_fwd_qkv(qkv, B, N, H, hd, scale):
     Long sequences of small heads (the 1024-token VMAE decoder: the kernel is bound by vector issue) first take one pass over the k slots
     for max |k|^2 per (image, head): with each query's own norm it bounds the scores, and the softmax runs with that static shift instead of
     a running maximum (same result; ldmae_k_norm_max + ldmae_attention_fwd_qkv_bounded)."""
-    if hd not in _ATTN_HDS:                                   # (see attention_fwd: head-major zero-padded copies)
+    if hd not in _attn_hds(qkv.dtype):                        # (see attention_fwd: head-major zero-padded copies)
         return attention_fwd(*heads_split(qkv, B, N, H, hd), scale)
     o = torch.empty(B, N, H * hd, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
@@ -528,7 +533,7 @@ def attention_fwd_qkv(qkv, B, N, H, hd, scale):
 
 def attention_bwd_qkv(qkv, o, do, lse, B, N, H, hd, scale):
     """-> dqkv [B*N, 3*H*hd] (dq / dk / dv written in the packed layout)."""
-    if hd not in _ATTN_HDS:                                   # (see attention_fwd: head-major zero-padded copies)
+    if hd not in _attn_hds(qkv.dtype):                        # (see attention_fwd: head-major zero-padded copies)
         q, k, v = heads_split(qkv, B, N, H, hd)
         return heads_merge(*attention_bwd(q, k, v, o, do, lse, scale), B, N, H, hd)
     dqkv = torch.empty_like(qkv)

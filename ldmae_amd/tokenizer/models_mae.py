@@ -245,6 +245,16 @@ class _LinearFn(torch.autograd.Function):
         return dx, ops.gemm_tn(g2, x2), ops.colsum(g2)
 
 
+def _linear(x, w, b):
+    """_LinearFn with output widths off the GEMMs' 16-grid (the prediction head of a patch-14 tokenizer: 14 * 14 * 3 = 588, mae_vit_huge_patch14) zero-padded:
+    extra zero rows of the weight, sliced off the result; the weight gradient comes back through the pad cut to the real rows."""
+    n = w.shape[0]
+    if n % 16 == 0:
+        return _LinearFn.apply(x, w, b)
+    pad = (-n) % 16
+    return _LinearFn.apply(x, torch.nn.functional.pad(w, (0, 0, 0, pad)), torch.nn.functional.pad(b, (0, pad)))[..., :n]
+
+
 class _Conv3x3Fn(torch.autograd.Function):
     """conv_smoother (:254,275): 3x3 / stride 1 / pad 1 on the RGB prediction, f32."""
 
@@ -363,9 +373,14 @@ class Block(nn.Module):
         call ran in (tests)."""
         a, m = self.attn, self.mlp
         dtype = dtype if dtype is not None else _act_dtype(self.precision, allow_f16=True)
-        if dtype != torch.float32 and (self.norm1.weight.numel() % 64 != 0 or m.fc1.weight.shape[0] % 64 != 0):
+        D_, rows_ = self.norm1.weight.numel(), x.shape[0] * x.shape[1]
+        if dtype != torch.float32 and (D_ % 64 != 0 or m.fc1.weight.shape[0] % 64 != 0):
             # the 16-bit MFMA GEMMs contract in steps of 64: widths off that grid (96: the pre-training tree's mae_for_ldmae_f8d16_small,
             # VMAE/models_mae.py:1036-1048) keep f32 activations on the exact-f32 kernels -- more precision than the caller's autocast asked for, never less
+            dtype = torch.float32
+        if dtype == torch.float16 and not tf32_class and (D_ // a.num_heads != 16 or rows_ % 8 != 0):
+            # fp16 AUTOCAST (the reference's torch.amp.autocast('cuda'), engine_pretrain.py:51-57) on a geometry the fp16 kernel family does not cover -- it is built
+            # for the shipped heads of 16 and whole groups of 8 token rows (no fallback GEMM): f32 activations, by the same rule
             dtype = torch.float32
         self.last_dtype = dtype
         yres_f32 = self.last_tf32_class = bool(tf32_class) and dtype == torch.float16
@@ -406,7 +421,7 @@ class conv_decoder_pred(nn.Module):
 
     def forward(self, x, return_image=False):
         h = w = int(x.shape[1] ** .5)
-        x = _LinearFn.apply(x, self.linear_pred.weight, self.linear_pred.bias)
+        x = _linear(x, self.linear_pred.weight, self.linear_pred.bias)
         x = x.reshape(x.shape[0], h, w, self.p, self.p, 3)
         x = torch.einsum('nhwpqc->nchpwq', x).reshape(x.shape[0], 3, h * self.p, w * self.p)
         img = _Conv3x3Fn.apply(x, self.conv_smoother.weight, self.conv_smoother.bias)
@@ -604,7 +619,7 @@ class MaskedAutoencoderViT(nn.Module):
         if return_image:                     # (pred, smoothed image): only with the conv_decoder_pred head
             return self.decoder_pred(x, return_image=True)
         return self.decoder_pred(x) if not isinstance(self.decoder_pred, nn.Linear) else \
-            _LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)
+            _linear(x, self.decoder_pred.weight, self.decoder_pred.bias)
 
     def forward_loss(self, imgs, pred, mask, visible_loss_ratio=0.5):
         """:733-754."""
@@ -687,7 +702,7 @@ class MaskedAutoencoderViT(nn.Module):
                 x = self._run(self.decoder_blocks, x, dtype, tf32)
                 x = _LayerNormFn.apply(x, self.decoder_norm.weight, self.decoder_norm.bias, self.decoder_norm.eps)
             x = self.decoder_pred(x) if not isinstance(self.decoder_pred, nn.Linear) else \
-                _LinearFn.apply(x, self.decoder_pred.weight, self.decoder_pred.bias)
+                _linear(x, self.decoder_pred.weight, self.decoder_pred.bias)
             img = self.unpatchify(x)
         return DecoderOutput(sample=img) if return_dict else (img,)
 

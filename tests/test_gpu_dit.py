@@ -257,6 +257,30 @@ def test_other_registry_widths_vs_oracle(name, D, H):
         assert m.blocks[0].mlp.w12.weight.grad.shape == (2 * cfg.mlp_hidden, D) and m.blocks[0].mlp.w3.weight.grad.shape == (D, cfg.mlp_hidden)
 
 
+@pytest.mark.parametrize("kw", [dict(input_size=8, patch_size=1, in_channels=4), dict(input_size=8, patch_size=1, in_channels=3),
+                                dict(input_size=10, patch_size=2, in_channels=16), dict(input_size=12, patch_size=1, in_channels=16, hidden_size=96, num_heads=3)])
+def test_geometries_off_the_kernels_grids_vs_oracle(kw):
+    """Constructor geometries whose shapes fall off a kernel's grid, each handled exactly: 4- / 3-channel latents at patch size 1 (patch-embed K and final-layer N
+    of 4 / 3: zero-padded to 16), a 5 x 5 token grid (25 rows per sample: the per-sample reductions fall back to one row per workgroup; ragged attention tiles),
+    a width off the 16-bit GEMMs' 64-grid (96: f32 activations under autocast).  f32: output and every gradient against the oracle; bf16 autocast close."""
+    cfg = odit.DiTConfig(**{**dict(hidden_size=192, depth=1, num_heads=3, num_classes=10, class_dropout_prob=0.0), **kw})
+    sd = det_weights(odit.param_shapes(cfg), 43)
+    sd.update(odit.fixed_tables(cfg))
+    C, S = cfg.in_channels, cfg.input_size
+    x, t, y, tgt = det_randn("xg", (3, C, S, S), 3), torch.tensor([0.25, 0.5, 0.75]), torch.tensor([2, 8, 0]), det_randn("tg", (3, C, S, S), 5)
+    osd = {k: (v.clone().requires_grad_(True) if k != "pos_embed" and not k.startswith("feat_rope") else v) for k, v in sd.items()}
+    oout = odit.dit_forward(osd, x, t, y, cfg, True, None)
+    ((oout - tgt) ** 2).mean().backward()
+    for prec, otol, gtol in ((torch.float32, 1e-4, 2e-4), (torch.bfloat16, 3e-2, 1e-1)):
+        m = build(cfg, sd, prec)
+        out = m(x.cuda(), t.cuda(), y.cuda())
+        ((out - tgt.cuda()) ** 2).mean().backward()
+        assert out.shape == oout.shape and rel_err(out.detach().cpu(), oout.detach()) < otol, (kw, prec)
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                assert p.grad.shape == osd[k].shape and rel_err(p.grad.cpu(), osd[k].grad) < gtol, (kw, prec, k)
+
+
 def test_xl_head_dim_72_geometry_fp32_and_bf16():
     """LightningDiT-XL geometry in small: head_dim 72 (hidden 576 = 8 heads, XL is 1152 = 16 heads), SwiGLU hidden
     int(2/3*4*576) = 1536; forward and every parameter gradient vs the oracle in fp32; bf16 autocast (the head_dim-72 flash kernels,

@@ -858,3 +858,39 @@ def test_tensor_hook_between_blocks_sees_and_changes_the_gradient():
     a, b = grads(raw), grads(plain)
     assert all(torch.equal(a[k], b[k]) for k in a)
     assert any(not torch.equal(a[k], base[k]) for k in a)         # and the perturbation did reach the earlier blocks
+
+
+def test_every_registry_arch_trains_one_step_in_every_precision():
+    """Every constructor of BOTH trees' registries (LDMAE/tokenizer/models_mae.py:977-1083, VMAE/models_mae.py:1014-1134) at depth 1: one pre-training step
+    (loss + backward) in f32, bf16 autocast and fp16 autocast (the reference's own, engine_pretrain.py:51-57), then the docking calls.  Geometries off a kernel
+    family's grid fall back to MORE precision, never less (fp16 autocast off heads of 16 -> f32 activations; widths off the 16-bit GEMMs' 64-grid -> f32;
+    head dims 12 / 24 / 80 -> zero-padded heads; patch 14: patch-embed K = 588 and the prediction head's N = 588 zero-padded to the GEMMs' 16-grid;
+    D = 1280 LayerNorm).  A coverage sweep: finite loss / gradients / reconstructions -- parity per geometry is the other tests' job."""
+    from ldmae_amd.tokenizer import models_mae as mm
+    names = ["mae_for_ldmae", "mae_for_ldmae_f8d32", "mae_for_ldmae_f8d16_prev", "mae_for_ldmae_f8d16_small", "mae_for_ldmae_f8d16_asym_small",
+             "mae_for_ldmae_f8d16_prev_large", "mae_for_ldmae_f8d16", "mae_for_ldmae_f8d16_flexible", "mae_for_ldmae_f16d32", "mae_for_ldmae_f16d32_large",
+             "mae_for_ldmae_f8d32_flexible", "mae_for_ldmae_16d", "mae_vit_base_patch16_dec512d8b", "mae_vit_base_patch16_dec128d8b",
+             "mae_vit_large_patch16_dec512d8b", "mae_vit_huge_patch14_dec512d8b"]
+    for n in names:
+        f = getattr(mm, n)
+        for prec in ("fp32", "bf16", "fp16"):
+            torch.manual_seed(0)
+            try:
+                p = f(no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=64).patch_embed.patch_size[0]
+                S = p * 8 if p != 14 else 112
+                m = f(no_cls=True, kl_loss_weight=1e-6, smooth_output=True, img_size=S)
+            except TypeError:                                   # constructors that fix img_size themselves, as in the reference
+                m = f(no_cls=True, kl_loss_weight=1e-6, smooth_output=True)
+                S = m.img_size
+            m.blocks, m.decoder_blocks = m.blocks[:1], m.decoder_blocks[:1]
+            m = m.cuda().train()
+            x = torch.rand(3, 3, S, S, device="cuda") * 2 - 1
+            with torch.autocast("cuda", dtype=torch.float16 if prec == "fp16" else torch.bfloat16, enabled=prec != "fp32"):
+                loss = m(x, mask_ratio=0.75, visible_loss_ratio=0.5)[0]
+            loss.backward()
+            assert bool(torch.isfinite(loss)) and all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None), (n, prec)
+            m.eval()
+            with torch.no_grad():
+                rec = m.decode(m._encode(x)[:, :m.latent_dim]).sample
+            assert rec.shape == x.shape and bool(torch.isfinite(rec).all()), (n, prec)
+            del m
