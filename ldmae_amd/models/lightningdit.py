@@ -613,6 +613,10 @@ class LabelEmbedder(nn.Module):
         self.num_classes = num_classes
         self.dropout_prob = dropout_prob
 
+    def token_drop(self, labels, force_drop_ids=None):
+        """:152-161 (integer work: the dropped labels become the null class)."""
+        return torch.where(self.token_drop_ids(labels, force_drop_ids), torch.full_like(labels, self.num_classes), labels)
+
     def token_drop_ids(self, labels, force_drop_ids=None):
         if force_drop_ids is None:
             return torch.rand(labels.shape[0], device=labels.device) < self.dropout_prob

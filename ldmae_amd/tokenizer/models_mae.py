@@ -48,6 +48,9 @@ class EncoderOutput:
     def sample(self):
         return self.latent
 
+    def mode(self):
+        return self.latent
+
 
 @dataclass
 class MAEOutput:
@@ -717,6 +720,39 @@ class MaskedAutoencoderViT(nn.Module):
     def img_transform(self, p_hflip=0, img_size=None):
         """:935-950 -- PIL image -> normalised CHW tensor (extract_features.py:105-108 builds its two ImageFolders with it)."""
         return ImageTransform(p_hflip, img_size if img_size is not None else self.img_size)
+
+    # ---- the token-level docking functions of the reference (:625-703: what evaluate_tokenizer.py and the probing heads call), on the kernels above
+    def ldmae_encoding(self, imgs, use_mode=False, return_kl=False):
+        """:625-654 (no cls token): all patches -> encoder -> to_latent -> posterior mode / sample, as TOKENS [B, N, latent]."""
+        mom = self._encode(imgs)                                             # [B, (2) latent, g, g]
+        B, C = mom.shape[0], mom.shape[1]
+        latent = mom.reshape(B, C, -1)                                       # B D HW
+        posterior = None
+        if self.kl_loss_weight is not None:
+            posterior = DiagonalGaussianDistribution(latent)
+            latent = posterior.mode() if use_mode else posterior.sample()
+        latent = latent.permute(0, 2, 1)
+        if return_kl:
+            return latent, posterior.kl()
+        return latent
+
+    def ldmae_decoding(self, x):
+        """:656-691: latent tokens [B, N, latent] -> from_latent -> decoder -> prediction head, as patch tokens [B, N, p * p * 3] (unpatchify is the caller's)."""
+        g = self.latent_resolution
+        z = x.permute(0, 2, 1).reshape(x.shape[0], x.shape[2], g, g)
+        return self.patchify(self.decode(z, return_dict=False)[0])
+
+    def reconstruct(self, imgs, use_mode=True, return_kl=False):
+        """:693-703."""
+        with torch.no_grad():
+            enc = self.ldmae_encoding(imgs, use_mode=use_mode, return_kl=return_kl)
+        x, kl_val = enc if return_kl else (enc, None)
+        x = self.ldmae_decoding(x)
+        return (x, kl_val) if return_kl else x
+
+    def forward_vanilla(self, imgs, mask_ratio=0.75, visible_loss_ratio=0.5):
+        """:756-790 -- the training forward under its reference name."""
+        return self.forward(imgs, mask_ratio=mask_ratio, visible_loss_ratio=visible_loss_ratio)
 
     def encode_images(self, images):
         with torch.no_grad():

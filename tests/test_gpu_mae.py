@@ -63,6 +63,14 @@ def test_encode_decode_docking_matches_reference_golden(golden):
     img8 = m.decode_to_images(mom[:, :16])
     assert img8.dtype == np.uint8 and img8.shape == (2, 256, 256, 3)
     assert (np.abs(img8[:, :4, :4].astype(int) - g["mae_img8_head"].astype(int)) <= 1).all()
+    # the token-level docking functions (models_mae.py:625-703: ldmae_encoding -> ldmae_decoding = reconstruct) are the same computation as tokens
+    lat, kl = m.ldmae_encoding(imgs, use_mode=True, return_kl=True)
+    assert lat.shape == (2, 1024, 16) and torch.equal(lat, mom[:, :16].reshape(2, 16, -1).permute(0, 2, 1)) and kl.shape == (2,)
+    rt = m.reconstruct(imgs, use_mode=True)
+    assert rt.shape == (2, 1024, 192) and rel_err(m.unpatchify(rt)[:, :, :4, :4].cpu(), g["mae_rec_head"]) < 1e-4
+    torch.manual_seed(3)
+    a_ = m.ldmae_encoding(imgs)                                   # a posterior SAMPLE: mean + std * noise
+    assert a_.shape == lat.shape and not torch.equal(a_, lat) and bool(torch.isfinite(a_).all())
     # the bf16 docking paths (tiled fused encoder, fused decoder stack) DIRECTLY against the reference goldens
     m.set_precision(torch.bfloat16)
     try:

@@ -135,3 +135,18 @@ def test_out_of_scope_transport_configurations_raise_by_design():
     t = create_transport("Linear", "velocity", None, None, None)
     with pytest.raises(NotImplementedError):
         Sampler(t).sample_sde()
+
+
+def test_reference_method_names_exist():
+    """Names a caller of the reference finds on the two model classes (LDMAE/tokenizer/models_mae.py, LDMAE/models/lightningdit.py) -- beyond forward / state dict."""
+    from ldmae_amd.models.lightningdit import LabelEmbedder, LightningDiT
+    from ldmae_amd.tokenizer.models_mae import EncoderOutput, MaskedAutoencoderViT
+    for n in ("patchify", "unpatchify", "random_masking", "forward_encoder", "forward_decoder", "forward_loss", "forward_vanilla", "forward", "_encode", "encode", "decode",
+              "ldmae_encoding", "ldmae_decoding", "reconstruct", "encode_images", "decode_to_images", "img_transform"):
+        assert callable(getattr(MaskedAutoencoderViT, n)), n
+    for n in ("forward", "forward_with_cfg", "unpatchify", "initialize_weights"):
+        assert callable(getattr(LightningDiT, n)), n
+    assert callable(LabelEmbedder.token_drop) and callable(EncoderOutput.mode)
+    le = LabelEmbedder(10, 8, 0.1)
+    out = le.token_drop(torch.tensor([1, 2, 3]), force_drop_ids=torch.tensor([1, 0, 1]))
+    assert out.tolist() == [10, 2, 10]
