@@ -115,8 +115,18 @@ def do_sample(cfg, ckpt_path, out_dir, num_samples=None, precision="bf16"):
     vck = torch.load(cfg['vae']['weight_path'], map_location='cpu')
     vae.load_state_dict(vck['model'], strict=False)
     vae = vae.to(device).eval()
-    stats = torch.load(os.path.join(cfg['data']['data_path'] + ('_sample' if 'sample' in cfg['data'] else ''), "latents_stats.pt"))
-    mean, std = stats['mean'].to(device), stats['std'].to(device)
+    # inference.py:203-217: the statistics come through the latent dataset -- the cached latents_stats.pt when it is there (downloaded with the checkpoint),
+    # otherwise computed from the shards of data_path and cached, exactly as the reference's ImgLatentDataset.get_latent_stats does
+    data_dir = cfg['data']['data_path'] + ('_sample' if 'sample' in cfg['data'] else '')
+    cache = os.path.join(data_dir, "latents_stats.pt")
+    if os.path.exists(cache):
+        stats = torch.load(cache)
+        mean, std = stats['mean'], stats['std']
+    else:
+        from ldmae_amd.datasets.img_latent_dataset import ImgLatentDataset
+        mean, std = ImgLatentDataset(data_dir, latent_norm=cfg['data'].get('latent_norm', False), latent_multiplier=cfg['data'].get('latent_multiplier', 0.18215),
+                                     sample=cfg['data'].get('sample', False)).get_latent_stats()
+    mean, std = mean.to(device), std.to(device)
     mult = cfg['data'].get('latent_multiplier', 0.18215)
     s = cfg['sample']
     n = s['per_proc_batch_size']
