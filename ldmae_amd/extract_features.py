@@ -190,6 +190,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--data_split", type=str, default="train")
     ap.add_argument("--output_dir", type=str, default=None, help="default: dirname(data.origin_path), like the reference")
+    ap.add_argument("--output_path", type=str, default="/data/dataset/imagenet/", help="accepted and ignored, as in the reference (extract_features.py:226 parses it; :45 derives the output from data.origin_path)")
     ap.add_argument("--image_size", type=int, default=256)
     ap.add_argument("--batch_size", type=int, default=64)
     ap.add_argument("--seed", type=int, default=42)

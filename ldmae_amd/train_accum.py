@@ -173,6 +173,10 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
     if getattr(dataset, "raw", False):
         from ldmae_amd.datasets.img_latent_dataset import LatentPrologue
         prologue = LatentPrologue(dataset).to(device)
+    if 'valid_path' in cfg['data']:
+        # train_accum.py:148-163,288-297 builds a validation loader and calls an `evaluate` that the reference never defines (NameError at the
+        # first checkpoint step); no shipped config sets the key.  Said once instead of dying after ckpt_every steps.
+        logger.info(f"data.valid_path={cfg['data']['valid_path']!r} is ignored: the reference's validation pass calls an undefined evaluate()")
     logger.info(f"LightningDiT Parameters: {sum(p.numel() for p in model.parameters()) / 1e6:.2f}M; {len(dataset):,} samples; "
                 f"batch {per_gpu}/gpu x {world} gpus x {accum} accumulation; precision {precision}")
     max_steps = max_steps or tr_cfg['max_steps']

@@ -304,3 +304,17 @@ def test_vmae_pretrain_cli_takes_the_references_flag_set():
             vp.main(["--synthetic", "--no_cls", "--smooth_output", "--fixed_std", "1e-3", "--log_dir", "x", "--pin_mem", "--world_size", "8", "--local-rank", "0",
                      "--dist_url", "env://"] + bad)
         assert e.value.code == 2
+
+
+def test_sample_folder_name_follows_the_reference_rule():
+    """inference.py:45-52: <model>-ckpt-<stem>-<method>-<steps>, lower-cased; the guidance suffix only when cfg_scale > 1."""
+    import yaml
+    from ldmae_amd.inference import sample_folder_name, DEMO_LABELS
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "ldmae_amd/configs/imagenet/lightningdit_b_vmae_f8d16_cfg.yaml")))
+    s = cfg["sample"]
+    base = f"lightningdit-b-1-ckpt-0100000-{s['sampling_method']}-{s['num_sampling_steps']}".lower()
+    assert sample_folder_name(cfg, cfg["ckpt_path"], 1.0) == base
+    assert sample_folder_name(cfg, cfg["ckpt_path"]) == base + f"-interval{s['cfg_interval_start']:.2f}-cfg{s['cfg_scale']:.2f}-shift{s['timestep_shift']:.2f}"
+    cel = yaml.safe_load(open(os.path.join(ROOT, "ldmae_amd/configs/celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml")))
+    assert sample_folder_name(cel, cel["ckpt_path"]).startswith("lightningdit-b-1-ckpt-0060000-") and "cfg" not in sample_folder_name(cel, cel["ckpt_path"])
+    assert DEMO_LABELS == [975, 3, 207, 387, 388, 88, 979, 279]

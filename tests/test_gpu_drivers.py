@@ -135,12 +135,32 @@ def test_do_sample_end_to_end_writes_pngs(tmp_path, monkeypatch, dataset, cfg_sc
     os.makedirs(str(tmp_path / "feat_sample"))
     torch.save({"mean": torch.randn(1, 16, 1, 1, generator=g) * 0.1, "std": torch.rand(1, 16, 1, 1, generator=g) + 0.5},
                tmp_path / "feat_sample" / "latents_stats.pt")
-    out = inf.do_sample(cfg, str(tmp_path / "ckpt.pt"), str(tmp_path / "samples"))
+    out = inf.do_sample(cfg, str(tmp_path / "ckpt.pt"))
+    # the directory rule of inference.py:45-58: <output_dir>/<exp_name>/<model>-ckpt-<stem>-<method>-<steps>[-interval..-cfg..-shift..]
+    tail = "-interval0.10-cfg4.00-shift0.30" if cfg_scale > 1 else ""
+    assert out == os.path.join(cfg["train"]["output_dir"], cfg["train"]["exp_name"], "lightningdit-b-1-ckpt-ckpt-euler-2" + tail)
     files = sorted(os.listdir(out))
     assert files == [f"{i:06d}.png" for i in range(8)]                       # 2 batches of 4, world 1
     ims = [np.asarray(Image.open(os.path.join(out, f))) for f in files]
     assert all(im.shape == (64, 64, 3) and im.dtype == np.uint8 for im in ims)
     assert len({im.tobytes() for im in ims}) == 8 and all(im.std() > 0 for im in ims)      # eight different, non-constant images
+    # a folder that already holds more than fid_num PNGs is left alone (inference.py:69-77)
+    Image.fromarray(ims[0]).save(os.path.join(out, "extra.png"))
+    stamp = {f: os.path.getmtime(os.path.join(out, f)) for f in os.listdir(out)}
+    assert inf.do_sample(cfg, str(tmp_path / "ckpt.pt")) == out
+    assert stamp == {f: os.path.getmtime(os.path.join(out, f)) for f in os.listdir(out)}
+    # --demo (inference.py:54-57, 219-262): eight single-image calls with guidance on every step of the unshifted grid (the fixed ImageNet
+    # classes when guided, class 0 eight times otherwise), one 2 x 4 sheet under ./demo_images, nothing returned
+    monkeypatch.chdir(tmp_path)
+    assert inf.do_sample(cfg, str(tmp_path / "ckpt.pt"), demo=True) is None
+    sheet = np.asarray(Image.open(tmp_path / "demo_images" / f"{cfg['train']['exp_name']}_cfg{cfg_scale}_ckpt_demo_samples.png"))
+    assert sheet.shape == (128, 256, 3)
+    tiles = [sheet[i * 64:(i + 1) * 64, j * 64:(j + 1) * 64] for i in range(2) for j in range(4)]
+    assert len({t_.tobytes() for t_ in tiles}) == 8 and all(t_.std() > 0 for t_ in tiles)
+    # the diffusers AutoencoderKL branch of the reference (inference.py:137-167) is refused by name
+    cfg["vae"]["model_name"] = "sdv3_f8d16"
+    with pytest.raises(NotImplementedError, match="VMAE"):
+        inf.do_sample(cfg, str(tmp_path / "ckpt.pt"), str(tmp_path / "other"))
 
 
 def test_png_writer_surfaces_errors(tmp_path):
