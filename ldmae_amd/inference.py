@@ -239,7 +239,14 @@ if __name__ == "__main__":
     c = yaml.safe_load(open(a.config))
     if a.ckpt is None:
         assert 'ckpt_path' in c, "ckpt_path must be specified in config"
-    folder = do_sample(c, a.ckpt or c['ckpt_path'], a.out, demo=a.demo)
+    # run_inference.sh passes --mixed_precision $PRECISION (default bf16) to the launcher, which exports ACCELERATE_MIXED_PRECISION; the
+    # reference's sampler never prepares the model, so there the flag is inert and it samples in f32 with TF32 matmuls -- here it selects the
+    # activation type (bf16 = BASELINE config 5; PRECISION=fp32 / no -> the exact-f32 kernels)
+    precision = os.environ.get("PRECISION") or os.environ.get("ACCELERATE_MIXED_PRECISION") or "bf16"
+    precision = {"no": "fp32"}.get(precision, precision)
+    if precision not in ("bf16", "fp32"):
+        raise SystemExit(f"PRECISION={precision!r}: the sampler runs in bf16 or fp32")
+    folder = do_sample(c, a.ckpt or c['ckpt_path'], a.out, demo=a.demo, precision=precision)
     if not a.demo and int(os.environ.get("RANK", 0)) == 0:
         # inference.py:352-367 goes on to an Inception FID against data.fid_reference_file (tools/calculate_fid.py); that needs the Inception
         # weights, which this package does not carry (evaluation tools are out of scope)

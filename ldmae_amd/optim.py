@@ -195,6 +195,39 @@ class AdamWEMA:
             self.m[o:o + k].copy_(e["exp_avg"].reshape(-1)); self.v[o:o + k].copy_(e["exp_avg_sq"].reshape(-1))
         self.step_count = max(steps) if steps else 0                     # one bias-correction step for the fused kernel: torch's per-parameter steps agree
 
+    def torch_adamw_state_dict(self):
+        """The inverse of `load_torch_adamw_state`: this optimizer's step count and moments as a ``torch.optim.AdamW.state_dict()``, so that a
+        checkpoint written here resumes under the REFERENCE's drivers (VMAE/util/misc.py:523-525 `optimizer.load_state_dict(checkpoint
+        ['optimizer'])`; LDMAE/train_accum.py:180 keeps its own call commented out).  Groups as the reference builds them: one list of the trainable
+        parameters, or timm's [no_decay, decay] when this optimizer was built with per-group weight decay.  The group dicts carry torch's full
+        key set (taken from a throw-away torch.optim.AdamW over empty tensors), the state tensors are views of the slabs in parameter shape."""
+        named = [(n, p) for n, p in self.module.named_parameters() if p.requires_grad]
+        if len(self.flat.groups) == 2:
+            gwd = self.group_weight_decay or {}
+            nd = lambda n, p: p.ndim <= 1 or n.endswith(".bias")      # noqa: E731
+            first, second = [n for n, p in named if nd(n, p)], [n for n, p in named if not nd(n, p)]
+            f = self.flat
+            gid = lambda n: next(g for g, (lo, hi) in f.groups.items() if lo <= f.offsets[n][0] < hi)      # noqa: E731
+            wds = [{gwd.get(gid(n), self.weight_decay) for n in part} for part in (first, second)]
+            if any(len(w) > 1 for w in wds):
+                raise RuntimeError("AdamWEMA.torch_adamw_state_dict: the weight-decay groups of this optimizer are not timm's [no_decay, decay] split")
+            parts = [(first, wds[0].pop() if wds[0] else 0.0), (second, wds[1].pop() if wds[1] else self.weight_decay)]
+        elif len(self.flat.groups) > 2:
+            raise RuntimeError(f"AdamWEMA.torch_adamw_state_dict: {len(self.flat.groups)} parameter groups; one or timm's two can be written")
+        else:
+            parts = [([n for n, _ in named], self.weight_decay)]
+        dummy = {n: torch.nn.Parameter(torch.empty(0)) for n, _ in named}
+        shell = torch.optim.AdamW([{"params": [dummy[n] for n in part], "weight_decay": wd} for part, wd in parts],
+                                  lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay)
+        sd = shell.state_dict()
+        shapes = dict(named)
+        if self.step_count > 0:
+            order = [n for part, _ in parts for n in part]
+            for i, n in enumerate(order):
+                sd["state"][i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.flat.view(self.m, n, shapes[n].shape),
+                                  "exp_avg_sq": self.flat.view(self.v, n, shapes[n].shape)}
+        return sd
+
     @torch.no_grad()
     def swap_in_ema(self):
         """Exchange the live parameters with their EMA (sampling from the EMA weights inside a training process; call again to swap

@@ -227,7 +227,7 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
             if train_steps % tr_cfg['ckpt_every'] == 0 and train_steps > 0:
                 if rank == 0:
                     path = f"{ckpt_dir}/{train_steps:07d}.pt"
-                    torch.save({"model": model.state_dict(), "ema": opt.ema_state_dict(), "opt": opt.state_dict(), "config": cfg}, path)
+                    torch.save({"model": model.state_dict(), "ema": opt.ema_state_dict(), "opt": opt.torch_adamw_state_dict(), "config": cfg}, path)   # train_accum.py:275-280: "opt" = AdamW.state_dict()
                     logger.info(f"Saved checkpoint to {path}")
                 if world > 1:
                     dist.barrier()

@@ -292,7 +292,9 @@ def save_model(args, epoch, model, opt, scaler, rank=0):
         return None
     os.makedirs(args.output_dir, exist_ok=True)
     path = os.path.join(args.output_dir, f"checkpoint-{epoch}.pth")
-    torch.save({"model": model.state_dict(), "optimizer": opt.state_dict(), "epoch": epoch,
+    # 'optimizer' in torch.optim.AdamW's own format over timm's [no_decay, decay] groups: what the reference's save_model writes and its load_model
+    # feeds to optimizer.load_state_dict (misc.py:474-481, 523-525) -- a checkpoint written here resumes there and the other way round
+    torch.save({"model": model.state_dict(), "optimizer": opt.torch_adamw_state_dict(), "epoch": epoch,
                 "scaler": scaler.state_dict() if scaler is not None else None, "args": vars(args)}, path)
     return path
 
@@ -319,10 +321,9 @@ def load_model(args, model, opt, scaler, log=print):
     start = args.start_epoch
     if "optimizer" in ck and "epoch" in ck:
         if not resized:                     # (a resized grid changes the slab: the moments of the old layout do not apply)
-            # our own checkpoints carry the slab state with its layout record; the reference's save_model (misc.py:474-481) writes
-            # torch.optim.AdamW.state_dict() -- its moments are mapped by parameter order (AdamWEMA.load_torch_adamw_state).  A state that fits
-            # neither is skipped with a message (model / epoch / scaler are still restored); the 'optimizer' entry written HERE is
-            # framework-specific and not loadable by the reference.
+            # the reference's save_model (misc.py:474-481) and ours both write torch.optim.AdamW.state_dict(): its moments are mapped by parameter
+            # order (AdamWEMA.load_torch_adamw_state); checkpoints of earlier rounds carry the slab state with its layout record.  A state that
+            # fits neither is skipped with a message (model / epoch / scaler are still restored).
             try:
                 opt.load_state_dict(ck["optimizer"])
                 opt.ema.copy_(opt.flat.params) if "param_groups" in ck["optimizer"] else None     # a torch state has no EMA: restart it from the weights

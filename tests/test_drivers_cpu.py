@@ -265,7 +265,7 @@ def test_resume_from_a_reference_style_optimizer_state(tmp_path):
     path = tmp_path / "checkpoint-7.pth"
     torch.save({"model": ref.state_dict(), "optimizer": topt.state_dict(), "epoch": 7, "scaler": {"scale": 1024.0, "_growth_tracker": 5}, "args": None}, path)
     net = Net()
-    opt = AdamWEMA(net, flat=FlatParams(net, group_fn=vp.no_decay))
+    opt = AdamWEMA(net, flat=FlatParams(net, group_fn=vp.no_decay), weight_decay=0.05, group_weight_decay={0: 0.05, 1: 0.0})    # as vp.build_optimizer
     scaler = vp.LossScaler()
     args = argparse.Namespace(resume=str(path), start_epoch=0)
     msgs = []
@@ -282,6 +282,23 @@ def test_resume_from_a_reference_style_optimizer_state(tmp_path):
     t1.zero_grad(); ref.b(ref.n(ref.a(torch.randn(5, 8)))).pow(2).sum().backward(); t1.step()
     opt.load_state_dict(t1.state_dict())
     assert opt.step_count == 1
+    # ... and back: the state this optimizer WRITES is a torch.optim.AdamW.state_dict() the reference's load_model can feed to its optimizer
+    # (misc.py:523-525), group for group, and reading it again reproduces the slabs bit for bit
+    opt.load_state_dict(topt.state_dict())
+    out = opt.torch_adamw_state_dict()
+    assert [len(g["params"]) for g in out["param_groups"]] == [len(nd), len(dc)] and [g["weight_decay"] for g in out["param_groups"]] == [0.0, 0.05]
+    assert set(out["param_groups"][0]) == set(topt.state_dict()["param_groups"][0])
+    t2 = torch.optim.AdamW([{"params": nd, "weight_decay": 0.0}, {"params": dc, "weight_decay": 0.05}], lr=1e-3, betas=(0.9, 0.95))
+    t2.load_state_dict(out)
+    for g_a, g_b in zip(t2.param_groups, topt.param_groups):
+        for p_a, p_b in zip(g_a["params"], g_b["params"]):
+            assert all(torch.equal(t2.state[p_a][k], topt.state[p_b][k]) for k in ("exp_avg", "exp_avg_sq")) and float(t2.state[p_a]["step"]) == 3
+    net2 = Net()
+    opt2 = AdamWEMA(net2, flat=FlatParams(net2, group_fn=vp.no_decay))
+    opt2.load_state_dict(out)
+    assert opt2.step_count == 3 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    single = AdamWEMA(Net()).torch_adamw_state_dict()                 # one list of parameters, never stepped: torch's empty state
+    assert len(single["param_groups"]) == 1 and len(single["param_groups"][0]["params"]) == len(named) and single["state"] == {}
     # states that fit nothing: refused with the optimizer untouched; load_model logs and goes on
     m0, step0 = opt.m.clone(), opt.step_count
     bad = topt.state_dict()
@@ -318,3 +335,45 @@ def test_sample_folder_name_follows_the_reference_rule():
     cel = yaml.safe_load(open(os.path.join(ROOT, "ldmae_amd/configs/celeba_hq/lightningdit_b_vmae_f8d16_cfg.yaml")))
     assert sample_folder_name(cel, cel["ckpt_path"]).startswith("lightningdit-b-1-ckpt-0060000-") and "cfg" not in sample_folder_name(cel, cel["ckpt_path"])
     assert DEMO_LABELS == [975, 3, 207, 387, 388, 88, 979, 279]
+
+
+def test_pe_reset_writes_the_resized_checkpoint(tmp_path):
+    """Stage 2 of VMAE/train_ae.sh (pe_reset.py:20-77): both position embeddings resized to the target grid (bilinear, the resume path's rule),
+    everything else untouched, written as <checkpoint>_pe.pth; both spellings of the path flag (pe_reset.py:90 / train_ae.sh:66) parse."""
+    from ldmae_amd import pe_reset
+    from ldmae_amd.tokenizer import models_mae
+    from ldmae_amd.vmae_pretrain import resize_pos_embed
+    torch.manual_seed(0)
+    m = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=True, no_cls=True, img_size=64, smooth_output=True, kl_loss_weight=None)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["pos_embed"] = torch.randn_like(sd["pos_embed"])
+    sd["decoder_pos_embed"] = torch.randn_like(sd["decoder_pos_embed"])
+    path = tmp_path / "checkpoint-90.pth"
+    torch.save({"model": sd, "epoch": 90}, path)
+    out = pe_reset.main(["--ckpt_dir", str(path), "--input_size", "128"])
+    assert out == str(tmp_path / "checkpoint-90_pe.pth")
+    new = torch.load(out, map_location="cpu")
+    assert new["epoch"] == 90 and new["model"]["pos_embed"].shape == (1, 256, sd["pos_embed"].shape[2])
+    assert torch.equal(new["model"]["pos_embed"], resize_pos_embed(sd["pos_embed"], 16))
+    assert torch.equal(new["model"]["decoder_pos_embed"], resize_pos_embed(sd["decoder_pos_embed"], 16))
+    assert all(torch.equal(new["model"][k], v) for k, v in sd.items() if "pos_embed" not in k)
+    big = models_mae.mae_for_ldmae_f8d16_prev(ldmae_mode=True, no_cls=True, img_size=128, smooth_output=True, kl_loss_weight=None)
+    assert not big.load_state_dict(new["model"], strict=False).unexpected_keys
+    same = pe_reset.main(["--chkpt_dir", str(path), "--input_size", "64"])          # same grid: a plain copy
+    assert torch.equal(torch.load(same, map_location="cpu")["model"]["pos_embed"], sd["pos_embed"])
+
+
+def test_launcher_scripts_mirror_the_references():
+    """run_train.sh / run_inference.sh / run_fast_inference.sh / run_extract_feature.sh / train_ae.sh: present, executable, valid bash, the driver and
+    the default port of the reference script each stands for."""
+    import subprocess
+    want = {"run_train.sh": ("train_accum.py", "1235"), "run_inference.sh": ("inference.py", "1237"), "run_fast_inference.sh": ("inference.py", "1236"),
+            "run_extract_feature.sh": ("extract_features.py", "1235"), "train_ae.sh": ("vmae_pretrain.py", None)}
+    for name, (driver, port) in want.items():
+        path = os.path.join(ROOT, "ldmae_amd", name)
+        assert os.access(path, os.X_OK), name
+        assert subprocess.run(["bash", "-n", path]).returncode == 0, name
+        text = open(path).read()
+        assert driver in text and (port is None or f"MASTER_PORT:-{port}" in text), name
+    assert "--demo" in open(os.path.join(ROOT, "ldmae_amd", "run_fast_inference.sh")).read()
+    assert "pe_reset.py" in open(os.path.join(ROOT, "ldmae_amd", "train_ae.sh")).read()
