@@ -171,7 +171,7 @@ def do_sample(cfg, ckpt_path, out_dir=None, num_samples=None, precision="bf16", 
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     torch.manual_seed(cfg['train']['global_seed'] * world + rank)
-    model = build_model(cfg)
+    model = build_model(cfg, learn_sigma=cfg['model'].get('learn_sigma', False))        # inference.py:336-348
     ck = torch.load(ckpt_path, map_location='cpu')
     model.load_state_dict(ck["ema"] if "ema" in ck else ck)
     model = model.to(device).eval()

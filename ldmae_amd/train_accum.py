@@ -48,8 +48,8 @@ def create_logger(logging_dir, rank):
     return logger
 
 
-def build_model(cfg):
-    """train_accum.py:73-90."""
+def build_model(cfg, **extra):
+    """train_accum.py:73-90.  `extra`: keywords only the sampler's call passes (inference.py:346 `learn_sigma`)."""
     ds = cfg['vae'].get('downsample_ratio', 16)
     assert cfg['data']['image_size'] % ds == 0, "Image size must be divisible by the VAE downsample ratio."
     m = cfg['model']
@@ -57,7 +57,7 @@ def build_model(cfg):
         input_size=cfg['data']['image_size'] // ds, num_classes=cfg['data']['num_classes'], use_qknorm=m['use_qknorm'],
         use_swiglu=m.get('use_swiglu', False), use_rope=m.get('use_rope', False), use_rmsnorm=m.get('use_rmsnorm', False),
         wo_shift=m.get('wo_shift', False), in_channels=m.get('in_chans', 4), use_checkpoint=m.get('use_checkpoint', False),
-        class_dropout_prob=0 if cfg['data']['num_classes'] == 1 else 0.1)
+        class_dropout_prob=0 if cfg['data']['num_classes'] == 1 else 0.1, **extra)
 
 
 def load_weights_with_shape_check(model, checkpoint, rank=0):
