@@ -229,13 +229,13 @@ def do_sample(cfg, ckpt_path, out_dir=None, num_samples=None, precision="bf16", 
     return out_dir
 
 
-if __name__ == "__main__":
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', type=str, default='configs/lightningdit_b_ldmvae_f16d16.yaml')           # inference.py:318
     ap.add_argument('--demo', action='store_true', default=False)                                          # inference.py:319
     ap.add_argument('--ckpt', type=str, default=None, help="default: the config's ckpt_path (inference.py:324-327)")
     ap.add_argument('--out', type=str, default=None, help="default: <output_dir>/<exp_name>/<the reference's folder name>")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     c = yaml.safe_load(open(a.config))
     if a.ckpt is None:
         assert 'ckpt_path' in c, "ckpt_path must be specified in config"
@@ -251,3 +251,8 @@ if __name__ == "__main__":
         # inference.py:352-367 goes on to an Inception FID against data.fid_reference_file (tools/calculate_fid.py); that needs the Inception
         # weights, which this package does not carry (evaluation tools are out of scope)
         print(f"samples written to {folder}; FID (tools/calculate_fid.py in the reference) is not part of this package")
+    return folder
+
+
+if __name__ == "__main__":
+    main()

@@ -157,10 +157,26 @@ def test_do_sample_end_to_end_writes_pngs(tmp_path, monkeypatch, dataset, cfg_sc
     assert sheet.shape == (128, 256, 3)
     tiles = [sheet[i * 64:(i + 1) * 64, j * 64:(j + 1) * 64] for i in range(2) for j in range(4)]
     assert len({t_.tobytes() for t_ in tiles}) == 8 and all(t_.std() > 0 for t_ in tiles)
+    # the command line of run_inference.sh: --config only, checkpoint from the YAML's ckpt_path (inference.py:324-327), PRECISION from the launcher's
+    # environment (fp32 -> the exact-f32 kernels: a second folder of eight PNGs, close to but not bit-equal with the bf16 ones)
+    cfg["ckpt_path"] = str(tmp_path / "0000007.pt")
+    os.replace(tmp_path / "ckpt.pt", cfg["ckpt_path"])
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    monkeypatch.setenv("PRECISION", "fp32")
+    out32 = inf.main(["--config", str(tmp_path / "cfg.yaml")])
+    assert os.path.basename(out32) == "lightningdit-b-1-ckpt-0000007-euler-2" + tail and out32 != out
+    ims32 = [np.asarray(Image.open(os.path.join(out32, f"{i:06d}.png"))).astype(np.int32) for i in range(8)]
+    diff = np.mean([np.abs(a_ - b_.astype(np.int32)).mean() for a_, b_ in zip(ims32, ims)])
+    assert diff < 8.0, diff                                      # same seeds, same noise: bf16 against f32 sampling, in uint8 steps
+    monkeypatch.setenv("PRECISION", "fp8")
+    with pytest.raises(SystemExit):
+        inf.main(["--config", str(tmp_path / "cfg.yaml")])
+    monkeypatch.delenv("PRECISION")
     # the diffusers AutoencoderKL branch of the reference (inference.py:137-167) is refused by name
     cfg["vae"]["model_name"] = "sdv3_f8d16"
     with pytest.raises(NotImplementedError, match="VMAE"):
-        inf.do_sample(cfg, str(tmp_path / "ckpt.pt"), str(tmp_path / "other"))
+        inf.do_sample(cfg, cfg["ckpt_path"], str(tmp_path / "other"))
 
 
 def test_png_writer_surfaces_errors(tmp_path):
