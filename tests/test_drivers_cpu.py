@@ -363,17 +363,36 @@ def test_pe_reset_writes_the_resized_checkpoint(tmp_path):
     assert torch.equal(torch.load(same, map_location="cpu")["model"]["pos_embed"], sd["pos_embed"])
 
 
-def test_launcher_scripts_mirror_the_references():
-    """run_train.sh / run_inference.sh / run_fast_inference.sh / run_extract_feature.sh / train_ae.sh: present, executable, valid bash, the driver and
-    the default port of the reference script each stands for."""
+def test_launcher_scripts_mirror_the_references(tmp_path):
+    """run_train.sh / run_inference.sh / run_fast_inference.sh / run_extract_feature.sh (shared body _launch.sh) and train_ae.sh: executable, valid
+    bash, and -- run here against a stand-in `python` that prints its arguments -- the command each one starts: the driver, the process count from
+    GPUS_PER_NODE x WORLD_SIZE (machines), RANK as the machine index, the reference script's own default port, PRECISION exported, extra
+    arguments handed on to the driver."""
     import subprocess
-    want = {"run_train.sh": ("train_accum.py", "1235"), "run_inference.sh": ("inference.py", "1237"), "run_fast_inference.sh": ("inference.py", "1236"),
-            "run_extract_feature.sh": ("extract_features.py", "1235"), "train_ae.sh": ("vmae_pretrain.py", None)}
-    for name, (driver, port) in want.items():
-        path = os.path.join(ROOT, "ldmae_amd", name)
-        assert os.access(path, os.X_OK), name
-        assert subprocess.run(["bash", "-n", path]).returncode == 0, name
-        text = open(path).read()
-        assert driver in text and (port is None or f"MASTER_PORT:-{port}" in text), name
-    assert "--demo" in open(os.path.join(ROOT, "ldmae_amd", "run_fast_inference.sh")).read()
-    assert "pe_reset.py" in open(os.path.join(ROOT, "ldmae_amd", "train_ae.sh")).read()
+    d = os.path.join(ROOT, "ldmae_amd")
+    for name in ("run_train.sh", "run_inference.sh", "run_fast_inference.sh", "run_extract_feature.sh", "train_ae.sh"):
+        assert os.access(os.path.join(d, name), os.X_OK), name
+    for name in ("run_train.sh", "run_inference.sh", "run_fast_inference.sh", "run_extract_feature.sh", "train_ae.sh", "_launch.sh"):
+        assert subprocess.run(["bash", "-n", os.path.join(d, name)]).returncode == 0, name
+    shim = tmp_path / "bin"
+    shim.mkdir()
+    (shim / "python").write_text('#!/bin/bash\necho "ARGS $@"\necho "ENV PRECISION=$PRECISION RANK=${RANK:-unset} WORLD_SIZE=${WORLD_SIZE:-unset}"\n')
+    os.chmod(shim / "python", 0o755)
+    env = {"PATH": f"{shim}:/usr/bin:/bin", "LDMAE_USE_TORCHRUN": "1"}
+
+    def run(name, *args, **extra):
+        r = subprocess.run(["bash", os.path.join(d, name), *args], env={**env, **extra}, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return r.stdout
+    out = run("run_train.sh", "configs/imagenet/x.yaml", "--synthetic", GPUS_PER_NODE="4", WORLD_SIZE="2", RANK="1", PRECISION="fp32")
+    assert "--nnodes 2 --node-rank 1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 1235 train_accum.py --config configs/imagenet/x.yaml --synthetic" in out
+    assert "ENV PRECISION=fp32 RANK=unset WORLD_SIZE=unset" in out           # WORLD_SIZE / RANK meant machines: not leaked to the launcher
+    out = run("run_inference.sh", "c.yaml")
+    assert "--nnodes 1 --node-rank 0 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 1237 inference.py --config c.yaml" in out and "PRECISION=bf16" in out
+    out = run("run_fast_inference.sh", "c.yaml", GPUS_PER_NODE="8", WORLD_SIZE="4", MASTER_PORT="2000")
+    assert "--nnodes 1 --node-rank 0 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2000 inference.py --config c.yaml --demo" in out
+    out = run("run_extract_feature.sh", "c.yaml", GPUS_PER_NODE="2")
+    assert "--nproc-per-node 2 --master-addr 127.0.0.1 --master-port 1235 extract_features.py --config c.yaml" in out
+    out = run("train_ae.sh", GPUS_PER_NODE="2", DATA_PATH="/d/imagenet", OUT=str(tmp_path / "w"))
+    assert "vmae_pretrain.py --batch_size 128 --no_cls --accum_iter 2" in out and "--fixed_std 1e-3" in out and "--data_path /d/imagenet" in out
+    assert f"pe_reset.py --model_name mae_for_ldmae_f8d16_prev --ckpt_dir {tmp_path / 'w'}/checkpoint-90.pth" in out and "perceptual" not in out.split("Stage 3")[0]
