@@ -53,6 +53,8 @@ extern "C" {
                                   [ceil(M/128)][2Hs] f32 partial column sums of dh12 as stored (bias gradient; caller sums the rows) */
 #define LDMAE_EPI_GELU_BWD 6   /* C = dpre [M,N] = g * gelu_erf'(pre), g = acc (+ bias) rounded to out_dtype first; xin (read as out_dtype*) = pre [M, ldc]:
                                   the input gradient of fc2 with the GELU backward of the VMAE Mlp fused (models_mae.py:172: timm Mlp) */
+#define LDMAE_EPI_QKV_ROPE 7   /* bf16 only, through ldmae_gemm_nt_qkv_rope: the qkv Linear with the QK-RMSNorm + RoPE front end of the attention fused
+                                  (a wave's 64 output columns are one head of q, k or v) */
 /* launch mode, or'ed into `epi` per call (bf16 GEMMs): one 256x256 tile per workgroup instead of one persistent workgroup per CU.  A
    data-parallel caller sets it while RCCL's collective kernels share the chip with backward (ldmae_amd/distributed.py); results are
    bitwise equal to the persistent launch */
@@ -80,6 +82,16 @@ const char* ldmae_arch(void);     /* "gfx950" */
 int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                   int M, int N, int K, const float* bias, float beta, const float* xin, float* xout,
                   const float* gate, int gate_ld, int rows_per_batch, void* stream);
+/* The qkv Linear of the DiT block (lightningdit.py:68) with q_norm / k_norm / RoPE (:70-74) applied in the GEMM's epilogue, head dim 64, bf16:
+ *   qkv [B*N, 3*H*64] = A [B*N, K] . W [3*H*64, K]^T + bias as ldmae_gemm_nt(EPI_BIAS) writes it (the backward pass reads the pre-norm q / k rows; with
+ *   store_raw_qk = 0 -- forward-only calls -- only the v third is written), and q2, k2 [B, H, N, 64] = what ldmae_qknorm_rope_fwd makes of the stored
+ *   (bf16-rounded) q and k: bitwise the same values, without the pass that re-reads them.  wq = wk = NULL: RoPE only (use_qknorm = False).
+ *   Covers B*N % 256 == 0, N % 128 == 0, K % 64 == 0, 128-B aligned operands (ldmae_gemm_nt_qkv_rope_ok says whether a shape is covered; the
+ *   caller otherwise runs ldmae_gemm_nt + ldmae_qknorm_rope_fwd).  tile_launch: as LDMAE_EPI_TILE_LAUNCH. */
+int ldmae_gemm_nt_qkv_rope_ok(int B, int N, int H, int hd, int K, int lda, int ldb);
+int ldmae_gemm_nt_qkv_rope(const void* A, int lda, const void* W, int ldb, const float* bias, void* qkv, void* q2, void* k2, const float* wq,
+                           const float* wk, const float* cos, const float* sin, int B, int N, int H, int hd, int K, float eps, int store_raw_qk,
+                           int tile_launch, void* stream);
 /* C[N,K] (f32) = beta*C + A[M,N]^T . B[M,K]: weight gradient of the same layers (contraction over
  * token rows, split over workgroups; partial slabs are summed in fixed order -> deterministic). */
 int ldmae_gemm_tn_splits(int dtype, int M, int N, int K);

@@ -25,6 +25,8 @@ SIGNATURES = {
     "ldmae_version": (C.c_char_p, []),
     "ldmae_arch": (C.c_char_p, []),
     "ldmae_gemm_nt": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _i, _i, _vp]),
+    "ldmae_gemm_nt_qkv_rope_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "ldmae_gemm_nt_qkv_rope": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "ldmae_gemm_tn_splits": (_i, [_i, _i, _i, _i]),
     "ldmae_gemm_tn_workspace_bytes": (_l, [_i, _i, _i, _i]),
     "ldmae_gemm_tn": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _l, _vp]),

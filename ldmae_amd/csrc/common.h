@@ -160,6 +160,12 @@ template <int W> __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// RoPE on two interleaved pairs (VisionRotaryEmbeddingFast.forward, pos_embed.py:135: t * cos + rotate_half(t) * sin, rotate_half: (x0, x1) -> (-x1, x0)).
+// One definition for the QK-norm / RoPE kernels of elementwise.hip and the fused qkv epilogue of gemm_nt_common.h: they agree bit for bit.
+__device__ __forceinline__ float4 rope_apply(float4 t, float4 c, float4 s) {
+  return make_float4(t.x * c.x - t.y * s.x, t.y * c.y + t.x * s.y, t.z * c.z - t.w * s.z, t.w * c.w + t.z * s.w);
+}
+
 // XCD-aware bijective block remap (8 XCDs, blocks dealt round-robin): consecutive
 // logical tiles land on one XCD so neighbours share that XCD's L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {

@@ -507,9 +507,7 @@ extern "C" int ldmae_layernorm_modulate_bwd_gate(int dtype, const void* dout, co
 
 // ------------------------------------------------------------------ QK-RMSNorm + RoPE + head-major relayout
 // item = (b, n, h); LPR lanes per item, 4 elements per lane.
-__device__ __forceinline__ float4 rope_apply(float4 t, float4 c, float4 s) {
-  return make_float4(t.x * c.x - t.y * s.x, t.y * c.y + t.x * s.y, t.z * c.z - t.w * s.z, t.w * c.w + t.z * s.w);
-}
+// (rope_apply: common.h -- shared with the fused qkv epilogue of gemm_nt_common.h)
 __device__ __forceinline__ float4 rope_apply_bwd(float4 g, float4 c, float4 s) {
   return make_float4(g.x * c.x + g.y * s.y, g.y * c.y - g.x * s.x, g.z * c.z + g.w * s.w, g.w * c.w - g.z * s.z);
 }

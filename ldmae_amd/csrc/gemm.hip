@@ -903,6 +903,44 @@ extern "C" int ldmae_gemm_nt(int dtype, int out_dtype, int epi, const void* A, i
                                  : launch_nt<float>(dtype, epi, tile_launch, half_lines, A, B, M, N, K, lda, ldb, e, as_stream(stream));
 }
 
+// ---- the qkv Linear with QK-RMSNorm + RoPE in the epilogue (whole-line kernel only; include/ldmae_hip.h)
+extern "C" int ldmae_gemm_nt_qkv_rope_ok(int B, int N, int H, int hd, int K, int lda, int ldb) {
+  const long M = (long)B * N;
+  return hd == 64 && B > 0 && N > 0 && H > 0 && M % 256 == 0 && M < (1l << 31) && N % 128 == 0 && (3 * H * 64) % 256 == 0 && K > 0 && K % 64 == 0 &&
+         lda % 64 == 0 && ldb % 64 == 0 && lda >= K && ldb >= K;
+}
+
+extern "C" int ldmae_gemm_nt_qkv_rope(const void* A, int lda, const void* W, int ldb, const float* bias, void* qkv, void* q2, void* k2, const float* wq,
+                                      const float* wk, const float* cos, const float* sin, int B, int N, int H, int hd, int K, float eps,
+                                      int store_raw_qk, int tile_launch, void* stream) {
+  LDMAE_REQUIRE(A && W && qkv && q2 && k2 && cos && sin, "gemm_nt_qkv_rope: null pointer (only bias and wq / wk may be NULL)");
+  LDMAE_REQUIRE(!wq == !wk, "gemm_nt_qkv_rope: pass both QK-norm weights or neither (RoPE only)");
+  LDMAE_REQUIRE(ldmae_gemm_nt_qkv_rope_ok(B, N, H, hd, K, lda, ldb),
+                "gemm_nt_qkv_rope: shape outside the fused kernel (head_dim 64, B*N %% 256 == 0, N %% 128 == 0, 3*H*64 %% 256 == 0, K / lda / ldb %% 64 == 0): "
+                "B=%d N=%d H=%d hd=%d K=%d lda=%d ldb=%d -- use ldmae_gemm_nt + ldmae_qknorm_rope_fwd", B, N, H, hd, K, lda, ldb);
+  LDMAE_REQUIRE(((uintptr_t)A & 127) == 0 && ((uintptr_t)W & 127) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)q2 & 15) == 0 && ((uintptr_t)k2 & 15) == 0 &&
+                ((uintptr_t)cos & 15) == 0 && ((uintptr_t)sin & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) && (!wq || (((uintptr_t)wq | (uintptr_t)wk) & 3) == 0),
+                "gemm_nt_qkv_rope: operands must start on 128-B lines, outputs / tables / bias on 16 B");
+  const int M = B * N, Nc = 3 * H * 64;
+  EpiArgs e{};
+  e.C = qkv; e.ldc = Nc; e.bias = bias; e.rows_per_batch = N; e.f16_max = 65504.f;
+  e.q2 = q2; e.k2 = k2; e.wq = wq; e.wk = wk; e.cosT = cos; e.sinT = sin; e.heads = H; e.store_raw_qk = store_raw_qk; e.eps = eps;
+  hipStream_t st = as_stream(stream);
+  const long pi = ldmae_prof_is_on() ? ldmae_prof_begin(st, 2.0 * M * Nc * K) : -1;
+  int ncu = 0, dev = 0;
+  hipGetDevice(&dev);
+  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  ncu = ncu >= 8 ? ncu / 8 * 8 : 8;
+  const int ntiles = cdiv(M, 256) * cdiv(Nc, 256);
+  const bool pers = !tile_launch && cdiv(M, 256) >= 8;
+  const int pgrid = (pers && ntiles != ncu) ? ncu : ntiles;
+  ldmae_count(LDMAE_COUNT_NT_BF16);
+  LDMAE_REQUIRE(ldmae_launch_nt_lines(LDMAE_EPI_QKV_ROPE, 1, A, W, M, Nc, K, lda, ldb, e, pgrid, ntiles, st), "gemm_nt_qkv_rope: the whole-line kernel refused the shape");
+  if (pi >= 0) ldmae_prof_end(pi, st);
+  LDMAE_CHECK_LAUNCH("gemm_nt_qkv_rope");
+  return LDMAE_OK;
+}
+
 static int tn_plan(int dtype, int M, int N, int K, int* rows_out) {
   const bool ring = dtype == LDMAE_BF16 && ldmae_tune_get(1) == 0 && M % 32 == 0;
   const int bn = ring ? 256 : (dtype == LDMAE_BF16 ? TN_BN : FT_BN), bk = ring ? 256 : (dtype == LDMAE_BF16 ? TN_BK : FT_BK);

@@ -20,6 +20,16 @@ struct EpiArgs {
   int ldc;              // row stride of C in elements
   float beta;           // EPI_BIAS with f32 out: C = acc + bias + beta*C   (beta 0 or 1: gradient accumulation)
   float f16_max;        // fp16 outputs: clamp to +-f16_max before the conversion (65504: forward GEMMs saturate; infinity: gradient GEMMs overflow to inf)
+  // EPI_QKV_ROPE: C = packed qkv [M, 3*heads*64]; q2 / k2 head-major [B, heads, rows_per_batch, 64]; QK-norm weights (NULL: RoPE only), tables [rows_per_batch, 64]
+  void* q2;
+  void* k2;
+  const float* wq;
+  const float* wk;
+  const float* cosT;
+  const float* sinT;
+  int heads;
+  int store_raw_qk;     // 0: forward-only call, the pre-norm q / k thirds of C are not written
+  float eps;
 };
 
 // gemm_nt_lines.hip: the whole-line form of the persistent bf16 NT kernel (128-B LDS rows, seamless ring of five half-block slots).  Returns 0
@@ -192,6 +202,82 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MI][NI], float* ew, flo
       for (int r = 0; r < 4; ++r) ew[((lane >> 4) * 4 + r) * ELD + j * 16 + (lane & 15)] = acc[i][cblk * 4 + j][r];
     consumed(i, cblk);
   };
+  if constexpr (EPI == LDMAE_EPI_QKV_ROPE) {
+    // The qkv Linear of the DiT block with q_norm / k_norm / RoPE in the epilogue.  TNn == 64: a wave's column slice is ONE head of q, k or v, and the
+    // strip lane map (8 lanes x 8 columns per row) is the lane group of qknorm_rope_fwd8_kernel (elementwise.hip) -- the same arithmetic in the same
+    // order on the same bf16-rounded values, so q2 / k2 are bitwise what GEMM + that kernel produce, without its 806-MB re-read at bs 256.
+    // Host contract (ldmae_gemm_nt_qkv_rope_ok): M % 256 == 0, rows_per_batch % 128 == 0 (a wave's 128 rows lie in one sample), N == 3 * heads * 64.
+    static_assert(TNn == 64 && sizeof(OutT) == 2, "EPI_QKV_ROPE: 64-column wave slices, bf16 outputs");
+    const int nb = n0 + wn * TNn, c8 = (lane & 7) * 8, mw = m0 + wm * TM;
+    const int which = nb / (e.heads * 64), hh = (nb >> 6) % e.heads;                      // wave-uniform: 0 q, 1 k, 2 v
+    const int bsmp = mw / e.rows_per_batch, tok0 = mw - bsmp * e.rows_per_batch;
+    const float4 b0 = e.bias ? *(const float4*)(e.bias + nb + c8) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b1 = e.bias ? *(const float4*)(e.bias + nb + c8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned coff = ((unsigned)(lane >> 3) * (unsigned)e.ldc + (unsigned)(nb + c8)) * 2u;       // raw qkv: wave-uniform row base + this lane offset
+    auto raw8 = [&](int i, int it, const bf16x8& o) {
+      char* rb = (char*)e.C + (size_t)(mw + i * 16 + it * 8) * (size_t)e.ldc * 2;
+      __builtin_nontemporal_store(o, (bf16x8*)(rb + coff));
+    };
+    auto round8 = [&](const float4& u, const float4& v) {
+      bf16x8 o;
+      o[0] = (bf16)(u.x + b0.x); o[1] = (bf16)(u.y + b0.y); o[2] = (bf16)(u.z + b0.z); o[3] = (bf16)(u.w + b0.w);
+      o[4] = (bf16)(v.x + b1.x); o[5] = (bf16)(v.y + b1.y); o[6] = (bf16)(v.z + b1.z); o[7] = (bf16)(v.w + b1.w);
+      return o;
+    };
+    if (which == 2) {                                                                       // v: the plain bias epilogue
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        fill(i, 0);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = it * 8 + (lane >> 3);
+          raw8(i, it, round8(*(const float4*)(ew + row * ELD + c8), *(const float4*)(ew + row * ELD + c8 + 4)));
+        }
+      }
+      return;
+    }
+    const bool norm = e.wq != nullptr;
+    const float* wsel = which == 0 ? e.wq : e.wk;
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = norm ? wsel[c8 + j] : 1.f;
+    // this wave's 128 rows of head hh are 128 consecutive 128-B rows of q2 / k2
+    char* const dstb = (char*)(which == 0 ? e.q2 : e.k2) + (((size_t)bsmp * e.heads + hh) * e.rows_per_batch + tok0) * 128 + (size_t)(lane >> 3) * 128 + c8 * 2;
+    const unsigned toff = ((unsigned)(tok0 + (lane >> 3)) * 64u + (unsigned)c8) * 4u;      // tables: row tok0 + strip row, this lane's 8 columns
+    float4 cs[2 * MI][2], sn[2 * MI][2];                                                    // fully unrolled: only the look-ahead's worth is live
+    // table rows of half-strip s = 2 i + it, requested one HALF-strip ahead and BEFORE the previous half's stores (vmcnt retires in issue order: a
+    // load issued behind a store cannot be waited for without draining that store); a whole strip ahead costs 32 more live registers and spilled
+    auto ldt = [&](int s2) {
+      const unsigned o = toff + (unsigned)(s2 * 8) * 256u;
+      cs[s2][0] = *(const float4*)((const char*)e.cosT + o); cs[s2][1] = *(const float4*)((const char*)e.cosT + o + 16);
+      sn[s2][0] = *(const float4*)((const char*)e.sinT + o); sn[s2][1] = *(const float4*)((const char*)e.sinT + o + 16);
+    };
+    ldt(0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      fill(i, 0);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int s2 = 2 * i + it;
+        if (s2 + 1 < 2 * MI) ldt(s2 + 1);
+        const int row = it * 8 + (lane >> 3);
+        const bf16x8 x = round8(*(const float4*)(ew + row * ELD + c8), *(const float4*)(ew + row * ELD + c8 + 4));
+        if (e.store_raw_qk) raw8(i, it, x);
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = (float)x[j];
+        // the association of qknorm_rope_fwd8_kernel: pairs, 4-chunks, the 8-lane butterfly
+        const float sq = ((xv[0] * xv[0] + xv[1] * xv[1]) + (xv[2] * xv[2] + xv[3] * xv[3])) + ((xv[4] * xv[4] + xv[5] * xv[5]) + (xv[6] * xv[6] + xv[7] * xv[7]));
+        const float r = norm ? rsqrtf(group_sum<8>(sq) / 64.f + e.eps) : 1.f;
+        const float4 a0 = rope_apply(make_float4(xv[0] * r * wv[0], xv[1] * r * wv[1], xv[2] * r * wv[2], xv[3] * r * wv[3]), cs[s2][0], sn[s2][0]);
+        const float4 a1 = rope_apply(make_float4(xv[4] * r * wv[4], xv[5] * r * wv[5], xv[6] * r * wv[6], xv[7] * r * wv[7]), cs[s2][1], sn[s2][1]);
+        bf16x8 o;
+        o[0] = (bf16)a0.x; o[1] = (bf16)a0.y; o[2] = (bf16)a0.z; o[3] = (bf16)a0.w; o[4] = (bf16)a1.x; o[5] = (bf16)a1.y; o[6] = (bf16)a1.z; o[7] = (bf16)a1.w;
+        __builtin_nontemporal_store(o, (bf16x8*)(dstb + (size_t)(s2 * 8) * 128));
+      }
+    }
+    return;
+  }
   if constexpr (EPI == LDMAE_EPI_SWIGLU) {
     // strip cols 0..31 = x1 (hid columns hc..), 32..63 = x2.  Values are rounded to bf16 BEFORE silu so the result
     // matches the unfused ldmae_swiglu_fwd on the stored h12 (same formula; last-bit FMA-contraction differences are possible).

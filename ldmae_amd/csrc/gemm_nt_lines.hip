@@ -182,6 +182,7 @@ static int launch_lines(int epi, const void* A, const void* B, int M, int N, int
     case LDMAE_EPI_GELU_BWD: LINES_GO(LDMAE_EPI_GELU_BWD);
     case LDMAE_EPI_SWIGLU: if constexpr (sizeof(OutT) == 2) LINES_GO(LDMAE_EPI_SWIGLU) else return 0;
     case LDMAE_EPI_SWIGLU_BWD: if constexpr (sizeof(OutT) == 2) LINES_GO(LDMAE_EPI_SWIGLU_BWD) else return 0;
+    case LDMAE_EPI_QKV_ROPE: if constexpr (sizeof(OutT) == 2) LINES_GO(LDMAE_EPI_QKV_ROPE) else return 0;
     default: return 0;
   }
 #undef LINES_GO

@@ -326,13 +326,19 @@ class _DiTBlockFn(torch.autograd.Function):
         W3, W3T = _wcopies(w3, dtype, bwd)
         # attention branch (:248)
         xm1, rstd1 = ops.rmsnorm_modulate_fwd(x2, n1w, sh1, s1, N, dtype, eps)
-        qkv = ops.gemm_nt(xm1, Wqkv, qkvb)                                               # [M, 3D] == [B,N,3,H,hd]
         qk_saved = None
+        fused_qkv = qnb is None and dtype == torch.bfloat16 and ops.gemm_nt_qkv_rope_ok(xm1, Wqkv, B, N, H, hd)
+        if not fused_qkv:
+            qkv = ops.gemm_nt(xm1, Wqkv, qkvb)                                           # [M, 3D] == [B,N,3,H,hd]
         if qnb is not None:              # nn.LayerNorm QK-norm: composed path (see _qk_layernorm_fwd)
             q, k, v, qk_saved = _qk_layernorm_fwd(qkv, qnw, qnb, knw, knb, cos, sin, B, N, H, hd, dtype)
             o, lse = ops.attention_fwd(q, k, v, hd ** -0.5)
         elif dtype == torch.bfloat16:    # v is consumed where the qkv Linear wrote it: no head-major copy of v (nor of dv in backward)
-            q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps, copy_v=False)
+            if fused_qkv:                # q_norm / k_norm / RoPE in the qkv GEMM's epilogue (bitwise the pair below; forward-only calls skip the pre-norm q / k)
+                qkv, q, k = ops.gemm_nt_qkv_rope(xm1, Wqkv, qkvb, qnw, knw, cos, sin, B, N, H, hd, eps, store_raw_qk=bwd)
+                v = None
+            else:
+                q, k, v = ops.qknorm_rope_fwd(qkv, qnw, knw, cos, sin, B, N, H, hd, eps, copy_v=False)
             # QK-RMSNorm bounds |q|, |k| by max|w| sqrt(hd) and the rotation keeps norms: a proven score bound, so the softmax runs with a
             # static shift (no running maximum in the kernel).  use_qknorm=False (qnw None; q_norm = nn.Identity, :60-61): nothing bounds the
             # scores, the kernel tracks the running maximum.

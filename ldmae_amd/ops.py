@@ -196,6 +196,32 @@ def gemm_nt_swiglu(a, w12, b12, save_h12=True):
     return h12, swiglu_fwd(h12)
 
 
+FUSED_QKV = os.environ.get("LDMAE_FUSED_QKV", "1") != "0"      # module switch for A/B runs (tools/bench_qkv_rope.py)
+
+
+def gemm_nt_qkv_rope_ok(a, w, B, N, H, hd):
+    """Does the fused qkv GEMM (QK-norm / RoPE in the epilogue) cover this call?  bf16, head dim 64, B*N % 256 == 0, N % 128 == 0, rows on 128-B lines.
+    LDMAE_FUSED_QKV=0 keeps the GEMM + ldmae_qknorm_rope_fwd pair (A/B runs; bitwise the same q2 / k2)."""
+    if a.dtype != torch.bfloat16 or not FUSED_QKV or _HALF_LINES:
+        return False
+    if a.data_ptr() % 128 or w.data_ptr() % 128 or w.shape[0] != 3 * H * hd:
+        return False
+    return bool(L.load().ldmae_gemm_nt_qkv_rope_ok(B, N, H, hd, a.shape[1], a.stride(0), w.stride(0)))
+
+
+def gemm_nt_qkv_rope(a, w, bias, wq, wk, cos, sin, B, N, H, hd, eps=1e-6, store_raw_qk=True):
+    """(qkv, q2, k2): the qkv Linear with q_norm / k_norm / RoPE applied in its epilogue (lightningdit.py:68-74 in one kernel).  qkv [B*N, 3*H*hd] as
+    gemm_nt writes it (store_raw_qk=False -- forward-only: only the v third is written, the q / k thirds stay uninitialised), q2 / k2 [B, H, N, hd] bitwise
+    what qknorm_rope_fwd makes of the stored q / k.  wq = wk = None: RoPE only.  Call gemm_nt_qkv_rope_ok first."""
+    M, K = a.shape
+    qkv = torch.empty(M, 3 * H * hd, dtype=a.dtype, device=a.device)
+    q2 = torch.empty(B, H, N, hd, dtype=a.dtype, device=a.device)
+    k2 = torch.empty_like(q2)
+    call("ldmae_gemm_nt_qkv_rope", ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(qkv), ptr(q2), ptr(k2), ptr(wq), ptr(wk), ptr(cos), ptr(sin),
+         B, N, H, hd, K, eps, 1 if store_raw_qk else 0, 1 if (_launch_flag() & EPI_TILE_LAUNCH) else 0, stream())
+    return qkv, q2, k2
+
+
 def gemm_nt_swiglu_bwd(dy, w3t, h12, with_bias=False):
     """dh12 = swiglu_bwd(dy @ w3t^T, h12)   (w3t = [Hs, D] transposed copy of w3).  with_bias: also the column sums of dh12 (the
     bias gradient of w12), formed in the GEMM epilogue as per-128-row partials and summed here."""

@@ -1020,3 +1020,59 @@ def test_gelu_tanh(ops, dtype):
     big = torch.tensor([-40.0, -12.0, 12.0, 40.0, 0.0])
     ob = ops.gelu_tanh_fwd(dev(big))
     assert torch.isfinite(ob).all() and rel_err(ob.cpu(), torch.nn.functional.gelu(big, approximate="tanh")) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,H,K", [(2, 128, 4, 192), (1, 256, 12, 768), (4, 128, 8, 64)])
+@pytest.mark.parametrize("with_norm", [True, False])
+def test_qkv_gemm_with_fused_qknorm_rope_is_bitwise_the_pair(B, N, H, K, with_norm):
+    """ldmae_gemm_nt_qkv_rope (lightningdit.py:68-74 in one kernel: the qkv Linear with q_norm / k_norm / RoPE in the GEMM epilogue) against the pair it
+    replaces, ldmae_gemm_nt + ldmae_qknorm_rope_fwd: the packed qkv, q2 and k2 must be BITWISE equal (same arithmetic on the same bf16-rounded values);
+    with_norm=False: the RoPE-only form of use_qknorm=False.  Forward-only calls (store_raw_qk=False) skip the pre-norm q / k thirds and nothing else."""
+    from ldmae_amd import ops
+    hd = 64
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + N + H)
+    a = torch.randn(B * N, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(3 * H * hd, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(3 * H * hd, device="cuda", generator=g) * 0.1
+    wq = 1 + 0.2 * torch.randn(hd, device="cuda", generator=g) if with_norm else None
+    wk = 1 + 0.2 * torch.randn(hd, device="cuda", generator=g) if with_norm else None
+    ang = torch.rand(N, hd // 2, device="cuda", generator=g) * 6.28
+    cos, sin = ang.cos().repeat_interleave(2, 1).contiguous(), ang.sin().repeat_interleave(2, 1).contiguous()
+    assert ops.gemm_nt_qkv_rope_ok(a, w, B, N, H, hd)
+    ref = ops.gemm_nt(a, w, bias)
+    q_ref, k_ref, _ = ops.qknorm_rope_fwd(ref, wq, wk, cos, sin, B, N, H, hd, 1e-6, copy_v=False)
+    qkv, q2, k2 = ops.gemm_nt_qkv_rope(a, w, bias, wq, wk, cos, sin, B, N, H, hd, 1e-6)
+    assert torch.equal(qkv, ref) and torch.equal(q2, q_ref) and torch.equal(k2, k_ref)
+    # against plain f32 torch as well (the pair is itself pinned by the reference goldens: test_qknorm_rope...)
+    x = (a.float() @ w.float().t() + bias).to(torch.bfloat16).float().view(B, N, 3, H, hd)
+    def front(t, wn):
+        if wn is not None:
+            t = t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-6) * wn
+        rot = torch.stack((-t[..., 1::2], t[..., 0::2]), -1).flatten(-2)
+        return (t * cos[None, :, None, :] + rot * sin[None, :, None, :]).permute(0, 2, 1, 3)
+    assert (q2.float() - front(x[:, :, 0], wq)).abs().max() < 0.04 and (k2.float() - front(x[:, :, 1], wk)).abs().max() < 0.04
+    qkv_f, q2_f, k2_f = ops.gemm_nt_qkv_rope(a, w, bias, wq, wk, cos, sin, B, N, H, hd, 1e-6, store_raw_qk=False)
+    assert torch.equal(q2_f, q_ref) and torch.equal(k2_f, k_ref) and torch.equal(qkv_f.view(B * N, 3, H * hd)[:, 2], ref.view(B * N, 3, H * hd)[:, 2])
+    # without a bias, and one tile per workgroup
+    ref0 = ops.gemm_nt(a, w, None)
+    q0, k0, _ = ops.qknorm_rope_fwd(ref0, wq, wk, cos, sin, B, N, H, hd, 1e-6, copy_v=False)
+    ops.set_gemm_launch_mode("tile")
+    try:
+        r0 = ops.gemm_nt_qkv_rope(a, w, None, wq, wk, cos, sin, B, N, H, hd, 1e-6)
+    finally:
+        ops.set_gemm_launch_mode("auto")
+    assert torch.equal(r0[0], ref0) and torch.equal(r0[1], q0) and torch.equal(r0[2], k0)
+
+
+@pytest.mark.gpu
+def test_qkv_rope_fused_gemm_refuses_what_it_does_not_cover():
+    from ldmae_amd import ops
+    a = torch.zeros(192, 64, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(3 * 4 * 64, 64, device="cuda", dtype=torch.bfloat16)
+    assert not ops.gemm_nt_qkv_rope_ok(a, w, 3, 64, 4, 64)                       # 64 tokens per sample: a wave's 128 rows would straddle samples
+    assert not ops.gemm_nt_qkv_rope_ok(a.float(), w.float(), 1, 256, 4, 64)      # f32
+    assert not ops.gemm_nt_qkv_rope_ok(torch.zeros(256, 64, device="cuda", dtype=torch.bfloat16), torch.zeros(3 * 4 * 72, 64, device="cuda", dtype=torch.bfloat16), 1, 256, 4, 72)
+    t = torch.zeros(64, 64, device="cuda")
+    with pytest.raises(RuntimeError, match="qkv_rope"):
+        ops.gemm_nt_qkv_rope(a, w, None, None, None, t, t, 3, 64, 4, 64)
