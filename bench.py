@@ -866,6 +866,7 @@ def main():
     local = int(os.environ.get("LDMAE_BENCH_DEVICE", local))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (this driver's only form): set before the first HIP call of the rank
         if backend == "nccl":
             # the RCCL run is refused rather than degraded: every rank needs its own GPU (a rehearsal on fewer GPUs asks for it explicitly:
             # LDMAE_BENCH_BACKEND=gloo LDMAE_BENCH_DEVICE=0), and the group that comes up must really be the nccl (= RCCL) backend

@@ -110,6 +110,7 @@ def do_train(cfg, synthetic=False, max_steps=None, precision=None):
     local = int(os.environ.get("LDMAE_DEVICE", local))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only form this driver supports (RCCL needs it)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
