@@ -1023,7 +1023,7 @@ def test_gelu_tanh(ops, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,N,H,K", [(2, 128, 4, 192), (1, 256, 12, 768), (4, 128, 8, 64)])
+@pytest.mark.parametrize("B,N,H,K", [(2, 128, 4, 192), (1, 256, 12, 768), (4, 128, 8, 64), (256, 1024, 12, 768)])      # last: BASELINE config 2's block, full size
 @pytest.mark.parametrize("with_norm", [True, False])
 def test_qkv_gemm_with_fused_qknorm_rope_is_bitwise_the_pair(B, N, H, K, with_norm):
     """ldmae_gemm_nt_qkv_rope (lightningdit.py:68-74 in one kernel: the qkv Linear with q_norm / k_norm / RoPE in the GEMM epilogue) against the pair it
@@ -1044,6 +1044,8 @@ def test_qkv_gemm_with_fused_qknorm_rope_is_bitwise_the_pair(B, N, H, K, with_no
     q_ref, k_ref, _ = ops.qknorm_rope_fwd(ref, wq, wk, cos, sin, B, N, H, hd, 1e-6, copy_v=False)
     qkv, q2, k2 = ops.gemm_nt_qkv_rope(a, w, bias, wq, wk, cos, sin, B, N, H, hd, 1e-6)
     assert torch.equal(qkv, ref) and torch.equal(q2, q_ref) and torch.equal(k2, k_ref)
+    if B * N > 65536:
+        return                                      # full size: the bitwise statement above is the test (the f32 torch check below would need 10 GB)
     # against plain f32 torch as well (the pair is itself pinned by the reference goldens: test_qknorm_rope...)
     x = (a.float() @ w.float().t() + bias).to(torch.bfloat16).float().view(B, N, 3, H, hd)
     def front(t, wn):
