@@ -46,6 +46,26 @@ def main():
     w = (torch.randn(2304, 768, device="cuda", generator=g) * 0.03).to(torch.bfloat16)
     bias = torch.zeros(2304, device="cuda")
     xf = torch.randn(B * N, 768, device="cuda", generator=g)
+    if len(sys.argv) > 1 and sys.argv[1] == "epilogues":
+        # the NT GEMMs with fused epilogues: do they hold the cap too, or do their HBM-bound epilogue phases leave power unused?
+        w12 = (torch.randn(4096, 768, device="cuda", generator=g) * 0.03).to(torch.bfloat16)
+        b12 = torch.zeros(4096, device="cuda")
+        w3 = (torch.randn(768, 2048, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+        w3t = w3.t().contiguous()
+        wp = (torch.randn(768, 768, device="cuda", generator=g) * 0.03).to(torch.bfloat16)
+        b768 = torch.zeros(768, device="cuda")
+        gate = torch.randn(B, 768, device="cuda", generator=g)
+        h12, hid = ops.gemm_nt_swiglu(x, w12, b12)
+        xo = torch.empty_like(xf)
+        for rnd in range(2):
+            sustained("NT plain qkv (N 2304, K 768)", lambda: ops.gemm_nt(x, w, bias=bias, out_dtype=torch.bfloat16))
+            sustained("NT SwiGLU fwd (EPI 4: N 4096, K 768)", lambda: ops.gemm_nt_swiglu(x, w12, b12))
+            sustained("NT SwiGLU bwd (EPI 5: N 2048, K 768)", lambda: ops.gemm_nt_swiglu_bwd(x, w3t, h12))
+            sustained("NT gated residual w3 (EPI 1: K 2048)", lambda: ops.gemm_nt_gate_res(hid, w3, b768, xf, gate, N, xout=xo))
+            sustained("NT gated residual proj (EPI 1: K 768)", lambda: ops.gemm_nt_gate_res(x, wp, b768, xf, gate, N, xout=xo))
+            sustained("row-wise rmsnorm_modulate_fwd", lambda: ops.rmsnorm_modulate_fwd(xf, b768 + 1, gate, gate, N, torch.bfloat16, 1e-6))
+            time.sleep(1.0)
+        return
     for rnd in range(2):
         sustained("attention forward", lambda: ops.attention_fwd_pv(q2, k2, qkv, scale))
         sustained("attention backward pair (fused)", lambda: ops.attention_bwd_pv_qknorm(q2, k2, qkv, o2, do, lse2, scale, wq, wk, cos, sin))
