@@ -473,6 +473,41 @@ def test_direct_param_grads_equal_autograd_accumulation():
     assert any(v.abs().sum() > 0 for k, v in b.items() if k.endswith("attn.qkv.weight"))
 
 
+@pytest.mark.parametrize("use_qknorm", [True, False])
+def test_qkv_epilogue_fusion_leaves_the_training_step_bitwise_unchanged(use_qknorm):
+    """B/1's block geometry (12 heads of 64, 256 tokens, bf16) with the QK-norm / RoPE front end inside the qkv GEMM (ldmae_gemm_nt_qkv_rope) and as the
+    GEMM + ldmae_qknorm_rope_fwd pair (ops.FUSED_QKV off): the training forward, every parameter gradient and the no-grad forward (which skips the
+    pre-norm q / k stores) are bitwise equal; use_qknorm=False = the CelebA-HQ configuration (RoPE only)."""
+    from ldmae_amd import ops
+    cfg = odit.DiTConfig(input_size=16, patch_size=1, in_channels=16, hidden_size=768, depth=2, num_heads=12, num_classes=10, class_dropout_prob=0.0,
+                         **dict(FLAGS, use_qknorm=use_qknorm))
+    sd = det_weights(odit.param_shapes(cfg), 3)
+    sd.update(odit.fixed_tables(cfg))
+    m = build(cfg, sd)                       # activation type from the autocast region below, as in training
+    x, t, y = det_randn("fx", (2, 16, 16, 16), 7).cuda(), torch.tensor([0.3, 0.7]).cuda(), torch.tensor([1, 2]).cuda()
+    assert ops.gemm_nt_qkv_rope_ok(torch.empty(512, 768, device="cuda", dtype=torch.bfloat16), torch.empty(2304, 768, device="cuda", dtype=torch.bfloat16), 2, 256, 12, 64)
+
+    def run(fused):
+        ops.FUSED_QKV = fused
+        try:
+            for p in m.parameters():
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = m(x, t, y)
+                out.float().square().mean().backward()
+                with torch.no_grad():
+                    ev = m(x, t, y)
+            return out.detach().clone(), ev.clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        finally:
+            ops.FUSED_QKV = True
+    o1, e1, g1 = run(True)
+    o0, e0, g0 = run(False)
+    assert torch.equal(o1, o0) and torch.equal(e1, e0) and g1.keys() == g0.keys()
+    for k in g1:
+        assert torch.equal(g1[k], g0[k]), k
+    assert float(g1["blocks.0.attn.qkv.weight"].abs().sum()) > 0 and torch.isfinite(o1).all()
+
+
 def test_xl1_real_width_forward_vs_oracle():
     """LightningDiT-XL/1 geometry at the real width (1152, 16 heads, head_dim 72, SwiGLU hidden 3072, 1024 tokens), depth 2, batch 1:
     fp32 forward within 1e-4 of the oracle; bf16 autocast (native head_dim-72 flash kernel, LDS padded to 96) within 2e-2."""
