@@ -39,7 +39,42 @@ def main_f16(n, rnd):
     sys.exit(1 if bad else 0)
 
 
+def main_qkv(n, rnd):
+    """ldmae_gemm_nt_qkv_rope (QK-norm / RoPE in the qkv GEMM's epilogue) against ldmae_gemm_nt + ldmae_qknorm_rope_fwd on random covered shapes: bitwise."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    bad = 0
+    for i in range(n):
+        N = 128 * rnd.choice([1, 2, 3, 5, 8, rnd.randint(1, 12)])
+        B = rnd.choice([1, 2, 3, 4, 7, rnd.randint(1, 24)])
+        if (B * N) % 256:
+            B *= 2
+        H = 4 * rnd.choice([1, 2, 3, 4, 6])
+        K = 64 * rnd.choice([1, 2, 3, 12, 18, rnd.randint(1, 24)])
+        norm, with_bias, raw, tile = rnd.random() < 0.6, rnd.random() < 0.7, rnd.random() < 0.7, rnd.random() < 0.4
+        a = torch.randn(B * N, K, device="cuda", generator=g).to(BF16)
+        w = (torch.randn(3 * H * 64, K, device="cuda", generator=g) * K ** -0.5).to(BF16)
+        bias = torch.randn(3 * H * 64, device="cuda", generator=g) * 0.2 if with_bias else None
+        wq = 1 + 0.3 * torch.randn(64, device="cuda", generator=g) if norm else None
+        wk = 1 + 0.3 * torch.randn(64, device="cuda", generator=g) if norm else None
+        cos, sin = torch.randn(N, 64, device="cuda", generator=g), torch.randn(N, 64, device="cuda", generator=g)      # arbitrary tables: no pair structure assumed
+        assert ops.gemm_nt_qkv_rope_ok(a, w, B, N, H, 64)
+        ops.set_gemm_launch_mode("tile" if tile else "persistent")
+        ref = ops.gemm_nt(a, w, bias)
+        qr, kr, _ = ops.qknorm_rope_fwd(ref, wq, wk, cos, sin, B, N, H, 64, 1e-6, copy_v=False)
+        qkv, q2, k2 = ops.gemm_nt_qkv_rope(a, w, bias, wq, wk, cos, sin, B, N, H, 64, 1e-6, store_raw_qk=raw)
+        ops.set_gemm_launch_mode("auto")
+        ok = torch.equal(q2, qr) and torch.equal(k2, kr)
+        ok = ok and (torch.equal(qkv, ref) if raw else torch.equal(qkv.view(B * N, 3, H * 64)[:, 2], ref.view(B * N, 3, H * 64)[:, 2]))
+        bad += not ok
+        print(f"{i:3d}  B {B:3d} N {N:5d} H {H:3d} K {K:5d}  norm {int(norm)} bias {int(with_bias)} raw {int(raw)} tile {int(tile)}  {'ok' if ok else 'FAIL'}", flush=True)
+    print(f"{n - bad} / {n} shapes bitwise equal to the GEMM + qknorm_rope_fwd pair")
+    sys.exit(1 if bad else 0)
+
+
 def main():
+    if "--qkv" in sys.argv:
+        sys.argv.remove("--qkv")
+        return main_qkv(int(sys.argv[1]) if len(sys.argv) > 1 else 40, random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0))
     if "--f16" in sys.argv:
         sys.argv.remove("--f16")
         return main_f16(int(sys.argv[1]) if len(sys.argv) > 1 else 40, random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0))
