@@ -22,28 +22,26 @@ from ldmae_amd.vmae_pretrain import resize_pos_embed            # noqa: E402
 
 def reset_positional_embedding(chkpt_path, arch="mae_for_ldmae_f8d16_prev", *, input_size=256, ldmae_mode=True, no_cls=True, gradual_resol=False,
                                smooth_output=True, pred_with_conv=False, kl_loss_weight=None, use_initialized_pe=False, modify_dec_pred=False):
-    """pe_reset.py:20-77, same keywords.  Returns the path of the new checkpoint."""
+    """pe_reset.py:20-77, same keywords and the same result.  Returns the path of the new checkpoint."""
     if gradual_resol or pred_with_conv:
         raise NotImplementedError("gradual_resol / pred_with_conv tokenizers are not built here (as vmae_pretrain.py)")
-    ckpt_all = torch.load(chkpt_path, map_location="cpu", weights_only=False)
-    ckpt = ckpt_all["model"]
-    # only the grid of the target model is needed: (input_size / patch)^2 positions
-    model = getattr(models_mae, arch)(ldmae_mode=ldmae_mode, no_cls=no_cls, img_size=input_size, smooth_output=smooth_output, kl_loss_weight=kl_loss_weight)
-    if model.pos_embed.shape[1] != ckpt["pos_embed"].shape[1]:
-        new_size = int(model.pos_embed.shape[1] ** 0.5)
-        ckpt["pos_embed"] = resize_pos_embed(ckpt["pos_embed"], new_size)
-        ckpt["decoder_pos_embed"] = resize_pos_embed(ckpt["decoder_pos_embed"], new_size)
-    if modify_dec_pred:                          # :64-66
-        ckpt["decoder_pred.linear_pred.bias"] = ckpt.pop("decoder_pred.bias")
-        ckpt["decoder_pred.linear_pred.weight"] = ckpt.pop("decoder_pred.weight")
-    if use_initialized_pe:                       # :69-71
-        ckpt.pop("pos_embed", None)
-        ckpt.pop("decoder_pos_embed", None)
-    ckpt_all["model"] = ckpt
-    save_path = os.path.splitext(chkpt_path)[0] + "_pe.pth"
-    torch.save(ckpt_all, save_path)
-    print(f"[+] Saved adjusted checkpoint -> {save_path}")
-    return save_path
+    blob = torch.load(chkpt_path, map_location="cpu", weights_only=False)
+    sd = blob["model"]
+    # only the GRID of the target model matters: (input_size / patch)^2 positions, read off a freshly built tokenizer of that architecture
+    target = getattr(models_mae, arch)(ldmae_mode=ldmae_mode, no_cls=no_cls, img_size=input_size, smooth_output=smooth_output, kl_loss_weight=kl_loss_weight)
+    side = int(round(target.pos_embed.shape[1] ** 0.5))
+    for key in ("pos_embed", "decoder_pos_embed"):
+        if use_initialized_pe:                       # :69-71 -- drop them: the loader then keeps the model's own sin-cos tables
+            sd.pop(key, None)
+        elif sd["pos_embed"].shape[1] != side * side or sd[key].shape[1] != side * side:      # :58-61 -- both follow the encoder table's grid
+            sd[key] = resize_pos_embed(sd[key], side)
+    if modify_dec_pred:                              # :64-66 -- the two-layer predictor's key names
+        for leaf in ("bias", "weight"):
+            sd[f"decoder_pred.linear_pred.{leaf}"] = sd.pop(f"decoder_pred.{leaf}")
+    out_path = os.path.splitext(chkpt_path)[0] + "_pe.pth"
+    torch.save(blob, out_path)
+    print(f"[+] Saved adjusted checkpoint -> {out_path}")
+    return out_path
 
 
 def main(argv=None):
